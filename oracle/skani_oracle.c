@@ -1,0 +1,290 @@
+/* oracle/skani_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT. See skani_oracle.h for
+ * scope, the reference call sites this restates, and the pinning status.           */
+#include "skani_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- constants restated from skani::params (source absent; see oracle/README.md) ---- */
+#define FRAGMENT_LENGTH 20000   /* chunk length on the query                         */
+#define MAX_GAP_LENGTH 50       /* max |dq - dr| between chained anchors             */
+#define ANCHOR_SCORE 20
+#define MIN_ANCHORS 3
+#define CHAIN_BAND 100          /* look-back in anchors                              */
+#define BP_CHAIN_BAND 2500      /* look-back in query bases                          */
+#define MIN_SCORE 45            /* 0.75 * MIN_ANCHORS * ANCHOR_SCORE                 */
+#define SMALL_MARKER_COUNT 20   /* "less than 20 marker k-mers", lib.rs:538-541      */
+
+/* skani::types::mm_hash64: minimap2's invertible mix, with the first line as the Rust
+ * expression `!key.wrapping_add(key << 21)` parses: NOT of the sum.                  */
+uint64_t orc_mm_hash64(uint64_t key) {
+    key = ~(key + (key << 21));
+    key = key ^ key >> 24;
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14;
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ key >> 28;
+    key = key + (key << 31);
+    return key;
+}
+
+static uint8_t BYTE_TO_SEQ[256];
+static int tab_ready = 0;
+static void init_tab(void) {
+    if (tab_ready) return;
+    memset(BYTE_TO_SEQ, 0, sizeof BYTE_TO_SEQ);
+    BYTE_TO_SEQ['C'] = BYTE_TO_SEQ['c'] = 1;
+    BYTE_TO_SEQ['G'] = BYTE_TO_SEQ['g'] = 2;
+    BYTE_TO_SEQ['T'] = BYTE_TO_SEQ['t'] = 3;
+    tab_ready = 1;
+}
+
+static int cmp_u64(const void* a, const void* b) {
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+/* fmh_seeds (lib.rs:165-171) applied by the _sketch driver (lib.rs:140-185). */
+orc_sketch* orc_sketch_new(const uint8_t* const* contigs, const uint64_t* lens, uint32_t n,
+                           int c, int marker_c, int k, int want_seeds) {
+    init_tab();
+    if (k < 1 || k > 16 || c < 1 || marker_c < 1) return NULL;
+    orc_sketch* s = calloc(1, sizeof *s);
+    s->c = c; s->marker_c = marker_c; s->k = k;
+    s->contig_len = malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint64_t cap_s = 1024, cap_m = 1024;
+    s->seeds = malloc(sizeof(orc_seed) * cap_s);
+    s->markers = malloc(sizeof(uint64_t) * cap_m);
+    const int mk = ORC_K_MARKER;
+    const int off_lo = (mk - k) / 2;                 /* seed k-mer is centred in the window */
+    const int shift_f = 2 * (mk - k - off_lo), shift_r = 2 * off_lo;
+    const uint64_t mmask = (~0ULL) >> (64 - 2 * mk);
+    const uint64_t smask = (~0ULL) >> (64 - 2 * k);
+    const uint64_t thr = UINT64_MAX / (uint64_t)c, thr_m = UINT64_MAX / (uint64_t)marker_c;
+    for (uint32_t ci = 0; ci < n; ci++) {
+        const uint8_t* str = contigs[ci];
+        uint64_t len = lens[ci];
+        if (len < ORC_MIN_LENGTH_CONTIG) continue;       /* lib.rs:156 */
+        uint32_t contig_index = s->n_contigs;            /* counts kept contigs, lib.rs:146,173 */
+        s->contig_len[s->n_contigs++] = (uint32_t)len;   /* lib.rs:158-160 */
+        s->total_len += len;                             /* lib.rs:161 */
+        uint64_t f = 0, r = 0;
+        for (uint64_t i = 0; i < len; i++) {
+            uint64_t b = BYTE_TO_SEQ[str[i]];
+            f = ((f << 2) | b) & mmask;
+            r = (r >> 2) | ((3 - b) << (2 * (mk - 1)));
+            if (i < (uint64_t)mk - 1) continue;
+            uint64_t fs = (f >> shift_f) & smask, rs = (r >> shift_r) & smask;
+            int canon = fs < rs;
+            uint64_t cs = canon ? fs : rs;
+            uint64_t h = orc_mm_hash64(cs);
+            if (h < thr) {
+                if (want_seeds) {
+                    if (s->n_seeds == cap_s) { cap_s *= 2; s->seeds = realloc(s->seeds, sizeof(orc_seed) * cap_s); }
+                    orc_seed* o = &s->seeds[s->n_seeds++];
+                    o->kmer = (uint32_t)cs; o->pos = (uint32_t)i; o->contig = contig_index; o->canon = (uint32_t)canon;
+                }
+                if (h < thr_m) {
+                    if (s->n_markers == cap_m) { cap_m *= 2; s->markers = realloc(s->markers, sizeof(uint64_t) * cap_m); }
+                    s->markers[s->n_markers++] = f < r ? f : r;
+                }
+            }
+        }
+    }
+    /* marker_seeds is a set: sorted + unique is its canonical form */
+    qsort(s->markers, s->n_markers, sizeof(uint64_t), cmp_u64);
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < s->n_markers; i++)
+        if (i == 0 || s->markers[i] != s->markers[i - 1]) s->markers[w++] = s->markers[i];
+    s->n_markers = w;
+    return s;
+}
+
+void orc_sketch_free(orc_sketch* s) {
+    if (!s) return;
+    free(s->contig_len); free(s->seeds); free(s->markers); free(s);
+}
+
+/* check_markers_quickly (lib.rs:623-628): containment of the smaller marker set. */
+int orc_screen(const orc_sketch* q, const orc_sketch* r, double screen_val, int rescue_small,
+               uint64_t* n_shared_out) {
+    uint64_t nq = q->n_markers, nr = r->n_markers;
+    uint64_t small = nq < nr ? nq : nr;
+    uint64_t i = 0, j = 0, shared = 0;
+    while (i < nq && j < nr) {
+        if (q->markers[i] < r->markers[j]) i++;
+        else if (q->markers[i] > r->markers[j]) j++;
+        else { shared++; i++; j++; }
+    }
+    if (n_shared_out) *n_shared_out = shared;
+    if (rescue_small && small < SMALL_MARKER_COUNT) return 1;
+    if (small == 0) return 0;
+    double thresh = pow(screen_val, (double)ORC_K_MARKER);
+    return (double)shared / (double)small > thresh;
+}
+
+typedef struct { uint32_t qc, qp, rp, rc, rev; } anchor_t;
+typedef struct { uint32_t kmer, pos, contig, canon; } kseed_t;
+
+static int cmp_kseed(const void* a, const void* b) {
+    const kseed_t* x = a; const kseed_t* y = b;
+    if (x->kmer != y->kmer) return x->kmer < y->kmer ? -1 : 1;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    if (x->contig != y->contig) return x->contig < y->contig ? -1 : 1;
+    return 0;
+}
+
+typedef struct { int32_t score; uint32_t q0, q1, r0, r1, nanch, order; } cand_t;
+static int cmp_cand(const void* a, const void* b) {      /* score desc, stable by generation order */
+    const cand_t* x = a; const cand_t* y = b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return x->order < y->order ? -1 : x->order > y->order;
+}
+static int cmp_dbl(const void* a, const void* b) {
+    double x = *(const double*)a, y = *(const double*)b;
+    return x < y ? -1 : x > y;
+}
+
+static __thread orc_chunk_rec* g_recs = NULL;
+static __thread uint32_t g_nrecs = 0;
+uint32_t orc_last_chunks(const orc_chunk_rec** recs) { *recs = g_recs; return g_nrecs; }
+
+/* number of query seeds on `contig` with pos in [lo, hi]; seeds are in (contig,pos) order */
+static uint32_t seeds_between(const orc_sketch* q, const uint64_t* cstart, uint32_t contig, uint32_t lo, uint32_t hi) {
+    uint64_t a = cstart[contig], b = cstart[contig + 1];
+    uint64_t l = a, r = b;
+    while (l < r) { uint64_t m = (l + r) / 2; if (q->seeds[m].pos < lo) l = m + 1; else r = m; }
+    uint64_t first = l; r = b;
+    while (l < r) { uint64_t m = (l + r) / 2; if (q->seeds[m].pos <= hi) l = m + 1; else r = m; }
+    return (uint32_t)(l - first);
+}
+
+/* chain_seeds (lib.rs:652-653) with the MapParams of map_params_from_sketch (lib.rs:646-651). */
+int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_opts* o, orc_result* out) {
+    memset(out, 0, sizeof *out);
+    out->ani = -1.0f;
+    free(g_recs); g_recs = NULL; g_nrecs = 0;
+    if (o->learned_ani) return -2;                    /* GBDT weights live inside the absent crate */
+    const int k = ref->k, c = ref->c;
+    uint64_t nq = query->n_seeds, nr = ref->n_seeds;
+    if (nq == 0 || nr == 0) return 0;
+    /* reference index: seeds ordered by (kmer, pos, contig) — the sorted stand-in for the k-mer map */
+    kseed_t* rs = malloc(sizeof(kseed_t) * nr);
+    for (uint64_t i = 0; i < nr; i++) { rs[i].kmer = ref->seeds[i].kmer; rs[i].pos = ref->seeds[i].pos; rs[i].contig = ref->seeds[i].contig; rs[i].canon = ref->seeds[i].canon; }
+    qsort(rs, nr, sizeof(kseed_t), cmp_kseed);
+    /* anchors: every (query seed, ref seed) pair with equal k-mer; walking query seeds in (contig,pos)
+     * order and ref matches in (pos,contig) order yields them sorted by (qc,qp,rp,rc) */
+    uint64_t cap = nq + 1024, na = 0;
+    anchor_t* A = malloc(sizeof(anchor_t) * cap);
+    for (uint64_t i = 0; i < nq; i++) {
+        uint32_t km = query->seeds[i].kmer;
+        uint64_t l = 0, r = nr;
+        while (l < r) { uint64_t m = (l + r) / 2; if (rs[m].kmer < km) l = m + 1; else r = m; }
+        for (uint64_t j = l; j < nr && rs[j].kmer == km; j++) {
+            if (na == cap) { cap *= 2; A = realloc(A, sizeof(anchor_t) * cap); }
+            A[na].qc = query->seeds[i].contig; A[na].qp = query->seeds[i].pos;
+            A[na].rp = rs[j].pos; A[na].rc = rs[j].contig; A[na].rev = query->seeds[i].canon != rs[j].canon;
+            na++;
+        }
+    }
+    free(rs);
+    out->n_anchors = na;
+    if (na == 0) { free(A); return 0; }
+    /* per-contig start offsets of the query seeds */
+    uint64_t* cstart = calloc(query->n_contigs + 2, sizeof(uint64_t));
+    for (uint64_t i = 0; i < nq; i++) cstart[query->seeds[i].contig + 1]++;
+    for (uint32_t i = 0; i < query->n_contigs; i++) cstart[i + 1] += cstart[i];
+
+    int32_t* f = malloc(sizeof(int32_t) * na);
+    uint32_t* ptr = malloc(sizeof(uint32_t) * na);
+    uint32_t* root = malloc(sizeof(uint32_t) * na);
+    uint32_t* depth = malloc(sizeof(uint32_t) * na);
+    uint32_t* best = malloc(sizeof(uint32_t) * na);
+    cand_t* cands = malloc(sizeof(cand_t) * na);
+    cand_t* kept = malloc(sizeof(cand_t) * na);
+    uint64_t rec_cap = 256; g_recs = malloc(sizeof(orc_chunk_rec) * rec_cap);
+    uint64_t dcap = 256, nd = 0; double* anis = malloc(sizeof(double) * dcap);
+
+    uint64_t s = 0;
+    while (s < na) {
+        /* chunk = run of anchors on one query contig within FRAGMENT_LENGTH of the chunk's first anchor */
+        uint64_t e = s; uint64_t endp = (uint64_t)A[s].qp + FRAGMENT_LENGTH;
+        while (e < na && A[e].qc == A[s].qc && (uint64_t)A[e].qp <= endp) e++;
+        /* banded chaining DP, integer scores */
+        for (uint64_t x = s; x < e; x++) {
+            int32_t bs = ANCHOR_SCORE; uint64_t bp = x;
+            for (uint64_t y = x; y-- > s && x - y <= CHAIN_BAND;) {
+                if (A[y].rc != A[x].rc || A[y].rev != A[x].rev) continue;
+                int64_t dq = (int64_t)A[x].qp - (int64_t)A[y].qp;
+                if (dq > BP_CHAIN_BAND) break;
+                int64_t dr = A[x].rev ? (int64_t)A[y].rp - (int64_t)A[x].rp : (int64_t)A[x].rp - (int64_t)A[y].rp;
+                if (dq <= 0 || dr <= 0) continue;
+                int64_t gap = dq > dr ? dq - dr : dr - dq;
+                if (gap > MAX_GAP_LENGTH) continue;
+                int32_t sc = f[y] + ANCHOR_SCORE - (int32_t)gap;
+                if (sc > bs) { bs = sc; bp = y; }
+            }
+            f[x] = bs; ptr[x] = (uint32_t)bp;
+            if (bp == x) { root[x] = (uint32_t)x; depth[x] = 1; }
+            else { root[x] = root[bp]; depth[x] = depth[bp] + 1; }
+        }
+        /* one candidate chain per DP tree: its best-scoring anchor (lowest index on ties), backtracked to the root */
+        for (uint64_t x = s; x < e; x++) best[x] = UINT32_MAX;
+        for (uint64_t x = s; x < e; x++) { uint32_t rt = root[x]; if (best[rt] == UINT32_MAX || f[x] > f[best[rt]]) best[rt] = (uint32_t)x; }
+        uint32_t nc = 0;
+        for (uint64_t x = s; x < e; x++) {
+            if (root[x] != x) continue;
+            uint32_t b = best[x];
+            if (depth[b] < MIN_ANCHORS || f[b] < MIN_SCORE) continue;
+            cand_t* cd = &cands[nc];
+            cd->score = f[b]; cd->q0 = A[x].qp; cd->q1 = A[b].qp; cd->nanch = depth[b]; cd->order = nc;
+            cd->r0 = A[x].rp < A[b].rp ? A[x].rp : A[b].rp; cd->r1 = A[x].rp < A[b].rp ? A[b].rp : A[x].rp;
+            nc++;
+        }
+        qsort(cands, nc, sizeof(cand_t), cmp_cand);
+        /* greedy non-overlapping (on the query) selection by score */
+        uint32_t nk = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            int ok = 1;
+            for (uint32_t j = 0; j < nk; j++) if (!(cands[i].q1 < kept[j].q0 || cands[i].q0 > kept[j].q1)) { ok = 0; break; }
+            if (ok) kept[nk++] = cands[i];
+        }
+        if (nk) {
+            uint32_t left = UINT32_MAX, right = 0, anch = 0;
+            for (uint32_t j = 0; j < nk; j++) {
+                if (kept[j].q0 < left) left = kept[j].q0;
+                if (kept[j].q1 > right) right = kept[j].q1;
+                anch += kept[j].nanch;
+                out->covered_query += (uint64_t)(kept[j].q1 - kept[j].q0) + 1 + 2 * (uint64_t)c;
+                out->covered_ref += (uint64_t)(kept[j].r1 - kept[j].r0) + 1 + 2 * (uint64_t)c;
+            }
+            uint32_t ns = seeds_between(query, cstart, A[s].qc, left, right);
+            double ratio = (double)anch / (double)ns; if (ratio > 1.0) ratio = 1.0;
+            if (nd == dcap) { dcap *= 2; anis = realloc(anis, sizeof(double) * dcap); }
+            anis[nd++] = pow(ratio, 1.0 / (double)k);
+            if (g_nrecs == rec_cap) { rec_cap *= 2; g_recs = realloc(g_recs, sizeof(orc_chunk_rec) * rec_cap); }
+            orc_chunk_rec* rc = &g_recs[g_nrecs++];
+            rc->contig = A[s].qc; rc->left = left; rc->right = right; rc->anchors = anch; rc->seeds = ns; rc->n_intervals = nk;
+            out->n_intervals += nk; out->sum_chain_anchors += anch; out->sum_chunk_seeds += ns;
+        }
+        s = e;
+    }
+    out->n_chunks = (uint32_t)nd;
+    if (nd) {
+        double ani;
+        if (o->median || o->robust) qsort(anis, nd, sizeof(double), cmp_dbl);
+        if (o->median) ani = anis[nd / 2];
+        else {
+            uint64_t lo = 0, hi = nd;
+            if (o->robust && nd - 2 * (nd / 10) > 0) { lo = nd / 10; hi = nd - nd / 10; }
+            double sum = 0; for (uint64_t i = lo; i < hi; i++) sum += anis[i];
+            ani = sum / (double)(hi - lo);
+        }
+        double afq = (double)out->covered_query / (double)query->total_len; if (afq > 1) afq = 1;
+        double afr = (double)out->covered_ref / (double)ref->total_len; if (afr > 1) afr = 1;
+        out->af_query = (float)afq; out->af_ref = (float)afr;
+        if (afq >= o->min_aligned_frac || afr >= o->min_aligned_frac) out->ani = (float)ani;
+    }
+    free(A); free(cstart); free(f); free(ptr); free(root); free(depth); free(best); free(cands); free(kept); free(anis);
+    return 0;
+}

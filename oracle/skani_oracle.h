@@ -1,0 +1,92 @@
+/* oracle/skani_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Plain-C, single-threaded CPU restatement of the pyskani hot path
+ *   Database.sketch()  (/root/reference/src/pyskani/_skani/lib.rs:140-185, 477-510)
+ *   Database.query()   (/root/reference/src/pyskani/_skani/lib.rs:549-660)
+ * i.e. of the third-party calls those functions make into crate `skani` v0.3.0
+ * (Cargo.lock:1599-1601, commit c57dbe72...; NOT vendored under /root/reference):
+ *   skani::seeding::fmh_seeds            (call site lib.rs:165-171)
+ *   skani::screen::check_markers_quickly (call site lib.rs:623-628)
+ *   skani::chain::map_params_from_sketch (call site lib.rs:646-651)
+ *   skani::chain::chain_seeds            (call site lib.rs:652-653)
+ *
+ * The skani source is absent, so this is a restatement of its published algorithm
+ * (FracMinHash seeds -> marker screen -> chunked banded chaining -> per-chunk
+ * (anchors/seeds)^(1/k) ANI, chain-length aligned fraction), with every constant
+ * that could not be read from a file chosen by the scripted search recorded in
+ * oracle/README.md. PINNING STATUS (see oracle/README.md, tests/test_oracle_kat.py):
+ *   - aligned fractions: match pyskani's KATs (test_ani.py:28-61) to 4 decimals;
+ *   - raw ANI (learned_ani=False) and median ANI: within 6e-4 / 3e-4 of the KATs,
+ *     i.e. NOT to the reference's own 4-decimal tolerance -> "parity partially pinned";
+ *   - seed / marker sets: "parity unpinned" (the reference exposes none).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
+ */
+#ifndef SKANI_ORACLE_H
+#define SKANI_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_K_MARKER 21          /* skani::params::K_MARKER_DNA */
+#define ORC_MIN_LENGTH_CONTIG 500 /* skani::params::MIN_LENGTH_CONTIG, used at lib.rs:156 */
+
+typedef struct {
+    uint32_t kmer;    /* canonical 2-bit packed k-mer (k <= 16) */
+    uint32_t pos;     /* index of the LAST base of the 21-base window */
+    uint32_t contig;  /* index among KEPT contigs (lib.rs:146,173) */
+    uint32_t canon;   /* 1 iff forward k-mer < reverse complement */
+} orc_seed;
+
+typedef struct {
+    int c, marker_c, k;
+    uint32_t n_contigs;        /* kept contigs */
+    uint32_t* contig_len;      /* per kept contig */
+    uint64_t total_len;        /* sum over kept contigs (lib.rs:161) */
+    uint64_t n_seeds;          /* seeds in (contig, pos) order */
+    orc_seed* seeds;
+    uint64_t n_markers;        /* sorted, unique canonical 21-mers */
+    uint64_t* markers;
+} orc_sketch;
+
+typedef struct {
+    int learned_ani;   /* must be 0: model weights are not available */
+    int median, robust;
+    double screen_val; /* 0 -> 0.80 (lib.rs:603-609) */
+    int rescue_small;  /* = !faster_small (lib.rs:597) */
+    double min_aligned_frac; /* 0.15 (lib.rs:589-590) */
+} orc_query_opts;
+
+typedef struct {
+    float ani, af_query, af_ref;
+    /* integer intermediates, exposed so the GPU path can be compared bit-exactly */
+    uint64_t n_anchors;
+    uint32_t n_chunks;       /* chunks that produced an ANI estimate */
+    uint32_t n_intervals;    /* kept chains */
+    uint64_t covered_query, covered_ref;
+    uint64_t sum_chain_anchors, sum_chunk_seeds;
+} orc_result;
+
+uint64_t orc_mm_hash64(uint64_t key);
+
+/* contigs shorter than ORC_MIN_LENGTH_CONTIG are skipped exactly as lib.rs:155-176 does */
+orc_sketch* orc_sketch_new(const uint8_t* const* contigs, const uint64_t* lens, uint32_t n,
+                           int c, int marker_c, int k, int want_seeds);
+void orc_sketch_free(orc_sketch*);
+
+/* check_markers_quickly(query, ref, screen_val, rescue_small) */
+int orc_screen(const orc_sketch* q, const orc_sketch* r, double screen_val, int rescue_small,
+               uint64_t* n_shared_out);
+
+/* chain_seeds(ref, query, map_params_from_sketch(ref, ...)) */
+int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_opts* o, orc_result* out);
+
+/* debug dumps for GPU parity tests: per-chunk records of the last orc_chain call on this thread */
+typedef struct { uint32_t contig, left, right, anchors, seeds, n_intervals; } orc_chunk_rec;
+uint32_t orc_last_chunks(const orc_chunk_rec** recs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
