@@ -1,0 +1,133 @@
+/* include/pyskani_amd.h — C-ABI of the MI355X-native ANI engine (libpyskani_amd.so).
+ *
+ * The drop-in boundary for pyskani's Database.sketch()/Database.query() hot path. pyskani
+ * has no FFI today: its PyO3 crate calls the Rust crate `skani` directly. Each entry point
+ * below replaces one of those call sites (paths are relative to /root/reference):
+ *
+ *   psk_sketch_host / psk_sketch_device / psk_sketch_batch_device
+ *        <- the per-contig loop over skani::seeding::fmh_seeds in Database::_sketch,
+ *           src/pyskani/_skani/lib.rs:140-185 (contig filter :156, metadata :157-161,
+ *           fmh_seeds :165-171) and skani::types::Sketch::get_markers_only at :495
+ *   psk_db_add  <- self.markers.push(marker) + sketches.store(sketch)   lib.rs:501-508
+ *   psk_screen  <- skani::screen::check_markers_quickly loop            lib.rs:617-637
+ *   psk_chain   <- skani::chain::map_params_from_sketch + chain_seeds   lib.rs:646-653
+ *   psk_query   <- the whole allow_threads closure of Database::query   lib.rs:569-659
+ *                  (screen_val default :603-609, learned rule :611-614, ani>0.1 filter :654)
+ *   psk_hit     <- the fields of skani::types::AniEstResult that Hit exposes, hit.rs:77-104
+ *
+ * Conventions: plain pointers and sizes, opaque handles, no exceptions cross the ABI.
+ * Every function returns a psk_status; psk_last_error() gives the thread-local message.
+ * Inputs are borrowed for the duration of the call only. Outputs returned through `**`
+ * are library-allocated and released with the matching psk_*_free / psk_free.
+ * Threading: psk_query/psk_screen/psk_chain on one db/ctx are serialised internally
+ * (one HIP stream per ctx); psk_db_add is exclusive, as `&mut self` makes it in lib.rs:479.
+ * A missing GPU is an error (PSK_EHIP) — there is no CPU fallback in this library.
+ */
+#ifndef PYSKANI_AMD_H
+#define PYSKANI_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PSK_OK = 0,
+    PSK_EINVAL = 1,   /* bad argument (k > 16, c == 0, NULL, ...)  -> ValueError          */
+    PSK_ENOMEM = 2,   /* host or device allocation failed          -> MemoryError         */
+    PSK_EHIP = 3,     /* HIP runtime error / no device             -> RuntimeError        */
+    PSK_ENOMODEL = 4, /* learned-ANI requested, no model loaded    -> RuntimeError        */
+    PSK_EKEY = 5,     /* unknown reference name                    -> KeyError            */
+    PSK_ELIMIT = 6    /* input exceeds a documented limit          -> OverflowError       */
+} psk_status;
+
+typedef struct psk_ctx psk_ctx;       /* one GPU: device id, stream, scratch arenas         */
+typedef struct psk_sketch psk_sketch; /* one genome's seeds+index+markers, resident in HBM  */
+typedef struct psk_db psk_db;         /* ordered reference set (insertion order = lib.rs:501) */
+
+/* SketchParams::new(marker_c, c, k, false, false)  lib.rs:416 */
+typedef struct {
+    int32_t c;        /* compression, default 125        */
+    int32_t marker_c; /* marker compression, default 1000 */
+    int32_t k;        /* k-mer size, default 15, <= 16    */
+} psk_params;
+
+/* kwargs of Database.query, lib.rs:549, and the CommandParams literal lib.rs:573-601 */
+typedef struct {
+    int32_t learned_ani;     /* -1 = default rule (lib.rs:611-613), 0 = off, 1 = on            */
+    int32_t median;          /* lib.rs:583 */
+    int32_t robust;          /* lib.rs:582 */
+    int32_t faster_small;    /* rescue_small = !faster_small, lib.rs:597 */
+    double cutoff;           /* 0 = SEARCH_ANI_CUTOFF_DEFAULT (0.80), lib.rs:603-609 */
+    double min_aligned_frac; /* 0 = D_FRAC_COVER_CUTOFF/100 = 0.15, lib.rs:589-590   */
+} psk_query_opts;
+
+typedef struct {
+    float ani;        /* AniEstResult.ani                   hit.rs:78  */
+    float af_query;   /* AniEstResult.align_fraction_query  hit.rs:90  */
+    float af_ref;     /* AniEstResult.align_fraction_ref    hit.rs:102 */
+    uint32_t ref_index; /* insertion index in the db; name via psk_db_name */
+    /* integer intermediates (bit-exact parity checks against the oracle) */
+    uint32_t n_chunks, n_intervals;
+    uint64_t n_anchors, covered_query, covered_ref, sum_chain_anchors, sum_chunk_seeds;
+} psk_hit;
+
+typedef struct { uint32_t kmer, pos, contig, canon; } psk_seed; /* export record (parity tests) */
+
+const char* psk_last_error(void);
+const char* psk_version(void);
+void psk_free(void* p);
+
+psk_status psk_ctx_create(int device, psk_ctx** out);
+void psk_ctx_destroy(psk_ctx* ctx);
+psk_status psk_ctx_synchronize(psk_ctx* ctx);
+/* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
+psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
+psk_status psk_device_free(psk_ctx* ctx, void* dptr);
+psk_status psk_memcpy_h2d(psk_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* Sketch one genome from host ASCII contigs. Contigs shorter than 500 are ignored (lib.rs:156). */
+psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs,
+                           const uint64_t* lens, uint32_t n_contigs, int want_seeds,
+                           psk_sketch** out);
+
+/* Sketch n_genomes genomes whose ASCII already sits in HBM. d_bases is a device pointer;
+ * contig i is bytes [contig_off[i], contig_off[i]+contig_len[i]) of it, contig_off[i] % 16 == 0
+ * and the allocation must extend 16 bytes past the last contig. genome g owns contigs
+ * [genome_first_contig[g], genome_first_contig[g+1]). out[] receives n_genomes handles. */
+psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
+                                   const uint64_t* contig_off, const uint64_t* contig_len,
+                                   const uint32_t* genome_first_contig, uint32_t n_genomes,
+                                   int want_seeds, psk_sketch** out);
+
+void psk_sketch_free(psk_sketch* s);
+psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds,
+                           uint64_t* n_markers, uint64_t* total_len, uint32_t* n_contigs);
+/* copy the sketch back to the host: seeds in (contig,pos) order, markers sorted unique */
+psk_status psk_sketch_export(const psk_sketch* s, psk_seed* seeds, uint64_t* markers);
+
+psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out);
+void psk_db_destroy(psk_db* db);
+/* takes ownership of s (also on failure) */
+psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s);
+uint32_t psk_db_size(const psk_db* db);
+const char* psk_db_name(const psk_db* db, uint32_t index);
+const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t index);
+
+/* check_markers_quickly(query, ref_i, screen_val, rescue_small) for every ref of the db.
+ * pass[i] in {0,1}; shared[i] = |markers(q) ∩ markers(ref_i)| (may be NULL). */
+psk_status psk_screen(psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
+                      uint8_t* pass, uint32_t* shared);
+
+/* chain_seeds(ref, query, map_params) for n_refs references against one query. */
+psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,
+                     const psk_sketch* query, const psk_query_opts* o, psk_hit* out);
+
+/* Database.query: screen, chain the shortlist, keep ani > 0.1. hits in ref insertion order. */
+psk_status psk_query(psk_db* db, const psk_sketch* query, const psk_query_opts* o,
+                     psk_hit** hits, uint64_t* n_hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -129,8 +129,8 @@ typedef struct { uint32_t kmer, pos, contig, canon; } kseed_t;
 static int cmp_kseed(const void* a, const void* b) {
     const kseed_t* x = a; const kseed_t* y = b;
     if (x->kmer != y->kmer) return x->kmer < y->kmer ? -1 : 1;
-    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
     if (x->contig != y->contig) return x->contig < y->contig ? -1 : 1;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
     return 0;
 }
 
@@ -168,12 +168,12 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
     const int k = ref->k, c = ref->c;
     uint64_t nq = query->n_seeds, nr = ref->n_seeds;
     if (nq == 0 || nr == 0) return 0;
-    /* reference index: seeds ordered by (kmer, pos, contig) — the sorted stand-in for the k-mer map */
+    /* reference index: seeds ordered by (kmer, contig, pos) = a stable sort by k-mer of the (contig,pos)-ordered seeds — the sorted stand-in for the k-mer map */
     kseed_t* rs = malloc(sizeof(kseed_t) * nr);
     for (uint64_t i = 0; i < nr; i++) { rs[i].kmer = ref->seeds[i].kmer; rs[i].pos = ref->seeds[i].pos; rs[i].contig = ref->seeds[i].contig; rs[i].canon = ref->seeds[i].canon; }
     qsort(rs, nr, sizeof(kseed_t), cmp_kseed);
     /* anchors: every (query seed, ref seed) pair with equal k-mer; walking query seeds in (contig,pos)
-     * order and ref matches in (pos,contig) order yields them sorted by (qc,qp,rp,rc) */
+     * order and ref matches in (contig,pos) order yields them sorted by (qc,qp,rc,rp) */
     uint64_t cap = nq + 1024, na = 0;
     anchor_t* A = malloc(sizeof(anchor_t) * cap);
     for (uint64_t i = 0; i < nq; i++) {

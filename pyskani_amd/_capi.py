@@ -1,0 +1,99 @@
+"""ctypes binding of libpyskani_amd.so (the C-ABI declared in include/pyskani_amd.h).
+
+The library is the product path: if it is missing this module raises ImportError — there is
+no CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never imported here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyskani_amd.so")
+
+PSK_OK, PSK_EINVAL, PSK_ENOMEM, PSK_EHIP, PSK_ENOMODEL, PSK_EKEY, PSK_ELIMIT = range(7)
+
+
+class Params(C.Structure):
+    _fields_ = [("c", C.c_int32), ("marker_c", C.c_int32), ("k", C.c_int32)]
+
+
+class QueryOpts(C.Structure):
+    _fields_ = [("learned_ani", C.c_int32), ("median", C.c_int32), ("robust", C.c_int32),
+                ("faster_small", C.c_int32), ("cutoff", C.c_double), ("min_aligned_frac", C.c_double)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("ani", C.c_float), ("af_query", C.c_float), ("af_ref", C.c_float),
+                ("ref_index", C.c_uint32), ("n_chunks", C.c_uint32), ("n_intervals", C.c_uint32),
+                ("n_anchors", C.c_uint64), ("covered_query", C.c_uint64), ("covered_ref", C.c_uint64),
+                ("sum_chain_anchors", C.c_uint64), ("sum_chunk_seeds", C.c_uint64)]
+
+
+class Seed(C.Structure):
+    _fields_ = [("kmer", C.c_uint32), ("pos", C.c_uint32), ("contig", C.c_uint32), ("canon", C.c_uint32)]
+
+
+# every symbol include/pyskani_amd.h declares
+SYMBOLS = [
+    "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
+    "psk_ctx_synchronize", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
+    "psk_sketch_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
+    "psk_sketch_export", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
+    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query",
+]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU is touched until a context is created)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pyskani_amd/csrc`. pyskani_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    lib.psk_last_error.restype = C.c_char_p
+    lib.psk_version.restype = C.c_char_p
+    lib.psk_free.argtypes = [vp]
+    lib.psk_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.psk_ctx_destroy.argtypes = [vp]
+    lib.psk_ctx_destroy.restype = None
+    lib.psk_ctx_synchronize.argtypes = [vp]
+    lib.psk_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.psk_device_free.argtypes = [vp, vp]
+    lib.psk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.psk_sketch_host.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(vp)]
+    lib.psk_sketch_batch_device.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), u32, C.c_int, C.POINTER(vp)]
+    lib.psk_sketch_free.argtypes = [vp]
+    lib.psk_sketch_free.restype = None
+    lib.psk_sketch_info.argtypes = [vp, C.POINTER(Params), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    lib.psk_sketch_export.argtypes = [vp, vp, vp]
+    lib.psk_db_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
+    lib.psk_db_destroy.argtypes = [vp]
+    lib.psk_db_destroy.restype = None
+    lib.psk_db_add.argtypes = [vp, C.c_char_p, vp]
+    lib.psk_db_size.argtypes = [vp]
+    lib.psk_db_size.restype = u32
+    lib.psk_db_name.argtypes = [vp, u32]
+    lib.psk_db_name.restype = C.c_char_p
+    lib.psk_db_sketch.argtypes = [vp, u32]
+    lib.psk_db_sketch.restype = vp
+    lib.psk_screen.argtypes = [vp, vp, C.c_double, C.c_int, vp, vp]
+    lib.psk_chain.argtypes = [vp, C.POINTER(vp), u32, vp, C.POINTER(QueryOpts), C.POINTER(Hit)]
+    lib.psk_query.argtypes = [vp, vp, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
+    _lib = lib
+    return lib
+
+
+_EXC = {PSK_EINVAL: ValueError, PSK_ENOMEM: MemoryError, PSK_EHIP: RuntimeError,
+        PSK_ENOMODEL: RuntimeError, PSK_EKEY: KeyError, PSK_ELIMIT: OverflowError}
+
+
+def check(status):
+    """Map a psk_status to the Python exception type the reference raises for that failure."""
+    if status != PSK_OK:
+        msg = load().psk_last_error().decode("utf-8", "replace")
+        raise _EXC.get(status, RuntimeError)(msg)

@@ -1,0 +1,215 @@
+// C-ABI surface of libpyskani_amd.so: context, sketch handles, database, query driver.
+// See include/pyskani_amd.h for the reference call sites each entry point replaces.
+#include "common.h"
+#include <cstdarg>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void psk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* psk_last_error(void) { return g_err; }
+const char* psk_version(void) { return "pyskani_amd 0.1.0 (gfx950; algorithm: skani 0.3.0 restatement)"; }
+void psk_free(void* p) { free(p); }
+
+psk_status psk_ctx_create(int device, psk_ctx** out) {
+    if (!out) { psk_set_error("ctx_create: NULL out"); return PSK_EINVAL; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        psk_set_error("no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return PSK_EHIP;
+    }
+    if (device < 0 || device >= n) { psk_set_error("device %d out of range (0..%d)", device, n - 1); return PSK_EINVAL; }
+    PSK_HIP(hipSetDevice(device));
+    psk_ctx* c = new psk_ctx();
+    c->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; psk_set_error("hipStreamCreate failed: %s", hipGetErrorString(se)); return PSK_EHIP; }
+    *out = c;
+    return PSK_OK;
+}
+
+void psk_ctx_destroy(psk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    Scratch* all[] = {&c->s_desc, &c->s_packed, &c->s_mask, &c->s_counts, &c->s_offs, &c->s_tmp, &c->s_mark, &c->s_flags, &c->s_misc,
+                      &c->q_a, &c->q_b, &c->q_c, &c->q_d, &c->q_e, &c->q_f, &c->q_g, &c->q_h, &c->q_i};
+    for (Scratch* s : all) s->release();
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+psk_status psk_ctx_synchronize(psk_ctx* c) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    PSK_HIP(hipSetDevice(c->device));
+    PSK_HIP(hipStreamSynchronize(c->stream));
+    return PSK_OK;
+}
+
+psk_status psk_device_alloc(psk_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) { psk_set_error("device_alloc: NULL argument"); return PSK_EINVAL; }
+    PSK_HIP(hipSetDevice(c->device));
+    PSK_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return PSK_OK;
+}
+psk_status psk_device_free(psk_ctx* c, void* dptr) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    PSK_HIP(hipSetDevice(c->device));
+    PSK_HIP(hipFree(dptr));
+    return PSK_OK;
+}
+psk_status psk_memcpy_h2d(psk_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) { psk_set_error("memcpy_h2d: NULL argument"); return PSK_EINVAL; }
+    PSK_HIP(hipSetDevice(c->device));
+    PSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PSK_HIP(hipStreamSynchronize(c->stream));
+    return PSK_OK;
+}
+
+psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases, const uint64_t* contig_off,
+                                   const uint64_t* contig_len, const uint32_t* genome_first_contig, uint32_t n_genomes,
+                                   int want_seeds, psk_sketch** out) {
+    if (!ctx) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    return sketch_batch_impl(ctx, p, d_bases, contig_off, contig_len, genome_first_contig, n_genomes, want_seeds, out);
+}
+
+psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
+                           uint32_t n_contigs, int want_seeds, psk_sketch** out) {
+    if (!ctx || !p || !out || (n_contigs && (!contigs || !lens))) { psk_set_error("sketch_host: NULL argument"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    // stage the contigs in HBM at 16-byte aligned offsets (short contigs are dropped later, lib.rs:156)
+    std::vector<uint64_t> off(n_contigs), len(n_contigs);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_contigs; i++) {
+        off[i] = total; len[i] = lens[i];
+        if (lens[i] >= MIN_LENGTH_CONTIG) total += (lens[i] + 15) & ~15ull;
+    }
+    PSK_TRY(ctx->s_misc.reserve(total + 64));
+    uint8_t* d = (uint8_t*)ctx->s_misc.p;
+    for (uint32_t i = 0; i < n_contigs; i++)
+        if (lens[i] >= MIN_LENGTH_CONTIG) PSK_HIP(hipMemcpyAsync(d + off[i], contigs[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+    uint32_t gfc[2] = {0, n_contigs};
+    return sketch_batch_impl(ctx, p, d, off.data(), len.data(), gfc, 1, want_seeds, out);
+}
+
+void psk_sketch_free(psk_sketch* s) { delete s; }
+
+psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds, uint64_t* n_markers, uint64_t* total_len, uint32_t* n_contigs) {
+    if (!s) { psk_set_error("NULL sketch"); return PSK_EINVAL; }
+    if (p) *p = s->params;
+    if (n_seeds) *n_seeds = s->n_seeds;
+    if (n_markers) *n_markers = s->n_markers;
+    if (total_len) *total_len = s->total_len;
+    if (n_contigs) *n_contigs = (uint32_t)s->contig_len.size();
+    return PSK_OK;
+}
+
+psk_status psk_sketch_export(const psk_sketch* s, psk_seed* seeds, uint64_t* markers) {
+    if (!s) { psk_set_error("NULL sketch"); return PSK_EINVAL; }
+    psk_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    if (seeds && s->n_seeds) {
+        size_t n = s->n_seeds;
+        std::vector<uint32_t> kmer(n), pos(n), meta(n);
+        PSK_HIP(hipMemcpyAsync(kmer.data(), s->store->seed_kmer + s->seed_off, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(hipMemcpyAsync(pos.data(), s->store->seed_pos + s->seed_off, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(hipMemcpyAsync(meta.data(), s->store->seed_meta + s->seed_off, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; i++) { seeds[i].kmer = kmer[i]; seeds[i].pos = pos[i]; seeds[i].contig = meta[i] >> 1; seeds[i].canon = meta[i] & 1; }
+    }
+    if (markers && s->n_markers) {
+        PSK_HIP(hipMemcpyAsync(markers, s->store->markers + s->marker_off, 8 * (size_t)s->n_markers, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PSK_OK;
+}
+
+psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out) {
+    if (!ctx || !p || !out) { psk_set_error("db_create: NULL argument"); return PSK_EINVAL; }
+    if (p->k < 1 || p->k > 16 || p->c < 1 || p->marker_c < 1) { psk_set_error("invalid sketch parameters (c=%d marker_c=%d k=%d)", p->c, p->marker_c, p->k); return PSK_EINVAL; }
+    psk_db* db = new psk_db();
+    db->ctx = ctx; db->params = *p;
+    *out = db;
+    return PSK_OK;
+}
+
+void psk_db_destroy(psk_db* db) {
+    if (!db) return;
+    (void)hipSetDevice(db->ctx->device);
+    for (psk_sketch* s : db->refs) delete s;
+    db->d_marker_ptr.release(); db->d_marker_n.release();
+    delete db;
+}
+
+psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
+    if (!db || !name || !s) { delete s; psk_set_error("db_add: NULL argument"); return PSK_EINVAL; }
+    if (s->ctx != db->ctx) { delete s; psk_set_error("db_add: sketch belongs to another context"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(db->ctx->mu);
+    db->refs.push_back(s);
+    db->names.emplace_back(name);
+    db->tables_dirty = true;
+    return PSK_OK;
+}
+
+uint32_t psk_db_size(const psk_db* db) { return db ? (uint32_t)db->refs.size() : 0; }
+const char* psk_db_name(const psk_db* db, uint32_t i) { return db && i < db->names.size() ? db->names[i].c_str() : nullptr; }
+const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t i) { return db && i < db->refs.size() ? db->refs[i] : nullptr; }
+
+psk_status psk_screen(psk_db* db, const psk_sketch* q, double screen_val, int rescue_small, uint8_t* pass, uint32_t* shared) {
+    if (!db || !q || (!pass && !db->refs.empty())) { psk_set_error("screen: NULL argument"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(db->ctx->mu);
+    PSK_HIP(hipSetDevice(db->ctx->device));
+    return screen_impl(db, q, screen_val, rescue_small, pass, shared);
+}
+
+psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs, const psk_sketch* q, const psk_query_opts* o, psk_hit* out) {
+    if (!ctx) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    return chain_impl(ctx, refs, n_refs, q, o, out);
+}
+
+psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, psk_hit** hits, uint64_t* n_hits) {
+    if (!db || !q || !o || !hits || !n_hits) { psk_set_error("query: NULL argument"); return PSK_EINVAL; }
+    *hits = nullptr; *n_hits = 0;
+    psk_ctx* ctx = db->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
+    const uint32_t n = (uint32_t)db->refs.size();
+    if (n == 0) return PSK_OK;
+    const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
+    std::vector<uint8_t> pass(n);
+    PSK_TRY(screen_impl(db, q, screen_val, !o->faster_small, pass.data(), nullptr));
+    std::vector<const psk_sketch*> shortlist;
+    std::vector<uint32_t> idx;
+    for (uint32_t i = 0; i < n; i++) if (pass[i]) { shortlist.push_back(db->refs[i]); idx.push_back(i); }
+    if (shortlist.empty()) return PSK_OK;
+    std::vector<psk_hit> res(shortlist.size());
+    PSK_TRY(chain_impl(ctx, shortlist.data(), (uint32_t)shortlist.size(), q, o, res.data()));
+    size_t m = 0;
+    for (size_t i = 0; i < res.size(); i++) if (res[i].ani > 0.1f) m++;   // lib.rs:654
+    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (m ? m : 1));
+    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+    m = 0;
+    for (size_t i = 0; i < res.size(); i++) if (res[i].ani > 0.1f) { outp[m] = res[i]; outp[m].ref_index = idx[i]; m++; }
+    *hits = outp; *n_hits = m;
+    return PSK_OK;
+}
+
+}  // extern "C"

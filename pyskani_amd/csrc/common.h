@@ -1,0 +1,146 @@
+// Internal types shared by the translation units of libpyskani_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/pyskani_amd.h"
+
+// ---- algorithm constants (normative definition: oracle/skani_oracle.c) ----
+constexpr int K_MARKER = 21;
+constexpr uint32_t MIN_LENGTH_CONTIG = 500;  // lib.rs:156
+constexpr uint32_t FRAGMENT_LENGTH = 20000;
+constexpr int MAX_GAP_LENGTH = 50;
+constexpr int ANCHOR_SCORE = 20;
+constexpr uint32_t MIN_ANCHORS = 3;
+constexpr int CHAIN_BAND = 100;
+constexpr int BP_CHAIN_BAND = 2500;
+constexpr int MIN_SCORE = 45;
+constexpr uint32_t SMALL_MARKER_COUNT = 20;
+
+// ---- sketch tiling ----
+constexpr int TILE_BASES = 16384;               // bases per workgroup
+constexpr int TILE_THREADS = 256;
+constexpr int TILE_WORDS = TILE_BASES / 16;     // 2-bit packed u32 words per tile
+constexpr int TILE_MASKS = TILE_BASES / 64;     // u64 seed-mask words per tile (one per thread)
+
+void psk_set_error(const char* fmt, ...);
+
+#define PSK_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            psk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                          __LINE__);                                                          \
+            return _e == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP;                         \
+        }                                                                                     \
+    } while (0)
+
+#define PSK_TRY(expr)                  \
+    do {                               \
+        psk_status _s = (expr);        \
+        if (_s != PSK_OK) return _s;   \
+    } while (0)
+
+// grow-only device scratch buffer
+struct Scratch {
+    void* p = nullptr;
+    size_t cap = 0;
+    psk_status reserve(size_t bytes) {
+        if (bytes <= cap) return PSK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        PSK_HIP(hipMalloc(&p, want));
+        cap = want;
+        return PSK_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct psk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                 // one stream per ctx: calls are serialised
+    Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
+    Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
+    void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
+    size_t h_pinned_cap = 0;
+    psk_status pinned(size_t bytes, void** out) {
+        if (bytes > h_pinned_cap) {
+            if (h_pinned) (void)hipHostFree(h_pinned);
+            h_pinned = nullptr; h_pinned_cap = 0;
+            size_t want = bytes * 2 + 4096;
+            PSK_HIP(hipHostMalloc(&h_pinned, want, hipHostMallocDefault));
+            h_pinned_cap = want;
+        }
+        *out = h_pinned;
+        return PSK_OK;
+    }
+};
+
+// Storage shared by the sketches of one batch: one device allocation, sliced.
+struct SketchStore {
+    void* base = nullptr;
+    size_t bytes = 0;
+    // slices (device pointers into base)
+    uint32_t* seed_kmer = nullptr;   // (contig,pos) order
+    uint32_t* seed_pos = nullptr;
+    uint32_t* seed_meta = nullptr;   // contig<<1 | canon
+    uint32_t* idx_kmer = nullptr;    // per genome sorted by k-mer (stable)
+    uint64_t* idx_pm = nullptr;      // pos<<32 | meta, permuted like idx_kmer
+    uint64_t* markers = nullptr;     // per genome sorted unique
+    uint32_t* contig_seed_start = nullptr;  // per kept contig (+1 sentinel per batch), global seed offsets
+    void* mbase = nullptr;           // second allocation: the marker sets
+    ~SketchStore() { if (base) (void)hipFree(base); if (mbase) (void)hipFree(mbase); }
+};
+
+struct psk_sketch {
+    psk_ctx* ctx = nullptr;
+    psk_params params{};
+    std::shared_ptr<SketchStore> store;
+    uint64_t seed_off = 0, n_seeds = 0;      // slice of store->seed_* / idx_*
+    uint64_t marker_off = 0, n_markers = 0;  // slice of store->markers
+    uint64_t contig_off = 0;                 // slice of store->contig_seed_start
+    std::vector<uint32_t> contig_len;        // kept contigs
+    std::vector<uint32_t> contig_seed_start; // host copy, LOCAL offsets, n_contigs+1
+    uint64_t total_len = 0;
+    bool has_seeds = true;
+};
+
+struct psk_db {
+    psk_ctx* ctx = nullptr;
+    psk_params params{};
+    std::vector<psk_sketch*> refs;
+    std::vector<std::string> names;
+    // device tables for the screen kernel, rebuilt lazily
+    bool tables_dirty = true;
+    Scratch d_marker_ptr, d_marker_n;
+};
+
+// ---- shared device helpers ----
+__device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
+    key = ~(key + (key << 21));
+    key = key ^ key >> 24;
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14;
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ key >> 28;
+    key = key + (key << 31);
+    return key;
+}
+
+// host-side entry points implemented across the translation units
+psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
+                             const uint64_t* contig_off, const uint64_t* contig_len,
+                             const uint32_t* genome_first_contig, uint32_t n_genomes,
+                             int want_seeds, psk_sketch** out);
+psk_status screen_impl(psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
+                       uint8_t* pass, uint32_t* shared);
+psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,
+                      const psk_sketch* query, const psk_query_opts* o, psk_hit* out);

@@ -1,0 +1,423 @@
+// FracMinHash sketching on gfx950 — replaces skani::seeding::fmh_seeds as driven by
+// Database::_sketch (/root/reference/src/pyskani/_skani/lib.rs:140-185).
+//
+// Two kernels per batch of genomes:
+//   sketch_scan  : ASCII -> 2-bit packed words (kept for the emit pass) + one seed bit per base
+//                  (rolling canonical k-mer, mm_hash64, threshold) + per-tile seed counts
+//   sketch_emit  : for every set bit rebuild the k-mer from the packed stream and write the seed
+//                  record at its scanned offset; seeds whose hash also passes the marker threshold
+//                  contribute their canonical 21-mer to the genome's marker list
+// followed by rocPRIM plumbing (scan, segmented radix sorts) for the marker set and the
+// k-mer-sorted reference index. Semantics are normative in oracle/skani_oracle.c.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+
+struct ContigDesc {
+    uint64_t byte_off;     // offset of the contig in the ASCII buffer (16-byte aligned)
+    uint32_t len;
+    uint32_t first_tile;   // tiles of one contig are consecutive
+    uint32_t genome;       // genome index inside the batch
+    uint32_t contig_index; // index among the genome's kept contigs
+    uint32_t pad0, pad1;
+};
+
+struct SketchConsts {
+    uint64_t thr, thr_marker;
+    uint32_t kmask;     // (1 << 2k) - 1
+    int k, d, rshift;   // d = distance from window end to the seed's last base; rshift = 2k-2
+};
+
+// ---- ASCII -> 2-bit, four bytes at a time; every byte that is not ACGT/acgt maps to 0 ----
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {  // 0x80 in each byte of v that is 0
+    uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | v | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ uint32_t codes4(uint32_t w) {
+    uint32_t x = w & 0xDFDFDFDFu;                 // fold case
+    uint32_t code = (x >> 1) & 0x03030303u;       // A0 C1 G3 T2
+    code ^= (code >> 1) & 0x01010101u;            // A0 C1 G2 T3
+    uint32_t ok = zero_bytes(x ^ 0x43434343u) | zero_bytes(x ^ 0x47474747u) | zero_bytes(x ^ 0x54545454u);
+    ok >>= 7;
+    ok |= ok << 1;
+    code &= ok;
+    return (code * 0x40100401u) >> 24;            // c0<<6 | c1<<4 | c2<<2 | c3  (first base highest)
+}
+__device__ __forceinline__ uint32_t pack16(uint4 v) {
+    return (codes4(v.x) << 24) | (codes4(v.y) << 16) | (codes4(v.z) << 8) | codes4(v.w);
+}
+
+__device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ contigs, int n_contigs, uint32_t tile) {
+    int lo = 0, hi = n_contigs - 1;  // last contig with first_tile <= tile
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (contigs[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
+    const uint8_t* __restrict__ ascii, const ContigDesc* __restrict__ contigs, int n_contigs,
+    uint32_t* __restrict__ packed, uint64_t* __restrict__ seedmask, uint32_t* __restrict__ tile_count,
+    SketchConsts C) {
+    __shared__ __align__(16) uint32_t s_w[4 + TILE_WORDS];
+    __shared__ uint32_t s_cnt[TILE_THREADS / 64];
+    const uint32_t tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ci = find_contig(contigs, n_contigs, tile);
+    const ContigDesc cd = contigs[ci];
+    const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
+    const uint32_t n = min((uint32_t)TILE_BASES, cd.len - pos0);
+    const uint8_t* src = ascii + cd.byte_off + pos0;
+
+    // phase 1: pack 16 bases per lane per round, coalesced 16-byte loads
+#pragma unroll
+    for (int r = 0; r < TILE_WORDS / TILE_THREADS; r++) {
+        int w = tid + r * TILE_THREADS;
+        uint32_t word = 0;
+        if ((uint32_t)w * 16 < n) {
+            uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)w * 16);
+            word = pack16(v);
+            uint32_t rem = n - (uint32_t)w * 16;          // bases of this word inside the contig
+            if (rem < 16) word &= ~(0xFFFFFFFFu >> (2 * rem));
+        }
+        s_w[2 + w] = word;
+        packed[(size_t)tile * TILE_WORDS + w] = word;
+    }
+    if (tid < 2) {
+        uint32_t word = 0;
+        if (pos0 > 0) word = pack16(*reinterpret_cast<const uint4*>(src - 32 + tid * 16));
+        s_w[tid] = word;
+    }
+    __syncthreads();
+
+    // phase 2: 64 window positions per lane. The lane's 96-base neighbourhood is delayed by d bases
+    // so that the seed's last base for window position i sits at a compile-time bit offset.
+    const uint4 wa = *reinterpret_cast<const uint4*>(&s_w[4 * tid]);       // 16-byte stride: conflict-free b128
+    const uint2 wb = *reinterpret_cast<const uint2*>(&s_w[4 * tid + 4]);
+    uint32_t W0 = wa.x, W1 = wa.y, W2 = wa.z, W3 = wa.w, W4 = wb.x, W5 = wb.y;
+    const uint32_t sh = 2 * C.d;
+    uint32_t V[5];
+    V[0] = __funnelshift_r(W1, W0, sh);
+    V[1] = __funnelshift_r(W2, W1, sh);
+    V[2] = __funnelshift_r(W3, W2, sh);
+    V[3] = __funnelshift_r(W4, W3, sh);
+    V[4] = __funnelshift_r(W5, W4, sh);
+    uint32_t fs = 0, rs = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {   // warm-up: the (at most 15) bases preceding the first seed
+        uint32_t b = (V[0] >> (30 - 2 * j)) & 3u;
+        fs = ((fs << 2) | b) & C.kmask;
+        rs = (rs >> 2) | ((b ^ 3u) << C.rshift);
+    }
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t b = (V[1 + i / 16] >> (30 - 2 * (i % 16))) & 3u;
+        fs = ((fs << 2) | b) & C.kmask;
+        rs = (rs >> 2) | ((b ^ 3u) << C.rshift);
+        uint64_t h = mm_hash64((uint64_t)min(fs, rs));
+        uint32_t bit = (h < C.thr) ? (1u << (i & 31)) : 0u;
+        if (i < 32) mlo |= bit; else mhi |= bit;
+    }
+    // windows must lie inside the contig: K_MARKER-1 <= pos < len
+    const uint32_t p0 = pos0 + 64u * tid;
+    int lo_i = p0 >= (uint32_t)(K_MARKER - 1) ? 0 : (int)(K_MARKER - 1 - p0);
+    int hi_i = cd.len > p0 ? (int)min(64u, cd.len - p0) : 0;
+    uint64_t vm = 0;
+    if (hi_i > lo_i) {
+        uint64_t upto_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1);
+        vm = upto_hi & ~((1ull << lo_i) - 1);
+    }
+    uint64_t m = (((uint64_t)mhi << 32) | mlo) & vm;
+    seedmask[(size_t)tile * TILE_MASKS + tid] = m;
+    int cnt = __popcll(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) tile_count[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// n (<= 32) bases starting at contig-relative base `start` of a packed stream, first base highest
+__device__ __forceinline__ uint64_t get_bases(const uint32_t* __restrict__ words, uint32_t start, int n) {
+    uint32_t first = start >> 4, off = start & 15;
+    uint64_t top = ((uint64_t)words[first] << 32) | words[first + 1];
+    uint64_t x = off ? ((top << (2 * off)) | ((uint64_t)words[first + 2] >> (32 - 2 * off))) : top;
+    return x >> (64 - 2 * n);
+}
+__device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
+    uint64_t y = __brevll(x);
+    y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+    y >>= (64 - 2 * n);
+    return y ^ (n == 32 ? ~0ull : ((1ull << (2 * n)) - 1));
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
+    const ContigDesc* __restrict__ contigs, int n_contigs, const uint32_t* __restrict__ packed,
+    const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ genome_first_tile,
+    uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
+    uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ marker_count,
+    SketchConsts C) {
+    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    const uint32_t tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint64_t m = seedmask[(size_t)tile * TILE_MASKS + tid];
+    int cnt = __popcll(m);
+    // block exclusive scan of cnt
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < (tid >> 6); w++) wave_base += s_wave[w];
+    if (m == 0) return;
+    const int ci = find_contig(contigs, n_contigs, tile);
+    const ContigDesc cd = contigs[ci];
+    const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
+    const uint32_t* words = packed + (size_t)cd.first_tile * TILE_WORDS;   // the contig's packed stream
+    uint32_t out = tile_off[tile] + wave_base + incl - cnt;
+    const uint32_t g_seed0 = tile_off[genome_first_tile[cd.genome]];
+    while (m) {
+        int i = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        uint32_t p = pos0 + 64u * tid + i;                 // last base of the 21-base window
+        uint32_t e = p - C.d;                              // last base of the seed k-mer
+        uint64_t f = get_bases(words, e + 1 - C.k, C.k);
+        uint64_t r = revcomp(f, C.k);
+        uint32_t canon = f < r;
+        uint64_t cs = canon ? f : r;
+        seed_kmer[out] = (uint32_t)cs;
+        seed_pos[out] = p;
+        uint32_t meta = (cd.contig_index << 1) | canon;
+        seed_meta[out] = meta;
+        seed_pm[out] = ((uint64_t)p << 32) | meta;
+        out++;
+        if (mm_hash64(cs) < C.thr_marker) {
+            uint64_t f21 = get_bases(words, p + 1 - K_MARKER, K_MARKER);
+            uint64_t r21 = revcomp(f21, K_MARKER);
+            uint32_t slot = atomicAdd(&marker_count[cd.genome], 1u);
+            marker_stage[(size_t)g_seed0 + slot] = f21 < r21 ? f21 : r21;
+        }
+    }
+}
+
+// out[i] = tile_off[idx[i]]
+__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+__global__ void marker_segments_kernel(const uint32_t* __restrict__ g_off, const uint32_t* __restrict__ marker_count,
+                                       uint32_t* __restrict__ beg, uint32_t* __restrict__ end, int n) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) { beg[g] = g_off[g]; end[g] = g_off[g] + marker_count[g]; }
+}
+// one block per genome: flag the first occurrence of every distinct marker of the sorted segment
+__global__ void marker_flag_kernel(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ beg,
+                                   const uint32_t* __restrict__ end, uint32_t* __restrict__ flags) {
+    uint32_t b = beg[blockIdx.x], e = end[blockIdx.x];
+    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) flags[i] = (i == b || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+}
+__global__ void marker_scatter_kernel(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ beg,
+                                      const uint32_t* __restrict__ end, const uint32_t* __restrict__ flags,
+                                      const uint32_t* __restrict__ pos, uint64_t* __restrict__ out) {
+    uint32_t b = beg[blockIdx.x], e = end[blockIdx.x];
+    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) if (flags[i]) out[pos[i]] = sorted[i];
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
+                             const uint64_t* contig_off, const uint64_t* contig_len,
+                             const uint32_t* genome_first_contig, uint32_t n_genomes,
+                             int want_seeds, psk_sketch** out) {
+    if (!ctx || !p || !out || (!genome_first_contig && n_genomes)) { psk_set_error("sketch: NULL argument"); return PSK_EINVAL; }
+    if (p->k < 1 || p->k > 16) { psk_set_error("Value of k > 16 for DNA; not allowed (k=%d)", p->k); return PSK_EINVAL; }
+    if (p->c < 1 || p->marker_c < 1) { psk_set_error("compression factors must be >= 1"); return PSK_EINVAL; }
+    hipStream_t st = ctx->stream;
+    for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
+
+    // ---- host: contig filter (lib.rs:156) and tile layout ----
+    std::vector<ContigDesc> descs;
+    std::vector<uint32_t> g_first_desc(n_genomes + 1), g_first_tile(n_genomes + 1);
+    std::vector<psk_sketch*> sk(n_genomes, nullptr);
+    uint64_t n_tiles64 = 0, total_bases = 0;
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        g_first_desc[g] = (uint32_t)descs.size();
+        g_first_tile[g] = (uint32_t)n_tiles64;
+        psk_sketch* s = new psk_sketch();
+        s->ctx = ctx; s->params = *p; s->has_seeds = want_seeds != 0;
+        sk[g] = s;
+        for (uint32_t ci = genome_first_contig[g]; ci < genome_first_contig[g + 1]; ci++) {
+            uint64_t len = contig_len[ci];
+            if (len < MIN_LENGTH_CONTIG) continue;
+            if (len > 0xFFFFFFFFull || (contig_off[ci] & 15)) {
+                for (auto* x : sk) delete x;
+                psk_set_error(len > 0xFFFFFFFFull ? "contig longer than 2^32-1 bases" : "contig offset not 16-byte aligned");
+                return len > 0xFFFFFFFFull ? PSK_ELIMIT : PSK_EINVAL;
+            }
+            ContigDesc d{};
+            d.byte_off = contig_off[ci]; d.len = (uint32_t)len; d.first_tile = (uint32_t)n_tiles64;
+            d.genome = g; d.contig_index = (uint32_t)s->contig_len.size();
+            descs.push_back(d);
+            s->contig_len.push_back((uint32_t)len);
+            s->total_len += len;
+            n_tiles64 += (len + TILE_BASES - 1) / TILE_BASES;
+            total_bases += len;
+        }
+    }
+    g_first_desc[n_genomes] = (uint32_t)descs.size();
+    g_first_tile[n_genomes] = (uint32_t)n_tiles64;
+    if (n_tiles64 * (uint64_t)TILE_BASES >= (1ull << 32)) {
+        for (auto* x : sk) delete x;
+        psk_set_error("batch of %llu bases exceeds the 2^32-base batch limit; split it", (unsigned long long)total_bases);
+        return PSK_ELIMIT;
+    }
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
+    const int n_desc = (int)descs.size();
+    auto fail = [&](psk_status s) { for (auto* x : sk) delete x; return s; };
+    if (n_tiles == 0) {   // nothing to seed: empty sketches
+        for (uint32_t g = 0; g < n_genomes; g++) { sk[g]->contig_seed_start.assign(sk[g]->contig_len.size() + 1, 0); out[g] = sk[g]; }
+        return PSK_OK;
+    }
+
+    SketchConsts C{};
+    C.k = p->k; C.thr = UINT64_MAX / (uint64_t)p->c; C.thr_marker = UINT64_MAX / (uint64_t)p->marker_c;
+    C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
+    C.rshift = 2 * p->k - 2;
+    C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
+
+    // ---- device scratch ----
+    // offs: [tile_count n_tiles+1][tile_off n_tiles+1][gft n_genomes+1][cft n_desc+1][g_off n_genomes+1][c_off n_desc+1]
+    //       [marker_count n_genomes][seg_beg n_genomes][seg_end n_genomes][m_off n_genomes+1]
+    size_t o_cnt = 0, o_toff = o_cnt + n_tiles + 1, o_gft = o_toff + n_tiles + 1, o_cft = o_gft + n_genomes + 1,
+           o_goff = o_cft + n_desc + 1, o_coff = o_goff + n_genomes + 1, o_mcnt = o_coff + n_desc + 1,
+           o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes, o_moff = o_send + n_genomes, o_end = o_moff + n_genomes + 1;
+    psk_status rc;
+    if ((rc = ctx->s_desc.reserve(sizeof(ContigDesc) * n_desc)) != PSK_OK) return fail(rc);
+    if ((rc = ctx->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8))) != PSK_OK) return fail(rc);
+    if ((rc = ctx->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS)) != PSK_OK) return fail(rc);
+    if ((rc = ctx->s_offs.reserve(sizeof(uint32_t) * o_end)) != PSK_OK) return fail(rc);
+    uint32_t* d_offs = (uint32_t*)ctx->s_offs.p;
+    uint32_t *d_cnt = d_offs + o_cnt, *d_toff = d_offs + o_toff, *d_gft = d_offs + o_gft, *d_cft = d_offs + o_cft,
+             *d_goff = d_offs + o_goff, *d_coff = d_offs + o_coff, *d_mcnt = d_offs + o_mcnt, *d_sbeg = d_offs + o_sbeg,
+             *d_send = d_offs + o_send, *d_moff = d_offs + o_moff;
+    ContigDesc* d_desc = (ContigDesc*)ctx->s_desc.p;
+    uint32_t* d_packed = (uint32_t*)ctx->s_packed.p;
+    uint64_t* d_mask = (uint64_t*)ctx->s_mask.p;
+
+    // small host tables through pinned staging
+    size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
+    void* hp;
+    if ((rc = ctx->pinned(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4), &hp)) != PSK_OK) return fail(rc);
+    ContigDesc* h_desc = (ContigDesc*)hp;
+    uint32_t* h_gft = (uint32_t*)(h_desc + n_desc);
+    uint32_t* h_cft = h_gft + n_genomes + 1;
+    uint32_t* h_back = h_cft + n_desc + 1;   // D2H area
+    memcpy(h_desc, descs.data(), sizeof(ContigDesc) * n_desc);
+    memcpy(h_gft, g_first_tile.data(), sizeof(uint32_t) * (n_genomes + 1));
+    for (int i = 0; i < n_desc; i++) h_cft[i] = descs[i].first_tile;
+    h_cft[n_desc] = n_tiles;
+#define HIPF(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { psk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return fail(_e == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP); } } while (0)
+    HIPF(hipMemcpyAsync(d_desc, h_desc, sizeof(ContigDesc) * n_desc, hipMemcpyHostToDevice, st));
+    HIPF(hipMemcpyAsync(d_gft, h_gft, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyHostToDevice, st));
+    HIPF(hipMemcpyAsync(d_cft, h_cft, sizeof(uint32_t) * (n_desc + 1), hipMemcpyHostToDevice, st));
+    HIPF(hipMemsetAsync(d_cnt + n_tiles, 0, sizeof(uint32_t), st));
+    HIPF(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
+
+    // ---- pass 1 ----
+    hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, n_desc, d_packed, d_mask, d_cnt, C);
+    size_t tmp_bytes = 0;
+    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
+    if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
+    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
+    {
+        int n1 = n_genomes + 1, n2 = n_desc + 1;
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_toff, d_gft, d_goff, n1);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, d_toff, d_cft, d_coff, n2);
+    }
+    uint32_t* h_goff = h_back;
+    uint32_t* h_coff = h_back + n_genomes + 1;
+    HIPF(hipMemcpyAsync(h_goff, d_goff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
+    HIPF(hipMemcpyAsync(h_coff, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToHost, st));
+    HIPF(hipStreamSynchronize(st));
+    const uint32_t total_seeds = h_goff[n_genomes];
+    if (total_seeds >= 0x7FFFFFF0u) { psk_set_error("batch yields >= 2^31 seeds; split it"); return fail(PSK_ELIMIT); }
+
+    // ---- allocate the batch store: seeds (position order) + index (k-mer order) + contig starts ----
+    auto store = std::make_shared<SketchStore>();
+    size_t ns = total_seeds;
+    size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
+           b_ikmer = align_up(b_meta + 4 * ns, 256), b_ipm = align_up(b_ikmer + 4 * ns, 256),
+           b_cstart = align_up(b_ipm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
+    HIPF(hipMalloc(&store->base, b_end));
+    store->bytes = b_end;
+    char* sb = (char*)store->base;
+    store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
+    store->idx_kmer = (uint32_t*)(sb + b_ikmer); store->idx_pm = (uint64_t*)(sb + b_ipm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
+    HIPF(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
+
+    if ((rc = ctx->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2))) != PSK_OK) return fail(rc);   // stage + sorted
+    if ((rc = ctx->s_flags.reserve(sizeof(uint32_t) * (2 * ns + 2) + sizeof(uint64_t) * (ns + 1))) != PSK_OK) return fail(rc);
+    uint64_t* d_mstage = (uint64_t*)ctx->s_mark.p;
+    uint64_t* d_msorted = d_mstage + ns + 1;
+    uint64_t* d_pm = (uint64_t*)ctx->s_flags.p;                  // seed {pos,meta} in position order
+    uint32_t* d_flags = (uint32_t*)(d_pm + ns + 1);
+    uint32_t* d_fpos = d_flags + ns + 1;
+
+    // ---- pass 2 ----
+    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_desc, n_desc, d_packed, d_mask, d_toff, d_gft,
+                       store->seed_kmer, store->seed_pos, store->seed_meta, d_pm, d_mstage, d_mcnt, C);
+
+    // ---- marker sets: per-genome sort + unique ----
+    hipLaunchKernelGGL(marker_segments_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_goff, d_mcnt, d_sbeg, d_send, (int)n_genomes);
+    if (ns > 0) {
+        tmp_bytes = 0;
+        HIPF(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+        if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
+        HIPF(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->s_tmp.p, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+    }
+    HIPF(hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * (ns + 1), st));
+    hipLaunchKernelGGL(marker_flag_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_sbeg, d_send, d_flags);
+    tmp_bytes = 0;
+    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flags, d_fpos, (int)(ns + 1), st));
+    if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
+    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_flags, d_fpos, (int)(ns + 1), st));
+    // marker offsets per genome = fpos[g_off[g]] ; total = fpos[ns]
+    hipLaunchKernelGGL(gather_u32_kernel, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, st, d_fpos, d_goff, d_moff, (int)(n_genomes + 1));
+    uint32_t* h_moff = h_coff + n_desc + 1;
+    HIPF(hipMemcpyAsync(h_moff, d_moff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
+
+    // ---- reference index: stable per-genome radix sort of the seeds by k-mer ----
+    if (ns > 0 && want_seeds) {
+        tmp_bytes = 0;
+        HIPF(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, store->seed_kmer, store->idx_kmer, d_pm, store->idx_pm, (int)ns, (int)n_genomes, d_goff, d_goff + 1, 0, 2 * p->k, st));
+        if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
+        HIPF(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->s_tmp.p, tmp_bytes, store->seed_kmer, store->idx_kmer, d_pm, store->idx_pm, (int)ns, (int)n_genomes, d_goff, d_goff + 1, 0, 2 * p->k, st));
+    }
+    HIPF(hipStreamSynchronize(st));
+    const uint32_t total_markers = h_moff[n_genomes];
+    HIPF(hipMalloc(&store->mbase, sizeof(uint64_t) * ((size_t)total_markers + 1)));
+    store->markers = (uint64_t*)store->mbase;
+    hipLaunchKernelGGL(marker_scatter_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_sbeg, d_send, d_flags, d_fpos, store->markers);
+    HIPF(hipStreamSynchronize(st));
+#undef HIPF
+
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        psk_sketch* s = sk[g];
+        s->store = store;
+        s->seed_off = h_goff[g]; s->n_seeds = h_goff[g + 1] - h_goff[g];
+        s->marker_off = h_moff[g]; s->n_markers = h_moff[g + 1] - h_moff[g];
+        s->contig_off = g_first_desc[g];
+        uint32_t nc = g_first_desc[g + 1] - g_first_desc[g];
+        s->contig_seed_start.resize(nc + 1);
+        for (uint32_t c = 0; c <= nc; c++) s->contig_seed_start[c] = h_coff[g_first_desc[g] + c] - h_goff[g];
+        out[g] = s;
+    }
+    return PSK_OK;
+}

@@ -1,0 +1,250 @@
+"""Host-side mirror of pyskani's `Database` / `Hit` / `Sketch` classes for the hot path.
+
+Same names, argument meaning and error behaviour as the PyO3 classes in
+/root/reference/src/pyskani/_skani/{lib,hit,sketch}.rs; all arithmetic runs in HIP kernels
+behind the C-ABI of include/pyskani_amd.h. Persistence (`load/open/save/flush` with a path)
+is outside the hot path and raises NotImplementedError.
+"""
+import ctypes as C
+import threading
+import warnings
+
+import numpy as np
+
+from . import _capi
+
+_ctx_lock = threading.Lock()
+_ctxs = {}
+
+
+class Context:
+    """One GPU: owns the psk_ctx handle."""
+
+    def __init__(self, device=0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        _capi.check(self._lib.psk_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.psk_ctx_destroy(self._h)
+            self._h = None
+
+    def synchronize(self):
+        _capi.check(self._lib.psk_ctx_synchronize(self._h))
+
+
+def default_context(device=0):
+    with _ctx_lock:
+        if device not in _ctxs:
+            _ctxs[device] = Context(device)
+        return _ctxs[device]
+
+
+def _as_bytes(obj):
+    """utils::Text::new (utils.rs:74-102): str -> UTF-8 view, bytes/bytearray -> view, buffers -> copy."""
+    if isinstance(obj, str):
+        return obj.encode("utf-8")
+    if isinstance(obj, bytes):
+        return obj
+    if isinstance(obj, bytearray):
+        return bytes(obj)
+    try:
+        return bytes(memoryview(obj))
+    except TypeError:
+        raise TypeError(f"expected str, bytes, bytearray or buffer, found {type(obj).__name__}")
+
+
+class Hit:
+    """A single hit found when querying a `Database` with a genome (hit.rs:18-104)."""
+
+    __slots__ = ("_identity", "_query_name", "_query_fraction", "_reference_name", "_reference_fraction", "_raw")
+
+    def __init__(self, identity, query_name, query_fraction, reference_name, reference_fraction):
+        identity = float(np.float32(identity))
+        query_fraction = float(np.float32(query_fraction))
+        reference_fraction = float(np.float32(reference_fraction))
+        if identity < 0.0 or identity > 1.0:                      # hit.rs:34-37
+            raise ValueError(f"Invalid value for `identity`: {identity}")
+        if query_fraction < 0.0 or query_fraction > 1.0:          # hit.rs:38-41
+            raise ValueError(f"Invalid value for `query_fraction`: {query_fraction}")
+        if reference_fraction < 0.0 or reference_fraction > 1.0:  # hit.rs:42-48
+            raise ValueError(f"Invalid value for `reference_fraction`: {reference_fraction}")
+        self._identity = identity
+        self._query_name = str(query_name)
+        self._query_fraction = query_fraction
+        self._reference_name = str(reference_name)
+        self._reference_fraction = reference_fraction
+        self._raw = None
+
+    def __repr__(self):  # hit.rs:61-74
+        return ("Hit(identity={!r}, query_name={!r}, query_fraction={!r}, reference_name={!r}, "
+                "reference_fraction={!r})").format(self.identity, self.query_name, self.query_fraction,
+                                                    self.reference_name, self.reference_fraction)
+
+    identity = property(lambda self: self._identity)
+    query_name = property(lambda self: self._query_name)
+    query_fraction = property(lambda self: self._query_fraction)
+    reference_name = property(lambda self: self._reference_name)
+    reference_fraction = property(lambda self: self._reference_fraction)
+
+
+class Sketch:
+    """A sketched genome resident in HBM (sketch.rs:4-31)."""
+
+    def __init__(self, ctx, handle, name, owned=True):
+        self._ctx = ctx
+        self._h = handle
+        self._name = name
+        self._owned = owned
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "_h", None):
+            self._ctx._lib.psk_sketch_free(self._h)
+            self._h = None
+
+    def _info(self):
+        p = _capi.Params()
+        ns, nm, tl, nc = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _capi.check(self._ctx._lib.psk_sketch_info(self._h, C.byref(p), C.byref(ns), C.byref(nm), C.byref(tl), C.byref(nc)))
+        return p, ns.value, nm.value, tl.value, nc.value
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def c(self):
+        return self._info()[0].c
+
+    @property
+    def amino_acid(self):
+        return False  # use_aa is hard-wired false, lib.rs:416
+
+    def export(self):
+        """(seeds, markers) copied back to the host — used by the parity tests."""
+        _, ns, nm, _, _ = self._info()
+        seeds = np.zeros(ns, dtype=[("kmer", "<u4"), ("pos", "<u4"), ("contig", "<u4"), ("canon", "<u4")])
+        markers = np.zeros(nm, dtype=np.uint64)
+        _capi.check(self._ctx._lib.psk_sketch_export(self._h, seeds.ctypes.data_as(C.c_void_p), markers.ctypes.data_as(C.c_void_p)))
+        return seeds, markers
+
+
+_warned_no_model = False
+
+
+class Database:
+    """A database storing sketched genomes (lib.rs:132-137, 368-660), in-memory (HBM) storage only."""
+
+    def __init__(self, path=None, *, compression=125, marker_compression=1000, k=15, format=None, device=0):
+        if path is not None:
+            raise NotImplementedError("on-disk databases are outside the accelerated hot path (SURVEY.md §8f-1)")
+        if format not in (None, "consolidated", "separated"):
+            raise ValueError(f"invalid format: {format}")      # lib.rs:407-409
+        self._ctx = default_context(device)
+        self._lib = self._ctx._lib
+        self._params = _capi.Params(int(compression), int(marker_compression), int(k))
+        h = C.c_void_p()
+        _capi.check(self._lib.psk_db_create(self._ctx._h, C.byref(self._params), C.byref(h)))
+        self._h = h
+        self._lock = threading.Lock()   # `sketch` takes &mut self (lib.rs:479)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.psk_db_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self.flush()
+        return False
+
+    @property
+    def path(self):
+        return None                     # DatabaseStorage::Memory, lib.rs:441
+
+    @property
+    def compression(self):
+        return self._params.c           # lib.rs:456-458
+
+    @property
+    def marker_compression(self):
+        return self._params.marker_c    # lib.rs:462-464
+
+    def __len__(self):
+        return self._lib.psk_db_size(self._h)
+
+    def flush(self):
+        return None                     # Memory storage: nothing to do, lib.rs:219
+
+    @classmethod
+    def load(cls, path):
+        raise NotImplementedError("on-disk databases are outside the accelerated hot path (SURVEY.md §8f-1)")
+
+    open = load
+
+    def save(self, path, overwrite=False, format=None):
+        raise NotImplementedError("on-disk databases are outside the accelerated hot path (SURVEY.md §8f-1)")
+
+    # -- the hot path ------------------------------------------------------------------------
+    def _sketch(self, name, contigs, seed):
+        """Database::_sketch (lib.rs:140-185): one genome from N contigs."""
+        views = [_as_bytes(c) for c in contigs]
+        n = len(views)
+        arr = (C.c_char_p * max(n, 1))(*views)
+        lens = (C.c_uint64 * max(n, 1))(*[len(v) for v in views])
+        h = C.c_void_p()
+        _capi.check(self._lib.psk_sketch_host(self._ctx._h, C.byref(self._params), arr, lens, n, int(bool(seed)), C.byref(h)))
+        return Sketch(self._ctx, h, name)
+
+    def sketch(self, name, *contigs, seed=True):
+        """Add a reference genome to the database (lib.rs:477-510)."""
+        if not isinstance(name, str):
+            raise TypeError("name must be a str")
+        if not self._lock.acquire(blocking=False):
+            raise RuntimeError("Already borrowed")   # PyO3's &mut self borrow error
+        try:
+            sk = self._sketch(name, contigs, seed)
+            sk._owned = False                          # ownership moves into the db (lib.rs:501-508)
+            _capi.check(self._lib.psk_db_add(self._h, name.encode("utf-8"), sk._h))
+        finally:
+            self._lock.release()
+        return None
+
+    def query(self, name, *contigs, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
+              faster_small=False):
+        """Query the database with a genome (lib.rs:549-660); returns a list of `Hit`."""
+        global _warned_no_model
+        if not isinstance(name, str):
+            raise TypeError("name must be a str")
+        q = self._sketch(name, contigs, seed)
+        # default rule: learned ANI when c >= 70 and not median (lib.rs:611-613, docstring :522-527)
+        learned = learned_ani if learned_ani is not None else (self._params.c >= 70 and not median)
+        if learned and learned_ani is None:
+            # the GBDT weights live inside the skani crate and are not available to this build: say so
+            if not _warned_no_model:
+                warnings.warn("pyskani_amd: no learned-ANI regression model is available; returning the raw "
+                              "chain ANI (pass learned_ani=False to silence, learned_ani=True raises)", RuntimeWarning, stacklevel=2)
+                _warned_no_model = True
+            learned = False
+        opts = _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
+                               float(cutoff) if cutoff else 0.0, 0.0)
+        hits_p = C.POINTER(_capi.Hit)()
+        n = C.c_uint64(0)
+        _capi.check(self._lib.psk_query(self._h, q._h, C.byref(opts), C.byref(hits_p), C.byref(n)))
+        out = []
+        try:
+            for i in range(n.value):
+                r = hits_p[i]
+                ref_name = self._lib.psk_db_name(self._h, r.ref_index).decode("utf-8")
+                hit = Hit(r.ani, name, r.af_query, ref_name, r.af_ref)
+                hit._raw = {f: getattr(r, f) for f, _ in _capi.Hit._fields_}
+                out.append(hit)
+        finally:
+            if hits_p:
+                self._lib.psk_free(hits_p)
+        return out

@@ -1,0 +1,217 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+Bit-exact for seed sets, marker sets, shared-marker counts and every integer intermediate of
+chaining; ANI / AF within 1e-6 (BASELINE.json's tolerance is 1e-4)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, mutate, random_genome
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+
+
+@pytest.fixture(scope="module")
+def psk():
+    import pyskani_amd
+    return pyskani_amd
+
+
+def gpu_sketch(psk, contigs, **kw):
+    db = psk.Database(**kw)
+    return db, db._sketch("g", contigs, True)
+
+
+def assert_sketch_equal(gs, osk):
+    seeds, markers = gs.export()
+    o = osk.seeds
+    assert len(seeds) == len(o)
+    for f in ("kmer", "pos", "contig", "canon"):
+        assert np.array_equal(seeds[f], o[f]), f
+    assert np.array_equal(markers, osk.markers)
+
+
+def test_sketch_ecoli_bit_exact(psk, oracle, ecoli):
+    for seq in ecoli:
+        db, gs = gpu_sketch(psk, [seq])
+        assert_sketch_equal(gs, oracle.Sketch([seq]))
+
+
+@pytest.mark.parametrize("k,c,mc", [(15, 125, 1000), (15, 30, 200), (16, 125, 1000), (11, 50, 400), (13, 200, 1000), (8, 7, 20)])
+def test_sketch_params_and_ragged_contigs(psk, oracle, k, c, mc):
+    rng = np.random.default_rng(k * 1000 + c)
+    lens = [499, 500, 501, 16383, 16384, 16385, 16384 * 2 + 21, 40000, 20, 0, 777, 65536 + 15]
+    contigs = [random_genome(rng, n) for n in lens]
+    # lower case, N runs and IUPAC codes must all map to 0 like skani's BYTE_TO_SEQ
+    b = bytearray(contigs[7]); b[100:180] = b"N" * 80; b[5000:5040] = b"acgtnRYKM-" * 4; b[16380:16390] = b"NNNNNnnnnn"; contigs[7] = bytes(b)
+    contigs[3] = contigs[3].lower()
+    db, gs = gpu_sketch(psk, contigs, compression=c, marker_compression=mc, k=k)
+    assert_sketch_equal(gs, oracle.Sketch(contigs, c=c, marker_c=mc, k=k))
+
+
+def test_sketch_empty_and_short(psk, oracle):
+    db, gs = gpu_sketch(psk, [b"ATGC" * 100])        # 400 bp: below MIN_LENGTH_CONTIG (test_database.py:13)
+    seeds, markers = gs.export()
+    assert len(seeds) == 0 and len(markers) == 0
+    db, gs = gpu_sketch(psk, [])
+    assert len(gs.export()[0]) == 0
+
+
+def test_sketch_str_and_buffer_inputs(psk, oracle):
+    rng = np.random.default_rng(5)
+    seq = random_genome(rng, 30000)
+    want = oracle.Sketch([seq])
+    for obj in (seq.decode(), bytearray(seq), memoryview(seq), np.frombuffer(seq, dtype=np.uint8)):
+        db, gs = gpu_sketch(psk, [obj])
+        assert_sketch_equal(gs, want)
+
+
+def test_invalid_k_is_value_error(psk):
+    with pytest.raises(ValueError):
+        db = psk.Database(k=17)
+        db.sketch("x", b"A" * 1000)
+
+
+def chain_gpu(psk, ref_contigs, q_contigs, **kw):
+    db = psk.Database()
+    db.sketch("ref", *ref_contigs)
+    return db.query("q", *q_contigs, learned_ani=False, **kw)
+
+
+def check_pair(psk, oracle, ref_contigs, q_contigs, **kw):
+    r, q = oracle.Sketch(ref_contigs), oracle.Sketch(q_contigs)
+    want = oracle.query([("ref", r)], q, **kw)
+    got = chain_gpu(psk, ref_contigs, q_contigs, **kw)
+    assert len(got) == len(want)
+    if want:
+        w, g = want[0][1], got[0]
+        for f in INT_FIELDS:
+            assert g._raw[f] == getattr(w, f), f
+        assert abs(g.identity - w.ani) < 1e-6
+        assert abs(g.query_fraction - w.af_query) < 1e-6
+        assert abs(g.reference_fraction - w.af_ref) < 1e-6
+    return got
+
+
+@pytest.mark.parametrize("kw", [{}, {"median": True}, {"robust": True}])
+def test_chain_ecoli_matches_oracle(psk, oracle, ecoli, kw):
+    ec, k12 = ecoli
+    got = check_pair(psk, oracle, [ec], [k12], **kw)
+    assert len(got) == 1 and got[0].reference_name == "ref" and got[0].query_name == "q"
+
+
+def test_chain_ecoli_reference_kat_fractions(psk, ecoli):
+    """test_ani.py:35-40 through the HIP path: fractions to the reference's 4 places."""
+    ec, k12 = ecoli
+    db = psk.Database()
+    db.sketch("EC590", ec)
+    hits = db.query("K12", k12, learned_ani=False)
+    assert len(hits) == 1
+    assert abs(hits[0].reference_fraction - 0.9246) < 5e-5
+    assert abs(hits[0].query_fraction - 0.9189) < 5e-5
+    assert abs(hits[0].identity - 0.9946) < 1e-3     # see tests/test_oracle_kat.py
+
+
+def test_chain_multicontig_repeats_and_strands(psk, oracle):
+    rng = np.random.default_rng(11)
+    base = random_genome(rng, 300000)
+    rep = random_genome(rng, 3000)
+    # reference: 3 contigs with a repeated element; query: rearranged, partly reverse-complemented, mutated
+    ref = [base[:120000] + rep + base[120000:150000], base[150000:260000] + rep, rep + base[260000:]]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    q1 = mutate(rng, base[50000:200000], 0.03, 0.0005)
+    q2 = mutate(rng, base[200000:] + rep, 0.01)[::-1].translate(comp)
+    check_pair(psk, oracle, ref, [q2, q1, b"ACGT" * 50])
+
+
+def test_chain_unrelated_gives_no_hit(psk, oracle):
+    rng = np.random.default_rng(12)
+    a, b = random_genome(rng, 200000), random_genome(rng, 200000)
+    assert check_pair(psk, oracle, [a], [b]) == []
+    # cutoff=None screens at 0.80; a tiny genome (< 20 markers) is rescued unless faster_small
+    small = a[:8000]
+    check_pair(psk, oracle, [a], [small])
+    check_pair(psk, oracle, [a], [small], faster_small=True)
+
+
+def test_query_many_refs_matches_oracle(psk, oracle):
+    rng = np.random.default_rng(13)
+    anc = [random_genome(rng, 400000) for _ in range(3)]
+    refs = []
+    for f, a in enumerate(anc):
+        for j, d in enumerate((0.002, 0.01, 0.03, 0.06, 0.1)):
+            refs.append((f"f{f}_m{j}", mutate(rng, a, d, 0.0002)))
+    qseq = mutate(rng, anc[1], 0.02)
+    db = psk.Database()
+    for name, s in refs:
+        db.sketch(name, s)
+    got = {h.reference_name: h for h in db.query("q", qseq, learned_ani=False)}
+    osk = [(n, oracle.Sketch([s])) for n, s in refs]
+    want = {n: r for n, r in oracle.query(osk, oracle.Sketch([qseq]))}
+    assert set(got) == set(want) and len(want) == 5
+    for n, w in want.items():
+        for f in INT_FIELDS:
+            assert got[n]._raw[f] == getattr(w, f), (n, f)
+        assert abs(got[n].identity - w.ani) < 1e-6
+    # screen counts through the C-ABI
+    import ctypes as C
+    q = db._sketch("q", [qseq], True)
+    n = len(db)
+    flags = np.zeros(n, np.uint8); shared = np.zeros(n, np.uint32)
+    from pyskani_amd import _capi
+    _capi.check(db._lib.psk_screen(db._h, q._h, 0.80, 1, flags.ctypes.data_as(C.c_void_p), shared.ctypes.data_as(C.c_void_p)))
+    oq = oracle.Sketch([qseq])
+    for i, (nme, r) in enumerate(osk):
+        ok, sh = oracle.screen(oq, r, 0.80, True)
+        assert sh == shared[i] and ok == bool(flags[i]), nme
+
+
+def test_serial_chain_path_agrees_with_lds_path(ecoli):
+    """The lane-serial fallback (a transliteration of the oracle) and the LDS fast path must agree."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_fasta_first_record as L\n"
+        "import pyskani_amd\n"
+        "db = pyskani_amd.Database(); db.sketch('EC590', L('e.coli-EC590.fasta.gz'))\n"
+        "h = db.query('K12', L('e.coli-K12.fasta.gz'), learned_ani=False)[0]\n"
+        "print(h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for serial in (False, True):
+        env = dict(os.environ)
+        env.pop("PSK_CHAIN_SERIAL", None)
+        if serial:
+            env["PSK_CHAIN_SERIAL"] = "1"
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip())
+    assert outs[0] == outs[1], outs
+
+
+def test_learned_ani_without_model_raises(psk, ecoli):
+    db = psk.Database()
+    db.sketch("a", ecoli[0][:100000])
+    with pytest.raises(RuntimeError):
+        db.query("q", ecoli[0][:100000], learned_ani=True)
+    with pytest.warns(RuntimeWarning):
+        import pyskani_amd.database as D
+        D._warned_no_model = False
+        db.query("q", ecoli[0][:100000])
+
+
+def test_full_size_properties(psk):
+    """BASELINE configs[1]-sized property checks: self-query gives ANI 1 and AF ~1; ANI ordering follows divergence."""
+    rng = np.random.default_rng(21)
+    g = random_genome(rng, 5_000_000)
+    db = psk.Database()
+    db.sketch("self", g)
+    for j, d in enumerate((0.005, 0.02, 0.05)):
+        db.sketch(f"d{j}", mutate(rng, g, d))
+    hits = {h.reference_name: h for h in db.query("q", g, learned_ani=False)}
+    assert hits["self"].identity == 1.0 and hits["self"].query_fraction > 0.99
+    assert hits["self"].identity > hits["d0"].identity > hits["d1"].identity > hits["d2"].identity
+    for j, d in enumerate((0.005, 0.02, 0.05)):
+        # conftest.mutate redraws the base uniformly, so the substitution rate is 0.75 d
+        assert abs(hits[f"d{j}"].identity - (1 - 0.75 * d)) < 0.003
