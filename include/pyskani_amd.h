@@ -81,6 +81,11 @@ void psk_free(void* p);
 psk_status psk_ctx_create(int device, psk_ctx** out);
 void psk_ctx_destroy(psk_ctx* ctx);
 psk_status psk_ctx_synchronize(psk_ctx* ctx);
+/* Measurement: bracket the named kernels' launches with HIP events on the ctx stream.
+ * kernel in {"sketch_scan","sketch_emit","sketch_sort","screen","anchor","chain_chunk",
+ * "pair_reduce"}; "reset" clears the accumulators. psk_ctx_timing synchronises the stream. */
+psk_status psk_ctx_set_timing(psk_ctx* ctx, int on);
+psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
 psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
 psk_status psk_device_free(psk_ctx* ctx, void* dptr);
@@ -110,6 +115,8 @@ psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out);
 void psk_db_destroy(psk_db* db);
 /* takes ownership of s (also on failure) */
 psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s);
+/* n x psk_db_add in one call; ownership moves only on PSK_OK */
+psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* const* sketches, uint32_t n);
 uint32_t psk_db_size(const psk_db* db);
 const char* psk_db_name(const psk_db* db, uint32_t index);
 const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t index);

@@ -1,0 +1,73 @@
+// Micro-benchmark: throughput of mm_hash64(x) < thr formulations on gfx950 (VALU-bound inner op of sketch_scan).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+__device__ __forceinline__ uint64_t hashA(uint64_t key) {
+    key = ~(key + (key << 21)); key = key ^ key >> 24; key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14; key = (key + (key << 2)) + (key << 4); key = key ^ key >> 28; key = key + (key << 31);
+    return key;
+}
+__device__ __forceinline__ void opq(uint64_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ uint64_t hashC1(uint64_t key) {   // native 64-bit shifts, no multiply folding
+    uint64_t t = key << 21; opq(t); key = ~(key + t);
+    key = key ^ key >> 24;
+    t = key << 3; opq(t); uint64_t u = key << 8; opq(u); key = (key + t) + u;
+    key = key ^ key >> 14;
+    t = key << 2; opq(t); u = key << 4; opq(u); key = (key + t) + u;
+    key = key ^ key >> 28;
+    t = key << 31; opq(t); key = key + t;
+    return key;
+}
+__device__ __forceinline__ uint64_t shl(uint64_t k, int s) {   // alignbit-based 64-bit shift by constant
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    uint32_t h2 = __builtin_amdgcn_alignbit(hi, lo, 32 - s), l2 = lo << s;
+    uint64_t r = ((uint64_t)h2 << 32) | l2; opq(r); return r;
+}
+__device__ __forceinline__ uint64_t xshr(uint64_t k, int s) {
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    uint32_t l2 = lo ^ __builtin_amdgcn_alignbit(hi, lo, s), h2 = hi ^ (hi >> s);
+    return ((uint64_t)h2 << 32) | l2;
+}
+__device__ __forceinline__ uint64_t hashC2(uint64_t key) {
+    key = ~(key + shl(key, 21));
+    key = xshr(key, 24);
+    key = (key + shl(key, 3)) + shl(key, 8);
+    key = xshr(key, 14);
+    key = (key + shl(key, 2)) + shl(key, 4);
+    key = xshr(key, 28);
+    key = key + shl(key, 31);
+    return key;
+}
+template <int V> __global__ void bench(uint32_t* out, uint64_t thr, int iters) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, cnt = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            x = x * 1664525u + 1013904223u;
+            uint64_t k = x & 0x3FFFFFFFu;
+            uint64_t h = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : hashC2(k);
+            cnt += h < thr;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = cnt;
+}
+template <int V> __global__ void check(uint64_t* out) { uint64_t k = threadIdx.x * 2654435761u & 0x3FFFFFFF; out[threadIdx.x] = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : hashC2(k); }
+int main() {
+    uint32_t* d; hipMalloc(&d, 4 * 2048 * 256);
+    uint64_t *c0, *c1, *c2; hipMalloc(&c0, 8 * 256); hipMalloc(&c1, 8 * 256); hipMalloc(&c2, 8 * 256);
+    check<0><<<1, 256>>>(c0); check<1><<<1, 256>>>(c1); check<2><<<1, 256>>>(c2);
+    uint64_t h0[256], h1[256], h2[256]; hipMemcpy(h0, c0, 2048, hipMemcpyDeviceToHost); hipMemcpy(h1, c1, 2048, hipMemcpyDeviceToHost); hipMemcpy(h2, c2, 2048, hipMemcpyDeviceToHost);
+    int bad = 0; for (int i = 0; i < 256; i++) bad += (h0[i] != h1[i]) + (h0[i] != h2[i]);
+    printf("mismatches %d\n", bad);
+    uint64_t thr = UINT64_MAX / 125; int iters = 4096;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int v = 0; v < 3; v++) for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(a);
+        if (v == 0) bench<0><<<2048, 256>>>(d, thr, iters); else if (v == 1) bench<1><<<2048, 256>>>(d, thr, iters); else bench<2><<<2048, 256>>>(d, thr, iters);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        double n = 2048.0 * 256 * iters * 16;
+        printf("variant %d: %.3f ms  %.1f Ghash/s\n", v, ms, n / ms / 1e6);
+    }
+    return 0;
+}

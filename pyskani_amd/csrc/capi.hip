@@ -57,6 +57,35 @@ psk_status psk_ctx_synchronize(psk_ctx* c) {
     return PSK_OK;
 }
 
+psk_status psk_ctx_set_timing(psk_ctx* c, int on) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->timing = on != 0;
+    return PSK_OK;
+}
+
+psk_status psk_ctx_timing(psk_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!c || !kernel) { psk_set_error("ctx_timing: NULL argument"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    PSK_HIP(hipSetDevice(c->device));
+    PSK_HIP(hipStreamSynchronize(c->stream));
+    for (TimerRec& r : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.id] += ms; c->acc_n[r.id]++; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    c->pending.clear();
+    for (int i = 0; i < K_COUNT; i++) if (!strcmp(kernel, KERNEL_NAMES[i])) {
+        if (total_ms) *total_ms = c->acc_ms[i];
+        if (launches) *launches = c->acc_n[i];
+        if (!strcmp(kernel, "reset")) break;
+        return PSK_OK;
+    }
+    if (!strcmp(kernel, "reset")) { for (int i = 0; i < K_COUNT; i++) { c->acc_ms[i] = 0; c->acc_n[i] = 0; } return PSK_OK; }
+    psk_set_error("unknown kernel name '%s'", kernel);
+    return PSK_EINVAL;
+}
+
 psk_status psk_device_alloc(psk_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) { psk_set_error("device_alloc: NULL argument"); return PSK_EINVAL; }
     PSK_HIP(hipSetDevice(c->device));
@@ -80,10 +109,32 @@ psk_status psk_memcpy_h2d(psk_ctx* c, void* dst, const void* src, size_t bytes) 
 psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases, const uint64_t* contig_off,
                                    const uint64_t* contig_len, const uint32_t* genome_first_contig, uint32_t n_genomes,
                                    int want_seeds, psk_sketch** out) {
-    if (!ctx) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    if (!ctx || !out || (n_genomes && (!genome_first_contig || !contig_off || !contig_len))) { psk_set_error("sketch_batch: NULL argument"); return PSK_EINVAL; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
-    return sketch_batch_impl(ctx, p, d_bases, contig_off, contig_len, genome_first_contig, n_genomes, want_seeds, out);
+    // seed offsets are 32-bit per launch: size sub-batches so that the expected seed count
+    // (bases / c) stays far below 2^31; if a launch still overflows (PSK_ELIMIT) halve and retry
+    const uint64_t c_eff = p && p->c > 0 ? (uint64_t)p->c : 1;
+    uint64_t limit = std::min<uint64_t>(1ull << 36, (1ull << 30) * c_eff);
+    uint32_t g0 = 0;
+    while (g0 < n_genomes) {
+        uint32_t g1 = g0;
+        uint64_t bases = 0;
+        while (g1 < n_genomes) {
+            uint64_t gb = 0;
+            for (uint32_t c = genome_first_contig[g1]; c < genome_first_contig[g1 + 1]; c++) gb += contig_len[c] + TILE_BASES;
+            if (g1 > g0 && bases + gb > limit) break;
+            bases += gb; g1++;
+        }
+        psk_status rc = sketch_batch_impl(ctx, p, d_bases, contig_off, contig_len, genome_first_contig + g0, g1 - g0, want_seeds, out + g0);
+        if (rc == PSK_ELIMIT && g1 - g0 > 1) { limit = bases / 2; continue; }
+        if (rc != PSK_OK) {
+            for (uint32_t g = 0; g < g0; g++) { delete out[g]; out[g] = nullptr; }
+            return rc;
+        }
+        g0 = g1;
+    }
+    return PSK_OK;
 }
 
 psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
@@ -162,6 +213,18 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     std::lock_guard<std::mutex> lk(db->ctx->mu);
     db->refs.push_back(s);
     db->names.emplace_back(name);
+    db->tables_dirty = true;
+    return PSK_OK;
+}
+
+psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* const* sketches, uint32_t n) {
+    if (!db || (n && (!names || !sketches))) { psk_set_error("db_add_batch: NULL argument"); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(db->ctx->mu);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!sketches[i] || !names[i] || sketches[i]->ctx != db->ctx) { psk_set_error("db_add_batch: bad entry %u", i); return PSK_EINVAL; }
+        db->refs.push_back(sketches[i]);
+        db->names.emplace_back(names[i]);
+    }
     db->tables_dirty = true;
     return PSK_OK;
 }

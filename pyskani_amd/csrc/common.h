@@ -63,9 +63,26 @@ struct Scratch {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// kernels whose launches can be bracketed by HIP events on the ctx stream (psk_ctx_timing)
+enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANCHOR, K_CHAIN_CHUNK, K_PAIR_REDUCE, K_COUNT };
+static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "pair_reduce"};
+struct TimerRec { int id; hipEvent_t a, b; };
+
 struct psk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool timing = false;
+    std::vector<TimerRec> pending;
+    double acc_ms[K_COUNT] = {0};
+    uint64_t acc_n[K_COUNT] = {0};
+    void t_begin(int id) {
+        if (!timing) return;
+        TimerRec r{id, nullptr, nullptr};
+        (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, stream);
+        pending.push_back(r);
+    }
+    void t_end() { if (timing && !pending.empty()) (void)hipEventRecord(pending.back().b, stream); }
     std::mutex mu;                 // one stream per ctx: calls are serialised
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query

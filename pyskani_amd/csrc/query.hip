@@ -62,8 +62,10 @@ psk_status screen_impl(psk_db* db, const psk_sketch* q, double screen_val, int r
     uint32_t* d_shared = (uint32_t*)((char*)ctx->q_a.p + (((size_t)n + 3) & ~(size_t)3));
     const uint64_t* qm = q->store ? q->store->markers + q->marker_off : nullptr;
     double thresh = pow(screen_val, (double)K_MARKER);
+    ctx->t_begin(K_SCREEN);
     hipLaunchKernelGGL(screen_kernel, dim3(n), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, qm, (uint32_t)q->n_markers,
                        thresh, rescue_small, d_pass, d_shared);
+    ctx->t_end();
     void* hp;
     PSK_TRY(ctx->pinned((size_t)n * 8 + 16, &hp));
     uint8_t* h_pass = (uint8_t*)hp;
@@ -523,7 +525,9 @@ static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint3
     const uint32_t* q_pos = q->store->seed_pos + q->seed_off;
     const uint32_t* q_meta = q->store->seed_meta + q->seed_off;
     dim3 g2((nq + 255) / 256, n_pairs);
+    ctx->t_begin(K_ANCHOR);
     hipLaunchKernelGGL(anchor_count_kernel, g2, dim3(256), 0, st, d_refs, q_kmer, nq, d_lb, d_cnt);
+    ctx->t_end();
     size_t tmp = 0;
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_cnt, d_aoff, (int)(npq + 1), st));
     PSK_TRY(ctx->q_c.reserve(tmp));
@@ -553,12 +557,16 @@ static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint3
     }
     hipLaunchKernelGGL(chunk_heads_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, d_aoff, a_nxt, nq, n_pairs, max_chunks, d_chunks, d_nch, d_misc);
     const uint32_t slots = n_pairs * max_chunks;
+    ctx->t_begin(K_CHAIN_CHUNK);
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((slots + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(64 * CHAIN_WAVES), 0, st, A);
+    ctx->t_end();
     ReduceArgs R{};
     R.chunks = d_cout; R.n_chunks = d_nch; R.max_chunks = max_chunks; R.aoff = d_aoff; R.nq = nq; R.ref_total_len = d_rlen;
     R.q_total_len = q->total_len; R.k = q->params.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = d_hits;
+    ctx->t_begin(K_PAIR_REDUCE);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
+    ctx->t_end();
     psk_hit* h_hits = (psk_hit*)((char*)hp + 256);
     PSK_HIP(hipMemcpyAsync(h_hits, d_hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipMemcpyAsync(h_small, d_misc, 16, hipMemcpyDeviceToHost, st));

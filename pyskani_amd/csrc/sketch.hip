@@ -160,29 +160,25 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
     uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ marker_count,
     SketchConsts C) {
-    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    __shared__ uint32_t s_wave[TILE_THREADS / 64], s_mwave[TILE_THREADS / 64], s_mbase;
     const uint32_t tile = blockIdx.x;
-    const int tid = threadIdx.x;
-    uint64_t m = seedmask[(size_t)tile * TILE_MASKS + tid];
-    int cnt = __popcll(m);
-    // block exclusive scan of cnt
-    int incl = cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t m0 = seedmask[(size_t)tile * TILE_MASKS + tid];
+    const int cnt = __popcll(m0);
+    int incl = cnt;   // block exclusive scan of the per-lane seed counts
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
-    __syncthreads();
-    int wave_base = 0;
-    for (int w = 0; w < (tid >> 6); w++) wave_base += s_wave[w];
-    if (m == 0) return;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wave[wv] = incl;
     const int ci = find_contig(contigs, n_contigs, tile);
     const ContigDesc cd = contigs[ci];
     const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
     const uint32_t* words = packed + (size_t)cd.first_tile * TILE_WORDS;   // the contig's packed stream
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wv; w++) wave_base += s_wave[w];
     uint32_t out = tile_off[tile] + wave_base + incl - cnt;
-    const uint32_t g_seed0 = tile_off[genome_first_tile[cd.genome]];
+    // pass A: seed records; remember which of this lane's seeds are markers
+    uint64_t m = m0, mark = 0;
     while (m) {
         int i = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
@@ -198,12 +194,31 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
         seed_meta[out] = meta;
         seed_pm[out] = ((uint64_t)p << 32) | meta;
         out++;
-        if (mm_hash64(cs) < C.thr_marker) {
-            uint64_t f21 = get_bases(words, p + 1 - K_MARKER, K_MARKER);
-            uint64_t r21 = revcomp(f21, K_MARKER);
-            uint32_t slot = atomicAdd(&marker_count[cd.genome], 1u);
-            marker_stage[(size_t)g_seed0 + slot] = f21 < r21 ? f21 : r21;
-        }
+        if (mm_hash64(cs) < C.thr_marker) mark |= 1ull << i;
+    }
+    // pass B: one atomic per tile reserves the tile's slots in the genome's marker staging area
+    const int mc = __popcll(mark);
+    int mincl = mc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(mincl, o); if (lane >= o) mincl += v; }
+    if (lane == 63) s_mwave[wv] = mincl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = s_mwave[0] + s_mwave[1] + s_mwave[2] + s_mwave[3];
+        s_mbase = tot ? atomicAdd(&marker_count[cd.genome], tot) : 0;
+    }
+    __syncthreads();
+    if (!mark) return;
+    uint32_t mbase = 0;
+    for (int w = 0; w < wv; w++) mbase += s_mwave[w];
+    size_t slot = (size_t)tile_off[genome_first_tile[cd.genome]] + s_mbase + mbase + mincl - mc;
+    while (mark) {
+        int i = __ffsll((unsigned long long)mark) - 1;
+        mark &= mark - 1;
+        uint32_t p = pos0 + 64u * tid + i;
+        uint64_t f21 = get_bases(words, p + 1 - K_MARKER, K_MARKER);
+        uint64_t r21 = revcomp(f21, K_MARKER);
+        marker_stage[slot++] = f21 < r21 ? f21 : r21;
     }
 }
 
@@ -273,9 +288,9 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     }
     g_first_desc[n_genomes] = (uint32_t)descs.size();
     g_first_tile[n_genomes] = (uint32_t)n_tiles64;
-    if (n_tiles64 * (uint64_t)TILE_BASES >= (1ull << 32)) {
+    if (n_tiles64 >= (1ull << 31)) {
         for (auto* x : sk) delete x;
-        psk_set_error("batch of %llu bases exceeds the 2^32-base batch limit; split it", (unsigned long long)total_bases);
+        psk_set_error("batch of %llu bases exceeds the per-launch tile limit; split it", (unsigned long long)total_bases);
         return PSK_ELIMIT;
     }
     const uint32_t n_tiles = (uint32_t)n_tiles64;
@@ -331,7 +346,9 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     HIPF(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
 
     // ---- pass 1 ----
+    ctx->t_begin(K_SKETCH_SCAN);
     hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, n_desc, d_packed, d_mask, d_cnt, C);
+    ctx->t_end();
     size_t tmp_bytes = 0;
     HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
     if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
@@ -371,8 +388,11 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     uint32_t* d_fpos = d_flags + ns + 1;
 
     // ---- pass 2 ----
+    ctx->t_begin(K_SKETCH_EMIT);
     hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_desc, n_desc, d_packed, d_mask, d_toff, d_gft,
                        store->seed_kmer, store->seed_pos, store->seed_meta, d_pm, d_mstage, d_mcnt, C);
+    ctx->t_end();
+    ctx->t_begin(K_SKETCH_SORT);
 
     // ---- marker sets: per-genome sort + unique ----
     hipLaunchKernelGGL(marker_segments_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_goff, d_mcnt, d_sbeg, d_send, (int)n_genomes);
@@ -400,6 +420,7 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
         if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
         HIPF(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->s_tmp.p, tmp_bytes, store->seed_kmer, store->idx_kmer, d_pm, store->idx_pm, (int)ns, (int)n_genomes, d_goff, d_goff + 1, 0, 2 * p->k, st));
     }
+    ctx->t_end();
     HIPF(hipStreamSynchronize(st));
     const uint32_t total_markers = h_moff[n_genomes];
     HIPF(hipMalloc(&store->mbase, sizeof(uint64_t) * ((size_t)total_markers + 1)));
