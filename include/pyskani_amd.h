@@ -4,7 +4,7 @@
  * has no FFI today: its PyO3 crate calls the Rust crate `skani` directly. Each entry point
  * below replaces one of those call sites (paths are relative to /root/reference):
  *
- *   psk_sketch_host / psk_sketch_device / psk_sketch_batch_device
+ *   psk_sketch_host / psk_sketch_batch_device
  *        <- the per-contig loop over skani::seeding::fmh_seeds in Database::_sketch,
  *           src/pyskani/_skani/lib.rs:140-185 (contig filter :156, metadata :157-161,
  *           fmh_seeds :165-171) and skani::types::Sketch::get_markers_only at :495
