@@ -86,6 +86,32 @@ struct psk_ctx {
     std::mutex mu;                 // one stream per ctx: calls are serialised
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
+    // device block pool: sketch stores are recycled instead of hipMalloc/hipFree'd per batch
+    struct PoolBlock { void* p; size_t bytes; };
+    std::vector<PoolBlock> pool;
+    std::mutex pool_mu;
+    psk_status pool_alloc(size_t bytes, void** out, size_t* got) {
+        {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            int best = -1;
+            for (int i = 0; i < (int)pool.size(); i++)
+                if (pool[i].bytes >= bytes && pool[i].bytes <= bytes + bytes / 4 + (1 << 20) && (best < 0 || pool[i].bytes < pool[best].bytes)) best = i;
+            if (best >= 0) { *out = pool[best].p; *got = pool[best].bytes; pool.erase(pool.begin() + best); return PSK_OK; }
+        }
+        size_t want = bytes + bytes / 16 + 256;
+        PSK_HIP(hipMalloc(out, want));
+        *got = want;
+        return PSK_OK;
+    }
+    void pool_release(void* p, size_t bytes) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(pool_mu);
+        size_t held = 0;
+        for (auto& b : pool) held += b.bytes;
+        if (held + bytes > (size_t)64 << 30 || pool.size() >= 16) { (void)hipFree(p); return; }   // cap what the pool keeps
+        pool.push_back({p, bytes});
+    }
+    void pool_drain() { std::lock_guard<std::mutex> lk(pool_mu); for (auto& b : pool) (void)hipFree(b.p); pool.clear(); }
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
     size_t h_pinned_cap = 0;
     psk_status pinned(size_t bytes, void** out) {
@@ -103,18 +129,23 @@ struct psk_ctx {
 
 // Storage shared by the sketches of one batch: one device allocation, sliced.
 struct SketchStore {
+    psk_ctx* ctx = nullptr;          // blocks go back to ctx's pool (the ctx must outlive its sketches)
     void* base = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, mbytes = 0;
     // slices (device pointers into base)
     uint32_t* seed_kmer = nullptr;   // (contig,pos) order
     uint32_t* seed_pos = nullptr;
     uint32_t* seed_meta = nullptr;   // contig<<1 | canon
+    uint64_t* seed_pm = nullptr;     // pos<<32 | meta, (contig,pos) order: the value array of the lazy index sort
     uint32_t* idx_kmer = nullptr;    // per genome sorted by k-mer (stable)
     uint64_t* idx_pm = nullptr;      // pos<<32 | meta, permuted like idx_kmer
     uint64_t* markers = nullptr;     // per genome sorted unique
     uint32_t* contig_seed_start = nullptr;  // per kept contig (+1 sentinel per batch), global seed offsets
     void* mbase = nullptr;           // second allocation: the marker sets
-    ~SketchStore() { if (base) (void)hipFree(base); if (mbase) (void)hipFree(mbase); }
+    ~SketchStore() {
+        if (ctx) { ctx->pool_release(base, bytes); ctx->pool_release(mbase, mbytes); }
+        else { if (base) (void)hipFree(base); if (mbase) (void)hipFree(mbase); }
+    }
 };
 
 struct psk_sketch {
@@ -128,6 +159,7 @@ struct psk_sketch {
     std::vector<uint32_t> contig_seed_start; // host copy, LOCAL offsets, n_contigs+1
     uint64_t total_len = 0;
     bool has_seeds = true;
+    mutable bool indexed = false;            // idx_kmer/idx_pm slice filled (built on first chaining use)
 };
 
 struct psk_db {
@@ -157,6 +189,8 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
                              int want_seeds, psk_sketch** out);
+// sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
+psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n);
 psk_status screen_impl(psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,

@@ -588,6 +588,7 @@ psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_re
         if (!refs[i] || !refs[i]->has_seeds) { psk_set_error("reference %u was sketched with seed=False; it cannot be chained", i); return PSK_EINVAL; }
         if (refs[i]->params.k != q->params.k || refs[i]->params.c != q->params.c) { psk_set_error("reference %u and query were sketched with different parameters", i); return PSK_EINVAL; }
     }
+    PSK_TRY(ensure_index(ctx, refs, n_refs));
     // bound the scratch of one launch: lb/cnt/aoff cost 12 B per (pair, query seed)
     const uint64_t nq = q->n_seeds ? q->n_seeds : 1;
     uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2048, (1ull << 31) / (nq * 2)));

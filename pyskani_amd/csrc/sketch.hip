@@ -56,16 +56,27 @@ __device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ contig
     return lo;
 }
 
+__global__ void tile_contig_kernel(const ContigDesc* __restrict__ contigs, int n_contigs, uint32_t n_tiles, uint32_t* __restrict__ tile_ci) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) tile_ci[t] = (uint32_t)find_contig(contigs, n_contigs, t);
+}
+
+// reverse-complement of the 16 bases of a packed word
+__device__ __forceinline__ uint32_t rc_word(uint32_t w) {
+    uint32_t y = __brev(w);
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    return ~y;
+}
+
 __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
-    const uint8_t* __restrict__ ascii, const ContigDesc* __restrict__ contigs, int n_contigs,
+    const uint8_t* __restrict__ ascii, const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci,
     uint32_t* __restrict__ packed, uint64_t* __restrict__ seedmask, uint32_t* __restrict__ tile_count,
     SketchConsts C) {
     __shared__ __align__(16) uint32_t s_w[4 + TILE_WORDS];
     __shared__ uint32_t s_cnt[TILE_THREADS / 64];
     const uint32_t tile = blockIdx.x;
     const int tid = threadIdx.x;
-    const int ci = find_contig(contigs, n_contigs, tile);
-    const ContigDesc cd = contigs[ci];
+    const ContigDesc cd = contigs[tile_ci[tile]];
     const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
     const uint32_t n = min((uint32_t)TILE_BASES, cd.len - pos0);
     const uint8_t* src = ascii + cd.byte_off + pos0;
@@ -97,29 +108,40 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     const uint2 wb = *reinterpret_cast<const uint2*>(&s_w[4 * tid + 4]);
     uint32_t W0 = wa.x, W1 = wa.y, W2 = wa.z, W3 = wa.w, W4 = wb.x, W5 = wb.y;
     const uint32_t sh = 2 * C.d;
+    // V: the lane's neighbourhood delayed by d bases; delayed index 16+j of the 80 bases V[0..4] is the
+    // last base of the seed for window position j-16. No rolling state: every k-mer is a funnel shift.
     uint32_t V[5];
     V[0] = __funnelshift_r(W1, W0, sh);
     V[1] = __funnelshift_r(W2, W1, sh);
     V[2] = __funnelshift_r(W3, W2, sh);
     V[3] = __funnelshift_r(W4, W3, sh);
     V[4] = __funnelshift_r(W5, W4, sh);
-    uint32_t fs = 0, rs = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {   // warm-up: the (at most 15) bases preceding the first seed
-        uint32_t b = (V[0] >> (30 - 2 * j)) & 3u;
-        fs = ((fs << 2) | b) & C.kmask;
-        rs = (rs >> 2) | ((b ^ 3u) << C.rshift);
+    // RC: reverse complement of those 80 bases, delayed by 16-k bases so that the reverse k-mer of window
+    // position i ends at the compile-time index 78-i
+    const uint32_t rsh = 2 * (16 - C.k);
+    uint32_t Q[5];
+    {
+        uint32_t r0 = rc_word(V[4]), r1 = rc_word(V[3]), r2 = rc_word(V[2]), r3 = rc_word(V[1]), r4 = rc_word(V[0]);
+        Q[0] = __funnelshift_r(r0, 0u, rsh);
+        Q[1] = __funnelshift_r(r1, r0, rsh);
+        Q[2] = __funnelshift_r(r2, r1, rsh);
+        Q[3] = __funnelshift_r(r3, r2, rsh);
+        Q[4] = __funnelshift_r(r4, r3, rsh);
     }
     uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int i = 0; i < 64; i++) {
-        uint32_t b = (V[1 + i / 16] >> (30 - 2 * (i % 16))) & 3u;
-        fs = ((fs << 2) | b) & C.kmask;
-        rs = (rs >> 2) | ((b ^ 3u) << C.rshift);
+        const int je = 16 + i;                 // forward: k-mer ends at delayed index je
+        const int fw = je / 16, fo = je % 16;
+        uint32_t fs = (fo == 15 ? V[fw] : __funnelshift_r(V[fw], V[fw - 1], 30 - 2 * fo)) & C.kmask;
+        const int me = 78 - i;                 // reverse: k-mer ends at index me of the delayed RC stream
+        const int rw = me / 16, ro = me % 16;
+        uint32_t rs = (ro == 15 ? Q[rw] : __funnelshift_r(Q[rw], Q[rw - 1], 30 - 2 * ro)) & C.kmask;
         uint64_t h = mm_hash64((uint64_t)min(fs, rs));
-        uint32_t bit = (h < C.thr) ? (1u << (i & 31)) : 0u;
-        if (i < 32) mlo |= bit; else mhi |= bit;
+        // mask = mask*2 + bit: first window position ends up in the HIGHEST bit; reversed below
+        if (i < 32) mlo = mlo + mlo + (h < C.thr ? 1u : 0u); else mhi = mhi + mhi + (h < C.thr ? 1u : 0u);
     }
+    mlo = __brev(mlo); mhi = __brev(mhi);
     // windows must lie inside the contig: K_MARKER-1 <= pos < len
     const uint32_t p0 = pos0 + 64u * tid;
     int lo_i = p0 >= (uint32_t)(K_MARKER - 1) ? 0 : (int)(K_MARKER - 1 - p0);
@@ -154,7 +176,7 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
 }
 
 __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
-    const ContigDesc* __restrict__ contigs, int n_contigs, const uint32_t* __restrict__ packed,
+    const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci, const uint32_t* __restrict__ packed,
     const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
     const uint32_t* __restrict__ genome_first_tile,
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
@@ -169,8 +191,7 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     if (lane == 63) s_wave[wv] = incl;
-    const int ci = find_contig(contigs, n_contigs, tile);
-    const ContigDesc cd = contigs[ci];
+    const ContigDesc cd = contigs[tile_ci[tile]];
     const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
     const uint32_t* words = packed + (size_t)cd.first_tile * TILE_WORDS;   // the contig's packed stream
     __syncthreads();
@@ -232,17 +253,36 @@ __global__ void marker_segments_kernel(const uint32_t* __restrict__ g_off, const
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) { beg[g] = g_off[g]; end[g] = g_off[g] + marker_count[g]; }
 }
-// one block per genome: flag the first occurrence of every distinct marker of the sorted segment
-__global__ void marker_flag_kernel(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ beg,
-                                   const uint32_t* __restrict__ end, uint32_t* __restrict__ flags) {
-    uint32_t b = beg[blockIdx.x], e = end[blockIdx.x];
-    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) flags[i] = (i == b || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+// one block per genome: write the distinct values of the sorted segment, in order, to `uniq` at the same
+// segment offset; cnt[g] = number of distinct markers (cnt[n_genomes] must be pre-zeroed by the caller's scan input)
+__global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __restrict__ sorted, uint64_t* __restrict__ uniq,
+                                                             const uint32_t* __restrict__ beg, const uint32_t* __restrict__ end,
+                                                             uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_w[4], s_base;
+    const uint32_t b = beg[blockIdx.x], e = end[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t i0 = b; i0 < e; i0 += 256) {
+        uint32_t i = i0 + threadIdx.x;
+        bool f = i < e && (i == b || sorted[i] != sorted[i - 1]);
+        unsigned long long bal = __ballot(f);
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (int w = 0; w < wv; w++) off += s_w[w];
+        if (f) uniq[b + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = sorted[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_base;
 }
-__global__ void marker_scatter_kernel(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ beg,
-                                      const uint32_t* __restrict__ end, const uint32_t* __restrict__ flags,
-                                      const uint32_t* __restrict__ pos, uint64_t* __restrict__ out) {
-    uint32_t b = beg[blockIdx.x], e = end[blockIdx.x];
-    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) if (flags[i]) out[pos[i]] = sorted[i];
+// moff = exclusive scan of the distinct counts: copy each genome's distinct markers to its dense slot
+__global__ void marker_copy_kernel(const uint64_t* __restrict__ uniq, const uint32_t* __restrict__ beg,
+                                   const uint32_t* __restrict__ moff, uint64_t* __restrict__ out) {
+    uint32_t b = beg[blockIdx.x], o = moff[blockIdx.x], n = moff[blockIdx.x + 1] - o;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = uniq[b + i];
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -322,6 +362,8 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     uint32_t *d_cnt = d_offs + o_cnt, *d_toff = d_offs + o_toff, *d_gft = d_offs + o_gft, *d_cft = d_offs + o_cft,
              *d_goff = d_offs + o_goff, *d_coff = d_offs + o_coff, *d_mcnt = d_offs + o_mcnt, *d_sbeg = d_offs + o_sbeg,
              *d_send = d_offs + o_send, *d_moff = d_offs + o_moff;
+    if ((rc = ctx->s_counts.reserve(sizeof(uint32_t) * ((size_t)n_tiles + 1))) != PSK_OK) return fail(rc);
+    uint32_t* d_tci = (uint32_t*)ctx->s_counts.p;
     ContigDesc* d_desc = (ContigDesc*)ctx->s_desc.p;
     uint32_t* d_packed = (uint32_t*)ctx->s_packed.p;
     uint64_t* d_mask = (uint64_t*)ctx->s_mask.p;
@@ -344,10 +386,12 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     HIPF(hipMemcpyAsync(d_cft, h_cft, sizeof(uint32_t) * (n_desc + 1), hipMemcpyHostToDevice, st));
     HIPF(hipMemsetAsync(d_cnt + n_tiles, 0, sizeof(uint32_t), st));
     HIPF(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
+    HIPF(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
 
     // ---- pass 1 ----
+    hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci);
     ctx->t_begin(K_SKETCH_SCAN);
-    hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, n_desc, d_packed, d_mask, d_cnt, C);
+    hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
     ctx->t_end();
     size_t tmp_bytes = 0;
     HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
@@ -371,25 +415,22 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     size_t ns = total_seeds;
     size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
            b_ikmer = align_up(b_meta + 4 * ns, 256), b_ipm = align_up(b_ikmer + 4 * ns, 256),
-           b_cstart = align_up(b_ipm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
-    HIPF(hipMalloc(&store->base, b_end));
-    store->bytes = b_end;
+           b_pm = align_up(b_ipm + 8 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
+    store->ctx = ctx;
+    { psk_status prc = ctx->pool_alloc(b_end, &store->base, &store->bytes); if (prc != PSK_OK) return fail(prc); }
     char* sb = (char*)store->base;
     store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
-    store->idx_kmer = (uint32_t*)(sb + b_ikmer); store->idx_pm = (uint64_t*)(sb + b_ipm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
+    store->idx_kmer = (uint32_t*)(sb + b_ikmer); store->idx_pm = (uint64_t*)(sb + b_ipm); store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
     HIPF(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
 
     if ((rc = ctx->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2))) != PSK_OK) return fail(rc);   // stage + sorted
-    if ((rc = ctx->s_flags.reserve(sizeof(uint32_t) * (2 * ns + 2) + sizeof(uint64_t) * (ns + 1))) != PSK_OK) return fail(rc);
     uint64_t* d_mstage = (uint64_t*)ctx->s_mark.p;
     uint64_t* d_msorted = d_mstage + ns + 1;
-    uint64_t* d_pm = (uint64_t*)ctx->s_flags.p;                  // seed {pos,meta} in position order
-    uint32_t* d_flags = (uint32_t*)(d_pm + ns + 1);
-    uint32_t* d_fpos = d_flags + ns + 1;
+    uint64_t* d_pm = store->seed_pm;                              // seed {pos,meta} in position order
 
     // ---- pass 2 ----
     ctx->t_begin(K_SKETCH_EMIT);
-    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_desc, n_desc, d_packed, d_mask, d_toff, d_gft,
+    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_desc, d_tci, d_packed, d_mask, d_toff, d_gft,
                        store->seed_kmer, store->seed_pos, store->seed_meta, d_pm, d_mstage, d_mcnt, C);
     ctx->t_end();
     ctx->t_begin(K_SKETCH_SORT);
@@ -402,30 +443,22 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
         if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
         HIPF(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->s_tmp.p, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
     }
-    HIPF(hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * (ns + 1), st));
-    hipLaunchKernelGGL(marker_flag_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_sbeg, d_send, d_flags);
+    // per genome: unique the sorted segment in place (one block per genome), count, then compact
+    hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_send, d_moff);
     tmp_bytes = 0;
-    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flags, d_fpos, (int)(ns + 1), st));
+    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
     if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
-    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_flags, d_fpos, (int)(ns + 1), st));
-    // marker offsets per genome = fpos[g_off[g]] ; total = fpos[ns]
-    hipLaunchKernelGGL(gather_u32_kernel, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, st, d_fpos, d_goff, d_moff, (int)(n_genomes + 1));
+    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
     uint32_t* h_moff = h_coff + n_desc + 1;
     HIPF(hipMemcpyAsync(h_moff, d_moff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
 
-    // ---- reference index: stable per-genome radix sort of the seeds by k-mer ----
-    if (ns > 0 && want_seeds) {
-        tmp_bytes = 0;
-        HIPF(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, store->seed_kmer, store->idx_kmer, d_pm, store->idx_pm, (int)ns, (int)n_genomes, d_goff, d_goff + 1, 0, 2 * p->k, st));
-        if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
-        HIPF(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->s_tmp.p, tmp_bytes, store->seed_kmer, store->idx_kmer, d_pm, store->idx_pm, (int)ns, (int)n_genomes, d_goff, d_goff + 1, 0, 2 * p->k, st));
-    }
+    // the k-mer-sorted reference index is built lazily, on a sketch's first use in chaining (ensure_index)
     ctx->t_end();
     HIPF(hipStreamSynchronize(st));
     const uint32_t total_markers = h_moff[n_genomes];
-    HIPF(hipMalloc(&store->mbase, sizeof(uint64_t) * ((size_t)total_markers + 1)));
+    { psk_status prc = ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes); if (prc != PSK_OK) return fail(prc); }
     store->markers = (uint64_t*)store->mbase;
-    hipLaunchKernelGGL(marker_scatter_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_sbeg, d_send, d_flags, d_fpos, store->markers);
+    hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, d_mstage, d_sbeg, d_moff, store->markers);
     HIPF(hipStreamSynchronize(st));
 #undef HIPF
 
@@ -439,6 +472,48 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
         s->contig_seed_start.resize(nc + 1);
         for (uint32_t c = 0; c <= nc; c++) s->contig_seed_start[c] = h_coff[g_first_desc[g] + c] - h_goff[g];
         out[g] = s;
+    }
+    return PSK_OK;
+}
+
+// ---- reference index: stable per-genome radix sort of the seeds by k-mer, built on first use ----
+psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n) {
+    hipStream_t st = ctx->stream;
+    std::vector<const psk_sketch*> todo;
+    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->indexed && refs[i]->n_seeds && refs[i]->store) todo.push_back(refs[i]);
+    // group by store: one segmented sort per store, segments = the sketches' seed ranges
+    std::sort(todo.begin(), todo.end(), [](const psk_sketch* a, const psk_sketch* b) {
+        return a->store.get() != b->store.get() ? a->store.get() < b->store.get() : a->seed_off < b->seed_off; });
+    size_t i0 = 0;
+    while (i0 < todo.size()) {
+        size_t i1 = i0;
+        SketchStore* S = todo[i0]->store.get();
+        std::vector<uint32_t> seg;   // begins then ends
+        while (i1 < todo.size() && todo[i1]->store.get() == S) {
+            if (i1 == i0 || todo[i1]->seed_off != todo[i1 - 1]->seed_off) seg.push_back((uint32_t)todo[i1]->seed_off);
+            i1++;
+        }
+        const size_t m = seg.size();
+        seg.resize(2 * m);
+        {
+            size_t j = 0;
+            for (size_t t = i0; t < i1; t++) if (t == i0 || todo[t]->seed_off != todo[t - 1]->seed_off) { seg[m + j] = (uint32_t)(todo[t]->seed_off + todo[t]->n_seeds); j++; }
+        }
+        uint32_t hi = 0;
+        for (size_t j = 0; j < m; j++) hi = std::max(hi, seg[m + j]);
+        PSK_TRY(ctx->s_offs.reserve(sizeof(uint32_t) * 2 * m));
+        uint32_t* d_seg = (uint32_t*)ctx->s_offs.p;
+        PSK_HIP(hipMemcpyAsync(d_seg, seg.data(), sizeof(uint32_t) * 2 * m, hipMemcpyHostToDevice, st));
+        size_t tmp = 0;
+        const int bits = 2 * todo[i0]->params.k;
+        PSK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, S->seed_kmer, S->idx_kmer, S->seed_pm, S->idx_pm, (int)hi, (int)m, d_seg, d_seg + m, 0, bits, st));
+        PSK_TRY(ctx->s_tmp.reserve(tmp));
+        ctx->t_begin(K_SKETCH_SORT);
+        PSK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->s_tmp.p, tmp, S->seed_kmer, S->idx_kmer, S->seed_pm, S->idx_pm, (int)hi, (int)m, d_seg, d_seg + m, 0, bits, st));
+        ctx->t_end();
+        PSK_HIP(hipStreamSynchronize(st));   // seg (host vector) is read by the async copy above
+        for (size_t t = i0; t < i1; t++) todo[t]->indexed = true;
+        i0 = i1;
     }
     return PSK_OK;
 }
