@@ -127,6 +127,18 @@ struct psk_ctx {
     }
 };
 
+// k-mer-sorted reference index of a group of sketches, built on first chaining use (ensure_index)
+struct IndexStore {
+    psk_ctx* ctx = nullptr;
+    void* base = nullptr;
+    size_t bytes = 0;
+    uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
+    uint64_t* pm = nullptr;    // pos<<32 | meta, permuted alike
+    ~IndexStore();
+};
+
+inline IndexStore::~IndexStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
+
 // Storage shared by the sketches of one batch: one device allocation, sliced.
 struct SketchStore {
     psk_ctx* ctx = nullptr;          // blocks go back to ctx's pool (the ctx must outlive its sketches)
@@ -137,8 +149,6 @@ struct SketchStore {
     uint32_t* seed_pos = nullptr;
     uint32_t* seed_meta = nullptr;   // contig<<1 | canon
     uint64_t* seed_pm = nullptr;     // pos<<32 | meta, (contig,pos) order: the value array of the lazy index sort
-    uint32_t* idx_kmer = nullptr;    // per genome sorted by k-mer (stable)
-    uint64_t* idx_pm = nullptr;      // pos<<32 | meta, permuted like idx_kmer
     uint64_t* markers = nullptr;     // per genome sorted unique
     uint32_t* contig_seed_start = nullptr;  // per kept contig (+1 sentinel per batch), global seed offsets
     void* mbase = nullptr;           // second allocation: the marker sets
@@ -159,7 +169,8 @@ struct psk_sketch {
     std::vector<uint32_t> contig_seed_start; // host copy, LOCAL offsets, n_contigs+1
     uint64_t total_len = 0;
     bool has_seeds = true;
-    mutable bool indexed = false;            // idx_kmer/idx_pm slice filled (built on first chaining use)
+    mutable std::shared_ptr<IndexStore> idx;  // built on first chaining use
+    mutable uint64_t idx_off = 0;
 };
 
 struct psk_db {

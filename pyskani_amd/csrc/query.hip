@@ -79,7 +79,7 @@ psk_status screen_impl(psk_db* db, const psk_sketch* q, double screen_val, int r
 }
 
 // ------------------------------------------------------------------ anchors
-struct RefIndex { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t pad; };
+struct RefIndex { const uint64_t* key; const uint64_t* pm; uint32_t n; uint32_t pad; };   // key = slot<<32 | kmer
 
 // one thread per (pair, query seed): range of equal k-mers in the ref index
 __global__ __launch_bounds__(256) void anchor_count_kernel(const RefIndex* __restrict__ refs, const uint32_t* __restrict__ q_kmer,
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const RefIndex* __res
     const RefIndex r = refs[blockIdx.y];
     uint32_t km = q_kmer[i];
     uint32_t lo = 0, hi = r.n;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (r.kmer[mid] < km) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)r.key[mid] < km) lo = mid + 1; else hi = mid; }
     uint32_t cnt = 0;
-    if (lo < r.n && r.kmer[lo] == km) {
+    if (lo < r.n && (uint32_t)r.key[lo] == km) {
         uint32_t step = 1;
-        while (lo + step < r.n && r.kmer[lo + step] == km) step <<= 1;
+        while (lo + step < r.n && (uint32_t)r.key[lo + step] == km) step <<= 1;
         uint32_t a = lo + (step >> 1), b = lo + step < r.n ? lo + step : r.n;   // kmer[a]==km, kmer[b]!=km or b==n
-        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if (r.kmer[mid] == km) a = mid; else b = mid; }
+        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)r.key[mid] == km) a = mid; else b = mid; }
         cnt = b - lo;
     }
     size_t o = (size_t)blockIdx.y * nq + i;
@@ -500,8 +500,8 @@ static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint3
     std::vector<uint64_t> h_rlen(n_pairs);
     for (uint32_t p = 0; p < n_pairs; p++) {
         const psk_sketch* r = refs[p];
-        h_refs[p].kmer = r->store && r->n_seeds ? r->store->idx_kmer + r->seed_off : nullptr;
-        h_refs[p].pm = r->store && r->n_seeds ? r->store->idx_pm + r->seed_off : nullptr;
+        h_refs[p].key = r->idx ? r->idx->key + r->idx_off : nullptr;
+        h_refs[p].pm = r->idx ? r->idx->pm + r->idx_off : nullptr;
         h_refs[p].n = (uint32_t)r->n_seeds; h_refs[p].pad = 0;
         h_rlen[p] = r->total_len;
     }

@@ -56,9 +56,14 @@ __device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ contig
     return lo;
 }
 
-__global__ void tile_contig_kernel(const ContigDesc* __restrict__ contigs, int n_contigs, uint32_t n_tiles, uint32_t* __restrict__ tile_ci) {
+// per tile: contig id and a compact copy of what the emit pass needs {first_tile, genome, contig_index, contig id}
+__global__ void tile_contig_kernel(const ContigDesc* __restrict__ contigs, int n_contigs, uint32_t n_tiles, uint32_t* __restrict__ tile_ci,
+                                   uint4* __restrict__ tile_info) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_tiles) tile_ci[t] = (uint32_t)find_contig(contigs, n_contigs, t);
+    if (t >= n_tiles) return;
+    int ci = find_contig(contigs, n_contigs, t);
+    tile_ci[t] = (uint32_t)ci;
+    tile_info[t] = make_uint4(contigs[ci].first_tile, contigs[ci].genome, contigs[ci].contig_index, (uint32_t)ci);
 }
 
 // reverse-complement of the 16 bases of a packed word
@@ -176,9 +181,9 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
 }
 
 __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
-    const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci, const uint32_t* __restrict__ packed,
+    const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed,
     const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
-    const uint32_t* __restrict__ genome_first_tile,
+    const uint32_t* __restrict__ genome_seed_off,
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
     uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ marker_count,
     SketchConsts C) {
@@ -191,13 +196,15 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     if (lane == 63) s_wave[wv] = incl;
-    const ContigDesc cd = contigs[tile_ci[tile]];
-    const uint32_t pos0 = (tile - cd.first_tile) * TILE_BASES;
-    const uint32_t* words = packed + (size_t)cd.first_tile * TILE_WORDS;   // the contig's packed stream
+    const uint4 ti = tile_info[tile];          // {first_tile, genome, contig_index, contig id}
+    const uint32_t t_off = tile_off[tile];
+    const uint32_t g_seed0 = genome_seed_off[ti.y];
+    const uint32_t pos0 = (tile - ti.x) * TILE_BASES;
+    const uint32_t* words = packed + (size_t)ti.x * TILE_WORDS;   // the contig's packed stream
     __syncthreads();
     int wave_base = 0;
     for (int w = 0; w < wv; w++) wave_base += s_wave[w];
-    uint32_t out = tile_off[tile] + wave_base + incl - cnt;
+    uint32_t out = t_off + wave_base + incl - cnt;
     // pass A: seed records; remember which of this lane's seeds are markers
     uint64_t m = m0, mark = 0;
     while (m) {
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
         uint64_t cs = canon ? f : r;
         seed_kmer[out] = (uint32_t)cs;
         seed_pos[out] = p;
-        uint32_t meta = (cd.contig_index << 1) | canon;
+        uint32_t meta = (ti.z << 1) | canon;
         seed_meta[out] = meta;
         seed_pm[out] = ((uint64_t)p << 32) | meta;
         out++;
@@ -226,13 +233,13 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
     __syncthreads();
     if (tid == 0) {
         uint32_t tot = s_mwave[0] + s_mwave[1] + s_mwave[2] + s_mwave[3];
-        s_mbase = tot ? atomicAdd(&marker_count[cd.genome], tot) : 0;
+        s_mbase = tot ? atomicAdd(&marker_count[ti.y], tot) : 0;
     }
     __syncthreads();
     if (!mark) return;
     uint32_t mbase = 0;
     for (int w = 0; w < wv; w++) mbase += s_mwave[w];
-    size_t slot = (size_t)tile_off[genome_first_tile[cd.genome]] + s_mbase + mbase + mincl - mc;
+    size_t slot = (size_t)g_seed0 + s_mbase + mbase + mincl - mc;
     while (mark) {
         int i = __ffsll((unsigned long long)mark) - 1;
         mark &= mark - 1;
@@ -362,8 +369,9 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     uint32_t *d_cnt = d_offs + o_cnt, *d_toff = d_offs + o_toff, *d_gft = d_offs + o_gft, *d_cft = d_offs + o_cft,
              *d_goff = d_offs + o_goff, *d_coff = d_offs + o_coff, *d_mcnt = d_offs + o_mcnt, *d_sbeg = d_offs + o_sbeg,
              *d_send = d_offs + o_send, *d_moff = d_offs + o_moff;
-    if ((rc = ctx->s_counts.reserve(sizeof(uint32_t) * ((size_t)n_tiles + 1))) != PSK_OK) return fail(rc);
-    uint32_t* d_tci = (uint32_t*)ctx->s_counts.p;
+    if ((rc = ctx->s_counts.reserve(sizeof(uint4) * ((size_t)n_tiles + 1) + sizeof(uint32_t) * ((size_t)n_tiles + 4))) != PSK_OK) return fail(rc);
+    uint4* d_tinfo = (uint4*)ctx->s_counts.p;
+    uint32_t* d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
     ContigDesc* d_desc = (ContigDesc*)ctx->s_desc.p;
     uint32_t* d_packed = (uint32_t*)ctx->s_packed.p;
     uint64_t* d_mask = (uint64_t*)ctx->s_mask.p;
@@ -389,7 +397,7 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     HIPF(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
 
     // ---- pass 1 ----
-    hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci);
+    hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci, d_tinfo);
     ctx->t_begin(K_SKETCH_SCAN);
     hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
     ctx->t_end();
@@ -414,13 +422,12 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     auto store = std::make_shared<SketchStore>();
     size_t ns = total_seeds;
     size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
-           b_ikmer = align_up(b_meta + 4 * ns, 256), b_ipm = align_up(b_ikmer + 4 * ns, 256),
-           b_pm = align_up(b_ipm + 8 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
+           b_pm = align_up(b_meta + 4 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
     store->ctx = ctx;
     { psk_status prc = ctx->pool_alloc(b_end, &store->base, &store->bytes); if (prc != PSK_OK) return fail(prc); }
     char* sb = (char*)store->base;
     store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
-    store->idx_kmer = (uint32_t*)(sb + b_ikmer); store->idx_pm = (uint64_t*)(sb + b_ipm); store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
+    store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
     HIPF(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
 
     if ((rc = ctx->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2))) != PSK_OK) return fail(rc);   // stage + sorted
@@ -430,7 +437,7 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
 
     // ---- pass 2 ----
     ctx->t_begin(K_SKETCH_EMIT);
-    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_desc, d_tci, d_packed, d_mask, d_toff, d_gft,
+    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff,
                        store->seed_kmer, store->seed_pos, store->seed_meta, d_pm, d_mstage, d_mcnt, C);
     ctx->t_end();
     ctx->t_begin(K_SKETCH_SORT);
@@ -476,43 +483,58 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     return PSK_OK;
 }
 
-// ---- reference index: stable per-genome radix sort of the seeds by k-mer, built on first use ----
+// ---- reference index, built on first use: ONE device radix sort of (slot<<32 | kmer) over all the
+// sketches that need one; LSD radix sort is stable, so equal k-mers keep their (contig,pos) order ----
+struct IdxSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t out_off; };
+
+__global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint64_t* __restrict__ val) {
+    const IdxSeg sg = segs[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) {
+        key[sg.out_off + i] = ((uint64_t)blockIdx.y << 32) | sg.kmer[i];
+        val[sg.out_off + i] = sg.pm[i];
+    }
+}
+
 psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n) {
     hipStream_t st = ctx->stream;
     std::vector<const psk_sketch*> todo;
-    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->indexed && refs[i]->n_seeds && refs[i]->store) todo.push_back(refs[i]);
-    // group by store: one segmented sort per store, segments = the sketches' seed ranges
-    std::sort(todo.begin(), todo.end(), [](const psk_sketch* a, const psk_sketch* b) {
-        return a->store.get() != b->store.get() ? a->store.get() < b->store.get() : a->seed_off < b->seed_off; });
+    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store) {
+        bool dup = false;
+        for (const psk_sketch* t : todo) if (t == refs[i]) { dup = true; break; }
+        if (!dup) todo.push_back(refs[i]);
+    }
+    const uint64_t GROUP = 1ull << 26;   // seeds per sort
     size_t i0 = 0;
     while (i0 < todo.size()) {
-        size_t i1 = i0;
-        SketchStore* S = todo[i0]->store.get();
-        std::vector<uint32_t> seg;   // begins then ends
-        while (i1 < todo.size() && todo[i1]->store.get() == S) {
-            if (i1 == i0 || todo[i1]->seed_off != todo[i1 - 1]->seed_off) seg.push_back((uint32_t)todo[i1]->seed_off);
-            i1++;
+        size_t i1 = i0; uint64_t T = 0;
+        while (i1 < todo.size() && i1 - i0 < 65535 && (i1 == i0 || T + todo[i1]->n_seeds <= GROUP)) { T += todo[i1]->n_seeds; i1++; }
+        const uint32_t m = (uint32_t)(i1 - i0);
+        std::vector<IdxSeg> segs(m);
+        uint32_t off = 0, maxn = 0;
+        for (uint32_t j = 0; j < m; j++) {
+            const psk_sketch* s = todo[i0 + j];
+            segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, s->store->seed_pm + s->seed_off, (uint32_t)s->n_seeds, off};
+            off += (uint32_t)s->n_seeds; maxn = std::max(maxn, (uint32_t)s->n_seeds);
         }
-        const size_t m = seg.size();
-        seg.resize(2 * m);
-        {
-            size_t j = 0;
-            for (size_t t = i0; t < i1; t++) if (t == i0 || todo[t]->seed_off != todo[t - 1]->seed_off) { seg[m + j] = (uint32_t)(todo[t]->seed_off + todo[t]->n_seeds); j++; }
-        }
-        uint32_t hi = 0;
-        for (size_t j = 0; j < m; j++) hi = std::max(hi, seg[m + j]);
-        PSK_TRY(ctx->s_offs.reserve(sizeof(uint32_t) * 2 * m));
-        uint32_t* d_seg = (uint32_t*)ctx->s_offs.p;
-        PSK_HIP(hipMemcpyAsync(d_seg, seg.data(), sizeof(uint32_t) * 2 * m, hipMemcpyHostToDevice, st));
-        size_t tmp = 0;
-        const int bits = 2 * todo[i0]->params.k;
-        PSK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, S->seed_kmer, S->idx_kmer, S->seed_pm, S->idx_pm, (int)hi, (int)m, d_seg, d_seg + m, 0, bits, st));
-        PSK_TRY(ctx->s_tmp.reserve(tmp));
+        auto ix = std::make_shared<IndexStore>();
+        ix->ctx = ctx;
+        size_t kb = align_up(8 * (size_t)T, 256);
+        PSK_TRY(ctx->pool_alloc(2 * kb, &ix->base, &ix->bytes));
+        ix->key = (uint64_t*)ix->base; ix->pm = (uint64_t*)((char*)ix->base + kb);
+        PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
+        PSK_TRY(ctx->s_mark.reserve(2 * kb));
+        uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint64_t* v_in = (uint64_t*)((char*)ctx->s_mark.p + kb);
+        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SKETCH_SORT);
-        PSK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->s_tmp.p, tmp, S->seed_kmer, S->idx_kmer, S->seed_pm, S->idx_pm, (int)hi, (int)m, d_seg, d_seg + m, 0, bits, st));
+        hipLaunchKernelGGL(index_gather_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, k_in, v_in);
+        int slot_bits = 1; while ((1u << slot_bits) < m) slot_bits++;
+        size_t tmp = 0;
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->pm, (int)T, 0, 32 + slot_bits, st));
+        PSK_TRY(ctx->s_tmp.reserve(tmp));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->pm, (int)T, 0, 32 + slot_bits, st));
         ctx->t_end();
-        PSK_HIP(hipStreamSynchronize(st));   // seg (host vector) is read by the async copy above
-        for (size_t t = i0; t < i1; t++) todo[t]->indexed = true;
+        PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
+        for (uint32_t j = 0; j < m; j++) { todo[i0 + j]->idx = ix; todo[i0 + j]->idx_off = segs[j].out_off; }
         i0 = i1;
     }
     return PSK_OK;
