@@ -180,6 +180,9 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
     return y ^ (n == 32 ? ~0ull : ((1ull << (2 * n)) - 1));
 }
 
+// One SEED per lane (not one 64-base stripe per lane): the tile's seed bits are ranked with a block scan,
+// lane j then locates the j-th set bit of the tile by binary search over the per-stripe prefix counts, so
+// every lane of a wave does the same amount of work (k-mer rebuild, canonical form, marker hash).
 __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
     const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed,
     const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
@@ -187,66 +190,79 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
     uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ marker_count,
     SketchConsts C) {
+    __shared__ unsigned long long s_mask[TILE_THREADS];
+    __shared__ __align__(16) uint32_t s_words[TILE_WORDS + 8];   // the tile's packed bases + 4 words either side
+    __shared__ uint32_t s_incl[TILE_THREADS];           // inclusive prefix of per-stripe seed counts
     __shared__ uint32_t s_wave[TILE_THREADS / 64], s_mwave[TILE_THREADS / 64], s_mbase;
     const uint32_t tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t m0 = seedmask[(size_t)tile * TILE_MASKS + tid];
-    const int cnt = __popcll(m0);
-    int incl = cnt;   // block exclusive scan of the per-lane seed counts
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) s_wave[wv] = incl;
     const uint4 ti = tile_info[tile];          // {first_tile, genome, contig_index, contig id}
     const uint32_t t_off = tile_off[tile];
     const uint32_t g_seed0 = genome_seed_off[ti.y];
-    const uint32_t pos0 = (tile - ti.x) * TILE_BASES;
-    const uint32_t* words = packed + (size_t)ti.x * TILE_WORDS;   // the contig's packed stream
+    const int cnt = __popcll(m0);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wave[wv] = incl;
+    s_mask[tid] = m0;
     __syncthreads();
     int wave_base = 0;
     for (int w = 0; w < wv; w++) wave_base += s_wave[w];
-    uint32_t out = t_off + wave_base + incl - cnt;
-    // pass A: seed records; remember which of this lane's seeds are markers
-    uint64_t m = m0, mark = 0;
-    while (m) {
-        int i = __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        uint32_t p = pos0 + 64u * tid + i;                 // last base of the 21-base window
-        uint32_t e = p - C.d;                              // last base of the seed k-mer
-        uint64_t f = get_bases(words, e + 1 - C.k, C.k);
-        uint64_t r = revcomp(f, C.k);
-        uint32_t canon = f < r;
-        uint64_t cs = canon ? f : r;
-        seed_kmer[out] = (uint32_t)cs;
-        seed_pos[out] = p;
-        uint32_t meta = (ti.z << 1) | canon;
-        seed_meta[out] = meta;
-        seed_pm[out] = ((uint64_t)p << 32) | meta;
-        out++;
-        if (mm_hash64(cs) < C.thr_marker) mark |= 1ull << i;
+    s_incl[tid] = wave_base + incl;
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const uint32_t pos0 = (tile - ti.x) * TILE_BASES;
+    {   // stage the packed tile in LDS with coalesced 16-byte loads; k-mers are rebuilt from LDS
+        const uint32_t* gsrc = packed + (size_t)tile * TILE_WORDS;
+        *reinterpret_cast<uint4*>(&s_words[4 + 4 * tid]) = *reinterpret_cast<const uint4*>(gsrc + 4 * tid);
+        if (tid < 4) s_words[tid] = tile > ti.x ? gsrc[tid - 4] : 0u;                 // halo: previous tile of the same contig
+        if (tid >= 4 && tid < 8) s_words[TILE_WORDS + tid] = gsrc[TILE_WORDS + tid - 4]; // next words (slot or padding)
     }
-    // pass B: one atomic per tile reserves the tile's slots in the genome's marker staging area
-    const int mc = __popcll(mark);
-    int mincl = mc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(mincl, o); if (lane >= o) mincl += v; }
-    if (lane == 63) s_mwave[wv] = mincl;
+    const uint32_t* words = s_words + 4;      // word w of the tile; base b of the tile lives in word b/16
     __syncthreads();
-    if (tid == 0) {
-        uint32_t tot = s_mwave[0] + s_mwave[1] + s_mwave[2] + s_mwave[3];
-        s_mbase = tot ? atomicAdd(&marker_count[ti.y], tot) : 0;
-    }
-    __syncthreads();
-    if (!mark) return;
-    uint32_t mbase = 0;
-    for (int w = 0; w < wv; w++) mbase += s_mwave[w];
-    size_t slot = (size_t)g_seed0 + s_mbase + mbase + mincl - mc;
-    while (mark) {
-        int i = __ffsll((unsigned long long)mark) - 1;
-        mark &= mark - 1;
-        uint32_t p = pos0 + 64u * tid + i;
-        uint64_t f21 = get_bases(words, p + 1 - K_MARKER, K_MARKER);
-        uint64_t r21 = revcomp(f21, K_MARKER);
-        marker_stage[slot++] = f21 < r21 ? f21 : r21;
+    uint32_t mtotal_before = 0;   // markers reserved by earlier rounds of this tile
+    for (uint32_t j0 = 0; j0 < total; j0 += TILE_THREADS) {       // one round unless the tile has > 256 seeds
+        const uint32_t j = j0 + tid;
+        const bool have = j < total;
+        uint32_t p = 0; uint64_t cs = 0; bool is_marker = false;
+        if (have) {
+            int lo = 0, hi = TILE_THREADS - 1;                    // first stripe with incl > j
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > j) hi = mid; else lo = mid + 1; }
+            unsigned long long mm = s_mask[lo];
+            uint32_t r = j - (s_incl[lo] - (uint32_t)__popcll(mm));   // rank of the wanted bit inside the stripe
+            for (uint32_t q = 0; q < r; q++) mm &= mm - 1;
+            const int i = __ffsll(mm) - 1;
+            const uint32_t pl = 64u * lo + i;                     // tile-relative; +64 keeps the halo index positive
+            p = pos0 + pl;                                        // last base of the 21-base window
+            uint64_t f = get_bases(words - 4, pl + 64 + 1 - C.d - C.k, C.k);
+            uint64_t rc = revcomp(f, C.k);
+            uint32_t canon = f < rc;
+            cs = canon ? f : rc;
+            uint32_t meta = (ti.z << 1) | canon;
+            seed_kmer[t_off + j] = (uint32_t)cs;
+            seed_pos[t_off + j] = p;
+            seed_meta[t_off + j] = meta;
+            seed_pm[t_off + j] = ((uint64_t)p << 32) | meta;
+            is_marker = mm_hash64(cs) < C.thr_marker;
+        }
+        // marker slots: ballot inside the wave, one atomic per tile and round
+        unsigned long long bal = __ballot(is_marker);
+        if (lane == 0) s_mwave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = s_mwave[0] + s_mwave[1] + s_mwave[2] + s_mwave[3];
+            s_mbase = tot ? atomicAdd(&marker_count[ti.y], tot) : 0;
+        }
+        __syncthreads();
+        if (is_marker) {
+            uint32_t mb = 0;
+            for (int w = 0; w < wv; w++) mb += s_mwave[w];
+            uint64_t f21 = get_bases(words - 4, (p - pos0) + 64 + 1 - K_MARKER, K_MARKER);
+            uint64_t r21 = revcomp(f21, K_MARKER);
+            marker_stage[(size_t)g_seed0 + s_mbase + mb + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = f21 < r21 ? f21 : r21;
+        }
+        __syncthreads();
+        (void)mtotal_before;
     }
 }
 
