@@ -194,6 +194,10 @@ def main():
         alg_bytes = bases * 1.25 * args.steps / max(1, scan_n)   # per launch (a step may split into sub-batches)
         avg_s = (scan_ms / max(1, scan_n)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_sketch_scan.json")
+        if os.path.exists(pmc):   # PMC pass is offline (rocprofv3 --pmc, separate runs); scaled by this launch's bases
+            traffic = json.load(open(pmc))["traffic_bytes_per_base"] * bases * args.steps / max(1, scan_n)
         line = {
             "metric": "genome-pairs/sec (sketch+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -201,7 +205,7 @@ def main():
             "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_ms_per_step": kernel_ms,
         }

@@ -134,6 +134,11 @@ psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_ref
 psk_status psk_query(psk_db* db, const psk_sketch* query, const psk_query_opts* o,
                      psk_hit** hits, uint64_t* n_hits);
 
+/* n_queries x Database.query against one database (all-vs-all and metagenome-bin workloads, BASELINE
+ * configs[2]/[3]); offsets has n_queries+1 entries, hits of query i are hits[offsets[i]..offsets[i+1]). */
+psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries,
+                          const psk_query_opts* o, psk_hit** hits, uint64_t* offsets);
+
 #ifdef __cplusplus
 }
 #endif

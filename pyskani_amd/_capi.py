@@ -38,7 +38,7 @@ SYMBOLS = [
     "psk_ctx_synchronize", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
     "psk_sketch_export", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
-    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query",
+    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load():
     lib.psk_screen.argtypes = [vp, vp, C.c_double, C.c_int, vp, vp]
     lib.psk_chain.argtypes = [vp, C.POINTER(vp), u32, vp, C.POINTER(QueryOpts), C.POINTER(Hit)]
     lib.psk_query.argtypes = [vp, vp, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
+    lib.psk_query_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     _lib = lib
     return lib
 

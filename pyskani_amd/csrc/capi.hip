@@ -276,4 +276,27 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
     return PSK_OK;
 }
 
+/* Many queries against one database. Same result as n_queries x psk_query; hits of query i are
+ * hits[offsets[i] .. offsets[i+1]). This round it is a host loop over the single-query kernels. */
+psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                          psk_hit** hits, uint64_t* offsets) {
+    if (!db || (!queries && n_queries) || !o || !hits || !offsets) { psk_set_error("query_many: NULL argument"); return PSK_EINVAL; }
+    *hits = nullptr;
+    std::vector<psk_hit> all;
+    offsets[0] = 0;
+    for (uint32_t i = 0; i < n_queries; i++) {
+        psk_hit* h = nullptr; uint64_t n = 0;
+        psk_status rc = psk_query(db, queries[i], o, &h, &n);
+        if (rc != PSK_OK) return rc;
+        all.insert(all.end(), h, h + n);
+        free(h);
+        offsets[i + 1] = all.size();
+    }
+    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (all.size() ? all.size() : 1));
+    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+    if (!all.empty()) memcpy(outp, all.data(), sizeof(psk_hit) * all.size());
+    *hits = outp;
+    return PSK_OK;
+}
+
 }  // extern "C"

@@ -215,35 +215,57 @@ class Database:
             self._lock.release()
         return None
 
-    def query(self, name, *contigs, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
-              faster_small=False):
-        """Query the database with a genome (lib.rs:549-660); returns a list of `Hit`."""
+    def _opts(self, learned_ani, median, robust, cutoff, faster_small):
         global _warned_no_model
-        if not isinstance(name, str):
-            raise TypeError("name must be a str")
-        q = self._sketch(name, contigs, seed)
         # default rule: learned ANI when c >= 70 and not median (lib.rs:611-613, docstring :522-527)
         learned = learned_ani if learned_ani is not None else (self._params.c >= 70 and not median)
         if learned and learned_ani is None:
             # the GBDT weights live inside the skani crate and are not available to this build: say so
             if not _warned_no_model:
                 warnings.warn("pyskani_amd: no learned-ANI regression model is available; returning the raw "
-                              "chain ANI (pass learned_ani=False to silence, learned_ani=True raises)", RuntimeWarning, stacklevel=2)
+                              "chain ANI (pass learned_ani=False to silence, learned_ani=True raises)", RuntimeWarning, stacklevel=3)
                 _warned_no_model = True
             learned = False
-        opts = _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
+        return _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
                                float(cutoff) if cutoff else 0.0, 0.0)
+
+    def _hit(self, r, qname):
+        ref_name = self._lib.psk_db_name(self._h, r.ref_index).decode("utf-8")
+        hit = Hit(r.ani, qname, r.af_query, ref_name, r.af_ref)
+        hit._raw = {f: getattr(r, f) for f, _ in _capi.Hit._fields_}
+        return hit
+
+    def query_many(self, genomes, *, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
+                   faster_small=False):
+        """[(name, contigs...)] -> list of hit lists; equals [self.query(name, *contigs, ...) for ...].
+        An addition to the reference API for all-vs-all / many-bin workloads."""
+        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
+        sketches = [self._sketch(g[0], g[1:], seed) for g in genomes]
+        n = len(sketches)
+        arr = (C.c_void_p * max(n, 1))(*[s._h for s in sketches])
+        hits_p = C.POINTER(_capi.Hit)()
+        offs = (C.c_uint64 * (n + 1))()
+        _capi.check(self._lib.psk_query_many(self._h, arr, n, C.byref(opts), C.byref(hits_p), offs))
+        try:
+            return [[self._hit(hits_p[j], genomes[i][0]) for j in range(offs[i], offs[i + 1])] for i in range(n)]
+        finally:
+            if hits_p:
+                self._lib.psk_free(hits_p)
+
+    def query(self, name, *contigs, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
+              faster_small=False):
+        """Query the database with a genome (lib.rs:549-660); returns a list of `Hit`."""
+        if not isinstance(name, str):
+            raise TypeError("name must be a str")
+        q = self._sketch(name, contigs, seed)
+        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         hits_p = C.POINTER(_capi.Hit)()
         n = C.c_uint64(0)
         _capi.check(self._lib.psk_query(self._h, q._h, C.byref(opts), C.byref(hits_p), C.byref(n)))
         out = []
         try:
             for i in range(n.value):
-                r = hits_p[i]
-                ref_name = self._lib.psk_db_name(self._h, r.ref_index).decode("utf-8")
-                hit = Hit(r.ani, name, r.af_query, ref_name, r.af_ref)
-                hit._raw = {f: getattr(r, f) for f, _ in _capi.Hit._fields_}
-                out.append(hit)
+                out.append(self._hit(hits_p[i], name))
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)

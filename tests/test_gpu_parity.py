@@ -215,3 +215,33 @@ def test_full_size_properties(psk):
     for j, d in enumerate((0.005, 0.02, 0.05)):
         # conftest.mutate redraws the base uniformly, so the substitution rate is 0.75 d
         assert abs(hits[f"d{j}"].identity - (1 - 0.75 * d)) < 0.003
+
+
+def test_metagenome_mode_short_contigs(psk, oracle):
+    """BASELINE configs[3] in miniature: c=30 / marker_c=200, short contigs as separate queries, both
+    faster_small settings; every hit list must equal the oracle's."""
+    rng = np.random.default_rng(31)
+    anc = [random_genome(rng, 300000) for _ in range(2)]
+    refs = [(f"r{f}_{j}", mutate(rng, a, d)) for f, a in enumerate(anc) for j, d in enumerate((0.0, 0.02, 0.05))]
+    db = psk.Database(compression=30, marker_compression=200)
+    for n, s in refs:
+        db.sketch(n, s)
+    osk = [(n, oracle.Sketch([s], c=30, marker_c=200)) for n, s in refs]
+    contigs = []
+    for i in range(6):
+        L = int(np.exp(rng.uniform(np.log(2000), np.log(50000))))
+        a = anc[i % 2]; st = int(rng.integers(0, len(a) - L))
+        contigs.append((f"ctg{i}", mutate(rng, a[st:st + L], rng.uniform(0, 0.05))))
+    for fs in (False, True):
+        got_all = db.query_many(contigs, learned_ani=False, faster_small=fs)
+        for (name, seq), got in zip(contigs, got_all):
+            want = {n: r for n, r in oracle.query(osk, oracle.Sketch([seq], c=30, marker_c=200), faster_small=fs)}
+            g = {h.reference_name: h for h in got}
+            assert set(g) == set(want), (name, fs, set(g) ^ set(want))
+            for n, w in want.items():
+                for f in INT_FIELDS:
+                    assert g[n]._raw[f] == getattr(w, f), (name, n, f)
+                assert abs(g[n].identity - w.ani) < 1e-6 and abs(g[n].query_fraction - w.af_query) < 1e-6
+            # query_many == repeated query
+            single = {h.reference_name: h.identity for h in db.query(name, seq, learned_ani=False, faster_small=fs)}
+            assert single == {n: h.identity for n, h in g.items()}
