@@ -277,20 +277,41 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
 }
 
 /* Many queries against one database. Same result as n_queries x psk_query; hits of query i are
- * hits[offsets[i] .. offsets[i+1]). This round it is a host loop over the single-query kernels. */
+ * hits[offsets[i] .. offsets[i+1]). Queries are screened in one launch per batch (one workgroup per
+ * (ref, query)) and all surviving pairs are chained in shared launches (chain_pairs_impl). */
 psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                           psk_hit** hits, uint64_t* offsets) {
     if (!db || (!queries && n_queries) || !o || !hits || !offsets) { psk_set_error("query_many: NULL argument"); return PSK_EINVAL; }
     *hits = nullptr;
-    std::vector<psk_hit> all;
     offsets[0] = 0;
-    for (uint32_t i = 0; i < n_queries; i++) {
-        psk_hit* h = nullptr; uint64_t n = 0;
-        psk_status rc = psk_query(db, queries[i], o, &h, &n);
-        if (rc != PSK_OK) return rc;
-        all.insert(all.end(), h, h + n);
-        free(h);
-        offsets[i + 1] = all.size();
+    psk_ctx* ctx = db->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
+    const uint32_t n = (uint32_t)db->refs.size();
+    std::vector<psk_hit> all;
+    const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
+    const uint32_t QB = n ? std::max<uint32_t>(1, std::min<uint32_t>(4096, (1u << 26) / n)) : 1;   // queries per round
+    std::vector<uint8_t> pass;
+    std::vector<const psk_sketch*> pr, pq;
+    std::vector<uint32_t> pri, pqi;
+    std::vector<psk_hit> res;
+    for (uint32_t b = 0; b < n_queries; b += QB) {
+        const uint32_t m = std::min(QB, n_queries - b);
+        for (uint32_t i = 0; i < m; i++) if (!queries[b + i]) { psk_set_error("query_many: NULL query %u", b + i); return PSK_EINVAL; }
+        pass.assign((size_t)m * n, 0);
+        if (n) PSK_TRY(screen_many_impl(db, queries + b, m, screen_val, !o->faster_small, pass.data()));
+        pr.clear(); pq.clear(); pri.clear(); pqi.clear();
+        for (uint32_t i = 0; i < m; i++) for (uint32_t r = 0; r < n; r++) if (pass[(size_t)i * n + r]) {
+            pr.push_back(db->refs[r]); pq.push_back(queries[b + i]); pri.push_back(r); pqi.push_back(i);
+        }
+        res.resize(pr.size());
+        if (!pr.empty()) PSK_TRY(chain_pairs_impl(ctx, pr.data(), pq.data(), (uint32_t)pr.size(), o, res.data()));
+        size_t k = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            for (; k < pr.size() && pqi[k] == i; k++) if (res[k].ani > 0.1f) { res[k].ref_index = pri[k]; all.push_back(res[k]); }   // lib.rs:654
+            offsets[b + i + 1] = all.size();
+        }
     }
     psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (all.size() ? all.size() : 1));
     if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }

@@ -204,5 +204,9 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
 psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n);
 psk_status screen_impl(psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
+psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
+                            const psk_query_opts* o, psk_hit* out);
+psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, double screen_val, int rescue_small,
+                            uint8_t* pass /* [n_queries][n_refs] */);
 psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);

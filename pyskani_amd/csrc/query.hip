@@ -10,6 +10,7 @@
 #include <algorithm>
 
 // ------------------------------------------------------------------ screen
+static inline size_t al256s(size_t x) { return (x + 255) & ~(size_t)255; }
 struct MarkerSet { const uint64_t* p; uint32_t n; uint32_t pad; };
 
 __global__ __launch_bounds__(256) void screen_kernel(const MarkerSet* __restrict__ refs, const uint64_t* __restrict__ qm,
@@ -78,46 +79,141 @@ psk_status screen_impl(psk_db* db, const psk_sketch* q, double screen_val, int r
     return PSK_OK;
 }
 
-// ------------------------------------------------------------------ anchors
-struct RefIndex { const uint64_t* key; const uint64_t* pm; uint32_t n; uint32_t pad; };   // key = slot<<32 | kmer
-
-// one thread per (pair, query seed): range of equal k-mers in the ref index
-__global__ __launch_bounds__(256) void anchor_count_kernel(const RefIndex* __restrict__ refs, const uint32_t* __restrict__ q_kmer,
-                                                           uint32_t nq, uint32_t* __restrict__ lb_out, uint32_t* __restrict__ cnt_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    const RefIndex r = refs[blockIdx.y];
-    uint32_t km = q_kmer[i];
-    uint32_t lo = 0, hi = r.n;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)r.key[mid] < km) lo = mid + 1; else hi = mid; }
+// many queries x all refs: one workgroup per (ref, query); pass[q * n_refs + r]
+__global__ __launch_bounds__(256) void screen_many_kernel(const MarkerSet* __restrict__ refs, const MarkerSet* __restrict__ queries,
+                                                          uint32_t n_refs, double thresh, int rescue_small, uint8_t* __restrict__ pass) {
+    __shared__ uint32_t s_cnt[4];
+    const MarkerSet r = refs[blockIdx.x];
+    const MarkerSet q = queries[blockIdx.y];
+    const uint32_t small = q.n < r.n ? q.n : r.n;
     uint32_t cnt = 0;
-    if (lo < r.n && (uint32_t)r.key[lo] == km) {
-        uint32_t step = 1;
-        while (lo + step < r.n && (uint32_t)r.key[lo + step] == km) step <<= 1;
-        uint32_t a = lo + (step >> 1), b = lo + step < r.n ? lo + step : r.n;   // kmer[a]==km, kmer[b]!=km or b==n
-        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)r.key[mid] == km) a = mid; else b = mid; }
-        cnt = b - lo;
+    if (!(rescue_small && small < SMALL_MARKER_COUNT) && small > 0) {
+        for (uint32_t i = threadIdx.x; i < q.n; i += blockDim.x) {
+            uint64_t m = q.p[i];
+            uint32_t lo = 0, hi = r.n;
+            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (r.p[mid] < m) lo = mid + 1; else hi = mid; }
+            cnt += (lo < r.n && r.p[lo] == m);
+        }
     }
-    size_t o = (size_t)blockIdx.y * nq + i;
-    lb_out[o] = lo; cnt_out[o] = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sh = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int ok;
+        if (rescue_small && small < SMALL_MARKER_COUNT) ok = 1;
+        else if (small == 0) ok = 0;
+        else ok = ((double)sh / (double)small) > thresh;
+        pass[(size_t)blockIdx.y * n_refs + blockIdx.x] = (uint8_t)ok;
+    }
 }
 
-__global__ __launch_bounds__(256) void anchor_emit_kernel(const RefIndex* __restrict__ refs, const uint32_t* __restrict__ q_pos,
-                                                          const uint32_t* __restrict__ q_meta, uint32_t nq,
+static psk_status upload_marker_table(psk_db* db) {
+    psk_ctx* ctx = db->ctx;
+    const uint32_t n = (uint32_t)db->refs.size();
+    if (!db->tables_dirty) return PSK_OK;
+    std::vector<MarkerSet> h(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const psk_sketch* r = db->refs[i];
+        h[i].p = r->store ? r->store->markers + r->marker_off : nullptr;
+        h[i].n = (uint32_t)r->n_markers; h[i].pad = 0;
+    }
+    PSK_TRY(db->d_marker_ptr.reserve(sizeof(MarkerSet) * n));
+    PSK_HIP(hipMemcpyAsync(db->d_marker_ptr.p, h.data(), sizeof(MarkerSet) * n, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(hipStreamSynchronize(ctx->stream));
+    db->tables_dirty = false;
+    return PSK_OK;
+}
+
+psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small, uint8_t* pass) {
+    psk_ctx* ctx = db->ctx;
+    const uint32_t n = (uint32_t)db->refs.size();
+    if (n == 0 || nq == 0) return PSK_OK;
+    hipStream_t st = ctx->stream;
+    PSK_TRY(upload_marker_table(db));
+    const double thresh = pow(screen_val, (double)K_MARKER);
+    const uint32_t per = std::max<uint32_t>(1, std::min<uint32_t>(65535, (1u << 24) / n));   // queries per launch
+    std::vector<MarkerSet> hq;
+    for (uint32_t b = 0; b < nq; b += per) {
+        const uint32_t m = std::min(per, nq - b);
+        hq.resize(m);
+        for (uint32_t i = 0; i < m; i++) {
+            const psk_sketch* q = queries[b + i];
+            hq[i].p = q->store ? q->store->markers + q->marker_off : nullptr; hq[i].n = (uint32_t)q->n_markers; hq[i].pad = 0;
+        }
+        PSK_TRY(ctx->q_a.reserve(al256s(sizeof(MarkerSet) * m) + (size_t)m * n));
+        MarkerSet* d_q = (MarkerSet*)ctx->q_a.p;
+        uint8_t* d_pass = (uint8_t*)ctx->q_a.p + al256s(sizeof(MarkerSet) * m);
+        PSK_HIP(hipMemcpyAsync(d_q, hq.data(), sizeof(MarkerSet) * m, hipMemcpyHostToDevice, st));
+        ctx->t_begin(K_SCREEN);
+        hipLaunchKernelGGL(screen_many_kernel, dim3(n, m), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, thresh, rescue_small, d_pass);
+        ctx->t_end();
+        PSK_HIP(hipMemcpyAsync(pass + (size_t)b * n, d_pass, (size_t)m * n, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipStreamSynchronize(st));
+    }
+    return PSK_OK;
+}
+
+// ------------------------------------------------------------------ anchors
+// One (reference, query) pair of a launch. Pairs may mix queries (query_many / all-vs-all).
+struct PairDesc {
+    const uint64_t* r_key; const uint64_t* r_pm;                              // ref index slice, key = slot<<32 | kmer
+    const uint32_t* q_kmer; const uint32_t* q_pos; const uint32_t* q_meta;   // query seeds, (contig,pos) order
+    const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
+    const uint32_t* q_contig_start;
+    uint64_t q_total_len, r_total_len;
+    uint32_t r_n, q_n;
+};
+// sbase[p] = first (pair, query seed) item of pair p in lb/cnt/aoff; cbase[p] = first row of pair p in the chunk table
+
+__device__ __forceinline__ uint32_t find_le(const uint32_t* __restrict__ base, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n - 1;   // largest p in [0,n) with base[p] <= x
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (base[mid] <= x) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// one lane per (pair, query seed): range of equal k-mers in the ref index
+__global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                           uint32_t n_pairs, uint32_t n_items,
+                                                           uint32_t* __restrict__ lb_out, uint32_t* __restrict__ cnt_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t p = find_le(sbase, n_pairs, i);
+    const PairDesc& P = pairs[p];
+    const uint64_t* __restrict__ key = P.r_key;
+    const uint32_t rn = P.r_n;
+    uint32_t km = P.q_kmer[i - sbase[p]];
+    uint32_t lo = 0, hi = rn;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)key[mid] < km) lo = mid + 1; else hi = mid; }
+    uint32_t cnt = 0;
+    if (lo < rn && (uint32_t)key[lo] == km) {
+        uint32_t step = 1;
+        while (lo + step < rn && (uint32_t)key[lo + step] == km) step <<= 1;
+        uint32_t a = lo + (step >> 1), b = lo + step < rn ? lo + step : rn;   // key[a]==km, key[b]!=km or b==n
+        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)key[mid] == km) a = mid; else b = mid; }
+        cnt = b - lo;
+    }
+    lb_out[i] = lo; cnt_out[i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                          uint32_t n_pairs, uint32_t n_items,
                                                           const uint32_t* __restrict__ lb, const uint32_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ aoff,
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
                                                           uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    size_t o = (size_t)blockIdx.y * nq + i;
-    uint32_t c = cnt[o];
+    if (i >= n_items) return;
+    uint32_t c = cnt[i];
     if (c == 0) return;
-    const RefIndex r = refs[blockIdx.y];
-    uint32_t l = lb[o], dst = aoff[o];
-    uint32_t qp = q_pos[i], qm = q_meta[i];
+    const uint32_t p = find_le(sbase, n_pairs, i);
+    const PairDesc& P = pairs[p];
+    const uint32_t j0 = i - sbase[p];
+    uint32_t l = lb[i], dst = aoff[i];
+    uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
     for (uint32_t j = 0; j < c; j++) {
-        uint64_t pm = r.pm[l + j];
+        uint64_t pm = P.r_pm[l + j];
         uint32_t rmeta = (uint32_t)pm;
         a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
         a_rp[dst + j] = (uint32_t)(pm >> 32);
@@ -125,30 +221,36 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const RefIndex* __rest
     }
 }
 
+// pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
+__global__ void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= n_pairs) pstart[p] = aoff[sbase[p]];
+}
+
 // nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
 __global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
-                                                          const uint32_t* __restrict__ aoff, uint32_t nq, uint32_t n_pairs,
+                                                          const uint32_t* __restrict__ pstart, uint32_t n_pairs,
                                                           uint32_t total, uint32_t* __restrict__ nxt) {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= total) return;
-    uint32_t lo = 0, hi = n_pairs - 1;   // pair p owns [aoff[p*nq], aoff[(p+1)*nq])
-    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (aoff[(size_t)mid * nq] <= a) lo = mid; else hi = mid - 1; }
-    uint32_t pend = aoff[(size_t)(lo + 1) * nq];
+    const uint32_t p = find_le(pstart, n_pairs, a);
+    uint32_t pend = pstart[p + 1];
     uint64_t key = ((uint64_t)a_qc[a] << 32) + (uint64_t)a_qp[a] + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
     uint32_t l = a + 1, h = pend;
     while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)a_qc[mid] << 32) | a_qp[mid]; if (k2 <= key) l = mid + 1; else h = mid; }
     nxt[a] = l;
 }
 
-__global__ void chunk_heads_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ nxt, uint32_t nq,
-                                   uint32_t n_pairs, uint32_t max_chunks, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+__global__ void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ cbase,
+                                   uint32_t n_pairs, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
                                    uint32_t* __restrict__ err) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
-    uint32_t h = aoff[(size_t)p * nq], pend = aoff[(size_t)(p + 1) * nq], n = 0;
+    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
+    uint32_t h = pstart[p], pend = pstart[p + 1], n = 0;
     while (h < pend) {
         uint32_t e = nxt[h];
-        if (n < max_chunks) chunks[(size_t)p * max_chunks + n] = make_uint2(h, e); else atomicOr(err, 1u);
+        if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, e); else atomicOr(err, 1u);
         n++; h = e;
     }
     n_chunks[p] = n < max_chunks ? n : max_chunks;
@@ -159,9 +261,8 @@ struct ChunkOut { uint32_t anchors, seeds, n_intervals, flags; uint64_t cov_q, c
 
 struct ChainArgs {
     const uint32_t *a_qp, *a_qc, *a_rp, *a_rm;
-    const uint2* chunks; const uint32_t* n_chunks; uint32_t max_chunks, n_pairs;
-    const uint32_t* q_seed_pos;      // store base
-    const uint32_t* q_contig_start;  // query's slice of contig_seed_start (global seed offsets)
+    const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs, n_rows;
+    const PairDesc* pairs;
     ChunkOut* out;
     // serial-path scratch, one entry per anchor
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
@@ -181,18 +282,19 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 
 // number of query seeds on contig qc with pos in [lo, hi]
-__device__ uint32_t seeds_between(const ChainArgs& A, uint32_t qc, uint32_t lo, uint32_t hi) {
-    uint32_t a = A.q_contig_start[qc], b = A.q_contig_start[qc + 1];
+__device__ uint32_t seeds_between(const PairDesc& P, uint32_t qc, uint32_t lo, uint32_t hi) {
+    const uint32_t* __restrict__ pos = P.q_seed_pos_base;
+    uint32_t a = P.q_contig_start[qc], b = P.q_contig_start[qc + 1];
     uint32_t l = a, r = b;
-    while (l < r) { uint32_t m = (l + r) >> 1; if (A.q_seed_pos[m] < lo) l = m + 1; else r = m; }
+    while (l < r) { uint32_t m = (l + r) >> 1; if (pos[m] < lo) l = m + 1; else r = m; }
     uint32_t first = l; r = b;
-    while (l < r) { uint32_t m = (l + r) >> 1; if (A.q_seed_pos[m] <= hi) l = m + 1; else r = m; }
+    while (l < r) { uint32_t m = (l + r) >> 1; if (pos[m] <= hi) l = m + 1; else r = m; }
     return l - first;
 }
 
 // Serial restatement of the oracle's per-chunk body, run by ONE lane on global scratch. Used for
 // chunks the LDS path cannot hold (many chain trees / candidates) and as an in-GPU cross-check.
-__device__ void chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t e, ChunkOut& o) {
+__device__ void chain_chunk_serial(const ChainArgs& A, const PairDesc& P, uint32_t s, uint32_t e, ChunkOut& o) {
     for (uint32_t x = s; x < e; x++) {
         int32_t bs = ANCHOR_SCORE; uint32_t bp = x;
         uint32_t qx = A.a_qp[x], rx = A.a_rp[x], mx = A.a_rm[x];
@@ -241,7 +343,7 @@ __device__ void chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t e, C
         }
     }
     o.anchors = anch; o.n_intervals = nk; o.cov_q = cq; o.cov_r = cr; o.flags = 1;
-    o.seeds = nk ? seeds_between(A, A.a_qc[s], left, right) : 0;
+    o.seeds = nk ? seeds_between(P, A.a_qc[s], left, right) : 0;
 }
 
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs A) {
@@ -252,12 +354,14 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     __shared__ uint32_t s_rootx[CHAIN_WAVES][RMAX];          // local index of each tree's root anchor
     __shared__ uint32_t s_cand[CHAIN_WAVES][6][64];          // score, q0, q1, r0, r1, nanch
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;
-    const uint32_t pair = slot / A.max_chunks, ck = slot % A.max_chunks;
-    if (pair >= A.n_pairs || ck >= A.n_chunks[pair]) return;
-    const uint2 se = A.chunks[(size_t)pair * A.max_chunks + ck];
+    const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
+    if (slot >= A.n_rows) return;
+    const uint32_t pair = find_le(A.cbase, A.n_pairs, slot), ck = slot - A.cbase[pair];
+    if (ck >= A.n_chunks[pair]) return;
+    const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
-    ChunkOut* op = &A.out[(size_t)pair * A.max_chunks + ck];
+    ChunkOut* op = &A.out[slot];
+    const PairDesc& P = A.pairs[pair];
     uint32_t (*ring)[RING] = s_ring[wave];
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
@@ -340,7 +444,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     if (!fast) {
         if (lane == 0) {
             ChunkOut o{};
-            chain_chunk_serial(A, s, e, o);
+            chain_chunk_serial(A, P, s, e, o);
             *op = o;
             atomicAdd(&A.stats[1], 1u);
         }
@@ -376,7 +480,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     if (lane == 0) {
         ChunkOut o{};
         o.anchors = anch; o.n_intervals = (uint32_t)__popcll(keptm); o.cov_q = cq; o.cov_r = cr; o.flags = 0;
-        o.seeds = o.n_intervals ? seeds_between(A, A.a_qc[s], left, right) : 0;
+        o.seeds = o.n_intervals ? seeds_between(P, A.a_qc[s], left, right) : 0;
         *op = o;
         atomicAdd(&A.stats[0], 1u);
     }
@@ -384,10 +488,8 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
 
 // ------------------------------------------------------------------ per-pair ANI / AF
 struct ReduceArgs {
-    const ChunkOut* chunks; const uint32_t* n_chunks; uint32_t max_chunks;
-    const uint32_t* aoff; uint32_t nq;
-    const uint64_t* ref_total_len;   // per pair
-    uint64_t q_total_len;
+    const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
+    const uint32_t* pstart; const PairDesc* pairs;
     int k, median, robust; double min_af;
     psk_hit* hits;
 };
@@ -399,7 +501,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     __shared__ unsigned long long s_acc[5];
     const uint32_t p = blockIdx.x;
     const uint32_t nc = R.n_chunks[p];
-    const ChunkOut* co = R.chunks + (size_t)p * R.max_chunks;
+    const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
     if (threadIdx.x == 0) { s_n = 0; for (int i = 0; i < 5; i++) s_acc[i] = 0; }
     __syncthreads();
     // integer totals (order-free)
@@ -456,7 +558,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     if (threadIdx.x == 0) {
         h.ref_index = p;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
-        h.n_anchors = R.aoff[(size_t)(p + 1) * R.nq] - R.aoff[(size_t)p * R.nq];
+        h.n_anchors = R.pstart[p + 1] - R.pstart[p];
         h.covered_query = s_acc[0]; h.covered_ref = s_acc[1]; h.sum_chain_anchors = s_acc[2]; h.sum_chunk_seeds = s_acc[3];
         if (m > 0) {
             double ani;
@@ -469,8 +571,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
                 double sum = 0; for (uint32_t i = lo; i < hi; i++) sum += s_v[i];
                 ani = sum / (double)(hi - lo);
             }
-            double afq = (double)s_acc[0] / (double)R.q_total_len; if (afq > 1) afq = 1;
-            double afr = (double)s_acc[1] / (double)R.ref_total_len[p]; if (afr > 1) afr = 1;
+            double afq = (double)s_acc[0] / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
+            double afr = (double)s_acc[1] / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;
             h.af_query = (float)afq; h.af_ref = (float)afr;
             if (!ok) h.ani = -2.0f;
             else if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
@@ -482,63 +584,75 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
 // ------------------------------------------------------------------ host orchestration
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_pairs, const psk_sketch* q,
-                              const psk_query_opts* o, psk_hit* out) {
+struct HostPair { const psk_sketch* r; const psk_sketch* q; };
+
+// one launch sequence over n_pairs (ref, query) pairs; out[p] in pair order
+static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs, const psk_query_opts* o, psk_hit* out) {
     hipStream_t st = ctx->stream;
-    const uint32_t nq = (uint32_t)q->n_seeds;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
-    // max chunks per pair: chunk heads on one contig are more than FRAGMENT_LENGTH apart
-    uint64_t max_chunks64 = 0;
-    for (uint32_t len : q->contig_len) max_chunks64 += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
-    const uint32_t max_chunks = (uint32_t)max_chunks64;
-    if (nq == 0 || max_chunks == 0) {
+    std::vector<PairDesc> h_pairs(n_pairs);
+    std::vector<uint32_t> h_sbase(n_pairs + 1), h_cbase(n_pairs + 1);
+    uint64_t items = 0, rows = 0;
+    for (uint32_t p = 0; p < n_pairs; p++) {
+        const psk_sketch* r = hp[p].r; const psk_sketch* q = hp[p].q;
+        PairDesc& P = h_pairs[p];
+        P.r_key = r->idx ? r->idx->key + r->idx_off : nullptr;
+        P.r_pm = r->idx ? r->idx->pm + r->idx_off : nullptr;
+        P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
+        P.q_n = q->store ? (uint32_t)q->n_seeds : 0;
+        P.q_kmer = q->store ? q->store->seed_kmer + q->seed_off : nullptr;
+        P.q_pos = q->store ? q->store->seed_pos + q->seed_off : nullptr;
+        P.q_meta = q->store ? q->store->seed_meta + q->seed_off : nullptr;
+        P.q_seed_pos_base = q->store ? q->store->seed_pos : nullptr;
+        P.q_contig_start = q->store ? q->store->contig_seed_start + q->contig_off : nullptr;
+        P.q_total_len = q->total_len; P.r_total_len = r->total_len;
+        h_sbase[p] = (uint32_t)items; h_cbase[p] = (uint32_t)rows;
+        items += P.q_n;
+        // chunk heads on one contig are more than FRAGMENT_LENGTH apart
+        uint64_t mc = 0;
+        if (P.q_n && P.r_n) for (uint32_t len : q->contig_len) mc += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
+        rows += mc;
+    }
+    h_sbase[n_pairs] = (uint32_t)items; h_cbase[n_pairs] = (uint32_t)rows;
+    if (items == 0 || rows == 0) {
         for (uint32_t p = 0; p < n_pairs; p++) { out[p] = psk_hit{}; out[p].ani = -1.0f; }
         return PSK_OK;
     }
-    // ---- tables ----
-    std::vector<RefIndex> h_refs(n_pairs);
-    std::vector<uint64_t> h_rlen(n_pairs);
-    for (uint32_t p = 0; p < n_pairs; p++) {
-        const psk_sketch* r = refs[p];
-        h_refs[p].key = r->idx ? r->idx->key + r->idx_off : nullptr;
-        h_refs[p].pm = r->idx ? r->idx->pm + r->idx_off : nullptr;
-        h_refs[p].n = (uint32_t)r->n_seeds; h_refs[p].pad = 0;
-        h_rlen[p] = r->total_len;
-    }
-    const size_t npq = (size_t)n_pairs * nq;
-    size_t o_refs = 0, o_rlen = al256(o_refs + sizeof(RefIndex) * n_pairs), o_lb = al256(o_rlen + 8 * (size_t)n_pairs),
-           o_cnt = al256(o_lb + 4 * npq), o_aoff = al256(o_cnt + 4 * (npq + 1)), o_nch = al256(o_aoff + 4 * (npq + 1)),
-           o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * (size_t)n_pairs * max_chunks),
-           o_hits = al256(o_cout + sizeof(ChunkOut) * (size_t)n_pairs * max_chunks), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
+    const size_t n_items = (size_t)items, n_rows = (size_t)rows;
+    size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (size_t)(n_pairs + 1)),
+           o_pstart = al256(o_cbase + 4 * (size_t)(n_pairs + 1)), o_lb = al256(o_pstart + 4 * (size_t)(n_pairs + 1)),
+           o_cnt = al256(o_lb + 4 * n_items), o_aoff = al256(o_cnt + 4 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
+           o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
+           o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_end = o_misc + 64;
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
-    RefIndex* d_refs = (RefIndex*)(B + o_refs); uint64_t* d_rlen = (uint64_t*)(B + o_rlen);
+    PairDesc* d_pairs = (PairDesc*)(B + o_pairs); uint32_t* d_sbase = (uint32_t*)(B + o_sbase); uint32_t* d_cbase = (uint32_t*)(B + o_cbase);
+    uint32_t* d_pstart = (uint32_t*)(B + o_pstart);
     uint32_t* d_lb = (uint32_t*)(B + o_lb); uint32_t* d_cnt = (uint32_t*)(B + o_cnt); uint32_t* d_aoff = (uint32_t*)(B + o_aoff);
     uint32_t* d_nch = (uint32_t*)(B + o_nch); uint2* d_chunks = (uint2*)(B + o_chunks); ChunkOut* d_cout = (ChunkOut*)(B + o_cout);
     psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..2] stats
-    PSK_HIP(hipMemcpyAsync(d_refs, h_refs.data(), sizeof(RefIndex) * n_pairs, hipMemcpyHostToDevice, st));
-    PSK_HIP(hipMemcpyAsync(d_rlen, h_rlen.data(), 8 * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(d_sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(d_cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemsetAsync(d_misc, 0, 64, st));
-    PSK_HIP(hipMemsetAsync(d_cnt + npq, 0, 4, st));
-    const uint32_t* q_kmer = q->store->seed_kmer + q->seed_off;
-    const uint32_t* q_pos = q->store->seed_pos + q->seed_off;
-    const uint32_t* q_meta = q->store->seed_meta + q->seed_off;
-    dim3 g2((nq + 255) / 256, n_pairs);
+    PSK_HIP(hipMemsetAsync(d_cnt + n_items, 0, 4, st));
+    const uint32_t gi = (uint32_t)((n_items + 255) / 256);
     ctx->t_begin(K_ANCHOR);
-    hipLaunchKernelGGL(anchor_count_kernel, g2, dim3(256), 0, st, d_refs, q_kmer, nq, d_lb, d_cnt);
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt);
     ctx->t_end();
     size_t tmp = 0;
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_cnt, d_aoff, (int)(npq + 1), st));
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_cnt, d_aoff, (int)(n_items + 1), st));
     PSK_TRY(ctx->q_c.reserve(tmp));
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, d_cnt, d_aoff, (int)(npq + 1), st));
-    void* hp;
-    PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 256, &hp));
-    uint32_t* h_small = (uint32_t*)hp;
-    PSK_HIP(hipMemcpyAsync(h_small, d_aoff + npq, 4, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipStreamSynchronize(st));
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, d_cnt, d_aoff, (int)(n_items + 1), st));
+    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, d_aoff, d_sbase, n_pairs, d_pstart);
+    void* hpin;
+    PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 256, &hpin));
+    uint32_t* h_small = (uint32_t*)hpin;
+    PSK_HIP(hipMemcpyAsync(h_small, d_aoff + n_items, 4, hipMemcpyDeviceToHost, st));
+    PSK_HIP(hipStreamSynchronize(st));   // also keeps h_pairs/h_sbase/h_cbase alive until copied
     const uint32_t total = h_small[0];
-    // ---- anchors + serial-path scratch: 4 + 5 + 7 arrays of u32 per anchor ----
+    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = (size_t)total + 64;
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
     uint32_t* D = (uint32_t*)ctx->q_d.p;
@@ -548,26 +662,25 @@ static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint3
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
     A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
     A.c_state = a_nxt;   // nxt is dead once the chunk table exists
-    A.chunks = d_chunks; A.n_chunks = d_nch; A.max_chunks = max_chunks; A.n_pairs = n_pairs;
-    A.q_seed_pos = q->store->seed_pos; A.q_contig_start = q->store->contig_seed_start + q->contig_off;
-    A.out = d_cout; A.two_c = 2u * (uint32_t)q->params.c; A.force_serial = force_serial; A.stats = d_misc + 1;
+    A.chunks = d_chunks; A.n_chunks = d_nch; A.cbase = d_cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
+    A.pairs = d_pairs;
+    A.out = d_cout; A.two_c = 2u * (uint32_t)hp[0].q->params.c; A.force_serial = force_serial; A.stats = d_misc + 1;
     if (total > 0) {
-        hipLaunchKernelGGL(anchor_emit_kernel, g2, dim3(256), 0, st, d_refs, q_pos, q_meta, nq, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
-        hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_aoff, nq, n_pairs, total, a_nxt);
+        hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
+        hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
     }
-    hipLaunchKernelGGL(chunk_heads_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, d_aoff, a_nxt, nq, n_pairs, max_chunks, d_chunks, d_nch, d_misc);
-    const uint32_t slots = n_pairs * max_chunks;
+    hipLaunchKernelGGL(chunk_heads_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     ctx->t_begin(K_CHAIN_CHUNK);
-    hipLaunchKernelGGL(chain_chunk_kernel, dim3((slots + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(64 * CHAIN_WAVES), 0, st, A);
+    hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
     ReduceArgs R{};
-    R.chunks = d_cout; R.n_chunks = d_nch; R.max_chunks = max_chunks; R.aoff = d_aoff; R.nq = nq; R.ref_total_len = d_rlen;
-    R.q_total_len = q->total_len; R.k = q->params.k; R.median = o->median; R.robust = o->robust;
+    R.chunks = d_cout; R.n_chunks = d_nch; R.cbase = d_cbase; R.pstart = d_pstart; R.pairs = d_pairs;
+    R.k = hp[0].q->params.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = d_hits;
     ctx->t_begin(K_PAIR_REDUCE);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
     ctx->t_end();
-    psk_hit* h_hits = (psk_hit*)((char*)hp + 256);
+    psk_hit* h_hits = (psk_hit*)((char*)hpin + 256);
     PSK_HIP(hipMemcpyAsync(h_hits, d_hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipMemcpyAsync(h_small, d_misc, 16, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipStreamSynchronize(st));
@@ -579,23 +692,37 @@ static psk_status chain_batch(psk_ctx* ctx, const psk_sketch* const* refs, uint3
     return PSK_OK;
 }
 
+// chain an arbitrary list of (ref, query) pairs; out[i] belongs to pair i (ref_index is left to the caller)
+psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
+                            const psk_query_opts* o, psk_hit* out) {
+    if (!ctx || !o || (n && (!refs || !queries || !out))) { psk_set_error("chain: NULL argument"); return PSK_EINVAL; }
+    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded (skani's GBDT weights are not redistributable here)"); return PSK_ENOMODEL; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (!refs[i] || !queries[i]) { psk_set_error("chain: NULL sketch in pair %u", i); return PSK_EINVAL; }
+        if (!queries[i]->has_seeds) { psk_set_error("query sketch was built with seed=False; it cannot be chained"); return PSK_EINVAL; }
+        if (!refs[i]->has_seeds) { psk_set_error("reference of pair %u was sketched with seed=False; it cannot be chained", i); return PSK_EINVAL; }
+        if (refs[i]->params.k != queries[i]->params.k || refs[i]->params.c != queries[i]->params.c) { psk_set_error("pair %u: reference and query were sketched with different parameters", i); return PSK_EINVAL; }
+    }
+    PSK_TRY(ensure_index(ctx, refs, n));
+    // bound one launch: lb/cnt/aoff cost 12 B per (pair, query seed); anchors ~64 B each
+    const uint64_t MAX_ITEMS = 1ull << 27; const uint32_t MAX_PAIRS = 4096;
+    std::vector<HostPair> hp;
+    uint32_t b = 0;
+    while (b < n) {
+        hp.clear();
+        uint64_t items = 0; uint32_t e = b;
+        while (e < n && hp.size() < MAX_PAIRS && (hp.empty() || items + queries[e]->n_seeds <= MAX_ITEMS)) { hp.push_back({refs[e], queries[e]}); items += queries[e]->n_seeds; e++; }
+        PSK_TRY(chain_batch(ctx, hp.data(), (uint32_t)hp.size(), o, out + b));
+        b = e;
+    }
+    return PSK_OK;
+}
+
 psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs, const psk_sketch* q,
                       const psk_query_opts* o, psk_hit* out) {
-    if (!ctx || !q || !o || (!refs && n_refs) || (!out && n_refs)) { psk_set_error("chain: NULL argument"); return PSK_EINVAL; }
-    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded (skani's GBDT weights are not redistributable here)"); return PSK_ENOMODEL; }
-    if (!q->has_seeds) { psk_set_error("query sketch was built with seed=False; it cannot be chained"); return PSK_EINVAL; }
-    for (uint32_t i = 0; i < n_refs; i++) {
-        if (!refs[i] || !refs[i]->has_seeds) { psk_set_error("reference %u was sketched with seed=False; it cannot be chained", i); return PSK_EINVAL; }
-        if (refs[i]->params.k != q->params.k || refs[i]->params.c != q->params.c) { psk_set_error("reference %u and query were sketched with different parameters", i); return PSK_EINVAL; }
-    }
-    PSK_TRY(ensure_index(ctx, refs, n_refs));
-    // bound the scratch of one launch: lb/cnt/aoff cost 12 B per (pair, query seed)
-    const uint64_t nq = q->n_seeds ? q->n_seeds : 1;
-    uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2048, (1ull << 31) / (nq * 2)));
-    for (uint32_t b = 0; b < n_refs; b += per) {
-        uint32_t nb = std::min(per, n_refs - b);
-        PSK_TRY(chain_batch(ctx, refs + b, nb, q, o, out + b));
-        for (uint32_t i = 0; i < nb; i++) out[b + i].ref_index = b + i;
-    }
+    if (!q) { psk_set_error("chain: NULL query"); return PSK_EINVAL; }
+    std::vector<const psk_sketch*> qs(n_refs, q);
+    PSK_TRY(chain_pairs_impl(ctx, refs, qs.data(), n_refs, o, out));
+    for (uint32_t i = 0; i < n_refs; i++) out[i].ref_index = i;
     return PSK_OK;
 }

@@ -245,3 +245,33 @@ def test_metagenome_mode_short_contigs(psk, oracle):
             # query_many == repeated query
             single = {h.reference_name: h.identity for h in db.query(name, seq, learned_ani=False, faster_small=fs)}
             assert single == {n: h.identity for n, h in g.items()}
+
+
+def test_all_vs_all_query_many_matches_oracle(psk, oracle):
+    """BASELINE configs[2] in miniature: every genome queried against a database of all of them in ONE
+    psk_query_many call (pairs with different queries share kernel launches)."""
+    rng = np.random.default_rng(41)
+    anc = [random_genome(rng, 250000), random_genome(rng, 180000), random_genome(rng, 90000)]
+    genomes = []
+    for f, a in enumerate(anc):
+        for j, d in enumerate((0.0, 0.01, 0.04, 0.08)):
+            m = mutate(rng, a, d, 0.0003)
+            cut = int(rng.integers(20000, len(m) - 20000))
+            genomes.append((f"g{f}_{j}", [m[:cut], m[cut:]] if j % 2 else [m]))
+    db = psk.Database()
+    for n, contigs in genomes:
+        db.sketch(n, *contigs)
+    got_all = db.query_many([(n, *contigs) for n, contigs in genomes], learned_ani=False)
+    osk = [(n, oracle.Sketch(contigs)) for n, contigs in genomes]
+    n_hits = 0
+    for (n, contigs), got, (_, oq) in zip(genomes, got_all, osk):
+        want = {rn: r for rn, r in oracle.query(osk, oq)}
+        g = {h.reference_name: h for h in got}
+        assert set(g) == set(want), (n, set(g) ^ set(want))
+        assert all(h.query_name == n for h in got)
+        for rn, w in want.items():
+            for f in INT_FIELDS:
+                assert g[rn]._raw[f] == getattr(w, f), (n, rn, f)
+            assert abs(g[rn].identity - w.ani) < 1e-6 and abs(g[rn].reference_fraction - w.af_ref) < 1e-6
+        n_hits += len(got)
+    assert n_hits >= 3 * 16 - 6     # every within-family pair is a hit (a few 8 %-vs-8 % pairs may fall below 0.15 AF)
