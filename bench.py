@@ -104,23 +104,51 @@ class Engine:
             lib.psk_db_destroy(db)
         return hits
 
+    def step_all_vs_all(self, d_ptr, offs, lens, names):
+        """BASELINE configs[2] shape on one GPU: every genome against a database of all of them."""
+        lib, capi = self.lib, self.capi
+        n = len(offs) - 1                      # the trailing query genome is not used here
+        c_off = (C.c_uint64 * n)(*offs[:n]); c_len = (C.c_uint64 * n)(*lens[:n])
+        gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        out = (C.c_void_p * n)()
+        capi.check(lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
+        db = C.c_void_p()
+        capi.check(lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
+        try:
+            capi.check(lib.psk_db_add_batch(db, names, out, n))
+            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0)
+            hits_p = C.POINTER(capi.Hit)()
+            offsets = (C.c_uint64 * (n + 1))()
+            capi.check(lib.psk_query_many(db, out, n, C.byref(opts), C.byref(hits_p), offsets))
+            nh = int(offsets[n])
+            if hits_p:
+                lib.psk_free(hits_p)
+        finally:
+            lib.psk_db_destroy(db)
+        return nh
+
     def timing(self, kernel):
         ms, n = C.c_double(0), C.c_uint64(0)
         self.capi.check(self.lib.psk_ctx_timing(self.ctx, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
 
-def cpu_baseline(host_genomes, n_sample):
+def cpu_baseline(fetch, n_sample):
     """The CPU oracle (a port of the restated skani path, single thread like one pyskani call) on
-    1 query vs the first n_sample references of this rank's shard."""
+    1 query vs the first n_sample references of this rank's shard. `fetch(i)` returns genome i's bytes
+    (i = -1: the query); only oracle time is counted, not the D2H copies that feed it."""
     from oracle import oracle as O
     O.build()
-    t0 = time.perf_counter()
-    q = O.Sketch([host_genomes[-1]])
-    refs = [(str(i), O.Sketch([host_genomes[i]])) for i in range(n_sample)]
-    hits = O.query(refs, q)
-    dt = time.perf_counter() - t0
-    return n_sample / dt, dt, len(hits)
+    secs = 0.0
+    g = fetch(-1)
+    t0 = time.perf_counter(); q = O.Sketch([g]); secs += time.perf_counter() - t0
+    refs = []
+    for i in range(n_sample):
+        g = fetch(i)
+        t0 = time.perf_counter(); refs.append((str(i), O.Sketch([g]))); secs += time.perf_counter() - t0
+    del g
+    t0 = time.perf_counter(); hits = O.query(refs, q); secs += time.perf_counter() - t0
+    return n_sample / secs, secs, len(hits)
 
 
 def main():
@@ -129,7 +157,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--refs", type=int, default=N_REFS, help="references per GPU (BASELINE configs[1]: 1000)")
-    ap.add_argument("--cpu-sample", type=int, default=150, help="references in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=["search", "allvsall"], default="search",
+                    help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes (extra, not the headline)")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="references in the CPU-baseline sample (0 = skip); 1000 = the whole workload, ~10-20 s")
     args = ap.parse_args()
 
     import torch
@@ -155,6 +185,8 @@ def main():
     names = (C.c_char_p * n_refs)(*[f"r{rank}_{i}".encode() for i in range(n_refs)])
 
     def step():
+        if args.workload == "allvsall":
+            return eng.step_all_vs_all(buf.data_ptr(), offs, lens, names)
         hits = eng.step(buf.data_ptr(), offs, lens, names)
         if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
             hits[:, 0] += rank * n_refs          # global ref index
@@ -186,7 +218,7 @@ def main():
     eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
 
     if rank == 0:
-        pairs = n_refs * world * args.steps
+        pairs = (n_refs * n_refs if args.workload == "allvsall" else n_refs) * world * args.steps
         value = pairs / dt
         # sketch_scan: ALGORITHMIC bytes per launch = sum over the launch's genomes of
         # L (ASCII read) + L/4 (2-bit packed write)   [SURVEY.md §8(d) B_sk, first two terms; DESIGN.md §4]
@@ -202,20 +234,18 @@ def main():
             "metric": "genome-pairs/sec (sketch+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
+            "config": {"workload": (f"all-vs-all {n_refs} x {n_refs} synthetic ~5 Mb genomes per GPU" if args.workload == "allvsall" else f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU") + f" (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_ms_per_step": kernel_ms,
         }
-        if args.cpu_sample > 0 and world == 1:
+        if args.cpu_sample > 0 and world == 1 and args.workload == "search":
             ns = min(args.cpu_sample, n_refs)
-            host = [bytes(buf[offs[i]:offs[i] + lens[i]].cpu().numpy()) for i in list(range(ns))]
-            host.append(bytes(buf[offs[-1]:offs[-1] + lens[-1]].cpu().numpy()))
-            v, secs, nh = cpu_baseline(host, ns)
+            v, secs, nh = cpu_baseline(lambda i: bytes(buf[offs[i]:offs[i] + lens[i]].cpu().numpy()), ns)
             line["cpu_baseline"] = {"value": v, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
-                                    "sample": f"1 query vs the first {ns} refs of the same workload (sketch {ns + 1} genomes + screen + chain {nh} hits), {secs:.1f} s"}
+                                    "sample": f"1 query vs the first {ns} of {n_refs} refs of the same workload (sketch {ns + 1} genomes + {ns} screens + {nh} chained hits), {secs:.1f} s of oracle time"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

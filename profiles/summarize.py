@@ -15,6 +15,8 @@ for r in rows:
     m = re.search(r"segmented_radix_sort_config<[^,]+, ([^,]+), ([^>]+)>", n)
     if m:
         short = f"rocprim segmented_radix_sort<{m.group(1).strip()},{m.group(2).strip().split('::')[-1]}>"
+    elif "radix_sort_onesweep" in n or "radix_sort" in n:
+        short = "rocprim device radix_sort (onesweep)" if "onesweep" in n else "rocprim radix_sort helper"
     elif "scan_impl" in n or "lookback_scan" in n:
         short = "rocprim scan (" + ("init" if "init_lookback" in n else "main") + ")"
     else:
