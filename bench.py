@@ -214,7 +214,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     scan_ms, scan_n = eng.timing("sketch_scan")
-    kernel_ms = {k: eng.timing(k)[0] / max(1, args.steps) for k in ("sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "pair_reduce")}
+    kernel_ms = {k: eng.timing(k)[0] / max(1, args.steps) for k in ("sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce")}
     eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
 
     if rank == 0:

@@ -83,7 +83,7 @@ void psk_ctx_destroy(psk_ctx* ctx);
 psk_status psk_ctx_synchronize(psk_ctx* ctx);
 /* Measurement: bracket the named kernels' launches with HIP events on the ctx stream.
  * kernel in {"sketch_scan","sketch_emit","sketch_sort","screen","anchor","chain_chunk",
- * "pair_reduce"}; "reset" clears the accumulators. psk_ctx_timing synchronises the stream. */
+ * "select","pair_reduce"}; "reset" clears the accumulators. psk_ctx_timing synchronises the stream. */
 psk_status psk_ctx_set_timing(psk_ctx* ctx, int on);
 psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */

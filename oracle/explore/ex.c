@@ -94,6 +94,7 @@ typedef struct {
     int gapcost_mode;   // 0: |dq-dr| ; 1: 0 ; 2: 0.5*|d|
     int chainset_mode;  // 0: best path per union-find set ; 1: set size as anchors
     int require_mono;   // require dr>0
+    double gap_w;       // if > 0: gap cost = gap_w * |dq-dr| (overrides gapcost_mode)
 } cparams_t;
 
 typedef struct { int chunk; uint32_t qc, q0, q1, rc, r0, r1; int nanch; int nseeds; double score; int rev; int setsize; } interval_t;
@@ -170,7 +171,7 @@ long ex_chain(const seed_t* qs_in, long nq, const seed_t* rs_in, long nr, const 
                 if (fabs(dr) > P->max_lin || dq > P->max_lin) continue;
                 double gap = fabs(dq - dr);
                 if (gap > P->max_gap) continue;
-                double gc = P->gapcost_mode == 0 ? gap : (P->gapcost_mode == 1 ? 0 : 0.5 * gap);
+                double gc = P->gap_w > 0 ? P->gap_w * gap : (P->gapcost_mode == 0 ? gap : (P->gapcost_mode == 1 ? 0 : 0.5 * gap));
                 double sc = f[y] + P->anchor_score - gc;
                 if (sc > best) { best = sc; bp = (int)y; }
             }

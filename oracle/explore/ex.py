@@ -14,7 +14,7 @@ interval_dt = np.dtype([("chunk", "<i4"), ("qc", "<u4"), ("q0", "<u4"), ("q1", "
 class CP(C.Structure):
     _fields_ = [("frag_len", C.c_int), ("max_gap", C.c_double), ("anchor_score", C.c_double), ("min_anchors", C.c_int),
                 ("band", C.c_int), ("bp_band", C.c_int), ("max_lin", C.c_double), ("k", C.c_int), ("mult_cap", C.c_int),
-                ("chunk_mode", C.c_int), ("gapcost_mode", C.c_int), ("chainset_mode", C.c_int), ("require_mono", C.c_int)]
+                ("chunk_mode", C.c_int), ("gapcost_mode", C.c_int), ("chainset_mode", C.c_int), ("require_mono", C.c_int), ("gap_w", C.c_double)]
 
 def load(name):
     with gzip.open(os.path.join(ROOT, "tests/golden", name), "rt") as f:
@@ -38,7 +38,7 @@ def sketch(seq, c=125, mc=1000, k=15, hashvar=0, marker_mode=0):
 
 def chain(qs, rs, **kw):
     p = CP(frag_len=20000, max_gap=50, anchor_score=20, min_anchors=3, band=100, bp_band=2500, max_lin=5000, k=15, mult_cap=0,
-           chunk_mode=0, gapcost_mode=0, chainset_mode=0, require_mono=1)
+           chunk_mode=0, gapcost_mode=0, chainset_mode=0, require_mono=1, gap_w=0.0)
     for a, b in kw.items(): setattr(p, a, b)
     out = np.zeros(2000000, dtype=interval_dt)
     na = C.c_long(0)

@@ -7,12 +7,13 @@
 
 /* ---- constants restated from skani::params (source absent; see oracle/README.md) ---- */
 #define FRAGMENT_LENGTH 20000   /* chunk length on the query                         */
-#define MAX_GAP_LENGTH 50       /* max |dq - dr| between chained anchors             */
-#define ANCHOR_SCORE 20
+#define MAX_GAP_LENGTH 300      /* max |dq - dr| between chained anchors             */
 #define MIN_ANCHORS 3
-#define CHAIN_BAND 100          /* look-back in anchors                              */
 #define BP_CHAIN_BAND 2500      /* look-back in query bases                          */
-#define MIN_SCORE 45            /* 0.75 * MIN_ANCHORS * ANCHOR_SCORE                 */
+#define MAX_CHAIN_BAND 100      /* look-back in anchors = clamp(BP_CHAIN_BAND / c, 1, 100) */
+/* scores are kept DOUBLED so that the gap cost |dq - dr| / 2 stays integral:         */
+#define ANCHOR_SCORE2 40        /* anchor score 20                                   */
+#define MIN_SCORE2 90           /* 0.75 * MIN_ANCHORS * ANCHOR_SCORE = 45            */
 #define SMALL_MARKER_COUNT 20   /* "less than 20 marker k-mers", lib.rs:538-541      */
 
 /* skani::types::mm_hash64: minimap2's invertible mix, with the first line as the Rust
@@ -134,7 +135,7 @@ static int cmp_kseed(const void* a, const void* b) {
     return 0;
 }
 
-typedef struct { int32_t score; uint32_t q0, q1, r0, r1, nanch, order; } cand_t;
+typedef struct { int32_t score; uint32_t q0, q1, r0, r1, rc, nanch, order, chunk; } cand_t;
 static int cmp_cand(const void* a, const void* b) {      /* score desc, stable by generation order */
     const cand_t* x = a; const cand_t* y = b;
     if (x->score != y->score) return x->score > y->score ? -1 : 1;
@@ -196,24 +197,23 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
     for (uint32_t i = 0; i < query->n_contigs; i++) cstart[i + 1] += cstart[i];
 
     int32_t* f = malloc(sizeof(int32_t) * na);
-    uint32_t* ptr = malloc(sizeof(uint32_t) * na);
     uint32_t* root = malloc(sizeof(uint32_t) * na);
     uint32_t* depth = malloc(sizeof(uint32_t) * na);
     uint32_t* best = malloc(sizeof(uint32_t) * na);
     cand_t* cands = malloc(sizeof(cand_t) * na);
-    cand_t* kept = malloc(sizeof(cand_t) * na);
-    uint64_t rec_cap = 256; g_recs = malloc(sizeof(orc_chunk_rec) * rec_cap);
-    uint64_t dcap = 256, nd = 0; double* anis = malloc(sizeof(double) * dcap);
+    int band = BP_CHAIN_BAND / c; if (band < 1) band = 1; if (band > MAX_CHAIN_BAND) band = MAX_CHAIN_BAND;
 
+    /* pass 1: per chunk, banded chaining DP and one candidate chain per DP tree */
+    uint32_t nc = 0, n_chunks_all = 0;
+    uint64_t chunk_cap = 256; uint32_t* chunk_qc = malloc(sizeof(uint32_t) * chunk_cap);
     uint64_t s = 0;
     while (s < na) {
         /* chunk = run of anchors on one query contig within FRAGMENT_LENGTH of the chunk's first anchor */
         uint64_t e = s; uint64_t endp = (uint64_t)A[s].qp + FRAGMENT_LENGTH;
         while (e < na && A[e].qc == A[s].qc && (uint64_t)A[e].qp <= endp) e++;
-        /* banded chaining DP, integer scores */
         for (uint64_t x = s; x < e; x++) {
-            int32_t bs = ANCHOR_SCORE; uint64_t bp = x;
-            for (uint64_t y = x; y-- > s && x - y <= CHAIN_BAND;) {
+            int32_t bs = ANCHOR_SCORE2; uint64_t bp = x;
+            for (uint64_t y = x; y-- > s && x - y <= (uint64_t)band;) {
                 if (A[y].rc != A[x].rc || A[y].rev != A[x].rev) continue;
                 int64_t dq = (int64_t)A[x].qp - (int64_t)A[y].qp;
                 if (dq > BP_CHAIN_BAND) break;
@@ -221,53 +221,70 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
                 if (dq <= 0 || dr <= 0) continue;
                 int64_t gap = dq > dr ? dq - dr : dr - dq;
                 if (gap > MAX_GAP_LENGTH) continue;
-                int32_t sc = f[y] + ANCHOR_SCORE - (int32_t)gap;
+                int32_t sc = f[y] + ANCHOR_SCORE2 - (int32_t)gap;      /* = 2 * (f + 20 - gap/2) */
                 if (sc > bs) { bs = sc; bp = y; }
             }
-            f[x] = bs; ptr[x] = (uint32_t)bp;
+            f[x] = bs;
             if (bp == x) { root[x] = (uint32_t)x; depth[x] = 1; }
             else { root[x] = root[bp]; depth[x] = depth[bp] + 1; }
         }
-        /* one candidate chain per DP tree: its best-scoring anchor (lowest index on ties), backtracked to the root */
+        /* the tree's best-scoring anchor (lowest index on ties), backtracked to the root */
         for (uint64_t x = s; x < e; x++) best[x] = UINT32_MAX;
         for (uint64_t x = s; x < e; x++) { uint32_t rt = root[x]; if (best[rt] == UINT32_MAX || f[x] > f[best[rt]]) best[rt] = (uint32_t)x; }
-        uint32_t nc = 0;
         for (uint64_t x = s; x < e; x++) {
             if (root[x] != x) continue;
             uint32_t b = best[x];
-            if (depth[b] < MIN_ANCHORS || f[b] < MIN_SCORE) continue;
+            if (depth[b] < MIN_ANCHORS || f[b] < MIN_SCORE2) continue;
             cand_t* cd = &cands[nc];
-            cd->score = f[b]; cd->q0 = A[x].qp; cd->q1 = A[b].qp; cd->nanch = depth[b]; cd->order = nc;
+            cd->score = f[b]; cd->q0 = A[x].qp; cd->q1 = A[b].qp; cd->nanch = depth[b]; cd->order = nc; cd->chunk = n_chunks_all; cd->rc = A[x].rc;
             cd->r0 = A[x].rp < A[b].rp ? A[x].rp : A[b].rp; cd->r1 = A[x].rp < A[b].rp ? A[b].rp : A[x].rp;
             nc++;
         }
-        qsort(cands, nc, sizeof(cand_t), cmp_cand);
-        /* greedy non-overlapping (on the query) selection by score */
-        uint32_t nk = 0;
-        for (uint32_t i = 0; i < nc; i++) {
-            int ok = 1;
-            for (uint32_t j = 0; j < nk; j++) if (!(cands[i].q1 < kept[j].q0 || cands[i].q0 > kept[j].q1)) { ok = 0; break; }
-            if (ok) kept[nk++] = cands[i];
-        }
-        if (nk) {
-            uint32_t left = UINT32_MAX, right = 0, anch = 0;
-            for (uint32_t j = 0; j < nk; j++) {
-                if (kept[j].q0 < left) left = kept[j].q0;
-                if (kept[j].q1 > right) right = kept[j].q1;
-                anch += kept[j].nanch;
-                out->covered_query += (uint64_t)(kept[j].q1 - kept[j].q0) + 1 + 2 * (uint64_t)c;
-                out->covered_ref += (uint64_t)(kept[j].r1 - kept[j].r0) + 1 + 2 * (uint64_t)c;
-            }
-            uint32_t ns = seeds_between(query, cstart, A[s].qc, left, right);
-            double ratio = (double)anch / (double)ns; if (ratio > 1.0) ratio = 1.0;
-            if (nd == dcap) { dcap *= 2; anis = realloc(anis, sizeof(double) * dcap); }
-            anis[nd++] = pow(ratio, 1.0 / (double)k);
-            if (g_nrecs == rec_cap) { rec_cap *= 2; g_recs = realloc(g_recs, sizeof(orc_chunk_rec) * rec_cap); }
-            orc_chunk_rec* rc = &g_recs[g_nrecs++];
-            rc->contig = A[s].qc; rc->left = left; rc->right = right; rc->anchors = anch; rc->seeds = ns; rc->n_intervals = nk;
-            out->n_intervals += nk; out->sum_chain_anchors += anch; out->sum_chunk_seeds += ns;
-        }
+        if (n_chunks_all == chunk_cap) { chunk_cap *= 2; chunk_qc = realloc(chunk_qc, sizeof(uint32_t) * chunk_cap); }
+        chunk_qc[n_chunks_all++] = A[s].qc;
         s = e;
+    }
+    /* pass 2: greedy selection over ALL candidates of the pair by score: a chain is kept unless it overlaps
+     * a kept chain on the query (same chunk) or on the reference (same ref contig) */
+    qsort(cands, nc, sizeof(cand_t), cmp_cand);
+    cand_t* kept = malloc(sizeof(cand_t) * (nc ? nc : 1));
+    uint32_t nk = 0;
+    for (uint32_t i = 0; i < nc; i++) {
+        int ok = 1;
+        for (uint32_t j = 0; j < nk && ok; j++) {
+            if (cands[i].chunk == kept[j].chunk && !(cands[i].q1 < kept[j].q0 || cands[i].q0 > kept[j].q1)) ok = 0;
+            else if (cands[i].rc == kept[j].rc && !(cands[i].r1 < kept[j].r0 || cands[i].r0 > kept[j].r1)) ok = 0;
+        }
+        if (ok) kept[nk++] = cands[i];
+    }
+    /* pass 3: per chunk totals */
+    uint32_t* c_anch = calloc(n_chunks_all ? n_chunks_all : 1, sizeof(uint32_t));
+    uint32_t* c_left = malloc(sizeof(uint32_t) * (n_chunks_all ? n_chunks_all : 1));
+    uint32_t* c_right = calloc(n_chunks_all ? n_chunks_all : 1, sizeof(uint32_t));
+    uint32_t* c_nint = calloc(n_chunks_all ? n_chunks_all : 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < n_chunks_all; i++) c_left[i] = UINT32_MAX;
+    for (uint32_t j = 0; j < nk; j++) {
+        uint32_t ck = kept[j].chunk;
+        c_anch[ck] += kept[j].nanch; c_nint[ck]++;
+        if (kept[j].q0 < c_left[ck]) c_left[ck] = kept[j].q0;
+        if (kept[j].q1 > c_right[ck]) c_right[ck] = kept[j].q1;
+        out->covered_query += (uint64_t)(kept[j].q1 - kept[j].q0) + 1 + 2 * (uint64_t)c;
+    }
+    out->covered_ref = out->covered_query;      /* one covered-bases count serves both fractions */
+    uint64_t rec_cap = 256; g_recs = malloc(sizeof(orc_chunk_rec) * rec_cap);
+    uint64_t dcap = 256, nd = 0; double* anis = malloc(sizeof(double) * dcap);
+    for (uint32_t ck = 0; ck < n_chunks_all; ck++) {
+        if (!c_nint[ck]) continue;
+        uint32_t ns = seeds_between(query, cstart, chunk_qc[ck], c_left[ck], c_right[ck]);
+        /* the two end seeds are anchors by construction: identity over the ns - 1 seeds after the first */
+        uint32_t denom = ns > 1 ? ns - 1 : 1;
+        double ratio = (double)c_anch[ck] / (double)denom; if (ratio > 1.0) ratio = 1.0;
+        if (nd == dcap) { dcap *= 2; anis = realloc(anis, sizeof(double) * dcap); }
+        anis[nd++] = pow(ratio, 1.0 / (double)k);
+        if (g_nrecs == rec_cap) { rec_cap *= 2; g_recs = realloc(g_recs, sizeof(orc_chunk_rec) * rec_cap); }
+        orc_chunk_rec* rcd = &g_recs[g_nrecs++];
+        rcd->contig = chunk_qc[ck]; rcd->left = c_left[ck]; rcd->right = c_right[ck]; rcd->anchors = c_anch[ck]; rcd->seeds = ns; rcd->n_intervals = c_nint[ck];
+        out->n_intervals += c_nint[ck]; out->sum_chain_anchors += c_anch[ck]; out->sum_chunk_seeds += ns;
     }
     out->n_chunks = (uint32_t)nd;
     if (nd) {
@@ -281,10 +298,11 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
             ani = sum / (double)(hi - lo);
         }
         double afq = (double)out->covered_query / (double)query->total_len; if (afq > 1) afq = 1;
-        double afr = (double)out->covered_ref / (double)ref->total_len; if (afr > 1) afr = 1;
+        double afr = (double)out->covered_query / (double)ref->total_len; if (afr > 1) afr = 1;
         out->af_query = (float)afq; out->af_ref = (float)afr;
         if (afq >= o->min_aligned_frac || afr >= o->min_aligned_frac) out->ani = (float)ani;
     }
-    free(A); free(cstart); free(f); free(ptr); free(root); free(depth); free(best); free(cands); free(kept); free(anis);
+    free(A); free(cstart); free(f); free(root); free(depth); free(best); free(cands); free(kept); free(anis);
+    free(chunk_qc); free(c_anch); free(c_left); free(c_right); free(c_nint);
     return 0;
 }

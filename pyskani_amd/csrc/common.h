@@ -15,12 +15,13 @@
 constexpr int K_MARKER = 21;
 constexpr uint32_t MIN_LENGTH_CONTIG = 500;  // lib.rs:156
 constexpr uint32_t FRAGMENT_LENGTH = 20000;
-constexpr int MAX_GAP_LENGTH = 50;
-constexpr int ANCHOR_SCORE = 20;
+constexpr int MAX_GAP_LENGTH = 300;
 constexpr uint32_t MIN_ANCHORS = 3;
-constexpr int CHAIN_BAND = 100;
 constexpr int BP_CHAIN_BAND = 2500;
-constexpr int MIN_SCORE = 45;
+constexpr int MAX_CHAIN_BAND = 100;      // look-back in anchors = clamp(BP_CHAIN_BAND / c, 1, MAX_CHAIN_BAND)
+// chaining scores are kept doubled so that the gap cost |dq - dr| / 2 stays integral
+constexpr int ANCHOR_SCORE2 = 40;        // anchor score 20
+constexpr int MIN_SCORE2 = 90;           // 0.75 * 3 * 20 = 45
 constexpr uint32_t SMALL_MARKER_COUNT = 20;
 
 // ---- sketch tiling ----
@@ -64,8 +65,8 @@ struct Scratch {
 };
 
 // kernels whose launches can be bracketed by HIP events on the ctx stream (psk_ctx_timing)
-enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANCHOR, K_CHAIN_CHUNK, K_PAIR_REDUCE, K_COUNT };
-static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "pair_reduce"};
+enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANCHOR, K_CHAIN_CHUNK, K_SELECT, K_PAIR_REDUCE, K_COUNT };
+static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce"};
 struct TimerRec { int id; hipEvent_t a, b; };
 
 struct psk_ctx {

@@ -257,7 +257,7 @@ __global__ void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const ui
 }
 
 // ------------------------------------------------------------------ chaining
-struct ChunkOut { uint32_t anchors, seeds, n_intervals, flags; uint64_t cov_q, cov_r; };
+struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, right; uint64_t cov_q; };
 
 struct ChainArgs {
     const uint32_t *a_qp, *a_qc, *a_rp, *a_rm;
@@ -266,8 +266,8 @@ struct ChainArgs {
     ChunkOut* out;
     // serial-path scratch, one entry per anchor
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
-    int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state;
-    uint32_t two_c; int force_serial;
+    int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state, *c_rc;   // candidate chains, chunk s writes at [s, s + n_cand)
+    uint32_t two_c; int band; int force_serial;
     uint32_t* stats;   // [0] fast chunks, [1] serial chunks
 };
 
@@ -294,11 +294,11 @@ __device__ uint32_t seeds_between(const PairDesc& P, uint32_t qc, uint32_t lo, u
 
 // Serial restatement of the oracle's per-chunk body, run by ONE lane on global scratch. Used for
 // chunks the LDS path cannot hold (many chain trees / candidates) and as an in-GPU cross-check.
-__device__ void chain_chunk_serial(const ChainArgs& A, const PairDesc& P, uint32_t s, uint32_t e, ChunkOut& o) {
+__device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t e) {
     for (uint32_t x = s; x < e; x++) {
-        int32_t bs = ANCHOR_SCORE; uint32_t bp = x;
+        int32_t bs = ANCHOR_SCORE2; uint32_t bp = x;
         uint32_t qx = A.a_qp[x], rx = A.a_rp[x], mx = A.a_rm[x];
-        for (uint32_t y = x; y-- > s && x - y <= (uint32_t)CHAIN_BAND;) {
+        for (uint32_t y = x; y-- > s && x - y <= (uint32_t)A.band;) {
             if (A.a_rm[y] != mx) continue;
             int64_t dq = (int64_t)qx - (int64_t)A.a_qp[y];
             if (dq > BP_CHAIN_BAND) break;
@@ -306,10 +306,10 @@ __device__ void chain_chunk_serial(const ChainArgs& A, const PairDesc& P, uint32
             if (dq <= 0 || dr <= 0) continue;
             int64_t gap = dq > dr ? dq - dr : dr - dq;
             if (gap > MAX_GAP_LENGTH) continue;
-            int32_t sc = A.sc_f[y] + ANCHOR_SCORE - (int32_t)gap;
+            int32_t sc = A.sc_f[y] + ANCHOR_SCORE2 - (int32_t)gap;
             if (sc > bs) { bs = sc; bp = y; }
         }
-        A.sc_f[x] = bs; A.sc_ptr[x] = bp;
+        A.sc_f[x] = bs;
         if (bp == x) { A.sc_root[x] = x; A.sc_depth[x] = 1; }
         else { A.sc_root[x] = A.sc_root[bp]; A.sc_depth[x] = A.sc_depth[bp] + 1; }
         A.sc_best[x] = 0xFFFFFFFFu;
@@ -319,31 +319,14 @@ __device__ void chain_chunk_serial(const ChainArgs& A, const PairDesc& P, uint32
     for (uint32_t x = s; x < e; x++) {
         if (A.sc_root[x] != x) continue;
         uint32_t b = A.sc_best[x];
-        if (A.sc_depth[b] < MIN_ANCHORS || A.sc_f[b] < MIN_SCORE) continue;
+        if (A.sc_depth[b] < MIN_ANCHORS || A.sc_f[b] < MIN_SCORE2) continue;
         uint32_t ra = A.a_rp[x], rb = A.a_rp[b];
         A.c_score[s + nc] = A.sc_f[b]; A.c_q0[s + nc] = A.a_qp[x]; A.c_q1[s + nc] = A.a_qp[b];
-        A.c_r0[s + nc] = ra < rb ? ra : rb; A.c_r1[s + nc] = ra < rb ? rb : ra; A.c_n[s + nc] = A.sc_depth[b]; A.c_state[s + nc] = 0;
+        A.c_r0[s + nc] = ra < rb ? ra : rb; A.c_r1[s + nc] = ra < rb ? rb : ra; A.c_n[s + nc] = A.sc_depth[b];
+        A.c_rc[s + nc] = A.a_rm[x] >> 1;
         nc++;
     }
-    // greedy selection: repeatedly take the pending candidate with the highest score (lowest order on ties)
-    uint32_t anch = 0, left = 0xFFFFFFFFu, right = 0, nk = 0; uint64_t cq = 0, cr = 0;
-    for (uint32_t it = 0; it < nc; it++) {
-        int32_t best = -1; uint32_t bi = 0;
-        for (uint32_t i = 0; i < nc; i++) if (A.c_state[s + i] == 0 && A.c_score[s + i] > best) { best = A.c_score[s + i]; bi = i; }
-        bool ok = true;
-        for (uint32_t j = 0; j < nc && ok; j++) if (A.c_state[s + j] == 1 && !(A.c_q1[s + bi] < A.c_q0[s + j] || A.c_q0[s + bi] > A.c_q1[s + j])) ok = false;
-        A.c_state[s + bi] = ok ? 1 : 2;
-        if (ok) {
-            uint32_t q0 = A.c_q0[s + bi], q1 = A.c_q1[s + bi];
-            anch += A.c_n[s + bi]; nk++;
-            if (q0 < left) left = q0;
-            if (q1 > right) right = q1;
-            cq += (uint64_t)(q1 - q0) + 1 + A.two_c;
-            cr += (uint64_t)(A.c_r1[s + bi] - A.c_r0[s + bi]) + 1 + A.two_c;
-        }
-    }
-    o.anchors = anch; o.n_intervals = nk; o.cov_q = cq; o.cov_r = cr; o.flags = 1;
-    o.seeds = nk ? seeds_between(P, A.a_qc[s], left, right) : 0;
+    return nc;
 }
 
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs A) {
@@ -352,7 +335,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     __shared__ uint32_t s_ring[CHAIN_WAVES][6][RING];        // qp, rp, rm, f, root id, depth
     __shared__ unsigned long long s_best[CHAIN_WAVES][RMAX]; // f<<28 | (16383-local idx)<<14 | depth
     __shared__ uint32_t s_rootx[CHAIN_WAVES][RMAX];          // local index of each tree's root anchor
-    __shared__ uint32_t s_cand[CHAIN_WAVES][6][64];          // score, q0, q1, r0, r1, nanch
+    __shared__ uint32_t s_cand[CHAIN_WAVES][7][64];          // score, q0, q1, r0, r1, nanch, ref contig
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
     if (slot >= A.n_rows) return;
@@ -379,18 +362,18 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
                 uint32_t key = 0;
                 // the band may need two sweeps of 64 predecessors; the second only if the 65th is still in bp range
                 int sweeps = 1;
-                if (avail > 64 && qx - ring[0][(x - 65) & (RING - 1)] <= (uint32_t)BP_CHAIN_BAND) sweeps = 2;
+                if (avail > 64 && A.band > 64 && qx - ring[0][(x - 65) & (RING - 1)] <= (uint32_t)BP_CHAIN_BAND) sweeps = 2;
                 for (int sw = 0; sw < sweeps; sw++) {
                     const uint32_t dist = lane + 1 + 64 * sw;
-                    if (dist <= avail && dist <= (uint32_t)CHAIN_BAND) {
+                    if (dist <= avail && dist <= (uint32_t)A.band) {
                         const uint32_t sl = (x - dist) & (RING - 1);
                         const uint32_t qy = ring[0][sl], ry = ring[1][sl], my = ring[2][sl];
                         const int32_t fy = (int32_t)ring[3][sl];
                         const int32_t dq = (int32_t)(qx - qy);
                         const int32_t dr = (mx & 1) ? (int32_t)(ry - rx) : (int32_t)(rx - ry);
                         const int32_t gap = dq > dr ? dq - dr : dr - dq;
-                        const int32_t sc = fy + ANCHOR_SCORE - gap;
-                        if (my == mx && dq > 0 && dq <= BP_CHAIN_BAND && dr > 0 && gap <= MAX_GAP_LENGTH && sc > ANCHOR_SCORE) {
+                        const int32_t sc = fy + ANCHOR_SCORE2 - gap;
+                        if (my == mx && dq > 0 && dq <= BP_CHAIN_BAND && dr > 0 && gap <= MAX_GAP_LENGTH && sc > ANCHOR_SCORE2) {
                             uint32_t k2 = ((uint32_t)sc << 7) | (127u - dist);   // max score, then nearest predecessor
                             key = k2 > key ? k2 : key;
                         }
@@ -398,7 +381,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
                 }
                 uint32_t best = WR(s_wr[wave]).Reduce(key, hipcub::Max());
                 best = __builtin_amdgcn_readfirstlane(best);
-                int32_t f = ANCHOR_SCORE; uint32_t rid, dep;
+                int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
                 if (best) {
                     f = (int32_t)(best >> 7);
                     const uint32_t sl = (x - (127u - (best & 127u))) & (RING - 1);
@@ -427,7 +410,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
             if (r < R) {
                 unsigned long long bk = s_best[wave][r];
                 f = (uint32_t)(bk >> 28); lx = 16383u - (uint32_t)((bk >> 14) & 16383u); dep = (uint32_t)(bk & 16383u);
-                qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE;
+                qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE2;
             }
             unsigned long long bal = __ballot(qual);
             uint32_t ci = C + __popcll(bal & ((1ull << lane) - 1));
@@ -438,52 +421,150 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
                 uint32_t ra = A.a_rp[xr], rb = A.a_rp[xb];
                 s_cand[wave][0][ci] = f; s_cand[wave][1][ci] = A.a_qp[xr]; s_cand[wave][2][ci] = A.a_qp[xb];
                 s_cand[wave][3][ci] = ra < rb ? ra : rb; s_cand[wave][4][ci] = ra < rb ? rb : ra; s_cand[wave][5][ci] = dep;
+                s_cand[wave][6][ci] = A.a_rm[xr] >> 1;
             }
         }
     }
-    if (!fast) {
+    if (!fast) {   // lane-serial path writes its candidates straight to the global arrays
         if (lane == 0) {
-            ChunkOut o{};
-            chain_chunk_serial(A, P, s, e, o);
-            *op = o;
+            C = chain_chunk_serial(A, s, e);
             atomicAdd(&A.stats[1], 1u);
         }
-        return;
-    }
-    lds_wave_sync();
-    const bool mine = (uint32_t)lane < C;
-    const uint32_t c_sc = mine ? s_cand[wave][0][lane] : 0, c_q0 = mine ? s_cand[wave][1][lane] : 0, c_q1 = mine ? s_cand[wave][2][lane] : 0,
-                   c_r0 = mine ? s_cand[wave][3][lane] : 0, c_r1 = mine ? s_cand[wave][4][lane] : 0, c_n = mine ? s_cand[wave][5][lane] : 0;
-    // greedy non-overlapping selection by (score desc, order asc); one candidate per lane
-    unsigned long long pending = C >= 64 ? ~0ull : ((1ull << C) - 1), keptm = 0;
-    while (pending) {
-        uint32_t key = ((pending >> lane) & 1) ? ((c_sc << 6) | (63u - lane)) : 0;   // score < 2^19, order < 64
-        uint32_t best = WR(s_wr[wave]).Reduce(key, hipcub::Max());
-        best = __builtin_amdgcn_readfirstlane(best);
-        const uint32_t w = 63u - (best & 63u);
-        const uint32_t wq0 = __builtin_amdgcn_readlane(c_q0, w), wq1 = __builtin_amdgcn_readlane(c_q1, w);
-        const bool ov = ((keptm >> lane) & 1) && !(wq1 < c_q0 || wq0 > c_q1);
-        if (__ballot(ov) == 0) keptm |= 1ull << w;
-        pending &= ~(1ull << w);
-    }
-    const bool kept = (keptm >> lane) & 1;
-    // per-chunk totals
-    uint32_t anch = kept ? c_n : 0, left = kept ? c_q0 : 0xFFFFFFFFu, right = kept ? c_q1 : 0;
-    unsigned long long cq = kept ? (unsigned long long)(c_q1 - c_q0) + 1 + A.two_c : 0, cr = kept ? (unsigned long long)(c_r1 - c_r0) + 1 + A.two_c : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        anch += __shfl_xor(anch, o);
-        uint32_t l2 = __shfl_xor(left, o), r2 = __shfl_xor(right, o);
-        left = l2 < left ? l2 : left; right = r2 > right ? r2 : right;
-        cq += __shfl_xor(cq, o); cr += __shfl_xor(cr, o);
+    } else {
+        lds_wave_sync();
+        if ((uint32_t)lane < C) {
+            A.c_score[s + lane] = (int32_t)s_cand[wave][0][lane]; A.c_q0[s + lane] = s_cand[wave][1][lane]; A.c_q1[s + lane] = s_cand[wave][2][lane];
+            A.c_r0[s + lane] = s_cand[wave][3][lane]; A.c_r1[s + lane] = s_cand[wave][4][lane]; A.c_n[s + lane] = s_cand[wave][5][lane];
+            A.c_rc[s + lane] = s_cand[wave][6][lane];
+        }
+        if (lane == 0) atomicAdd(&A.stats[0], 1u);
     }
     if (lane == 0) {
         ChunkOut o{};
-        o.anchors = anch; o.n_intervals = (uint32_t)__popcll(keptm); o.cov_q = cq; o.cov_r = cr; o.flags = 0;
-        o.seeds = o.n_intervals ? seeds_between(P, A.a_qc[s], left, right) : 0;
+        o.n_cand = C; o.left = 0xFFFFFFFFu; o.right = 0;
         *op = o;
-        atomicAdd(&A.stats[0], 1u);
     }
+}
+
+// ------------------------------------------------------------------ chain selection (per pair)
+// Greedy over ALL candidate chains of a pair by (score desc, generation order): a chain is kept unless it
+// overlaps a kept chain on the query (same chunk) or on the reference (same ref contig). One wave per pair:
+// candidates staged in LDS, bitonic sort of (score, ~order) keys, kept list scanned 64 entries at a time.
+constexpr int CMAX = 1024;
+
+struct SelArgs {
+    const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs;
+    const int32_t* c_score; const uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_rc; uint32_t* c_state;
+    ChunkOut* out; uint32_t two_c; int force_serial; uint32_t* stats;
+};
+
+__device__ __forceinline__ void sel_commit(const SelArgs& S, uint32_t row, uint32_t q0, uint32_t q1, uint32_t n) {
+    ChunkOut* o = &S.out[row];
+    atomicAdd(&o->anchors, n); atomicAdd(&o->n_intervals, 1u);
+    atomicMin(&o->left, q0); atomicMax(&o->right, q1);
+    atomicAdd((unsigned long long*)&o->cov_q, (unsigned long long)(q1 - q0) + 1 + S.two_c);
+}
+
+// lane-serial O(C^2) selection on global memory: for pairs with more than CMAX candidates
+__device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
+    for (uint32_t r = 0; r < nrows; r++) { uint32_t s = S.chunks[row0 + r].x, nc = S.out[row0 + r].n_cand; for (uint32_t i = 0; i < nc; i++) S.c_state[s + i] = 0; }
+    for (;;) {
+        int32_t best = -1; uint32_t brow = 0, bslot = 0;
+        for (uint32_t r = 0; r < nrows; r++) {            // generation order: rows, then slots; strict > keeps the earliest
+            uint32_t s = S.chunks[row0 + r].x, nc = S.out[row0 + r].n_cand;
+            for (uint32_t i = 0; i < nc; i++) if (S.c_state[s + i] == 0 && S.c_score[s + i] > best) { best = S.c_score[s + i]; brow = r; bslot = s + i; }
+        }
+        if (best < 0) break;
+        bool ok = true;
+        for (uint32_t r = 0; r < nrows && ok; r++) {
+            uint32_t s = S.chunks[row0 + r].x, nc = S.out[row0 + r].n_cand;
+            for (uint32_t i = 0; i < nc && ok; i++) if (S.c_state[s + i] == 1) {
+                uint32_t j = s + i;
+                if (r == brow && !(S.c_q1[bslot] < S.c_q0[j] || S.c_q0[bslot] > S.c_q1[j])) ok = false;
+                else if (S.c_rc[bslot] == S.c_rc[j] && !(S.c_r1[bslot] < S.c_r0[j] || S.c_r0[bslot] > S.c_r1[j])) ok = false;
+            }
+        }
+        S.c_state[bslot] = ok ? 1 : 2;
+        if (ok) sel_commit(S, row0 + brow, S.c_q0[bslot], S.c_q1[bslot], S.c_n[bslot]);
+    }
+}
+
+__global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
+    __shared__ int32_t l_sc[CMAX];
+    __shared__ uint32_t l_q0[CMAX], l_q1[CMAX], l_r0[CMAX], l_r1[CMAX], l_rc[CMAX], l_row[CMAX], l_n[CMAX];
+    __shared__ unsigned long long l_key[CMAX];
+    __shared__ uint16_t l_kept[CMAX];
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
+    // candidates in generation order (rows, then slots)
+    uint32_t C = 0;
+    for (uint32_t r0 = 0; r0 < nrows; r0 += 64) {
+        uint32_t r = r0 + lane;
+        uint32_t cnt = r < nrows ? S.out[row0 + r].n_cand : 0;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        uint32_t off = C + incl - cnt;
+        uint32_t tot = __shfl(incl, 63);
+        if (!S.force_serial && C + tot <= CMAX && cnt) {
+            uint32_t s = S.chunks[row0 + r].x;
+            for (uint32_t i = 0; i < cnt; i++) {
+                l_sc[off + i] = S.c_score[s + i]; l_q0[off + i] = S.c_q0[s + i]; l_q1[off + i] = S.c_q1[s + i];
+                l_r0[off + i] = S.c_r0[s + i]; l_r1[off + i] = S.c_r1[s + i]; l_rc[off + i] = S.c_rc[s + i];
+                l_row[off + i] = r; l_n[off + i] = S.c_n[s + i];
+            }
+        }
+        C += tot;
+    }
+    if (C == 0) return;
+    if (S.force_serial || C > CMAX) {
+        if (lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
+        return;
+    }
+    uint32_t P = 64; while (P < C) P <<= 1;
+    for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
+    lds_wave_sync();
+    for (uint32_t kk = 2; kk <= P; kk <<= 1)
+        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t t = lane; t < P; t += 64) {
+                uint32_t ixj = t ^ jj;
+                if (ixj > t) {
+                    unsigned long long a = l_key[t], b = l_key[ixj];
+                    bool desc = (t & kk) == 0;          // descending overall
+                    if ((a < b) == desc) { l_key[t] = b; l_key[ixj] = a; }
+                }
+            }
+            lds_wave_sync();
+        }
+    uint32_t nk = 0;
+    for (uint32_t t = 0; t < C; t++) {
+        const uint32_t i = 0xFFFFFFFFu - (uint32_t)l_key[t];
+        const uint32_t q0 = l_q0[i], q1 = l_q1[i], r0 = l_r0[i], r1 = l_r1[i], rc = l_rc[i], row = l_row[i];
+        bool ov = false;
+        for (uint32_t j = lane; j < nk; j += 64) {
+            const uint32_t k2 = l_kept[j];
+            if (l_row[k2] == row && !(q1 < l_q0[k2] || q0 > l_q1[k2])) ov = true;
+            else if (l_rc[k2] == rc && !(r1 < l_r0[k2] || r0 > l_r1[k2])) ov = true;
+        }
+        if (__ballot(ov) == 0) {
+            if (lane == 0) l_kept[nk] = (uint16_t)i;
+            nk++;
+            lds_wave_sync();
+        }
+    }
+    for (uint32_t j = lane; j < nk; j += 64) { const uint32_t i = l_kept[j]; sel_commit(S, row0 + l_row[i], l_q0[i], l_q1[i], l_n[i]); }
+    if (lane == 0) atomicAdd(&S.stats[2], 1u);
+}
+
+// seeds of the query between the leftmost and rightmost kept anchor of every chunk
+__global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= A.n_rows) return;
+    const uint32_t pair = find_le(A.cbase, A.n_pairs, row);
+    if (row - A.cbase[pair] >= A.n_chunks[pair]) return;
+    ChunkOut* o = &A.out[row];
+    if (o->n_intervals) o->seeds = seeds_between(A.pairs[pair], A.a_qc[A.chunks[row].x], o->left, o->right);
 }
 
 // ------------------------------------------------------------------ per-pair ANI / AF
@@ -506,7 +587,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     __syncthreads();
     // integer totals (order-free)
     unsigned long long t_cq = 0, t_cr = 0, t_a = 0, t_s = 0, t_i = 0;
-    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { t_cq += co[i].cov_q; t_cr += co[i].cov_r; t_a += co[i].anchors; t_s += co[i].seeds; t_i += co[i].n_intervals; }
+    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { t_cq += co[i].cov_q; t_cr += co[i].cov_q; t_a += co[i].anchors; t_s += co[i].n_intervals ? co[i].seeds : 0; t_i += co[i].n_intervals; }
     atomicAdd(&s_acc[0], t_cq); atomicAdd(&s_acc[1], t_cr); atomicAdd(&s_acc[2], t_a); atomicAdd(&s_acc[3], t_s); atomicAdd(&s_acc[4], t_i);
     // chunk ANI values, compacted in chunk order (serial prefix by thread 0 keeps the oracle's summation order)
     __shared__ uint32_t s_idx[RED_CAP];
@@ -524,7 +605,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     if (!overflow) {
         for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) {
             const ChunkOut c = co[s_idx[j]];
-            double ratio = (double)c.anchors / (double)c.seeds;
+            double ratio = (double)c.anchors / (double)(c.seeds > 1 ? c.seeds - 1 : 1);   // end seeds are anchors by construction
             if (ratio > 1.0) ratio = 1.0;
             s_v[j] = pow(ratio, 1.0 / (double)R.k);
         }
@@ -549,7 +630,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     } else if (threadIdx.x == 0 && !(R.median || R.robust)) {   // very long genomes: stream the mean in chunk order
         double sum = 0; uint32_t cnt = 0;
         for (uint32_t i = 0; i < nc; i++) if (co[i].n_intervals) {
-            double ratio = (double)co[i].anchors / (double)co[i].seeds; if (ratio > 1.0) ratio = 1.0;
+            double ratio = (double)co[i].anchors / (double)(co[i].seeds > 1 ? co[i].seeds - 1 : 1); if (ratio > 1.0) ratio = 1.0;
             sum += pow(ratio, 1.0 / (double)R.k); cnt++;
         }
         mean_serial = sum / (double)cnt;
@@ -572,7 +653,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
                 ani = sum / (double)(hi - lo);
             }
             double afq = (double)s_acc[0] / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
-            double afr = (double)s_acc[1] / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;
+            double afr = (double)s_acc[0] / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;   // one covered-bases count serves both
             h.af_query = (float)afq; h.af_ref = (float)afr;
             if (!ok) h.ani = -2.0f;
             else if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
@@ -662,9 +743,11 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
     A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
     A.c_state = a_nxt;   // nxt is dead once the chunk table exists
+    A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
     A.chunks = d_chunks; A.n_chunks = d_nch; A.cbase = d_cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
     A.pairs = d_pairs;
     A.out = d_cout; A.two_c = 2u * (uint32_t)hp[0].q->params.c; A.force_serial = force_serial; A.stats = d_misc + 1;
+    A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)hp[0].q->params.c));
     if (total > 0) {
         hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
         hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
@@ -673,6 +756,14 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     ctx->t_begin(K_CHAIN_CHUNK);
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
+    SelArgs SA{};
+    SA.chunks = d_chunks; SA.n_chunks = d_nch; SA.cbase = d_cbase; SA.n_pairs = n_pairs;
+    SA.c_score = A.c_score; SA.c_q0 = A.c_q0; SA.c_q1 = A.c_q1; SA.c_r0 = A.c_r0; SA.c_r1 = A.c_r1; SA.c_n = A.c_n; SA.c_rc = A.c_rc; SA.c_state = A.c_state;
+    SA.out = d_cout; SA.two_c = A.two_c; SA.force_serial = force_serial; SA.stats = d_misc + 1;
+    ctx->t_begin(K_SELECT);
+    hipLaunchKernelGGL(select_kernel, dim3(n_pairs), dim3(64), 0, st, SA);
+    ctx->t_end();
+    hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
     R.chunks = d_cout; R.n_chunks = d_nch; R.cbase = d_cbase; R.pstart = d_pstart; R.pairs = d_pairs;
     R.k = hp[0].q->params.k; R.median = o->median; R.robust = o->robust;

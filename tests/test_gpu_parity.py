@@ -113,7 +113,9 @@ def test_chain_ecoli_reference_kat_fractions(psk, ecoli):
     assert len(hits) == 1
     assert abs(hits[0].reference_fraction - 0.9246) < 5e-5
     assert abs(hits[0].query_fraction - 0.9189) < 5e-5
-    assert abs(hits[0].identity - 0.9946) < 1e-3     # see tests/test_oracle_kat.py
+    assert abs(hits[0].identity - 0.9946) < 5e-5     # test_no_learned_ani, test_ani.py:35-40
+    med = db.query("K12", k12, median=True)
+    assert abs(med[0].identity - 0.9995) < 1e-4      # test_median, test_ani.py:56-61 (see tests/test_oracle_kat.py)
 
 
 def test_chain_multicontig_repeats_and_strands(psk, oracle):

@@ -37,21 +37,32 @@ def test_aligned_fractions_match_reference_kat(oracle, pair):
     assert abs(res.af_query - KAT["query_fraction"]) < 5e-5
 
 
-@pytest.mark.parametrize("mode", ["no_learned_ani", "median"])
-def test_identity_near_reference_kat(oracle, pair, mode):
-    """Raw-ANI KATs reachable without skani's GBDT weights. The restatement is within
-    KAT['identity_tolerance_restatement'] of them, NOT within the reference's 4 decimals:
-    parity of the ANI value is only partially pinned (oracle/README.md)."""
+def test_raw_identity_matches_reference_kat(oracle, pair):
+    """test_no_learned_ani (test_ani.py:35-40): identity 0.9946 to the reference's own 4 decimals."""
     ref, q = pair
-    res = oracle.chain(ref, q, median=(mode == "median"))
-    want = KAT["identity"][mode]
-    assert abs(res.ani - want) < KAT["identity_tolerance_restatement"]
+    res = oracle.chain(ref, q)
+    assert abs(res.ani - KAT["identity"]["no_learned_ani"]) < 5e-5
 
 
-@pytest.mark.xfail(strict=True, reason="skani source absent: chunk ANI aggregation restated, not recovered to 4 decimals")
-def test_identity_exact_reference_kat(oracle, pair):
+def test_median_identity_near_reference_kat(oracle, pair):
+    """test_median (test_ani.py:56-61): the restatement gives 0.99959 against 0.9995 — inside
+    BASELINE.json's 1e-4 tolerance, outside the reference's 4 decimals (oracle/README.md)."""
     ref, q = pair
-    assert abs(oracle.chain(ref, q).ani - KAT["identity"]["no_learned_ani"]) < 5e-5
+    res = oracle.chain(ref, q, median=True)
+    assert abs(res.ani - KAT["identity"]["median"]) < KAT["restatement_tolerance"]["median"]
+
+
+@pytest.mark.xfail(strict=True, reason="skani source absent: median identity restated to 9e-5, not to the reference's 5e-5")
+def test_median_identity_exact_reference_kat(oracle, pair):
+    ref, q = pair
+    assert abs(oracle.chain(ref, q, median=True).ani - KAT["identity"]["median"]) < 5e-5
+
+
+def test_robust_raw_identity_is_recorded(oracle, pair):
+    """test_robust's KAT (0.9977) includes skani's learned-ANI model, which is unobtainable here; the raw
+    trimmed mean of the restatement is pinned by the self-generated golden only."""
+    ref, q = pair
+    assert abs(oracle.chain(ref, q, robust=True).ani - 0.99782) < 2e-5
 
 
 def test_golden_counts(oracle, pair):
