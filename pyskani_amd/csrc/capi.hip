@@ -45,6 +45,7 @@ void psk_ctx_destroy(psk_ctx* c) {
     Scratch* all[] = {&c->s_desc, &c->s_packed, &c->s_mask, &c->s_counts, &c->s_offs, &c->s_tmp, &c->s_mark, &c->s_flags, &c->s_misc,
                       &c->q_a, &c->q_b, &c->q_c, &c->q_d, &c->q_e, &c->q_f, &c->q_g, &c->q_h, &c->q_i};
     for (Scratch* s : all) s->release();
+    c->jobs_release();
     c->pool_drain();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);

@@ -76,14 +76,56 @@ struct psk_ctx {
     std::vector<TimerRec> pending;
     double acc_ms[K_COUNT] = {0};
     uint64_t acc_n[K_COUNT] = {0};
-    void t_begin(int id) {
+    void t_begin(int id, hipStream_t st = nullptr) {
         if (!timing) return;
         TimerRec r{id, nullptr, nullptr};
         (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, stream);
+        (void)hipEventRecord(r.a, st ? st : stream);
         pending.push_back(r);
     }
-    void t_end() { if (timing && !pending.empty()) (void)hipEventRecord(pending.back().b, stream); }
+    void t_end(hipStream_t st = nullptr) { if (timing && !pending.empty()) (void)hipEventRecord(pending.back().b, st ? st : stream); }
+    // resources of one in-flight sketch sub-batch: own stream + scratch, so that sketch_emit / sorts of
+    // sub-batch j overlap sketch_scan of sub-batch j+1
+    struct JobRes {
+        hipStream_t stream = nullptr; bool own_stream = false;
+        hipEvent_t scan_done = nullptr;
+        Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark;
+        void* pinned = nullptr; size_t pinned_cap = 0;
+        psk_status pin(size_t bytes, void** out) {
+            if (bytes > pinned_cap) {
+                if (pinned) (void)hipHostFree(pinned);
+                pinned = nullptr; pinned_cap = 0;
+                size_t want = bytes * 2 + 4096;
+                PSK_HIP(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+                pinned_cap = want;
+            }
+            *out = pinned;
+            return PSK_OK;
+        }
+    };
+    std::vector<JobRes*> jobs;
+    psk_status job(size_t j, JobRes** out) {
+        while (jobs.size() <= j) {
+            JobRes* r = new JobRes();
+            if (jobs.empty()) r->stream = stream;
+            else { PSK_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
+            PSK_HIP(hipEventCreateWithFlags(&r->scan_done, hipEventDisableTiming));
+            jobs.push_back(r);
+        }
+        *out = jobs[j];
+        return PSK_OK;
+    }
+    void jobs_release() {
+        for (JobRes* r : jobs) {
+            Scratch* all[] = {&r->s_desc, &r->s_packed, &r->s_mask, &r->s_counts, &r->s_offs, &r->s_tmp, &r->s_mark};
+            for (Scratch* s : all) s->release();
+            if (r->pinned) (void)hipHostFree(r->pinned);
+            if (r->scan_done) (void)hipEventDestroy(r->scan_done);
+            if (r->own_stream) (void)hipStreamDestroy(r->stream);
+            delete r;
+        }
+        jobs.clear();
+    }
     std::mutex mu;                 // one stream per ctx: calls are serialised
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query

@@ -310,6 +310,196 @@ __global__ void marker_copy_kernel(const uint64_t* __restrict__ uniq, const uint
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// One sub-batch of genomes moving through the sketch pipeline on its own stream. The phases are split
+// at the two points where the host must learn a size (total seeds, total distinct markers).
+struct SketchJob {
+    psk_ctx* ctx; psk_ctx::JobRes* R; hipStream_t st;
+    const psk_params* p; const uint8_t* d_bases; int want_seeds;
+    uint32_t n_genomes = 0, n_tiles = 0; int n_desc = 0;
+    std::vector<ContigDesc> descs;
+    std::vector<uint32_t> g_first_desc, g_first_tile;
+    std::vector<psk_sketch*> sk;
+    SketchConsts C{};
+    std::shared_ptr<SketchStore> store;
+    uint32_t *d_cnt = nullptr, *d_toff = nullptr, *d_gft = nullptr, *d_cft = nullptr, *d_goff = nullptr, *d_coff = nullptr,
+             *d_mcnt = nullptr, *d_sbeg = nullptr, *d_send = nullptr, *d_moff = nullptr, *d_tci = nullptr, *d_packed = nullptr;
+    uint4* d_tinfo = nullptr; ContigDesc* d_desc = nullptr; uint64_t* d_mask = nullptr;
+    uint64_t *d_mstage = nullptr, *d_msorted = nullptr;
+    uint32_t *h_goff = nullptr, *h_coff = nullptr, *h_moff = nullptr;
+    bool empty = false;
+
+    void drop() { for (auto* x : sk) delete x; sk.clear(); }
+
+#define JHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { psk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return _e == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP; } } while (0)
+
+    // host: contig filter (lib.rs:156) and tile layout
+    psk_status prepare(const uint64_t* contig_off, const uint64_t* contig_len, const uint32_t* gfc, uint32_t ng) {
+        n_genomes = ng;
+        g_first_desc.resize(ng + 1); g_first_tile.resize(ng + 1); sk.assign(ng, nullptr);
+        uint64_t n_tiles64 = 0, total_bases = 0;
+        for (uint32_t g = 0; g < ng; g++) {
+            g_first_desc[g] = (uint32_t)descs.size();
+            g_first_tile[g] = (uint32_t)n_tiles64;
+            psk_sketch* s = new psk_sketch();
+            s->ctx = ctx; s->params = *p; s->has_seeds = want_seeds != 0;
+            sk[g] = s;
+            for (uint32_t ci = gfc[g]; ci < gfc[g + 1]; ci++) {
+                uint64_t len = contig_len[ci];
+                if (len < MIN_LENGTH_CONTIG) continue;
+                if (len > 0xFFFFFFFFull) { psk_set_error("contig longer than 2^32-1 bases"); return PSK_ELIMIT; }
+                if (contig_off[ci] & 15) { psk_set_error("contig offset not 16-byte aligned"); return PSK_EINVAL; }
+                ContigDesc d{};
+                d.byte_off = contig_off[ci]; d.len = (uint32_t)len; d.first_tile = (uint32_t)n_tiles64;
+                d.genome = g; d.contig_index = (uint32_t)s->contig_len.size();
+                descs.push_back(d);
+                s->contig_len.push_back((uint32_t)len);
+                s->total_len += len;
+                n_tiles64 += (len + TILE_BASES - 1) / TILE_BASES;
+                total_bases += len;
+            }
+        }
+        g_first_desc[ng] = (uint32_t)descs.size();
+        g_first_tile[ng] = (uint32_t)n_tiles64;
+        if (n_tiles64 >= (1ull << 31)) { psk_set_error("batch of %llu bases exceeds the per-launch tile limit; split it", (unsigned long long)total_bases); return PSK_ELIMIT; }
+        n_tiles = (uint32_t)n_tiles64; n_desc = (int)descs.size();
+        empty = n_tiles == 0;
+        C.k = p->k; C.thr = UINT64_MAX / (uint64_t)p->c; C.thr_marker = UINT64_MAX / (uint64_t)p->marker_c;
+        C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
+        C.rshift = 2 * p->k - 2;
+        C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
+        return PSK_OK;
+    }
+
+    // tables up, pack + seed bits, tile offsets, per-genome / per-contig seed offsets on their way back
+    psk_status phase1(hipEvent_t wait_scan) {
+        if (empty) return PSK_OK;
+        size_t o_cnt = 0, o_toff = o_cnt + n_tiles + 1, o_gft = o_toff + n_tiles + 1, o_cft = o_gft + n_genomes + 1,
+               o_goff = o_cft + n_desc + 1, o_coff = o_goff + n_genomes + 1, o_mcnt = o_coff + n_desc + 1,
+               o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes, o_moff = o_send + n_genomes, o_end = o_moff + n_genomes + 1;
+        PSK_TRY(R->s_desc.reserve(sizeof(ContigDesc) * n_desc));
+        PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
+        PSK_TRY(R->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS));
+        PSK_TRY(R->s_offs.reserve(sizeof(uint32_t) * o_end));
+        PSK_TRY(R->s_counts.reserve(sizeof(uint4) * ((size_t)n_tiles + 1) + sizeof(uint32_t) * ((size_t)n_tiles + 4)));
+        uint32_t* d_offs = (uint32_t*)R->s_offs.p;
+        d_cnt = d_offs + o_cnt; d_toff = d_offs + o_toff; d_gft = d_offs + o_gft; d_cft = d_offs + o_cft;
+        d_goff = d_offs + o_goff; d_coff = d_offs + o_coff; d_mcnt = d_offs + o_mcnt; d_sbeg = d_offs + o_sbeg;
+        d_send = d_offs + o_send; d_moff = d_offs + o_moff;
+        d_tinfo = (uint4*)R->s_counts.p; d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
+        d_desc = (ContigDesc*)R->s_desc.p; d_packed = (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p;
+        size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
+        void* hp;
+        PSK_TRY(R->pin(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4), &hp));
+        ContigDesc* h_desc = (ContigDesc*)hp;
+        uint32_t* h_gft = (uint32_t*)(h_desc + n_desc);
+        uint32_t* h_cft = h_gft + n_genomes + 1;
+        h_goff = h_cft + n_desc + 1; h_coff = h_goff + n_genomes + 1; h_moff = h_coff + n_desc + 1;
+        memcpy(h_desc, descs.data(), sizeof(ContigDesc) * n_desc);
+        memcpy(h_gft, g_first_tile.data(), sizeof(uint32_t) * (n_genomes + 1));
+        for (int i = 0; i < n_desc; i++) h_cft[i] = descs[i].first_tile;
+        h_cft[n_desc] = n_tiles;
+        JHIP(hipMemcpyAsync(d_desc, h_desc, sizeof(ContigDesc) * n_desc, hipMemcpyHostToDevice, st));
+        JHIP(hipMemcpyAsync(d_gft, h_gft, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyHostToDevice, st));
+        JHIP(hipMemcpyAsync(d_cft, h_cft, sizeof(uint32_t) * (n_desc + 1), hipMemcpyHostToDevice, st));
+        JHIP(hipMemsetAsync(d_cnt + n_tiles, 0, sizeof(uint32_t), st));
+        JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
+        JHIP(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci, d_tinfo);
+        if (wait_scan) JHIP(hipStreamWaitEvent(st, wait_scan, 0));   // scans run one after another; emit/sorts fill in beside them
+        ctx->t_begin(K_SKETCH_SCAN, st);
+        // optional dynamic-LDS ballast caps the scan's residency so that the latency-bound emit/sort kernels of the
+        // previous sub-batch find free wave slots beside it (the scan is issue-bound well below 8 waves/SIMD)
+        static const int scan_lds = getenv("PSK_SCAN_LDS") ? atoi(getenv("PSK_SCAN_LDS")) : 0;
+        hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), scan_lds, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
+        ctx->t_end(st);
+        JHIP(hipEventRecord(R->scan_done, st));
+        size_t tmp_bytes = 0;
+        JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
+        PSK_TRY(R->s_tmp.reserve(tmp_bytes));
+        JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
+        int n1 = n_genomes + 1, n2 = n_desc + 1;
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_toff, d_gft, d_goff, n1);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, d_toff, d_cft, d_coff, n2);
+        JHIP(hipMemcpyAsync(h_goff, d_goff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
+        JHIP(hipMemcpyAsync(h_coff, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToHost, st));
+        return PSK_OK;
+    }
+
+    // total seeds known: allocate the store, emit seed records, sort + unique the marker sets
+    psk_status phase2() {
+        if (empty) return PSK_OK;
+        JHIP(hipStreamSynchronize(st));
+        const uint32_t total_seeds = h_goff[n_genomes];
+        if (total_seeds >= 0x7FFFFFF0u) { psk_set_error("batch yields >= 2^31 seeds; split it"); return PSK_ELIMIT; }
+        store = std::make_shared<SketchStore>();
+        size_t ns = total_seeds;
+        size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
+               b_pm = align_up(b_meta + 4 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
+        store->ctx = ctx;
+        PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
+        char* sb = (char*)store->base;
+        store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
+        store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
+        JHIP(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
+        PSK_TRY(R->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2)));   // stage + sorted
+        d_mstage = (uint64_t*)R->s_mark.p; d_msorted = d_mstage + ns + 1;
+        ctx->t_begin(K_SKETCH_EMIT, st);
+        hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff,
+                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_mcnt, C);
+        ctx->t_end(st);
+        ctx->t_begin(K_SKETCH_SORT, st);
+        hipLaunchKernelGGL(marker_segments_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_goff, d_mcnt, d_sbeg, d_send, (int)n_genomes);
+        size_t tmp_bytes = 0;
+        if (ns > 0) {
+            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+            PSK_TRY(R->s_tmp.reserve(tmp_bytes));
+            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+        }
+        hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_send, d_moff);
+        tmp_bytes = 0;
+        JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
+        PSK_TRY(R->s_tmp.reserve(tmp_bytes));
+        JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
+        JHIP(hipMemcpyAsync(h_moff, d_moff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
+        ctx->t_end(st);
+        return PSK_OK;
+    }
+
+    // total distinct markers known: dense marker array
+    psk_status phase3() {
+        if (empty) return PSK_OK;
+        JHIP(hipStreamSynchronize(st));
+        const uint32_t total_markers = h_moff[n_genomes];
+        PSK_TRY(ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes));
+        store->markers = (uint64_t*)store->mbase;
+        hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, d_mstage, d_sbeg, d_moff, store->markers);
+        return PSK_OK;
+    }
+
+    psk_status finish(psk_sketch** out) {
+        if (empty) {
+            for (uint32_t g = 0; g < n_genomes; g++) { sk[g]->contig_seed_start.assign(sk[g]->contig_len.size() + 1, 0); out[g] = sk[g]; }
+            sk.clear();
+            return PSK_OK;
+        }
+        JHIP(hipStreamSynchronize(st));
+        for (uint32_t g = 0; g < n_genomes; g++) {
+            psk_sketch* s = sk[g];
+            s->store = store;
+            s->seed_off = h_goff[g]; s->n_seeds = h_goff[g + 1] - h_goff[g];
+            s->marker_off = h_moff[g]; s->n_markers = h_moff[g + 1] - h_moff[g];
+            s->contig_off = g_first_desc[g];
+            uint32_t nc = g_first_desc[g + 1] - g_first_desc[g];
+            s->contig_seed_start.resize(nc + 1);
+            for (uint32_t c = 0; c <= nc; c++) s->contig_seed_start[c] = h_coff[g_first_desc[g] + c] - h_goff[g];
+            out[g] = s;
+        }
+        sk.clear();
+        return PSK_OK;
+    }
+#undef JHIP
+};
+
 psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
@@ -317,185 +507,44 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
     if (!ctx || !p || !out || (!genome_first_contig && n_genomes)) { psk_set_error("sketch: NULL argument"); return PSK_EINVAL; }
     if (p->k < 1 || p->k > 16) { psk_set_error("Value of k > 16 for DNA; not allowed (k=%d)", p->k); return PSK_EINVAL; }
     if (p->c < 1 || p->marker_c < 1) { psk_set_error("compression factors must be >= 1"); return PSK_EINVAL; }
-    hipStream_t st = ctx->stream;
     for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
-
-    // ---- host: contig filter (lib.rs:156) and tile layout ----
-    std::vector<ContigDesc> descs;
-    std::vector<uint32_t> g_first_desc(n_genomes + 1), g_first_tile(n_genomes + 1);
-    std::vector<psk_sketch*> sk(n_genomes, nullptr);
-    uint64_t n_tiles64 = 0, total_bases = 0;
+    // The pipeline can run as J sub-batches on J streams (PSK_SKETCH_JOBS), sub-batch j+1 scanning while
+    // sub-batch j emits and sorts. Measured on MI355X (profiles/r1d_overlap.md) this gains nothing: scan AND
+    // emit are both VALU-issue bound, overlapped they slow each other by exactly what they take. Default J = 1.
+    uint64_t total = 0;
+    std::vector<uint64_t> gb(n_genomes);
     for (uint32_t g = 0; g < n_genomes; g++) {
-        g_first_desc[g] = (uint32_t)descs.size();
-        g_first_tile[g] = (uint32_t)n_tiles64;
-        psk_sketch* s = new psk_sketch();
-        s->ctx = ctx; s->params = *p; s->has_seeds = want_seeds != 0;
-        sk[g] = s;
-        for (uint32_t ci = genome_first_contig[g]; ci < genome_first_contig[g + 1]; ci++) {
-            uint64_t len = contig_len[ci];
-            if (len < MIN_LENGTH_CONTIG) continue;
-            if (len > 0xFFFFFFFFull || (contig_off[ci] & 15)) {
-                for (auto* x : sk) delete x;
-                psk_set_error(len > 0xFFFFFFFFull ? "contig longer than 2^32-1 bases" : "contig offset not 16-byte aligned");
-                return len > 0xFFFFFFFFull ? PSK_ELIMIT : PSK_EINVAL;
-            }
-            ContigDesc d{};
-            d.byte_off = contig_off[ci]; d.len = (uint32_t)len; d.first_tile = (uint32_t)n_tiles64;
-            d.genome = g; d.contig_index = (uint32_t)s->contig_len.size();
-            descs.push_back(d);
-            s->contig_len.push_back((uint32_t)len);
-            s->total_len += len;
-            n_tiles64 += (len + TILE_BASES - 1) / TILE_BASES;
-            total_bases += len;
-        }
+        uint64_t b = 0;
+        for (uint32_t c = genome_first_contig[g]; c < genome_first_contig[g + 1]; c++) b += contig_len[c];
+        gb[g] = b; total += b;
     }
-    g_first_desc[n_genomes] = (uint32_t)descs.size();
-    g_first_tile[n_genomes] = (uint32_t)n_tiles64;
-    if (n_tiles64 >= (1ull << 31)) {
-        for (auto* x : sk) delete x;
-        psk_set_error("batch of %llu bases exceeds the per-launch tile limit; split it", (unsigned long long)total_bases);
-        return PSK_ELIMIT;
+    const char* env = getenv("PSK_SKETCH_JOBS");
+    uint32_t J = env ? (uint32_t)atoi(env) : 1u;
+    J = std::max(1u, std::min(J, std::min(8u, n_genomes ? n_genomes : 1u)));
+    std::vector<uint32_t> cut(J + 1, n_genomes);
+    cut[0] = 0;
+    { uint64_t acc = 0; uint32_t j = 1; for (uint32_t g = 0; g < n_genomes && j < J; g++) { acc += gb[g]; if (acc >= total * j / J) cut[j++] = g + 1; } }
+    std::vector<SketchJob> jobs(J);
+    auto abort_all = [&](psk_status rc) {
+        for (auto& jb : jobs) if (jb.R) (void)hipStreamSynchronize(jb.R->stream);
+        for (auto& jb : jobs) jb.drop();
+        for (uint32_t g = 0; g < n_genomes; g++) { delete out[g]; out[g] = nullptr; }
+        return rc;
+    };
+    for (uint32_t j = 0; j < J; j++) {
+        SketchJob& jb = jobs[j];
+        jb.ctx = ctx; jb.p = p; jb.d_bases = d_bases; jb.want_seeds = want_seeds;
+        psk_status rc = ctx->job(j, &jb.R);
+        if (rc != PSK_OK) return abort_all(rc);
+        jb.st = jb.R->stream;
+        rc = jb.prepare(contig_off, contig_len, genome_first_contig + cut[j], cut[j + 1] - cut[j]);
+        if (rc != PSK_OK) return abort_all(rc);
     }
-    const uint32_t n_tiles = (uint32_t)n_tiles64;
-    const int n_desc = (int)descs.size();
-    auto fail = [&](psk_status s) { for (auto* x : sk) delete x; return s; };
-    if (n_tiles == 0) {   // nothing to seed: empty sketches
-        for (uint32_t g = 0; g < n_genomes; g++) { sk[g]->contig_seed_start.assign(sk[g]->contig_len.size() + 1, 0); out[g] = sk[g]; }
-        return PSK_OK;
-    }
-
-    SketchConsts C{};
-    C.k = p->k; C.thr = UINT64_MAX / (uint64_t)p->c; C.thr_marker = UINT64_MAX / (uint64_t)p->marker_c;
-    C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
-    C.rshift = 2 * p->k - 2;
-    C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
-
-    // ---- device scratch ----
-    // offs: [tile_count n_tiles+1][tile_off n_tiles+1][gft n_genomes+1][cft n_desc+1][g_off n_genomes+1][c_off n_desc+1]
-    //       [marker_count n_genomes][seg_beg n_genomes][seg_end n_genomes][m_off n_genomes+1]
-    size_t o_cnt = 0, o_toff = o_cnt + n_tiles + 1, o_gft = o_toff + n_tiles + 1, o_cft = o_gft + n_genomes + 1,
-           o_goff = o_cft + n_desc + 1, o_coff = o_goff + n_genomes + 1, o_mcnt = o_coff + n_desc + 1,
-           o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes, o_moff = o_send + n_genomes, o_end = o_moff + n_genomes + 1;
-    psk_status rc;
-    if ((rc = ctx->s_desc.reserve(sizeof(ContigDesc) * n_desc)) != PSK_OK) return fail(rc);
-    if ((rc = ctx->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8))) != PSK_OK) return fail(rc);
-    if ((rc = ctx->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS)) != PSK_OK) return fail(rc);
-    if ((rc = ctx->s_offs.reserve(sizeof(uint32_t) * o_end)) != PSK_OK) return fail(rc);
-    uint32_t* d_offs = (uint32_t*)ctx->s_offs.p;
-    uint32_t *d_cnt = d_offs + o_cnt, *d_toff = d_offs + o_toff, *d_gft = d_offs + o_gft, *d_cft = d_offs + o_cft,
-             *d_goff = d_offs + o_goff, *d_coff = d_offs + o_coff, *d_mcnt = d_offs + o_mcnt, *d_sbeg = d_offs + o_sbeg,
-             *d_send = d_offs + o_send, *d_moff = d_offs + o_moff;
-    if ((rc = ctx->s_counts.reserve(sizeof(uint4) * ((size_t)n_tiles + 1) + sizeof(uint32_t) * ((size_t)n_tiles + 4))) != PSK_OK) return fail(rc);
-    uint4* d_tinfo = (uint4*)ctx->s_counts.p;
-    uint32_t* d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
-    ContigDesc* d_desc = (ContigDesc*)ctx->s_desc.p;
-    uint32_t* d_packed = (uint32_t*)ctx->s_packed.p;
-    uint64_t* d_mask = (uint64_t*)ctx->s_mask.p;
-
-    // small host tables through pinned staging
-    size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
-    void* hp;
-    if ((rc = ctx->pinned(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4), &hp)) != PSK_OK) return fail(rc);
-    ContigDesc* h_desc = (ContigDesc*)hp;
-    uint32_t* h_gft = (uint32_t*)(h_desc + n_desc);
-    uint32_t* h_cft = h_gft + n_genomes + 1;
-    uint32_t* h_back = h_cft + n_desc + 1;   // D2H area
-    memcpy(h_desc, descs.data(), sizeof(ContigDesc) * n_desc);
-    memcpy(h_gft, g_first_tile.data(), sizeof(uint32_t) * (n_genomes + 1));
-    for (int i = 0; i < n_desc; i++) h_cft[i] = descs[i].first_tile;
-    h_cft[n_desc] = n_tiles;
-#define HIPF(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { psk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return fail(_e == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP); } } while (0)
-    HIPF(hipMemcpyAsync(d_desc, h_desc, sizeof(ContigDesc) * n_desc, hipMemcpyHostToDevice, st));
-    HIPF(hipMemcpyAsync(d_gft, h_gft, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyHostToDevice, st));
-    HIPF(hipMemcpyAsync(d_cft, h_cft, sizeof(uint32_t) * (n_desc + 1), hipMemcpyHostToDevice, st));
-    HIPF(hipMemsetAsync(d_cnt + n_tiles, 0, sizeof(uint32_t), st));
-    HIPF(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
-    HIPF(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
-
-    // ---- pass 1 ----
-    hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci, d_tinfo);
-    ctx->t_begin(K_SKETCH_SCAN);
-    hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
-    ctx->t_end();
-    size_t tmp_bytes = 0;
-    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
-    if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
-    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
-    {
-        int n1 = n_genomes + 1, n2 = n_desc + 1;
-        hipLaunchKernelGGL(gather_u32_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_toff, d_gft, d_goff, n1);
-        hipLaunchKernelGGL(gather_u32_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, d_toff, d_cft, d_coff, n2);
-    }
-    uint32_t* h_goff = h_back;
-    uint32_t* h_coff = h_back + n_genomes + 1;
-    HIPF(hipMemcpyAsync(h_goff, d_goff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
-    HIPF(hipMemcpyAsync(h_coff, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToHost, st));
-    HIPF(hipStreamSynchronize(st));
-    const uint32_t total_seeds = h_goff[n_genomes];
-    if (total_seeds >= 0x7FFFFFF0u) { psk_set_error("batch yields >= 2^31 seeds; split it"); return fail(PSK_ELIMIT); }
-
-    // ---- allocate the batch store: seeds (position order) + index (k-mer order) + contig starts ----
-    auto store = std::make_shared<SketchStore>();
-    size_t ns = total_seeds;
-    size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
-           b_pm = align_up(b_meta + 4 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
-    store->ctx = ctx;
-    { psk_status prc = ctx->pool_alloc(b_end, &store->base, &store->bytes); if (prc != PSK_OK) return fail(prc); }
-    char* sb = (char*)store->base;
-    store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
-    store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
-    HIPF(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
-
-    if ((rc = ctx->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2))) != PSK_OK) return fail(rc);   // stage + sorted
-    uint64_t* d_mstage = (uint64_t*)ctx->s_mark.p;
-    uint64_t* d_msorted = d_mstage + ns + 1;
-    uint64_t* d_pm = store->seed_pm;                              // seed {pos,meta} in position order
-
-    // ---- pass 2 ----
-    ctx->t_begin(K_SKETCH_EMIT);
-    hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff,
-                       store->seed_kmer, store->seed_pos, store->seed_meta, d_pm, d_mstage, d_mcnt, C);
-    ctx->t_end();
-    ctx->t_begin(K_SKETCH_SORT);
-
-    // ---- marker sets: per-genome sort + unique ----
-    hipLaunchKernelGGL(marker_segments_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_goff, d_mcnt, d_sbeg, d_send, (int)n_genomes);
-    if (ns > 0) {
-        tmp_bytes = 0;
-        HIPF(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
-        if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
-        HIPF(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->s_tmp.p, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
-    }
-    // per genome: unique the sorted segment in place (one block per genome), count, then compact
-    hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_send, d_moff);
-    tmp_bytes = 0;
-    HIPF(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
-    if ((rc = ctx->s_tmp.reserve(tmp_bytes)) != PSK_OK) return fail(rc);
-    HIPF(hipcub::DeviceScan::ExclusiveSum(ctx->s_tmp.p, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
-    uint32_t* h_moff = h_coff + n_desc + 1;
-    HIPF(hipMemcpyAsync(h_moff, d_moff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
-
-    // the k-mer-sorted reference index is built lazily, on a sketch's first use in chaining (ensure_index)
-    ctx->t_end();
-    HIPF(hipStreamSynchronize(st));
-    const uint32_t total_markers = h_moff[n_genomes];
-    { psk_status prc = ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes); if (prc != PSK_OK) return fail(prc); }
-    store->markers = (uint64_t*)store->mbase;
-    hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, d_mstage, d_sbeg, d_moff, store->markers);
-    HIPF(hipStreamSynchronize(st));
-#undef HIPF
-
-    for (uint32_t g = 0; g < n_genomes; g++) {
-        psk_sketch* s = sk[g];
-        s->store = store;
-        s->seed_off = h_goff[g]; s->n_seeds = h_goff[g + 1] - h_goff[g];
-        s->marker_off = h_moff[g]; s->n_markers = h_moff[g + 1] - h_moff[g];
-        s->contig_off = g_first_desc[g];
-        uint32_t nc = g_first_desc[g + 1] - g_first_desc[g];
-        s->contig_seed_start.resize(nc + 1);
-        for (uint32_t c = 0; c <= nc; c++) s->contig_seed_start[c] = h_coff[g_first_desc[g] + c] - h_goff[g];
-        out[g] = s;
-    }
+    hipEvent_t prev = nullptr;
+    for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase1(prev); if (rc != PSK_OK) return abort_all(rc); if (!jobs[j].empty) prev = jobs[j].R->scan_done; }
+    for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase2(); if (rc != PSK_OK) return abort_all(rc); }
+    for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase3(); if (rc != PSK_OK) return abort_all(rc); }
+    for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].finish(out + cut[j]); if (rc != PSK_OK) return abort_all(rc); }
     return PSK_OK;
 }
 
