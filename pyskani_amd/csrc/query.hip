@@ -492,8 +492,12 @@ __device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
 __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
     __shared__ int32_t l_sc[CMAX];
     __shared__ uint32_t l_q0[CMAX], l_q1[CMAX], l_r0[CMAX], l_r1[CMAX], l_rc[CMAX], l_row[CMAX], l_n[CMAX];
-    __shared__ unsigned long long l_key[CMAX];
+    __shared__ unsigned long long l_key[CMAX];     // priority keys, then (ref contig, r0) keys
+    __shared__ uint32_t l_pm[CMAX];                // running max of r1 in reference order
+    __shared__ uint16_t l_ord[CMAX];               // candidate index by priority rank
+    __shared__ uint16_t l_idx[CMAX];               // payload of the reference-order sort, then the conflicted list
     __shared__ uint16_t l_kept[CMAX];
+    __shared__ uint8_t l_conf[CMAX];
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         return;
     }
     uint32_t P = 64; while (P < C) P <<= 1;
+    // ---- priority order: (score desc, generation order asc) ----
     for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
     lds_wave_sync();
     for (uint32_t kk = 2; kk <= P; kk <<= 1)
@@ -531,15 +536,78 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
                 uint32_t ixj = t ^ jj;
                 if (ixj > t) {
                     unsigned long long a = l_key[t], b = l_key[ixj];
-                    bool desc = (t & kk) == 0;          // descending overall
+                    bool desc = (t & kk) == 0;
                     if ((a < b) == desc) { l_key[t] = b; l_key[ixj] = a; }
                 }
             }
             lds_wave_sync();
         }
+    for (uint32_t t = lane; t < C; t += 64) l_ord[t] = (uint16_t)(0xFFFFFFFFu - (uint32_t)l_key[t]);
+    lds_wave_sync();
+    // ---- which candidates overlap ANY other candidate? Only those need the sequential greedy. ----
+    // query side: chunk mates are neighbours in generation order
+    for (uint32_t i = lane; i < C; i += 64) {
+        const uint32_t row = l_row[i], q0 = l_q0[i], q1 = l_q1[i];
+        bool cf = false;
+        for (uint32_t j = i; j-- > 0 && l_row[j] == row;) if (!(q1 < l_q0[j] || q0 > l_q1[j])) cf = true;
+        for (uint32_t j = i + 1; j < C && l_row[j] == row; j++) if (!(q1 < l_q0[j] || q0 > l_q1[j])) cf = true;
+        l_conf[i] = cf;
+    }
+    // reference side: sort by (ref contig, r0); u overlaps an earlier one iff the running max of r1 reaches r0[u],
+    // a later one iff the next r0 is <= r1[u]
+    for (uint32_t i = lane; i < P; i += 64) { l_key[i] = i < C ? (((unsigned long long)l_rc[i] << 32) | l_r0[i]) : ~0ull; l_idx[i] = (uint16_t)i; }
+    lds_wave_sync();
+    for (uint32_t kk = 2; kk <= P; kk <<= 1)
+        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t t = lane; t < P; t += 64) {
+                uint32_t ixj = t ^ jj;
+                if (ixj > t) {
+                    unsigned long long a = l_key[t], b = l_key[ixj];
+                    bool asc = (t & kk) == 0;
+                    if ((a > b) == asc) { l_key[t] = b; l_key[ixj] = a; uint16_t ia = l_idx[t]; l_idx[t] = l_idx[ixj]; l_idx[ixj] = ia; }
+                }
+            }
+            lds_wave_sync();
+        }
+    {
+        uint32_t carry_rc = 0xFFFFFFFFu, carry_max = 0;      // segmented inclusive max-scan of r1 in reference order
+        for (uint32_t u0 = 0; u0 < C; u0 += 64) {
+            const uint32_t u = u0 + lane;
+            const bool in = u < C;
+            const uint32_t rc = in ? (uint32_t)(l_key[u] >> 32) : 0xFFFFFFFEu;
+            uint32_t v = in ? l_r1[l_idx[u]] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t pv = __shfl_up(v, o), prc = __shfl_up(rc, o); if (lane >= o && prc == rc) v = pv > v ? pv : v; }
+            if (rc == carry_rc) v = carry_max > v ? carry_max : v;
+            if (in) l_pm[u] = v;
+            carry_rc = __shfl(rc, 63); carry_max = __shfl(v, 63);
+        }
+    }
+    lds_wave_sync();
+    for (uint32_t u = lane; u < C; u += 64) {
+        const uint32_t i = l_idx[u];
+        const uint32_t rc = (uint32_t)(l_key[u] >> 32), r0 = (uint32_t)l_key[u], r1 = l_r1[i];
+        bool cf = false;
+        if (u > 0 && (uint32_t)(l_key[u - 1] >> 32) == rc && l_pm[u - 1] >= r0) cf = true;
+        if (u + 1 < C && (uint32_t)(l_key[u + 1] >> 32) == rc && (uint32_t)l_key[u + 1] <= r1) cf = true;
+        if (cf) l_conf[i] = 1;
+    }
+    lds_wave_sync();
+    // ---- candidates that overlap nothing are kept outright; the others go through the greedy in priority order ----
+    uint32_t ncf = 0;
+    for (uint32_t t0 = 0; t0 < C; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t i = t < C ? l_ord[t] : 0;
+        const bool cf = t < C && l_conf[i];
+        if (t < C && !cf) sel_commit(S, row0 + l_row[i], l_q0[i], l_q1[i], l_n[i]);
+        unsigned long long bal = __ballot(cf);
+        if (cf) l_idx[ncf + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)i;   // l_idx is free again: conflicted list by rank
+        ncf += (uint32_t)__popcll(bal);
+    }
+    lds_wave_sync();
     uint32_t nk = 0;
-    for (uint32_t t = 0; t < C; t++) {
-        const uint32_t i = 0xFFFFFFFFu - (uint32_t)l_key[t];
+    for (uint32_t t = 0; t < ncf; t++) {
+        const uint32_t i = l_idx[t];
         const uint32_t q0 = l_q0[i], q1 = l_q1[i], r0 = l_r0[i], r1 = l_r1[i], rc = l_rc[i], row = l_row[i];
         bool ov = false;
         for (uint32_t j = lane; j < nk; j += 64) {
@@ -548,12 +616,11 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
             else if (l_rc[k2] == rc && !(r1 < l_r0[k2] || r0 > l_r1[k2])) ov = true;
         }
         if (__ballot(ov) == 0) {
-            if (lane == 0) l_kept[nk] = (uint16_t)i;
+            if (lane == 0) { l_kept[nk] = (uint16_t)i; sel_commit(S, row0 + row, q0, q1, l_n[i]); }
             nk++;
             lds_wave_sync();
         }
     }
-    for (uint32_t j = lane; j < nk; j += 64) { const uint32_t i = l_kept[j]; sel_commit(S, row0 + l_row[i], l_q0[i], l_q1[i], l_n[i]); }
     if (lane == 0) atomicAdd(&S.stats[2], 1u);
 }
 
