@@ -155,6 +155,13 @@ psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32
     return PSK_OK;
 }
 
+// LDS hand-off between lanes of ONE wave: order the ds ops, no workgroup barrier
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // ------------------------------------------------------------------ anchors
 // One (reference, query) pair of a launch. Pairs may mix queries (query_many / all-vs-all).
 struct PairDesc {
@@ -241,19 +248,36 @@ __global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __rest
     nxt[a] = l;
 }
 
-__global__ void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ cbase,
-                                   uint32_t n_pairs, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
-                                   uint32_t* __restrict__ err) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per pair follows nxt[] from the pair's first anchor. The walk is serial, so the wave stages a
+// 4 096-entry window of nxt[] in LDS with one round of coalesced loads and lane 0 hops inside it.
+constexpr int HEAD_WIN = 4096;
+__global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ cbase,
+                                                         uint32_t n_pairs, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+                                                         uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_win[HEAD_WIN];
+    __shared__ uint32_t s_h, s_n;
+    const uint32_t p = blockIdx.x;
     if (p >= n_pairs) return;
+    const int lane = threadIdx.x;
     const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
-    uint32_t h = pstart[p], pend = pstart[p + 1], n = 0;
+    const uint32_t pend = pstart[p + 1];
+    uint32_t h = pstart[p], n = 0;
     while (h < pend) {
-        uint32_t e = nxt[h];
-        if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, e); else atomicOr(err, 1u);
-        n++; h = e;
+        const uint32_t w0 = h, wn = pend - w0 < (uint32_t)HEAD_WIN ? pend - w0 : (uint32_t)HEAD_WIN;
+        for (uint32_t i = lane; i < wn; i += 64) s_win[i] = nxt[w0 + i];
+        lds_wave_sync();
+        if (lane == 0) {
+            while (h < pend && h - w0 < wn) {
+                uint32_t e = s_win[h - w0];
+                if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, e); else atomicOr(err, 1u);
+                n++; h = e;
+            }
+            s_h = h; s_n = n;
+        }
+        lds_wave_sync();
+        h = s_h; n = s_n;
     }
-    n_chunks[p] = n < max_chunks ? n : max_chunks;
+    if (lane == 0) n_chunks[p] = n < max_chunks ? n : max_chunks;
 }
 
 // ------------------------------------------------------------------ chaining
@@ -275,11 +299,6 @@ constexpr int RING = 128;   // power of two > CHAIN_BAND
 constexpr int RMAX = 256;   // chain trees per chunk handled in LDS
 constexpr int CHAIN_WAVES = 4;
 
-__device__ __forceinline__ void lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 // number of query seeds on contig qc with pos in [lo, hi]
 __device__ uint32_t seeds_between(const PairDesc& P, uint32_t qc, uint32_t lo, uint32_t hi) {
@@ -344,7 +363,6 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
     ChunkOut* op = &A.out[slot];
-    const PairDesc& P = A.pairs[pair];
     uint32_t (*ring)[RING] = s_ring[wave];
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
@@ -819,7 +837,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
         hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
         hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
     }
-    hipLaunchKernelGGL(chunk_heads_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+    hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     ctx->t_begin(K_CHAIN_CHUNK);
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
