@@ -51,6 +51,30 @@ __device__ __forceinline__ uint64_t hashD(uint32_t x) {
     r = (uint64_t)lo * 0x80000001u; hi = (uint32_t)(r >> 32) + (hi << 31) + hi; lo = (uint32_t)r;
     return ((uint64_t)hi << 32) | lo;
 }
+// E: low word by one 32x32->64 multiply, high word by v_mul_lo_u32 + add (no 64-bit addend to assemble)
+__device__ __forceinline__ uint64_t hashE(uint32_t x) {
+    uint64_t r = (uint64_t)x * 0x200001u;
+    uint32_t lo = ~(uint32_t)r, hi = ~(uint32_t)(r >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24); hi ^= hi >> 24;
+    r = (uint64_t)lo * 265u; hi = __umul24(hi, 265u) + (__umul24(hi >> 24, 265u) << 24) + (uint32_t)(r >> 32); lo = (uint32_t)r;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 14); hi ^= hi >> 14;
+    r = (uint64_t)lo * 21u; hi = __umul24(hi, 21u) + (__umul24(hi >> 24, 21u) << 24) + (uint32_t)(r >> 32); lo = (uint32_t)r;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 28); hi ^= hi >> 28;
+    r = (uint64_t)lo * 0x80000001u; hi = (uint32_t)(r >> 32) + (hi << 31) + hi; lo = (uint32_t)r;
+    return ((uint64_t)hi << 32) | lo;
+}
+// F: like the compiler's form but the high word's product is a plain 32-bit multiply
+__device__ __forceinline__ uint64_t hashF(uint32_t x) {
+    uint64_t r = (uint64_t)x * 0x200001u;
+    uint32_t lo = ~(uint32_t)r, hi = ~(uint32_t)(r >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24); hi ^= hi >> 24;
+    uint32_t t = hi * 265u; opq32(t); r = (uint64_t)lo * 265u; hi = (uint32_t)(r >> 32) + t; lo = (uint32_t)r;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 14); hi ^= hi >> 14;
+    t = hi * 21u; opq32(t); r = (uint64_t)lo * 21u; hi = (uint32_t)(r >> 32) + t; lo = (uint32_t)r;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 28); hi ^= hi >> 28;
+    t = hi * 0x80000001u; opq32(t); r = (uint64_t)lo * 0x80000001u; hi = (uint32_t)(r >> 32) + t; lo = (uint32_t)r;
+    return ((uint64_t)hi << 32) | lo;
+}
 template <int V> __global__ void bench(uint32_t* out, uint64_t thr, int iters) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, cnt = 0;
     for (int i = 0; i < iters; i++) {
@@ -58,25 +82,25 @@ template <int V> __global__ void bench(uint32_t* out, uint64_t thr, int iters) {
         for (int j = 0; j < 16; j++) {
             x = x * 1664525u + 1013904223u;
             uint64_t k = x & 0x3FFFFFFFu;
-            uint64_t h = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : hashD((uint32_t)k);
+            uint64_t h = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : hashF((uint32_t)k);
             cnt += h < thr;
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = cnt;
 }
-template <int V> __global__ void check(uint64_t* out) { uint64_t k = threadIdx.x * 2654435761u & 0x3FFFFFFF; out[threadIdx.x] = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : hashD((uint32_t)k); }
+template <int V> __global__ void check(uint64_t* out) { uint64_t k = threadIdx.x * 2654435761u & 0x3FFFFFFF; out[threadIdx.x] = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : hashF((uint32_t)k); }
 int main() {
     uint32_t* d; hipMalloc(&d, 4 * 2048 * 256);
-    uint64_t *c0, *c1, *c2, *c3; hipMalloc(&c0, 8 * 256); hipMalloc(&c1, 8 * 256); hipMalloc(&c2, 8 * 256); hipMalloc(&c3, 8 * 256);
-    check<0><<<1, 256>>>(c0); check<1><<<1, 256>>>(c1); check<2><<<1, 256>>>(c2); check<3><<<1, 256>>>(c3);
-    uint64_t h0[256], h1[256], h2[256], h3[256]; hipMemcpy(h3, c3, 2048, hipMemcpyDeviceToHost); hipMemcpy(h0, c0, 2048, hipMemcpyDeviceToHost); hipMemcpy(h1, c1, 2048, hipMemcpyDeviceToHost); hipMemcpy(h2, c2, 2048, hipMemcpyDeviceToHost);
-    int bad = 0; for (int i = 0; i < 256; i++) bad += (h0[i] != h1[i]) + (h0[i] != h2[i]) + (h0[i] != h3[i]);
+    uint64_t *c0, *c1, *c2, *c3, *c4, *c5; hipMalloc(&c4, 8 * 256); hipMalloc(&c5, 8 * 256); hipMalloc(&c0, 8 * 256); hipMalloc(&c1, 8 * 256); hipMalloc(&c2, 8 * 256); hipMalloc(&c3, 8 * 256);
+    check<0><<<1, 256>>>(c0); check<1><<<1, 256>>>(c1); check<2><<<1, 256>>>(c2); check<3><<<1, 256>>>(c3); check<4><<<1, 256>>>(c4); check<5><<<1, 256>>>(c5);
+    uint64_t h0[256], h1[256], h2[256], h3[256], h4[256], h5[256]; hipMemcpy(h3, c3, 2048, hipMemcpyDeviceToHost); hipMemcpy(h4, c4, 2048, hipMemcpyDeviceToHost); hipMemcpy(h5, c5, 2048, hipMemcpyDeviceToHost); hipMemcpy(h0, c0, 2048, hipMemcpyDeviceToHost); hipMemcpy(h1, c1, 2048, hipMemcpyDeviceToHost); hipMemcpy(h2, c2, 2048, hipMemcpyDeviceToHost);
+    int bad = 0; for (int i = 0; i < 256; i++) bad += (h0[i] != h1[i]) + (h0[i] != h2[i]) + (h0[i] != h3[i]) + (h0[i] != h4[i]) + (h0[i] != h5[i]);
     printf("mismatches %d\n", bad);
     uint64_t thr = UINT64_MAX / 125; int iters = 4096;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int v = 0; v < 4; v++) for (int rep = 0; rep < 2; rep++) {
+    for (int v = 0; v < 6; v++) for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(a);
-        if (v == 0) bench<0><<<2048, 256>>>(d, thr, iters); else if (v == 1) bench<1><<<2048, 256>>>(d, thr, iters); else if (v == 2) bench<2><<<2048, 256>>>(d, thr, iters); else bench<3><<<2048, 256>>>(d, thr, iters);
+        if (v == 0) bench<0><<<2048, 256>>>(d, thr, iters); else if (v == 1) bench<1><<<2048, 256>>>(d, thr, iters); else if (v == 2) bench<2><<<2048, 256>>>(d, thr, iters); else if (v == 3) bench<3><<<2048, 256>>>(d, thr, iters); else if (v == 4) bench<4><<<2048, 256>>>(d, thr, iters); else bench<5><<<2048, 256>>>(d, thr, iters);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         double n = 2048.0 * 256 * iters * 16;

@@ -180,90 +180,108 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
     return y ^ (n == 32 ? ~0ull : ((1ull << (2 * n)) - 1));
 }
 
-// One SEED per lane (not one 64-base stripe per lane): the tile's seed bits are ranked with a block scan,
-// lane j then locates the j-th set bit of the tile by binary search over the per-stripe prefix counts, so
-// every lane of a wave does the same amount of work (k-mer rebuild, canonical form, marker hash).
-__global__ __launch_bounds__(TILE_THREADS) void sketch_emit_kernel(
+// One WAVE per tile, one SEED per lane. The wave ranks the tile's seed bits with a shuffle scan (no workgroup
+// barrier anywhere), lists the seed positions in LDS, then every lane rebuilds one k-mer from the LDS-staged
+// packed tile: all lanes do the same work, and a tile costs ~0.5 k wave-instructions instead of ~2.8 k.
+constexpr int EMIT_WAVES = 4;      // tiles per workgroup (independent waves)
+constexpr int EMIT_LIST = 1024;    // seed positions listed per pass
+
+__global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
     const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed,
     const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
-    const uint32_t* __restrict__ genome_seed_off,
+    const uint32_t* __restrict__ genome_seed_off, uint32_t n_tiles,
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
-    uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ marker_count,
+    uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ tile_mcount,
     SketchConsts C) {
-    __shared__ unsigned long long s_mask[TILE_THREADS];
-    __shared__ __align__(16) uint32_t s_words[TILE_WORDS + 8];   // the tile's packed bases + 4 words either side
-    __shared__ uint32_t s_incl[TILE_THREADS];           // inclusive prefix of per-stripe seed counts
-    __shared__ uint32_t s_wave[TILE_THREADS / 64], s_mwave[TILE_THREADS / 64], s_mbase;
-    const uint32_t tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint64_t m0 = seedmask[(size_t)tile * TILE_MASKS + tid];
+    __shared__ __align__(16) uint32_t s_words_all[EMIT_WAVES][TILE_WORDS + 8];   // packed tile + 4 words either side
+    __shared__ uint16_t s_list_all[EMIT_WAVES][EMIT_LIST];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * EMIT_WAVES + wv;
+    if (tile >= n_tiles) return;
+    uint32_t* s_words = s_words_all[wv];
+    uint16_t* s_list = s_list_all[wv];
+    // four consecutive 64-base stripes per lane
+    const ulonglong2* mp = reinterpret_cast<const ulonglong2*>(seedmask + (size_t)tile * TILE_MASKS + 4 * lane);
+    const ulonglong2 ma = mp[0], mb = mp[1];
+    const unsigned long long m[4] = {ma.x, ma.y, mb.x, mb.y};
     const uint4 ti = tile_info[tile];          // {first_tile, genome, contig_index, contig id}
     const uint32_t t_off = tile_off[tile];
-    const uint32_t g_seed0 = genome_seed_off[ti.y];
-    const int cnt = __popcll(m0);
-    int incl = cnt;
+    const uint32_t cnt = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+    uint32_t incl = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) s_wave[wv] = incl;
-    s_mask[tid] = m0;
-    __syncthreads();
-    int wave_base = 0;
-    for (int w = 0; w < wv; w++) wave_base += s_wave[w];
-    s_incl[tid] = wave_base + incl;
-    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) { if (lane == 0) tile_mcount[tile] = 0; return; }
+    const uint32_t excl = incl - cnt;
+    uint32_t mrun = 0;   // markers of this tile so far: they go to marker_stage[t_off + 0 ..), no atomics
     const uint32_t pos0 = (tile - ti.x) * TILE_BASES;
     {   // stage the packed tile in LDS with coalesced 16-byte loads; k-mers are rebuilt from LDS
         const uint32_t* gsrc = packed + (size_t)tile * TILE_WORDS;
-        *reinterpret_cast<uint4*>(&s_words[4 + 4 * tid]) = *reinterpret_cast<const uint4*>(gsrc + 4 * tid);
-        if (tid < 4) s_words[tid] = tile > ti.x ? gsrc[tid - 4] : 0u;                 // halo: previous tile of the same contig
-        if (tid >= 4 && tid < 8) s_words[TILE_WORDS + tid] = gsrc[TILE_WORDS + tid - 4]; // next words (slot or padding)
+#pragma unroll
+        for (int r = 0; r < TILE_WORDS / 256; r++)
+            *reinterpret_cast<uint4*>(&s_words[4 + 4 * (lane + 64 * r)]) = *reinterpret_cast<const uint4*>(gsrc + 4 * (lane + 64 * r));
+        if (lane < 4) s_words[lane] = tile > ti.x ? gsrc[lane - 4] : 0u;                     // halo: previous tile of the same contig
+        if (lane >= 4 && lane < 8) s_words[TILE_WORDS + lane] = gsrc[TILE_WORDS + lane - 4]; // next words (slot or padding)
     }
-    const uint32_t* words = s_words + 4;      // word w of the tile; base b of the tile lives in word b/16
-    __syncthreads();
-    uint32_t mtotal_before = 0;   // markers reserved by earlier rounds of this tile
-    for (uint32_t j0 = 0; j0 < total; j0 += TILE_THREADS) {       // one round unless the tile has > 256 seeds
-        const uint32_t j = j0 + tid;
-        const bool have = j < total;
-        uint32_t p = 0; uint64_t cs = 0; bool is_marker = false;
-        if (have) {
-            int lo = 0, hi = TILE_THREADS - 1;                    // first stripe with incl > j
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > j) hi = mid; else lo = mid + 1; }
-            unsigned long long mm = s_mask[lo];
-            uint32_t r = j - (s_incl[lo] - (uint32_t)__popcll(mm));   // rank of the wanted bit inside the stripe
-            for (uint32_t q = 0; q < r; q++) mm &= mm - 1;
-            const int i = __ffsll(mm) - 1;
-            const uint32_t pl = 64u * lo + i;                     // tile-relative; +64 keeps the halo index positive
-            p = pos0 + pl;                                        // last base of the 21-base window
-            uint64_t f = get_bases(words - 4, pl + 64 + 1 - C.d - C.k, C.k);
-            uint64_t rc = revcomp(f, C.k);
-            uint32_t canon = f < rc;
-            cs = canon ? f : rc;
-            uint32_t meta = (ti.z << 1) | canon;
-            seed_kmer[t_off + j] = (uint32_t)cs;
-            seed_pos[t_off + j] = p;
-            seed_meta[t_off + j] = meta;
-            seed_pm[t_off + j] = ((uint64_t)p << 32) | meta;
-            is_marker = mm_hash64(cs) < C.thr_marker;
+    for (uint32_t base = 0; base < total; base += EMIT_LIST) {
+        // list the positions (tile-relative) of seeds with rank in [base, base + EMIT_LIST)
+        uint32_t off = excl;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned long long mm = m[r];
+            while (mm) {
+                int i = __ffsll(mm) - 1;
+                mm &= mm - 1;
+                if (off >= base && off < base + EMIT_LIST) s_list[off - base] = (uint16_t)((4 * lane + r) * 64 + i);
+                off++;
+            }
         }
-        // marker slots: ballot inside the wave, one atomic per tile and round
-        unsigned long long bal = __ballot(is_marker);
-        if (lane == 0) s_mwave[wv] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = s_mwave[0] + s_mwave[1] + s_mwave[2] + s_mwave[3];
-            s_mbase = tot ? atomicAdd(&marker_count[ti.y], tot) : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t seg = total - base < (uint32_t)EMIT_LIST ? total - base : (uint32_t)EMIT_LIST;
+        for (uint32_t j0 = 0; j0 < seg; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < seg;
+            uint32_t p = 0; bool is_marker = false;
+            if (have) {
+                const uint32_t pl = s_list[j];                        // tile-relative; +64 keeps the halo index positive
+                p = pos0 + pl;                                        // last base of the 21-base window
+                uint64_t f = get_bases(s_words, pl + 64 + 1 - C.d - C.k, C.k);
+                uint64_t rc = revcomp(f, C.k);
+                uint32_t canon = f < rc;
+                uint64_t cs = canon ? f : rc;
+                uint32_t meta = (ti.z << 1) | canon;
+                const uint32_t o = t_off + base + j;
+                seed_kmer[o] = (uint32_t)cs;
+                seed_pos[o] = p;
+                seed_meta[o] = meta;
+                seed_pm[o] = ((uint64_t)p << 32) | meta;
+                is_marker = mm_hash64(cs) < C.thr_marker;
+            }
+            // marker slots are tile-local (a tile has at most as many markers as seeds): ballot + running count
+            const unsigned long long bal = __ballot(is_marker);
+            if (is_marker) {
+                uint64_t f21 = get_bases(s_words, (p - pos0) + 64 + 1 - K_MARKER, K_MARKER);
+                uint64_t r21 = revcomp(f21, K_MARKER);
+                marker_stage[(size_t)t_off + mrun + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = f21 < r21 ? f21 : r21;
+            }
+            mrun += (uint32_t)__popcll(bal);
         }
-        __syncthreads();
-        if (is_marker) {
-            uint32_t mb = 0;
-            for (int w = 0; w < wv; w++) mb += s_mwave[w];
-            uint64_t f21 = get_bases(words - 4, (p - pos0) + 64 + 1 - K_MARKER, K_MARKER);
-            uint64_t r21 = revcomp(f21, K_MARKER);
-            marker_stage[(size_t)g_seed0 + s_mbase + mb + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = f21 < r21 ? f21 : r21;
-        }
-        __syncthreads();
-        (void)mtotal_before;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (lane == 0) tile_mcount[tile] = mrun;
+}
+
+// dense per-genome marker staging: tile t's markers move from marker_stage[tile_off[t] ..) to dense[tile_moff[t] ..)
+__global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t* __restrict__ stage, const uint32_t* __restrict__ tile_off,
+                                                             const uint32_t* __restrict__ tile_moff, uint32_t n_tiles, uint64_t* __restrict__ dense) {
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint32_t src = tile_off[tile], dst = tile_moff[tile], n = tile_moff[tile + 1] - dst;
+    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) dense[dst + i] = stage[src + i];
 }
 
 // out[i] = tile_off[idx[i]]
@@ -321,10 +339,10 @@ struct SketchJob {
     std::vector<psk_sketch*> sk;
     SketchConsts C{};
     std::shared_ptr<SketchStore> store;
-    uint32_t *d_cnt = nullptr, *d_toff = nullptr, *d_gft = nullptr, *d_cft = nullptr, *d_goff = nullptr, *d_coff = nullptr,
+    uint32_t *d_tmc = nullptr, *d_tmoff = nullptr, *d_cnt = nullptr, *d_toff = nullptr, *d_gft = nullptr, *d_cft = nullptr, *d_goff = nullptr, *d_coff = nullptr,
              *d_mcnt = nullptr, *d_sbeg = nullptr, *d_send = nullptr, *d_moff = nullptr, *d_tci = nullptr, *d_packed = nullptr;
     uint4* d_tinfo = nullptr; ContigDesc* d_desc = nullptr; uint64_t* d_mask = nullptr;
-    uint64_t *d_mstage = nullptr, *d_msorted = nullptr;
+    uint64_t *d_mstage = nullptr, *d_msorted = nullptr, *d_mdense = nullptr;
     uint32_t *h_goff = nullptr, *h_coff = nullptr, *h_moff = nullptr;
     bool empty = false;
 
@@ -375,7 +393,8 @@ struct SketchJob {
         if (empty) return PSK_OK;
         size_t o_cnt = 0, o_toff = o_cnt + n_tiles + 1, o_gft = o_toff + n_tiles + 1, o_cft = o_gft + n_genomes + 1,
                o_goff = o_cft + n_desc + 1, o_coff = o_goff + n_genomes + 1, o_mcnt = o_coff + n_desc + 1,
-               o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes, o_moff = o_send + n_genomes, o_end = o_moff + n_genomes + 1;
+               o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes + 1, o_moff = o_send + n_genomes, o_tmc = o_moff + n_genomes + 1,
+               o_tmoff = o_tmc + n_tiles + 1, o_end = o_tmoff + n_tiles + 1;
         PSK_TRY(R->s_desc.reserve(sizeof(ContigDesc) * n_desc));
         PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
         PSK_TRY(R->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS));
@@ -384,7 +403,7 @@ struct SketchJob {
         uint32_t* d_offs = (uint32_t*)R->s_offs.p;
         d_cnt = d_offs + o_cnt; d_toff = d_offs + o_toff; d_gft = d_offs + o_gft; d_cft = d_offs + o_cft;
         d_goff = d_offs + o_goff; d_coff = d_offs + o_coff; d_mcnt = d_offs + o_mcnt; d_sbeg = d_offs + o_sbeg;
-        d_send = d_offs + o_send; d_moff = d_offs + o_moff;
+        d_send = d_offs + o_send; d_moff = d_offs + o_moff; d_tmc = d_offs + o_tmc; d_tmoff = d_offs + o_tmoff;
         d_tinfo = (uint4*)R->s_counts.p; d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
         d_desc = (ContigDesc*)R->s_desc.p; d_packed = (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p;
         size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
@@ -402,7 +421,7 @@ struct SketchJob {
         JHIP(hipMemcpyAsync(d_gft, h_gft, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyHostToDevice, st));
         JHIP(hipMemcpyAsync(d_cft, h_cft, sizeof(uint32_t) * (n_desc + 1), hipMemcpyHostToDevice, st));
         JHIP(hipMemsetAsync(d_cnt + n_tiles, 0, sizeof(uint32_t), st));
-        JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t) * n_genomes, st));
+        JHIP(hipMemsetAsync(d_tmc + n_tiles, 0, sizeof(uint32_t), st));
         JHIP(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci, d_tinfo);
         if (wait_scan) JHIP(hipStreamWaitEvent(st, wait_scan, 0));   // scans run one after another; emit/sorts fill in beside them
@@ -441,21 +460,27 @@ struct SketchJob {
         store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
         store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
         JHIP(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
-        PSK_TRY(R->s_mark.reserve(sizeof(uint64_t) * (2 * ns + 2)));   // stage + sorted
-        d_mstage = (uint64_t*)R->s_mark.p; d_msorted = d_mstage + ns + 1;
+        PSK_TRY(R->s_mark.reserve(sizeof(uint64_t) * (3 * ns + 3)));   // tile-local stage, dense, sorted
+        d_mstage = (uint64_t*)R->s_mark.p; d_mdense = d_mstage + ns + 1; d_msorted = d_mdense + ns + 1;
         ctx->t_begin(K_SKETCH_EMIT, st);
-        hipLaunchKernelGGL(sketch_emit_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff,
-                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_mcnt, C);
+        hipLaunchKernelGGL(sketch_emit_kernel, dim3((n_tiles + EMIT_WAVES - 1) / EMIT_WAVES), dim3(64 * EMIT_WAVES), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff, n_tiles,
+                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_tmc, C);
         ctx->t_end(st);
         ctx->t_begin(K_SKETCH_SORT, st);
-        hipLaunchKernelGGL(marker_segments_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_goff, d_mcnt, d_sbeg, d_send, (int)n_genomes);
+        // marker sets: tile-local lists -> dense per-genome segments -> per-genome sort -> distinct values
         size_t tmp_bytes = 0;
+        JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_tmc, d_tmoff, (int)(n_tiles + 1), st));
+        PSK_TRY(R->s_tmp.reserve(tmp_bytes));
+        JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_tmc, d_tmoff, (int)(n_tiles + 1), st));
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, st, d_tmoff, d_gft, d_sbeg, (int)(n_genomes + 1));   // segment g = [sbeg[g], sbeg[g+1])
+        hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense);
         if (ns > 0) {
-            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+            tmp_bytes = 0;
+            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
-            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mstage, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_send, 0, 2 * K_MARKER, st));
+            JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
         }
-        hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_send, d_moff);
+        hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_moff);
         tmp_bytes = 0;
         JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
         PSK_TRY(R->s_tmp.reserve(tmp_bytes));
