@@ -111,6 +111,15 @@ psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds
 /* copy the sketch back to the host: seeds in (contig,pos) order, markers sorted unique */
 psk_status psk_sketch_export(const psk_sketch* s, psk_seed* seeds, uint64_t* markers);
 
+/* kept-contig lengths (n_contigs from psk_sketch_info), needed to serialise a sketch */
+psk_status psk_sketch_contig_lens(const psk_sketch* s, uint32_t* lens);
+/* Inverse of psk_sketch_export (+ contig lengths): rebuilds a device-resident sketch, e.g. from the records
+ * Database.open/load read back (lib.rs:95-122, 249-337). seeds in (contig,pos) order, markers sorted distinct.
+ * has_seeds = 0 builds a marker-only sketch (skani::types::Sketch::get_markers_only, lib.rs:495). */
+psk_status psk_sketch_import(psk_ctx* ctx, const psk_params* p, const uint32_t* contig_lens, uint32_t n_contigs,
+                             const psk_seed* seeds, uint64_t n_seeds, const uint64_t* markers, uint64_t n_markers,
+                             int has_seeds, psk_sketch** out);
+
 psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out);
 void psk_db_destroy(psk_db* db);
 /* takes ownership of s (also on failure) */

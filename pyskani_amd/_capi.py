@@ -37,7 +37,7 @@ SYMBOLS = [
     "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
     "psk_ctx_synchronize", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
-    "psk_sketch_export", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
+    "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
 ]
 
@@ -74,6 +74,8 @@ def load():
     lib.psk_sketch_free.restype = None
     lib.psk_sketch_info.argtypes = [vp, C.POINTER(Params), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     lib.psk_sketch_export.argtypes = [vp, vp, vp]
+    lib.psk_sketch_contig_lens.argtypes = [vp, vp]
+    lib.psk_sketch_import.argtypes = [vp, C.POINTER(Params), vp, u32, vp, u64, vp, u64, C.c_int, C.POINTER(vp)]
     lib.psk_db_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
     lib.psk_db_destroy.argtypes = [vp]
     lib.psk_db_destroy.restype = None

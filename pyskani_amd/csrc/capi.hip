@@ -192,6 +192,69 @@ psk_status psk_sketch_export(const psk_sketch* s, psk_seed* seeds, uint64_t* mar
     return PSK_OK;
 }
 
+psk_status psk_sketch_contig_lens(const psk_sketch* s, uint32_t* lens) {
+    if (!s || (!lens && !s->contig_len.empty())) { psk_set_error("contig_lens: NULL argument"); return PSK_EINVAL; }
+    for (size_t i = 0; i < s->contig_len.size(); i++) lens[i] = s->contig_len[i];
+    return PSK_OK;
+}
+
+/* Rebuild a device-resident sketch from its exported form (Database.open/load). */
+psk_status psk_sketch_import(psk_ctx* ctx, const psk_params* p, const uint32_t* contig_lens, uint32_t n_contigs,
+                             const psk_seed* seeds, uint64_t n_seeds, const uint64_t* markers, uint64_t n_markers,
+                             int has_seeds, psk_sketch** out) {
+    if (!ctx || !p || !out || (n_contigs && !contig_lens) || (n_seeds && !seeds) || (n_markers && !markers)) { psk_set_error("sketch_import: NULL argument"); return PSK_EINVAL; }
+    if (p->k < 1 || p->k > 16 || p->c < 1 || p->marker_c < 1) { psk_set_error("invalid sketch parameters"); return PSK_EINVAL; }
+    if (n_seeds >= 0x7FFFFFF0ull || n_markers >= 0x7FFFFFF0ull) { psk_set_error("sketch too large to import"); return PSK_ELIMIT; }
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<psk_sketch> s(new psk_sketch());
+    s->ctx = ctx; s->params = *p; s->has_seeds = has_seeds != 0;
+    s->contig_len.assign(contig_lens, contig_lens + n_contigs);
+    for (uint32_t i = 0; i < n_contigs; i++) s->total_len += contig_lens[i];
+    s->contig_seed_start.assign(n_contigs + 1, 0);
+    const size_t ns = (size_t)n_seeds;
+    std::vector<uint32_t> kmer(ns), pos(ns), meta(ns), cstart(n_contigs + 1, 0);
+    std::vector<uint64_t> pm(ns);
+    for (size_t i = 0; i < ns; i++) {
+        const psk_seed& sd = seeds[i];
+        if (sd.contig >= n_contigs || sd.pos >= contig_lens[sd.contig] || sd.canon > 1 ||
+            (i && (sd.contig < seeds[i - 1].contig || (sd.contig == seeds[i - 1].contig && sd.pos <= seeds[i - 1].pos)))) {
+            psk_set_error("sketch_import: seed %zu is out of range or out of (contig,pos) order", i);
+            return PSK_EINVAL;
+        }
+        kmer[i] = sd.kmer; pos[i] = sd.pos; meta[i] = (sd.contig << 1) | sd.canon; pm[i] = ((uint64_t)sd.pos << 32) | meta[i];
+        cstart[sd.contig + 1]++;
+    }
+    for (uint32_t c = 0; c < n_contigs; c++) cstart[c + 1] += cstart[c];
+    s->contig_seed_start = cstart;
+    for (uint64_t i = 1; i < n_markers; i++) if (markers[i] <= markers[i - 1]) { psk_set_error("sketch_import: markers must be sorted and distinct"); return PSK_EINVAL; }
+    auto store = std::make_shared<SketchStore>();
+    store->ctx = ctx;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t b_kmer = 0, b_pos = al(b_kmer + 4 * ns), b_meta = al(b_pos + 4 * ns), b_pm = al(b_meta + 4 * ns), b_cs = al(b_pm + 8 * ns), b_end = al(b_cs + 4 * (size_t)(n_contigs + 1));
+    PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
+    char* sb = (char*)store->base;
+    store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
+    store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cs);
+    PSK_TRY(ctx->pool_alloc(8 * ((size_t)n_markers + 1), &store->mbase, &store->mbytes));
+    store->markers = (uint64_t*)store->mbase;
+    hipStream_t st = ctx->stream;
+    if (ns) {
+        PSK_HIP(hipMemcpyAsync(store->seed_kmer, kmer.data(), 4 * ns, hipMemcpyHostToDevice, st));
+        PSK_HIP(hipMemcpyAsync(store->seed_pos, pos.data(), 4 * ns, hipMemcpyHostToDevice, st));
+        PSK_HIP(hipMemcpyAsync(store->seed_meta, meta.data(), 4 * ns, hipMemcpyHostToDevice, st));
+        PSK_HIP(hipMemcpyAsync(store->seed_pm, pm.data(), 8 * ns, hipMemcpyHostToDevice, st));
+    }
+    PSK_HIP(hipMemcpyAsync(store->contig_seed_start, cstart.data(), 4 * (size_t)(n_contigs + 1), hipMemcpyHostToDevice, st));
+    if (n_markers) PSK_HIP(hipMemcpyAsync(store->markers, markers, 8 * (size_t)n_markers, hipMemcpyHostToDevice, st));
+    PSK_HIP(hipStreamSynchronize(st));
+    s->store = store;
+    s->seed_off = 0; s->n_seeds = n_seeds; s->marker_off = 0; s->n_markers = n_markers; s->contig_off = 0;
+    *out = s.release();
+    return PSK_OK;
+}
+
 psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out) {
     if (!ctx || !p || !out) { psk_set_error("db_create: NULL argument"); return PSK_EINVAL; }
     if (p->k < 1 || p->k > 16 || p->c < 1 || p->marker_c < 1) { psk_set_error("invalid sketch parameters (c=%d marker_c=%d k=%d)", p->c, p->marker_c, p->k); return PSK_EINVAL; }
