@@ -540,10 +540,11 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         C += tot;
     }
     if (C == 0) return;
-    if (S.force_serial || C > CMAX) {
+    if (S.force_serial) {   // cross-check path: O(C^2) by one lane
         if (lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
         return;
     }
+    if (C > CMAX) return;   // select_big_kernel takes pairs that do not fit in LDS
     uint32_t P = 64; while (P < C) P <<= 1;
     // ---- priority order: (score desc, generation order asc) ----
     for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
@@ -640,6 +641,154 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         }
     }
     if (lane == 0) atomicAdd(&S.stats[2], 1u);
+}
+
+// ---- pairs with more than CMAX candidate chains (genomes beyond ~10 Mb): the same algorithm on global
+// scratch, one 1024-thread workgroup per pair. Scratch is indexed from the pair's first anchor: a pair with n
+// anchors has at most n/3 candidates, and the padded sort length stays below n.
+struct BigArgs {
+    SelArgs S; const uint32_t* pstart;
+    unsigned long long* key;   // sort keys
+    uint32_t *slot, *crow;     // candidate j -> global candidate slot, chunk row (generation order)
+    uint32_t *idx, *pm, *pm2;  // payload of the reference-order sort; running max of r1 (double buffer)
+    uint32_t *ord, *clist, *kept;
+    uint8_t* conf;
+};
+constexpr int BIG_T = 1024;
+
+__device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, bool descending) {
+    for (uint32_t kk = 2; kk <= P; kk <<= 1)
+        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t t = threadIdx.x; t < P; t += BIG_T) {
+                uint32_t ixj = t ^ jj;
+                if (ixj > t) {
+                    unsigned long long a = key[t], b = key[ixj];
+                    bool up = ((t & kk) == 0) != descending;      // ascending run?
+                    if ((a > b) == up) {
+                        key[t] = b; key[ixj] = a;
+                        if (pay) { uint32_t pa = pay[t]; pay[t] = pay[ixj]; pay[ixj] = pa; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
+    __shared__ uint32_t s_scan[BIG_T];
+    __shared__ uint32_t s_carry, s_nk, s_flag;
+    const SelArgs& S = B.S;
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
+    const uint32_t base = B.pstart[p];
+    if (S.force_serial) return;
+    // cheap exit for the common case: this pair fits the LDS kernel
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    {
+        uint32_t part = 0;
+        for (uint32_t r = tid; r < nrows; r += BIG_T) part += S.out[row0 + r].n_cand;
+        if (part) atomicAdd(&s_carry, part);
+    }
+    __syncthreads();
+    if (s_carry <= (uint32_t)CMAX) return;
+    __syncthreads();
+    // ---- candidates in generation order: block scan over the rows' candidate counts ----
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t r0 = 0; r0 < nrows; r0 += BIG_T) {
+        const uint32_t r = r0 + tid;
+        const uint32_t cnt = r < nrows ? S.out[row0 + r].n_cand : 0;
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (uint32_t o = 1; o < BIG_T; o <<= 1) { uint32_t v = tid >= o ? s_scan[tid - o] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
+        const uint32_t off = s_carry + s_scan[tid] - cnt;
+        if (cnt) { const uint32_t sl = S.chunks[row0 + r].x; for (uint32_t i = 0; i < cnt; i++) { B.slot[base + off + i] = sl + i; B.crow[base + off + i] = r; } }
+        __syncthreads();
+        if (tid == BIG_T - 1) s_carry += s_scan[tid];
+        __syncthreads();
+    }
+    const uint32_t C = s_carry;
+    unsigned long long* key = B.key + base; uint32_t* slot = B.slot + base; uint32_t* crow = B.crow + base;
+    uint32_t* idx = B.idx + base; uint32_t* pm = B.pm + base; uint32_t* pm2 = B.pm2 + base;
+    uint32_t* ord = B.ord + base; uint32_t* clist = B.clist + base; uint32_t* kept = B.kept + base; uint8_t* conf = B.conf + base;
+    uint32_t P = 1024; while (P < C) P <<= 1;
+    // ---- priority order ----
+    for (uint32_t j = tid; j < P; j += BIG_T) key[j] = j < C ? (((unsigned long long)(uint32_t)S.c_score[slot[j]] << 32) | (0xFFFFFFFFu - j)) : 0ull;
+    __syncthreads();
+    big_bitonic(key, nullptr, P, true);
+    for (uint32_t t = tid; t < C; t += BIG_T) ord[t] = 0xFFFFFFFFu - (uint32_t)key[t];
+    // ---- conflicts: chunk mates on the query ----
+    for (uint32_t j = tid; j < C; j += BIG_T) {
+        const uint32_t row = crow[j], q0 = S.c_q0[slot[j]], q1 = S.c_q1[slot[j]];
+        bool cf = false;
+        for (uint32_t v = j; v-- > 0 && crow[v] == row;) if (!(q1 < S.c_q0[slot[v]] || q0 > S.c_q1[slot[v]])) cf = true;
+        for (uint32_t v = j + 1; v < C && crow[v] == row; v++) if (!(q1 < S.c_q0[slot[v]] || q0 > S.c_q1[slot[v]])) cf = true;
+        conf[j] = cf;
+    }
+    __syncthreads();
+    // ---- conflicts on the reference: order by (ref contig, r0), running max of r1 by doubling ----
+    for (uint32_t j = tid; j < P; j += BIG_T) { key[j] = j < C ? (((unsigned long long)S.c_rc[slot[j]] << 32) | S.c_r0[slot[j]]) : ~0ull; idx[j] = j; }
+    __syncthreads();
+    big_bitonic(key, idx, P, false);
+    for (uint32_t u = tid; u < C; u += BIG_T) pm[u] = S.c_r1[slot[idx[u]]];
+    __syncthreads();
+    uint32_t* src = pm; uint32_t* dst = pm2;
+    for (uint32_t o = 1; o < C; o <<= 1) {
+        for (uint32_t u = tid; u < C; u += BIG_T) {
+            uint32_t v = src[u];
+            if (u >= o && (uint32_t)(key[u - o] >> 32) == (uint32_t)(key[u] >> 32)) { uint32_t w = src[u - o]; v = w > v ? w : v; }
+            dst[u] = v;
+        }
+        __syncthreads();
+        uint32_t* t2 = src; src = dst; dst = t2;
+    }
+    for (uint32_t u = tid; u < C; u += BIG_T) {
+        const uint32_t j = idx[u];
+        const uint32_t rc = (uint32_t)(key[u] >> 32), r0 = (uint32_t)key[u], r1 = S.c_r1[slot[j]];
+        bool cf = false;
+        if (u > 0 && (uint32_t)(key[u - 1] >> 32) == rc && src[u - 1] >= r0) cf = true;
+        if (u + 1 < C && (uint32_t)(key[u + 1] >> 32) == rc && (uint32_t)key[u + 1] <= r1) cf = true;
+        if (cf) conf[j] = 1;
+    }
+    __syncthreads();
+    // ---- unconflicted chains are kept; conflicted ones listed in priority order ----
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < C; t0 += BIG_T) {
+        const uint32_t t = t0 + tid;
+        const uint32_t j = t < C ? ord[t] : 0;
+        const uint32_t cf = (t < C && conf[j]) ? 1u : 0u;
+        if (t < C && !cf) { const uint32_t sl = slot[j]; sel_commit(S, row0 + crow[j], S.c_q0[sl], S.c_q1[sl], S.c_n[sl]); }
+        s_scan[tid] = cf;
+        __syncthreads();
+        for (uint32_t o = 1; o < BIG_T; o <<= 1) { uint32_t v = tid >= o ? s_scan[tid - o] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
+        if (cf) clist[s_carry + s_scan[tid] - 1] = j;
+        __syncthreads();
+        if (tid == BIG_T - 1) s_carry += s_scan[tid];
+        __syncthreads();
+    }
+    const uint32_t ncf = s_carry;
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+    for (uint32_t t = 0; t < ncf; t++) {
+        const uint32_t j = clist[t], sl = slot[j];
+        const uint32_t q0 = S.c_q0[sl], q1 = S.c_q1[sl], r0 = S.c_r0[sl], r1 = S.c_r1[sl], rc = S.c_rc[sl], row = crow[j];
+        const uint32_t nk = s_nk;
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        bool ov = false;
+        for (uint32_t v = tid; v < nk; v += BIG_T) {
+            const uint32_t j2 = kept[v], s2 = slot[j2];
+            if (crow[j2] == row && !(q1 < S.c_q0[s2] || q0 > S.c_q1[s2])) ov = true;
+            else if (S.c_rc[s2] == rc && !(r1 < S.c_r0[s2] || r0 > S.c_r1[s2])) ov = true;
+        }
+        if (ov) s_flag = 1;
+        __syncthreads();
+        if (tid == 0 && !s_flag) { kept[nk] = j; s_nk = nk + 1; sel_commit(S, row0 + row, q0, q1, S.c_n[sl]); }
+        __syncthreads();
+    }
+    if (tid == 0) atomicAdd(&S.stats[3], 1u);
 }
 
 // seeds of the query between the leftmost and rightmost kept anchor of every chunk
@@ -821,6 +970,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = (size_t)total + 64;
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
+    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 8 + 1) + 64));   // select_big_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
     uint32_t *a_qp = D, *a_qc = D + na, *a_rp = D + 2 * na, *a_rm = D + 3 * na, *a_nxt = D + 4 * na;
     ChainArgs A{};
@@ -847,6 +997,17 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     SA.out = d_cout; SA.two_c = A.two_c; SA.force_serial = force_serial; SA.stats = d_misc + 1;
     ctx->t_begin(K_SELECT);
     hipLaunchKernelGGL(select_kernel, dim3(n_pairs), dim3(64), 0, st, SA);
+    {   // pairs whose candidates do not fit the LDS kernel (large genomes); workgroups of small pairs exit at once
+        if (!force_serial) {
+            BigArgs BA{};
+            BA.S = SA; BA.pstart = d_pstart;
+            char* E = (char*)ctx->q_e.p;
+            BA.key = (unsigned long long*)E; uint32_t* U = (uint32_t*)(E + 8 * na);
+            BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na; BA.kept = U + 7 * na;
+            BA.conf = (uint8_t*)(U + 8 * na);
+            hipLaunchKernelGGL(select_big_kernel, dim3(n_pairs), dim3(BIG_T), 0, st, BA);
+        }
+    }
     ctx->t_end();
     hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};

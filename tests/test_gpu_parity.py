@@ -277,3 +277,16 @@ def test_all_vs_all_query_many_matches_oracle(psk, oracle):
             assert abs(g[rn].identity - w.ani) < 1e-6 and abs(g[rn].reference_fraction - w.af_ref) < 1e-6
         n_hits += len(got)
     assert n_hits >= 3 * 16 - 6     # every within-family pair is a hit (a few 8 %-vs-8 % pairs may fall below 0.15 AF)
+
+
+def test_chain_large_pair_global_selection(psk, oracle):
+    """> 1 024 candidate chains per pair (genomes beyond ~10 Mb) leave the LDS selection kernel for the
+    workgroup-per-pair kernel on global scratch; it must agree with the oracle, conflicts included."""
+    rng = np.random.default_rng(51)
+    base = random_genome(rng, 24_000_000)
+    rep = random_genome(rng, 6000)
+    ref = [base[:9_000_000] + rep, base[9_000_000:17_000_000] + rep + base[17_000_000:]]
+    q = mutate(rng, base[:12_000_000] + rep + base[12_000_000:] + rep, 0.02, 0.0002)
+    got = check_pair(psk, oracle, ref, [q[:15_000_000], q[15_000_000:]])
+    assert len(got) == 1 and got[0]._raw["n_chunks"] > 1024
+    check_pair(psk, oracle, ref, [q[:15_000_000], q[15_000_000:]], median=True)
