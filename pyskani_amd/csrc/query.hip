@@ -807,6 +807,7 @@ struct ReduceArgs {
     const uint32_t* pstart; const PairDesc* pairs;
     int k, median, robust; double min_af;
     psk_hit* hits;
+    double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
 };
 constexpr int RED_CAP = 4096;   // chunk ANI values sortable in LDS (genomes up to ~80 Mb at 20 kb chunks)
 
@@ -861,7 +862,31 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
                     __syncthreads();
                 }
         }
-    } else if (threadIdx.x == 0 && !(R.median || R.robust)) {   // very long genomes: stream the mean in chunk order
+    } else if (R.median || R.robust) {   // very long genomes: sort the chunk values in global scratch
+        double* gv = R.big_vals + 2 * (size_t)R.cbase[p] + 1024 * (size_t)p;
+        uint32_t P = 1024; while (P < nc) P <<= 1;
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+            double v = INFINITY;
+            if (i < nc && co[i].n_intervals) {
+                double ratio = (double)co[i].anchors / (double)(co[i].seeds > 1 ? co[i].seeds - 1 : 1); if (ratio > 1.0) ratio = 1.0;
+                v = pow(ratio, 1.0 / (double)R.k);
+            }
+            gv[i] = v;
+        }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= P; kk <<= 1)
+            for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (uint32_t t = threadIdx.x; t < P; t += blockDim.x) {
+                    uint32_t ixj = t ^ jj;
+                    if (ixj > t) {
+                        double a = gv[t], b = gv[ixj];
+                        bool up = (t & kk) == 0;
+                        if ((a > b) == up) { gv[t] = b; gv[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    } else if (threadIdx.x == 0) {   // very long genomes: stream the mean in chunk order
         double sum = 0; uint32_t cnt = 0;
         for (uint32_t i = 0; i < nc; i++) if (co[i].n_intervals) {
             double ratio = (double)co[i].anchors / (double)(co[i].seeds > 1 ? co[i].seeds - 1 : 1); if (ratio > 1.0) ratio = 1.0;
@@ -878,7 +903,17 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
         if (m > 0) {
             double ani;
             bool ok = true;
-            if (overflow) { if (R.median || R.robust) { ok = false; ani = -2.0; } else ani = mean_serial; }
+            if (overflow && (R.median || R.robust)) {
+                const double* gv = R.big_vals + 2 * (size_t)R.cbase[p] + 1024 * (size_t)p;
+                if (R.median) ani = gv[m / 2];
+                else {
+                    uint32_t lo = 0, hi = m;
+                    if (m - 2 * (m / 10) > 0) { lo = m / 10; hi = m - m / 10; }
+                    double sum = 0; for (uint32_t i = lo; i < hi; i++) sum += gv[i];
+                    ani = sum / (double)(hi - lo);
+                }
+            }
+            else if (overflow) ani = mean_serial;
             else if (R.median) ani = s_v[m / 2];
             else {
                 uint32_t lo = 0, hi = m;
@@ -1014,6 +1049,10 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     R.chunks = d_cout; R.n_chunks = d_nch; R.cbase = d_cbase; R.pstart = d_pstart; R.pairs = d_pairs;
     R.k = hp[0].q->params.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = d_hits;
+    if (o->median || o->robust) {
+        PSK_TRY(ctx->q_f.reserve(sizeof(double) * (2 * n_rows + 1024 * (size_t)n_pairs + 1024)));
+        R.big_vals = (double*)ctx->q_f.p;
+    }
     ctx->t_begin(K_PAIR_REDUCE);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
     ctx->t_end();

@@ -290,3 +290,13 @@ def test_chain_large_pair_global_selection(psk, oracle):
     got = check_pair(psk, oracle, ref, [q[:15_000_000], q[15_000_000:]])
     assert len(got) == 1 and got[0]._raw["n_chunks"] > 1024
     check_pair(psk, oracle, ref, [q[:15_000_000], q[15_000_000:]], median=True)
+
+
+def test_median_and_robust_beyond_lds_capacity(psk, oracle):
+    """> 4 096 chunk values per pair: median / trimmed mean sort in global scratch instead of LDS."""
+    rng = np.random.default_rng(52)
+    base = random_genome(rng, 86_000_000)
+    q = mutate(rng, base, 0.03)
+    for kw in ({"median": True}, {"robust": True}, {}):
+        got = check_pair(psk, oracle, [base], [q], **kw)
+        assert len(got) == 1 and got[0]._raw["n_chunks"] > 4096
