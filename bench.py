@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--refs", type=int, default=N_REFS, help="references per GPU (BASELINE configs[1]: 1000)")
     ap.add_argument("--workload", choices=["search", "allvsall"], default="search",
                     help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes (extra, not the headline)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
     ap.add_argument("--cpu-sample", type=int, default=1000, help="references in the CPU-baseline sample (0 = skip); 1000 = the whole workload, ~10-20 s")
     args = ap.parse_args()
 
@@ -168,13 +170,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if args.backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     n_refs = args.refs
     buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=N_FAMILIES)
@@ -190,7 +198,7 @@ def main():
         hits = eng.step(buf.data_ptr(), offs, lens, names)
         if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
             hits[:, 0] += rank * n_refs          # global ref index
-            return all_gather_hits(hits, dist, device=device).shape[0]
+            return all_gather_hits(hits, dist, device=coll_device).shape[0]
         return hits.shape[0]
 
     def fence():
@@ -210,7 +218,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     scan_ms, scan_n = eng.timing("sketch_scan")
