@@ -269,6 +269,7 @@ void psk_db_destroy(psk_db* db) {
     (void)hipSetDevice(db->ctx->device);
     for (psk_sketch* s : db->refs) delete s;
     db->d_marker_ptr.release(); db->d_marker_n.release();
+    db->inv_key.release(); db->inv_ref.release(); db->inv_tmp.release();
     delete db;
 }
 
@@ -278,7 +279,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     std::lock_guard<std::mutex> lk(db->ctx->mu);
     db->refs.push_back(s);
     db->names.emplace_back(name);
-    db->tables_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true;
     return PSK_OK;
 }
 
@@ -290,7 +291,7 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
         db->refs.push_back(sketches[i]);
         db->names.emplace_back(names[i]);
     }
-    db->tables_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true;
     return PSK_OK;
 }
 

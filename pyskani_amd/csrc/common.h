@@ -224,6 +224,10 @@ struct psk_db {
     // device tables for the screen kernel, rebuilt lazily
     bool tables_dirty = true;
     Scratch d_marker_ptr, d_marker_n;
+    // inverted marker index for many-query screens: every (marker, ref) of the db sorted by marker
+    bool inv_dirty = true;
+    Scratch inv_key, inv_ref, inv_tmp;
+    uint64_t inv_n = 0;
 };
 
 // ---- shared device helpers ----

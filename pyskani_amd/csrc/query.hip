@@ -126,6 +126,68 @@ static psk_status upload_marker_table(psk_db* db) {
     return PSK_OK;
 }
 
+// ---- inverted marker index: for 10^6+ (query, ref) pairs the screen costs O(shared markers), not O(Q x R x M) ----
+__global__ __launch_bounds__(256) void inv_gather_kernel(const MarkerSet* __restrict__ refs, const uint32_t* __restrict__ roff,
+                                                         uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const MarkerSet r = refs[blockIdx.x];
+    const uint32_t o = roff[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < r.n; i += blockDim.x) { key[o + i] = r.p[i]; val[o + i] = blockIdx.x; }
+}
+// one lane per (query, marker): every ref that holds the marker gets +1 in the query's row of the count matrix
+__global__ __launch_bounds__(256) void inv_lookup_kernel(const MarkerSet* __restrict__ queries, const uint32_t* __restrict__ qoff, uint32_t nq,
+                                                         uint32_t n_items, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                         uint32_t n_inv, uint32_t n_refs, uint32_t* __restrict__ count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t lo = 0, hi = nq - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (qoff[mid] <= i) lo = mid; else hi = mid - 1; }
+    const uint32_t q = lo;
+    const uint64_t m = queries[q].p[i - qoff[q]];
+    uint32_t l = 0, h = n_inv;
+    while (l < h) { uint32_t mid = (l + h) >> 1; if (key[mid] < m) l = mid + 1; else h = mid; }
+    for (; l < n_inv && key[l] == m; l++) atomicAdd(&count[(size_t)q * n_refs + val[l]], 1u);
+}
+__global__ __launch_bounds__(256) void inv_decide_kernel(const MarkerSet* __restrict__ refs, const MarkerSet* __restrict__ queries,
+                                                         uint32_t n_refs, uint32_t nq, const uint32_t* __restrict__ count,
+                                                         double thresh, int rescue_small, uint8_t* __restrict__ pass) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_refs * nq) return;
+    const uint32_t q = (uint32_t)(t / n_refs), r = (uint32_t)(t % n_refs);
+    const uint32_t a = queries[q].n, b = refs[r].n, small = a < b ? a : b;
+    int ok;
+    if (rescue_small && small < SMALL_MARKER_COUNT) ok = 1;
+    else if (small == 0) ok = 0;
+    else ok = ((double)count[t] / (double)small) > thresh;
+    pass[t] = (uint8_t)ok;
+}
+
+static psk_status build_inverted(psk_db* db) {
+    if (!db->inv_dirty) return PSK_OK;
+    psk_ctx* ctx = db->ctx; hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)db->refs.size();
+    std::vector<uint32_t> roff(n + 1, 0);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; i++) { roff[i] = (uint32_t)tot; tot += db->refs[i]->n_markers; }
+    roff[n] = (uint32_t)tot;
+    if (tot >= 0x7FFFFFF0ull) { psk_set_error("database holds too many markers for one inverted index"); return PSK_ELIMIT; }
+    db->inv_n = tot;
+    PSK_TRY(db->inv_key.reserve(8 * (tot + 1)));
+    PSK_TRY(db->inv_ref.reserve(4 * (tot + 1)));
+    PSK_TRY(db->inv_tmp.reserve(12 * (tot + 1) + 4 * (size_t)(n + 1)));
+    uint64_t* k_in = (uint64_t*)db->inv_tmp.p; uint32_t* v_in = (uint32_t*)(k_in + tot + 1); uint32_t* d_roff = v_in + tot + 1;
+    PSK_HIP(hipMemcpyAsync(d_roff, roff.data(), 4 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(inv_gather_kernel, dim3(n), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_roff, k_in, v_in);
+    if (tot) {
+        size_t tmp = 0;
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, (uint64_t*)db->inv_key.p, v_in, (uint32_t*)db->inv_ref.p, (int)tot, 0, 2 * K_MARKER, st));
+        PSK_TRY(ctx->q_c.reserve(tmp));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_c.p, tmp, k_in, (uint64_t*)db->inv_key.p, v_in, (uint32_t*)db->inv_ref.p, (int)tot, 0, 2 * K_MARKER, st));
+    }
+    PSK_HIP(hipStreamSynchronize(st));
+    db->inv_dirty = false;
+    return PSK_OK;
+}
+
 psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small, uint8_t* pass) {
     psk_ctx* ctx = db->ctx;
     const uint32_t n = (uint32_t)db->refs.size();
@@ -133,21 +195,43 @@ psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32
     hipStream_t st = ctx->stream;
     PSK_TRY(upload_marker_table(db));
     const double thresh = pow(screen_val, (double)K_MARKER);
-    const uint32_t per = std::max<uint32_t>(1, std::min<uint32_t>(65535, (1u << 24) / n));   // queries per launch
+    // small jobs: one workgroup per (ref, query). Large jobs: inverted index + count matrix.
+    const char* force = getenv("PSK_SCREEN");    // "inv" / "brute" for tests
+    const bool use_inv = force ? !strcmp(force, "inv") : ((uint64_t)n * nq >= (1ull << 18));
+    if (use_inv) PSK_TRY(build_inverted(db));
+    const uint32_t per = std::max<uint32_t>(1, std::min<uint32_t>(65535, (use_inv ? (1u << 26) : (1u << 24)) / n));   // queries per launch
     std::vector<MarkerSet> hq;
+    std::vector<uint32_t> qoff;
     for (uint32_t b = 0; b < nq; b += per) {
         const uint32_t m = std::min(per, nq - b);
-        hq.resize(m);
+        hq.resize(m); qoff.assign(m + 1, 0);
+        uint64_t items = 0;
         for (uint32_t i = 0; i < m; i++) {
             const psk_sketch* q = queries[b + i];
             hq[i].p = q->store ? q->store->markers + q->marker_off : nullptr; hq[i].n = (uint32_t)q->n_markers; hq[i].pad = 0;
+            qoff[i] = (uint32_t)items; items += q->n_markers;
         }
-        PSK_TRY(ctx->q_a.reserve(al256s(sizeof(MarkerSet) * m) + (size_t)m * n));
-        MarkerSet* d_q = (MarkerSet*)ctx->q_a.p;
-        uint8_t* d_pass = (uint8_t*)ctx->q_a.p + al256s(sizeof(MarkerSet) * m);
+        qoff[m] = (uint32_t)items;
+        if (items >= 0xFFFFFFF0ull) { psk_set_error("too many query markers in one screen launch"); return PSK_ELIMIT; }
+        const size_t o_q = 0, o_off = al256s(sizeof(MarkerSet) * m), o_pass = al256s(o_off + 4 * (size_t)(m + 1)),
+                     o_cnt = al256s(o_pass + (size_t)m * n), o_end = o_cnt + (use_inv ? 4 * (size_t)m * n : 0);
+        PSK_TRY(ctx->q_a.reserve(o_end + 256));
+        char* Bq = (char*)ctx->q_a.p;
+        MarkerSet* d_q = (MarkerSet*)(Bq + o_q); uint32_t* d_qoff = (uint32_t*)(Bq + o_off);
+        uint8_t* d_pass = (uint8_t*)(Bq + o_pass); uint32_t* d_cnt = (uint32_t*)(Bq + o_cnt);
         PSK_HIP(hipMemcpyAsync(d_q, hq.data(), sizeof(MarkerSet) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SCREEN);
-        hipLaunchKernelGGL(screen_many_kernel, dim3(n, m), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, thresh, rescue_small, d_pass);
+        if (use_inv) {
+            PSK_HIP(hipMemcpyAsync(d_qoff, qoff.data(), 4 * (size_t)(m + 1), hipMemcpyHostToDevice, st));
+            PSK_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)m * n, st));
+            if (items && db->inv_n)
+                hipLaunchKernelGGL(inv_lookup_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, st, d_q, d_qoff, m, (uint32_t)items,
+                                   (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (uint32_t)db->inv_n, n, d_cnt);
+            const size_t cells = (size_t)m * n;
+            hipLaunchKernelGGL(inv_decide_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, m, d_cnt, thresh, rescue_small, d_pass);
+        } else {
+            hipLaunchKernelGGL(screen_many_kernel, dim3(n, m), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, thresh, rescue_small, d_pass);
+        }
         ctx->t_end();
         PSK_HIP(hipMemcpyAsync(pass + (size_t)b * n, d_pass, (size_t)m * n, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipStreamSynchronize(st));

@@ -263,7 +263,16 @@ def test_all_vs_all_query_many_matches_oracle(psk, oracle):
     db = psk.Database()
     for n, contigs in genomes:
         db.sketch(n, *contigs)
-    got_all = db.query_many([(n, *contigs) for n, contigs in genomes], learned_ani=False)
+    # the batched screen has two implementations (workgroup per pair / inverted marker index): both must agree
+    per_mode = {}
+    for mode in ("brute", "inv"):
+        os.environ["PSK_SCREEN"] = mode
+        try:
+            per_mode[mode] = db.query_many([(n, *contigs) for n, contigs in genomes], learned_ani=False)
+        finally:
+            os.environ.pop("PSK_SCREEN", None)
+    assert [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["brute"]] == [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["inv"]]
+    got_all = per_mode["inv"]
     osk = [(n, oracle.Sketch(contigs)) for n, contigs in genomes]
     n_hits = 0
     for (n, contigs), got, (_, oq) in zip(genomes, got_all, osk):
