@@ -176,7 +176,7 @@ struct IndexStore {
     void* base = nullptr;
     size_t bytes = 0;
     uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
-    uint64_t* pm = nullptr;    // pos<<32 | meta, permuted alike
+    uint32_t* perm = nullptr;  // index of the seed in the sketch's (contig,pos)-ordered arrays
     ~IndexStore();
 };
 

@@ -249,8 +249,9 @@ __device__ __forceinline__ void lds_wave_sync() {
 // ------------------------------------------------------------------ anchors
 // One (reference, query) pair of a launch. Pairs may mix queries (query_many / all-vs-all).
 struct PairDesc {
-    const uint64_t* r_key; const uint64_t* r_pm;                              // ref index slice, key = slot<<32 | kmer
-    const uint32_t* q_kmer; const uint32_t* q_pos; const uint32_t* q_meta;   // query seeds, (contig,pos) order
+    const uint64_t* r_key; const uint32_t* r_perm; const uint64_t* r_pm;     // ref index slice (key = slot<<32 | kmer, perm into r_pm); r_pm = ref seeds pos<<32|meta, (contig,pos) order
+    const uint64_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
+    const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
     const uint32_t* q_contig_start;
     uint64_t q_total_len, r_total_len;
@@ -274,7 +275,11 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
     const PairDesc& P = pairs[p];
     const uint64_t* __restrict__ key = P.r_key;
     const uint32_t rn = P.r_n;
-    uint32_t km = P.q_kmer[i - sbase[p]];
+    // lane i takes the i-th query seed in K-MER order: neighbouring lanes search neighbouring keys, so the first
+    // levels of their binary searches read the same words and the last ones the same cache lines
+    const uint32_t iq = i - sbase[p];
+    const uint32_t km = (uint32_t)P.q_key[iq];
+    const uint32_t dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
     uint32_t lo = 0, hi = rn;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)key[mid] < km) lo = mid + 1; else hi = mid; }
     uint32_t cnt = 0;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
         while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)key[mid] == km) a = mid; else b = mid; }
         cnt = b - lo;
     }
-    lb_out[i] = lo; cnt_out[i] = cnt;
+    lb_out[dst] = lo; cnt_out[dst] = cnt;
 }
 
 __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
     uint32_t l = lb[i], dst = aoff[i];
     uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
     for (uint32_t j = 0; j < c; j++) {
-        uint64_t pm = P.r_pm[l + j];
+        uint64_t pm = P.r_pm[P.r_perm[l + j]];
         uint32_t rmeta = (uint32_t)pm;
         a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
         a_rp[dst + j] = (uint32_t)(pm >> 32);
@@ -1031,10 +1036,12 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
         const psk_sketch* r = hp[p].r; const psk_sketch* q = hp[p].q;
         PairDesc& P = h_pairs[p];
         P.r_key = r->idx ? r->idx->key + r->idx_off : nullptr;
-        P.r_pm = r->idx ? r->idx->pm + r->idx_off : nullptr;
+        P.r_perm = r->idx ? r->idx->perm + r->idx_off : nullptr;
+        P.r_pm = r->idx ? r->store->seed_pm + r->seed_off : nullptr;
         P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
-        P.q_n = q->store ? (uint32_t)q->n_seeds : 0;
-        P.q_kmer = q->store ? q->store->seed_kmer + q->seed_off : nullptr;
+        P.q_n = q->idx ? (uint32_t)q->n_seeds : 0;
+        P.q_key = q->idx ? q->idx->key + q->idx_off : nullptr;
+        P.q_perm = q->idx ? q->idx->perm + q->idx_off : nullptr;
         P.q_pos = q->store ? q->store->seed_pos + q->seed_off : nullptr;
         P.q_meta = q->store ? q->store->seed_meta + q->seed_off : nullptr;
         P.q_seed_pos_base = q->store ? q->store->seed_pos : nullptr;
@@ -1164,6 +1171,7 @@ psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const p
         if (refs[i]->params.k != queries[i]->params.k || refs[i]->params.c != queries[i]->params.c) { psk_set_error("pair %u: reference and query were sketched with different parameters", i); return PSK_EINVAL; }
     }
     PSK_TRY(ensure_index(ctx, refs, n));
+    PSK_TRY(ensure_index(ctx, queries, n));
     // bound one launch: lb/cnt/aoff cost 12 B per (pair, query seed); anchors ~64 B each
     const uint64_t MAX_ITEMS = 1ull << 27; const uint32_t MAX_PAIRS = 4096;
     std::vector<HostPair> hp;

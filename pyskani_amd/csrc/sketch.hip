@@ -575,13 +575,13 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
 
 // ---- reference index, built on first use: ONE device radix sort of (slot<<32 | kmer) over all the
 // sketches that need one; LSD radix sort is stable, so equal k-mers keep their (contig,pos) order ----
-struct IdxSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t out_off; };
+struct IdxSeg { const uint32_t* kmer; uint32_t n; uint32_t out_off; };
 
-__global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint64_t* __restrict__ val) {
+__global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const IdxSeg sg = segs[blockIdx.y];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) {
         key[sg.out_off + i] = ((uint64_t)blockIdx.y << 32) | sg.kmer[i];
-        val[sg.out_off + i] = sg.pm[i];
+        val[sg.out_off + i] = i;
     }
 }
 
@@ -603,25 +603,25 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         uint32_t off = 0, maxn = 0;
         for (uint32_t j = 0; j < m; j++) {
             const psk_sketch* s = todo[i0 + j];
-            segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, s->store->seed_pm + s->seed_off, (uint32_t)s->n_seeds, off};
+            segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, (uint32_t)s->n_seeds, off};
             off += (uint32_t)s->n_seeds; maxn = std::max(maxn, (uint32_t)s->n_seeds);
         }
         auto ix = std::make_shared<IndexStore>();
         ix->ctx = ctx;
-        size_t kb = align_up(8 * (size_t)T, 256);
-        PSK_TRY(ctx->pool_alloc(2 * kb, &ix->base, &ix->bytes));
-        ix->key = (uint64_t*)ix->base; ix->pm = (uint64_t*)((char*)ix->base + kb);
+        size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256);
+        PSK_TRY(ctx->pool_alloc(kb + vb, &ix->base, &ix->bytes));
+        ix->key = (uint64_t*)ix->base; ix->perm = (uint32_t*)((char*)ix->base + kb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
-        PSK_TRY(ctx->s_mark.reserve(2 * kb));
-        uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint64_t* v_in = (uint64_t*)((char*)ctx->s_mark.p + kb);
+        PSK_TRY(ctx->s_mark.reserve(kb + vb));
+        uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint32_t* v_in = (uint32_t*)((char*)ctx->s_mark.p + kb);
         PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SKETCH_SORT);
         hipLaunchKernelGGL(index_gather_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, k_in, v_in);
         int slot_bits = 1; while ((1u << slot_bits) < m) slot_bits++;
         size_t tmp = 0;
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->pm, (int)T, 0, 32 + slot_bits, st));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         PSK_TRY(ctx->s_tmp.reserve(tmp));
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->pm, (int)T, 0, 32 + slot_bits, st));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         ctx->t_end();
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) { todo[i0 + j]->idx = ix; todo[i0 + j]->idx_off = segs[j].out_off; }
