@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyskani_amd.so")
+LIB_PATH = os.environ.get("PSK_LIB_PATH") or os.path.join(_HERE, "libpyskani_amd.so")   # override: A/B builds only
 
 PSK_OK, PSK_EINVAL, PSK_ENOMEM, PSK_EHIP, PSK_ENOMODEL, PSK_EKEY, PSK_ELIMIT = range(7)
 
