@@ -31,7 +31,10 @@ class Context:
         self._h = h
         self.device = device
 
-    def __del__(self):
+    def close(self):
+        """Destroy the context. Every Database / Sketch created on it must be gone first: their device blocks
+        return to the context's pool when they are freed. Contexts are deliberately NOT destroyed by the garbage
+        collector (interpreter shutdown frees objects in arbitrary order); process exit releases the GPU memory."""
         if getattr(self, "_h", None):
             self._lib.psk_ctx_destroy(self._h)
             self._h = None

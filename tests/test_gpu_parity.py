@@ -309,3 +309,34 @@ def test_median_and_robust_beyond_lds_capacity(psk, oracle):
     for kw in ({"median": True}, {"robust": True}, {}):
         got = check_pair(psk, oracle, [base], [q], **kw)
         assert len(got) == 1 and got[0]._raw["n_chunks"] > 4096
+
+
+def test_concurrent_queries_from_threads(psk, oracle):
+    """`query` takes &self in the reference (lib.rs:551): concurrent queries from Python threads are legal.
+    ctypes releases the GIL around the C call; the library serialises them on the context's stream."""
+    import threading
+    rng = np.random.default_rng(61)
+    anc = random_genome(rng, 200000)
+    db = psk.Database()
+    for j, d in enumerate((0.0, 0.02, 0.05)):
+        db.sketch(f"r{j}", mutate(rng, anc, d))
+    queries = [mutate(rng, anc, 0.01 * (i + 1)) for i in range(4)]
+    want = [sorted((h.reference_name, h.identity) for h in db.query(f"q{i}", q, learned_ani=False)) for i, q in enumerate(queries)]
+    got = [None] * len(queries)
+
+    def work(i):
+        for _ in range(3):
+            got[i] = sorted((h.reference_name, h.identity) for h in db.query(f"q{i}", queries[i], learned_ani=False))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want
+    with pytest.raises(RuntimeError):       # `sketch` is &mut self: a second writer while one is active is refused
+        db._lock.acquire()
+        try:
+            db.sketch("x", anc)
+        finally:
+            db._lock.release()
