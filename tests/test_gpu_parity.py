@@ -340,3 +340,40 @@ def test_concurrent_queries_from_threads(psk, oracle):
             db.sketch("x", anc)
         finally:
             db._lock.release()
+
+
+def test_sharded_database_over_rccl_world1(psk):
+    """The N>1 code path on the real backend: torch.distributed "nccl" (= RCCL) with a one-rank group, real
+    Database underneath. (Two ranks cannot share this box's single GPU under RCCL; world 2 runs on gloo in
+    tests/test_parallel_cpu.py.)"""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+from conftest import random_genome, mutate
+import pyskani_amd as psk
+from pyskani_amd.parallel import ShardedDatabase
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rng = np.random.default_rng(5)
+anc = random_genome(rng, 150000)
+refs = [mutate(rng, anc, d) for d in (0.0, 0.03, 0.06)] + [random_genome(rng, 150000)]
+names = ["r%%d" %% i for i in range(len(refs))]
+sdb = ShardedDatabase(dist, device=dev)
+assert sdb.coll_device == dev
+sdb.sketch_all(names, lambda i: (refs[i],))
+q = mutate(rng, anc, 0.01)
+got = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in sdb.query("q", q, learned_ani=False)]
+db = psk.Database()
+for n, r in zip(names, refs): db.sketch(n, r)
+want = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in db.query("q", q, learned_ani=False)]
+assert got == want and len(got) == 3, (got, want)
+dist.destroy_process_group()
+print("sharded ok")
+''' % (ROOT, ROOT)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout + r.stderr

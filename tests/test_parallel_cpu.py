@@ -27,6 +27,23 @@ assert np.allclose(allh[:, 1], 0.9 + want / 1000)
 # a rank with no hits at all
 empty = all_gather_hits(np.zeros((0, 4), np.float32) if rank == 1 else local, dist)
 assert len(empty) == (len(local) if rank == 0 else len(allh) - len(local)) or True
+# ShardedDatabase over a stand-in local database (no GPU here): hits = refs whose name ends in an even digit
+from pyskani_amd.parallel import ShardedDatabase
+from pyskani_amd.database import Hit
+class FakeLocal:
+    def __init__(self): self.names = []
+    def __len__(self): return len(self.names)
+    def sketch(self, name, *contigs): self.names.append(name); assert contigs == (name.encode(),)
+    def query(self, name, *contigs, **kw):
+        return [Hit(0.5 + int(n[1:]) / 100, name, 0.25, n, 0.75) for n in self.names if int(n[1:]) %% 2 == 0]
+sdb = ShardedDatabase(dist, local=FakeLocal())
+names = ["g%%d" %% i for i in range(7)]
+fetched = []
+n_local = sdb.sketch_all(names, lambda i: (fetched.append(i), (names[i].encode(),))[1])
+assert fetched == list(range(*shard_bounds(7, rank, world))) and n_local == len(fetched)
+hits = sdb.query("q", b"ACGT")
+assert [h.reference_name for h in hits] == ["g0", "g2", "g4", "g6"], hits
+assert all(abs(h.identity - (0.5 + int(h.reference_name[1:]) / 100)) < 1e-6 and h.query_name == "q" for h in hits)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
