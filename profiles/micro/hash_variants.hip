@@ -75,6 +75,51 @@ __device__ __forceinline__ uint64_t hashF(uint32_t x) {
     t = hi * 0x80000001u; opq32(t); r = (uint64_t)lo * 0x80000001u; hi = (uint32_t)(r >> 32) + t; lo = (uint32_t)r;
     return ((uint64_t)hi << 32) | lo;
 }
+
+// G: NOT folded into the first xor-shift (P < 2^53), high-word products by v_mul_lo + add, 64-bit shifts for the xor-shifts
+__device__ __forceinline__ uint64_t hashG(uint32_t x) {
+    uint64_t P = (uint64_t)x * 0x200001u;
+    uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24); hi ^= 0xFFFFFF00u;         // = ~P ^ (~P >> 24)
+    uint64_t r = (uint64_t)lo * 265u; hi = hi * 265u + (uint32_t)(r >> 32);
+    uint64_t k = ((uint64_t)hi << 32) | (uint32_t)r; k ^= k >> 14;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+    r = (uint64_t)lo * 21u; hi = hi * 21u + (uint32_t)(r >> 32);
+    k = ((uint64_t)hi << 32) | (uint32_t)r; k ^= k >> 28;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+    r = (uint64_t)lo * 0x80000001u; hi = (hi << 31) + (uint32_t)(r >> 32) + hi;
+    return ((uint64_t)hi << 32) | (uint32_t)r;
+}
+// H: G with the x21 and x265 multiplies as v_lshl_add_u64 chains (shift <= 4)
+__device__ __forceinline__ uint64_t lsa(uint64_t a, int s, uint64_t b) {
+    uint64_t d;
+    if (s == 2) asm("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(d) : "v"(a), "v"(b));
+    else if (s == 3) asm("v_lshl_add_u64 %0, %1, 3, %2" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_lshl_add_u64 %0, %1, 4, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint64_t hashH(uint32_t x) {
+    uint64_t P = (uint64_t)x * 0x200001u;
+    uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24); hi ^= 0xFFFFFF00u;
+    uint64_t r = (uint64_t)lo * 265u; hi = hi * 265u + (uint32_t)(r >> 32);
+    uint64_t k = ((uint64_t)hi << 32) | (uint32_t)r; k ^= k >> 14;
+    k = lsa(k, 4, lsa(k, 2, k));                                   // 21 k
+    k ^= k >> 28;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+    r = (uint64_t)lo * 0x80000001u; hi = (hi << 31) + (uint32_t)(r >> 32) + hi;
+    return ((uint64_t)hi << 32) | (uint32_t)r;
+}
+// I: G's first step, then the compiler's own 64-bit forms
+__device__ __forceinline__ uint64_t hashI(uint32_t x) {
+    uint64_t P = (uint64_t)x * 0x200001u;
+    uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24); hi ^= 0xFFFFFF00u;
+    uint64_t key = ((uint64_t)hi << 32) | lo;
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14; key = (key + (key << 2)) + (key << 4); key = key ^ key >> 28; key = key + (key << 31);
+    return key;
+}
 template <int V> __global__ void bench(uint32_t* out, uint64_t thr, int iters) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, cnt = 0;
     for (int i = 0; i < iters; i++) {
@@ -82,29 +127,31 @@ template <int V> __global__ void bench(uint32_t* out, uint64_t thr, int iters) {
         for (int j = 0; j < 16; j++) {
             x = x * 1664525u + 1013904223u;
             uint64_t k = x & 0x3FFFFFFFu;
-            uint64_t h = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : hashF((uint32_t)k);
+            uint64_t h = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : V == 5 ? hashF((uint32_t)k) : V == 6 ? hashG((uint32_t)k) : V == 7 ? hashH((uint32_t)k) : hashI((uint32_t)k);
             cnt += h < thr;
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = cnt;
 }
-template <int V> __global__ void check(uint64_t* out) { uint64_t k = threadIdx.x * 2654435761u & 0x3FFFFFFF; out[threadIdx.x] = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : hashF((uint32_t)k); }
-int main() {
-    uint32_t* d; hipMalloc(&d, 4 * 2048 * 256);
-    uint64_t *c0, *c1, *c2, *c3, *c4, *c5; hipMalloc(&c4, 8 * 256); hipMalloc(&c5, 8 * 256); hipMalloc(&c0, 8 * 256); hipMalloc(&c1, 8 * 256); hipMalloc(&c2, 8 * 256); hipMalloc(&c3, 8 * 256);
-    check<0><<<1, 256>>>(c0); check<1><<<1, 256>>>(c1); check<2><<<1, 256>>>(c2); check<3><<<1, 256>>>(c3); check<4><<<1, 256>>>(c4); check<5><<<1, 256>>>(c5);
-    uint64_t h0[256], h1[256], h2[256], h3[256], h4[256], h5[256]; hipMemcpy(h3, c3, 2048, hipMemcpyDeviceToHost); hipMemcpy(h4, c4, 2048, hipMemcpyDeviceToHost); hipMemcpy(h5, c5, 2048, hipMemcpyDeviceToHost); hipMemcpy(h0, c0, 2048, hipMemcpyDeviceToHost); hipMemcpy(h1, c1, 2048, hipMemcpyDeviceToHost); hipMemcpy(h2, c2, 2048, hipMemcpyDeviceToHost);
-    int bad = 0; for (int i = 0; i < 256; i++) bad += (h0[i] != h1[i]) + (h0[i] != h2[i]) + (h0[i] != h3[i]) + (h0[i] != h4[i]) + (h0[i] != h5[i]);
-    printf("mismatches %d\n", bad);
+template <int V> __global__ void check(uint64_t* out) { uint64_t k = threadIdx.x * 2654435761u & 0x3FFFFFFF; out[threadIdx.x] = V == 0 ? hashA(k) : V == 1 ? hashC1(k) : V == 2 ? hashC2(k) : V == 3 ? hashD((uint32_t)k) : V == 4 ? hashE((uint32_t)k) : V == 5 ? hashF((uint32_t)k) : V == 6 ? hashG((uint32_t)k) : V == 7 ? hashH((uint32_t)k) : hashI((uint32_t)k); }
+template <int V> void run(uint32_t* d, uint64_t* c, const uint64_t* ref, uint64_t* mine) {
+    check<V><<<1, 256>>>(c); hipMemcpy(mine, c, 2048, hipMemcpyDeviceToHost);
+    int bad = 0; if (ref) for (int i = 0; i < 256; i++) bad += ref[i] != mine[i];
     uint64_t thr = UINT64_MAX / 125; int iters = 4096;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int v = 0; v < 6; v++) for (int rep = 0; rep < 2; rep++) {
-        hipEventRecord(a);
-        if (v == 0) bench<0><<<2048, 256>>>(d, thr, iters); else if (v == 1) bench<1><<<2048, 256>>>(d, thr, iters); else if (v == 2) bench<2><<<2048, 256>>>(d, thr, iters); else if (v == 3) bench<3><<<2048, 256>>>(d, thr, iters); else if (v == 4) bench<4><<<2048, 256>>>(d, thr, iters); else bench<5><<<2048, 256>>>(d, thr, iters);
-        hipEventRecord(b); hipEventSynchronize(b);
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(a); bench<V><<<2048, 256>>>(d, thr, iters); hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         double n = 2048.0 * 256 * iters * 16;
-        printf("variant %d: %.3f ms  %.1f Ghash/s\n", v, ms, n / ms / 1e6);
+        printf("variant %d: %.3f ms  %.1f Ghash/s  mismatches %d\n", V, ms, n / ms / 1e6, bad);
     }
+}
+int main() {
+    uint32_t* d; hipMalloc(&d, 4 * 2048 * 256);
+    uint64_t* c; hipMalloc(&c, 8 * 256);
+    uint64_t ref[256], mine[256];
+    run<0>(d, c, nullptr, ref);
+    run<1>(d, c, ref, mine); run<2>(d, c, ref, mine); run<3>(d, c, ref, mine); run<4>(d, c, ref, mine);
+    run<5>(d, c, ref, mine); run<6>(d, c, ref, mine); run<7>(d, c, ref, mine); run<8>(d, c, ref, mine);
     return 0;
 }

@@ -242,6 +242,30 @@ __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
     return key;
 }
 
+// mm_hash64 of a key below 2^32 (k <= 16), arranged for gfx950's VALU: there 32-bit add/sub/and/or/xor/not/mov and
+// right shifts issue at twice the rate of every other integer instruction (profiles/micro/valu_rates.hip), so
+// the cost is the number of multiplies, funnel and 64-bit shifts. P = key * (2^21+1) < 2^53, hence
+// ~P ^ (~P >> 24) = P ^ (P >> 24) ^ 0xFFFFFF00'00000000 with (P >> 56) = 0: the NOT costs one xor of the high word.
+__device__ __forceinline__ uint64_t mm_hash64_u32(uint32_t key) {
+    const uint64_t P = (uint64_t)key * 0x200001u;
+    uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24);
+    hi ^= 0xFFFFFF00u;
+    uint64_t r = (uint64_t)lo * 265u;
+    hi = hi * 265u + (uint32_t)(r >> 32);
+    uint64_t x = ((uint64_t)hi << 32) | (uint32_t)r;
+    x ^= x >> 14;
+    lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    r = (uint64_t)lo * 21u;
+    hi = hi * 21u + (uint32_t)(r >> 32);
+    x = ((uint64_t)hi << 32) | (uint32_t)r;
+    x ^= x >> 28;
+    lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    r = (uint64_t)lo * 0x80000001u;
+    hi = (hi << 31) + (uint32_t)(r >> 32) + hi;
+    return ((uint64_t)hi << 32) | (uint32_t)r;
+}
+
 // host-side entry points implemented across the translation units
 psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,

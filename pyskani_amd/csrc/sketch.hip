@@ -26,6 +26,7 @@ struct SketchConsts {
     uint64_t thr, thr_marker;
     uint32_t kmask;     // (1 << 2k) - 1
     int k, d, rshift;   // d = distance from window end to the seed's last base; rshift = 2k-2
+    int delta;          // 16 - (21-k)/2: delay (bases) that puts every seed's FIRST base at a fixed index in sketch_scan
 };
 
 // ---- ASCII -> 2-bit, four bytes at a time; every byte that is not ACGT/acgt maps to 0 ----
@@ -43,8 +44,25 @@ __device__ __forceinline__ uint32_t codes4(uint32_t w) {
     code &= ok;
     return (code * 0x40100401u) >> 24;            // c0<<6 | c1<<4 | c2<<2 | c3  (first base highest)
 }
-__device__ __forceinline__ uint32_t pack16(uint4 v) {
+__device__ __forceinline__ uint32_t pack16_checked(uint4 v) {   // any byte, ~35 instructions per 4 bases
     return (codes4(v.x) << 24) | (codes4(v.y) << 16) | (codes4(v.z) << 8) | codes4(v.w);
+}
+// Fast path, 7 instructions per 4 bases: bits 1-3 of the case-folded byte index two 8-entry byte tables through
+// v_perm_b32, one with the codes (A0 C1 T3 G2) and one with the letters themselves; a byte is ACGT/acgt exactly
+// when the looked-up letter equals it. Any other byte in the 16 sends the lane to the checked path.
+__device__ __forceinline__ uint32_t codes4_fast(uint32_t w, uint32_t& bad) {
+    const uint32_t x = w & 0xDFDFDFDFu;
+    const uint32_t idx = (x >> 1) & 0x07070707u;               // A 0, C 1, T 2, G 3
+    bad |= __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, idx) ^ x;
+    return __builtin_amdgcn_perm(0u, 0x02030100u, idx) * 0x40100401u;   // top byte = c0<<6 | c1<<4 | c2<<2 | c3
+}
+__device__ __forceinline__ uint32_t pack16(uint4 v) {
+    uint32_t bad = 0;
+    const uint32_t px = codes4_fast(v.x, bad), py = codes4_fast(v.y, bad), pz = codes4_fast(v.z, bad), pw = codes4_fast(v.w, bad);
+    uint32_t word = __builtin_amdgcn_perm(__builtin_amdgcn_perm(px, py, 0x07030000u), __builtin_amdgcn_perm(pz, pw, 0x00000703u), 0x07060100u);
+    asm("" : "+v"(bad));     // keep the four tests one OR-ed word: the compiler otherwise splits them into compares
+    if (__builtin_expect(bad != 0, 0)) word = pack16_checked(v);
+    return word;
 }
 
 __device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ contigs, int n_contigs, uint32_t tile) {
@@ -107,44 +125,52 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     }
     __syncthreads();
 
-    // phase 2: 64 window positions per lane. The lane's 96-base neighbourhood is delayed by d bases
-    // so that the seed's last base for window position i sits at a compile-time bit offset.
+    // phase 2: 64 window positions per lane, every k-mer a compile-time funnel shift of two pre-shifted streams.
+    // Index space: base i of the lane's 64 sits at index 32+i of its 96-base neighbourhood W0..W5. The seed of
+    // window position i starts at W-index 12+i+off_lo; delaying W by delta = 16-off_lo bases (6..14) puts that start
+    // at index 28+i of the stream V, whatever k is.
     const uint4 wa = *reinterpret_cast<const uint4*>(&s_w[4 * tid]);       // 16-byte stride: conflict-free b128
     const uint2 wb = *reinterpret_cast<const uint2*>(&s_w[4 * tid + 4]);
-    uint32_t W0 = wa.x, W1 = wa.y, W2 = wa.z, W3 = wa.w, W4 = wb.x, W5 = wb.y;
-    const uint32_t sh = 2 * C.d;
-    // V: the lane's neighbourhood delayed by d bases; delayed index 16+j of the 80 bases V[0..4] is the
-    // last base of the seed for window position j-16. No rolling state: every k-mer is a funnel shift.
-    uint32_t V[5];
-    V[0] = __funnelshift_r(W1, W0, sh);
-    V[1] = __funnelshift_r(W2, W1, sh);
-    V[2] = __funnelshift_r(W3, W2, sh);
-    V[3] = __funnelshift_r(W4, W3, sh);
-    V[4] = __funnelshift_r(W5, W4, sh);
-    // RC: reverse complement of those 80 bases, delayed by 16-k bases so that the reverse k-mer of window
-    // position i ends at the compile-time index 78-i
-    const uint32_t rsh = 2 * (16 - C.k);
-    uint32_t Q[5];
+    const uint32_t sh = 2 * C.delta;
+    uint32_t V[7];
+    V[0] = 0;
+    V[1] = __funnelshift_r(wa.y, wa.x, sh);
+    V[2] = __funnelshift_r(wa.z, wa.y, sh);
+    V[3] = __funnelshift_r(wa.w, wa.z, sh);
+    V[4] = __funnelshift_r(wb.x, wa.w, sh);
+    V[5] = __funnelshift_r(wb.y, wb.x, sh);
+    V[6] = __funnelshift_r(0u, wb.y, sh);
+    // Q: reverse complement of V's 112 bases, delayed by k-1 bases: the reverse k-mer of position i STARTS at index 83-i
+    const uint32_t rsh = 2 * (C.k - 1);
+    uint32_t Q[7];
     {
-        uint32_t r0 = rc_word(V[4]), r1 = rc_word(V[3]), r2 = rc_word(V[2]), r3 = rc_word(V[1]), r4 = rc_word(V[0]);
-        Q[0] = __funnelshift_r(r0, 0u, rsh);
+        uint32_t r0 = rc_word(V[6]), r1 = rc_word(V[5]), r2 = rc_word(V[4]), r3 = rc_word(V[3]), r4 = rc_word(V[2]),
+                 r5 = rc_word(V[1]), r6 = ~0u;   // V[0] is never read: its mirror only feeds junk bits
+        Q[0] = 0;
         Q[1] = __funnelshift_r(r1, r0, rsh);
         Q[2] = __funnelshift_r(r2, r1, rsh);
         Q[3] = __funnelshift_r(r3, r2, rsh);
         Q[4] = __funnelshift_r(r4, r3, rsh);
+        Q[5] = __funnelshift_r(r5, r4, rsh);
+        Q[6] = __funnelshift_r(r6, r5, rsh);
     }
+    // Both strands are taken LEFT-aligned (k-mer in the top 2k bits, following bases below): the smaller word holds
+    // the canonical k-mer on top (equal k-mers give the same key either way), one shift right-aligns it.
+    const uint32_t kdrop = 32 - 2 * C.k;
     uint32_t mlo = 0, mhi = 0;
+    const uint64_t thr = C.thr;
 #pragma unroll
     for (int i = 0; i < 64; i++) {
-        const int je = 16 + i;                 // forward: k-mer ends at delayed index je
-        const int fw = je / 16, fo = je % 16;
-        uint32_t fs = (fo == 15 ? V[fw] : __funnelshift_r(V[fw], V[fw - 1], 30 - 2 * fo)) & C.kmask;
-        const int me = 78 - i;                 // reverse: k-mer ends at index me of the delayed RC stream
-        const int rw = me / 16, ro = me % 16;
-        uint32_t rs = (ro == 15 ? Q[rw] : __funnelshift_r(Q[rw], Q[rw - 1], 30 - 2 * ro)) & C.kmask;
-        uint64_t h = mm_hash64((uint64_t)min(fs, rs));
-        // mask = mask*2 + bit: first window position ends up in the HIGHEST bit; reversed below
-        if (i < 32) mlo = mlo + mlo + (h < C.thr ? 1u : 0u); else mhi = mhi + mhi + (h < C.thr ? 1u : 0u);
+        const int s0 = 28 + i, sw = s0 / 16, so = s0 % 16;
+        const uint32_t fl = so == 0 ? V[sw] : __funnelshift_r(V[sw + 1], V[sw], 32 - 2 * so);
+        const int t0 = 83 - i, tw = t0 / 16, to = t0 % 16;
+        const uint32_t rl = to == 0 ? Q[tw] : __funnelshift_r(Q[tw + 1], Q[tw], 32 - 2 * to);
+        const uint32_t key = min(fl, rl) >> kdrop;
+        const uint64_t h = mm_hash64_u32(key);
+        // mask = mask*2 + (h < thr) as compare + add-with-carry (two instructions; the compiler's select + shift-add is
+        // three): the first window position ends up in the HIGHEST bit; reversed below
+        if (i < 32) asm("v_cmp_gt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mlo) : "s"(thr), "v"(h) : "vcc");
+        else asm("v_cmp_gt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mhi) : "s"(thr), "v"(h) : "vcc");
     }
     mlo = __brev(mlo); mhi = __brev(mhi);
     // windows must lie inside the contig: K_MARKER-1 <= pos < len
@@ -385,6 +411,7 @@ struct SketchJob {
         C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
         C.rshift = 2 * p->k - 2;
         C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
+        C.delta = 16 - (K_MARKER - p->k) / 2;
         return PSK_OK;
     }
 

@@ -53,6 +53,24 @@ def test_sketch_params_and_ragged_contigs(psk, oracle, k, c, mc):
     assert_sketch_equal(gs, oracle.Sketch(contigs, c=c, marker_c=mc, k=k))
 
 
+@pytest.mark.parametrize("k,c", [(15, 125), (16, 20), (9, 5), (1, 3), (2, 2)])
+def test_sketch_arbitrary_bytes(psk, oracle, k, c):
+    """Every one of the 256 byte values, scattered: only ACGT/acgt are bases, everything else is base 0
+    (the v_perm fast path of the packer must hand every other byte to the checked path)."""
+    rng = np.random.default_rng(700 + k)
+    contigs = []
+    for n in (70000, 16384 * 3, 5000):
+        b = bytearray(random_genome(rng, n))
+        pos = rng.choice(n, size=n // 50, replace=False)
+        for p_, v in zip(pos, rng.integers(0, 256, size=len(pos))):
+            b[p_] = int(v)
+        contigs.append(bytes(b))
+    contigs.append(bytes(rng.integers(0, 256, size=20000, dtype=np.uint8)))      # pure noise
+    contigs.append(bytes(range(256)) * 40)
+    db, gs = gpu_sketch(psk, contigs, compression=c, marker_compression=4 * c, k=k)
+    assert_sketch_equal(gs, oracle.Sketch(contigs, c=c, marker_c=4 * c, k=k))
+
+
 def test_sketch_empty_and_short(psk, oracle):
     db, gs = gpu_sketch(psk, [b"ATGC" * 100])        # 400 bp: below MIN_LENGTH_CONTIG (test_database.py:13)
     seeds, markers = gs.export()
