@@ -177,6 +177,8 @@ struct IndexStore {
     size_t bytes = 0;
     uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
     uint32_t* perm = nullptr;  // index of the seed in the sketch's (contig,pos)-ordered arrays
+    uint32_t* bucket = nullptr; // per sketch nb+1 offsets: bucket b = entries whose k-mer >> bshift == b (a lookup is one
+                               // table read plus a scan of ~4 keys instead of a 15-level binary search)
     ~IndexStore();
 };
 
@@ -214,6 +216,8 @@ struct psk_sketch {
     bool has_seeds = true;
     mutable std::shared_ptr<IndexStore> idx;  // built on first chaining use
     mutable uint64_t idx_off = 0;
+    mutable uint64_t idx_boff = 0;      // first entry of this sketch's bucket table in idx->bucket
+    mutable uint32_t idx_bshift = 0;
 };
 
 struct psk_db {

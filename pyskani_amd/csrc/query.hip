@@ -256,6 +256,7 @@ struct PairDesc {
     const uint32_t* q_contig_start;
     uint64_t q_total_len, r_total_len;
     uint32_t r_n, q_n;
+    const uint32_t* r_bucket; uint32_t r_bshift;                              // ref index bucket table (IndexStore::bucket)
 };
 // sbase[p] = first (pair, query seed) item of pair p in lb/cnt/aoff; cbase[p] = first row of pair p in the chunk table
 
@@ -265,13 +266,24 @@ __device__ __forceinline__ uint32_t find_le(const uint32_t* __restrict__ base, u
     return lo;
 }
 
+// find_le for a whole workgroup of consecutive x: one search by thread 0, then a short forward walk per thread
+// (a pair holds far more items than a workgroup has threads, so the walk is zero or one step)
+__device__ __forceinline__ uint32_t find_le_block(const uint32_t* __restrict__ base, uint32_t n, uint32_t x, uint32_t x_block0) {
+    __shared__ uint32_t s_p0;
+    if (threadIdx.x == 0) s_p0 = find_le(base, n, x_block0);
+    __syncthreads();
+    uint32_t p = s_p0;
+    while (p + 1 < n && base[p + 1] <= x) p++;
+    return p;
+}
+
 // one lane per (pair, query seed): range of equal k-mers in the ref index
 __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                            uint32_t n_pairs, uint32_t n_items,
                                                            uint32_t* __restrict__ lb_out, uint32_t* __restrict__ cnt_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
     if (i >= n_items) return;
-    const uint32_t p = find_le(sbase, n_pairs, i);
     const PairDesc& P = pairs[p];
     const uint64_t* __restrict__ key = P.r_key;
     const uint32_t rn = P.r_n;
@@ -280,8 +292,13 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
     const uint32_t iq = i - sbase[p];
     const uint32_t km = (uint32_t)P.q_key[iq];
     const uint32_t dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
-    uint32_t lo = 0, hi = rn;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)key[mid] < km) lo = mid + 1; else hi = mid; }
+    // bucket table: the k-mer's top bits give a range of ~4 index entries
+    uint32_t lo = 0, hi = 0;
+    if (rn) {
+        const uint32_t bk = km >> P.r_bshift;
+        lo = P.r_bucket[bk]; hi = P.r_bucket[bk + 1];
+    }
+    while (lo < hi && (uint32_t)key[lo] < km) lo++;
     uint32_t cnt = 0;
     if (lo < rn && (uint32_t)key[lo] == km) {
         uint32_t step = 1;
@@ -300,10 +317,10 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
                                                           uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
     if (i >= n_items) return;
     uint32_t c = cnt[i];
     if (c == 0) return;
-    const uint32_t p = find_le(sbase, n_pairs, i);
     const PairDesc& P = pairs[p];
     const uint32_t j0 = i - sbase[p];
     uint32_t l = lb[i], dst = aoff[i];
@@ -323,48 +340,44 @@ __global__ void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint3
     if (p <= n_pairs) pstart[p] = aoff[sbase[p]];
 }
 
-// nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
-__global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
-                                                          const uint32_t* __restrict__ pstart, uint32_t n_pairs,
-                                                          uint32_t total, uint32_t* __restrict__ nxt) {
-    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= total) return;
-    const uint32_t p = find_le(pstart, n_pairs, a);
-    uint32_t pend = pstart[p + 1];
-    uint64_t key = ((uint64_t)a_qc[a] << 32) + (uint64_t)a_qp[a] + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
-    uint32_t l = a + 1, h = pend;
-    while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)a_qc[mid] << 32) | a_qp[mid]; if (k2 <= key) l = mid + 1; else h = mid; }
-    nxt[a] = l;
-}
-
-// One wave per pair follows nxt[] from the pair's first anchor. The walk is serial, so the wave stages a
-// 4 096-entry window of nxt[] in LDS with one round of coalesced loads and lane 0 hops inside it.
-constexpr int HEAD_WIN = 4096;
-__global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ cbase,
-                                                         uint32_t n_pairs, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
-                                                         uint32_t* __restrict__ err) {
-    __shared__ uint32_t s_win[HEAD_WIN];
-    __shared__ uint32_t s_h, s_n;
+// Chunk table of one pair, one wave per pair. A chunk starts at anchor h and ends before the first anchor b of the
+// same pair with (qc, qp) > (qc, qp)(h) + FRAGMENT_LENGTH. The walk from head to head is serial, so the wave stages
+// a window of anchor keys in LDS with coalesced loads and finds each boundary with 64-wide compares + ballot
+// (a chunk is ~190 anchors at c = 125: three rounds).
+constexpr int HEAD_WIN = 2048;
+__global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
+                                                         const uint32_t* __restrict__ cbase, uint32_t n_pairs, uint2* __restrict__ chunks,
+                                                         uint32_t* __restrict__ n_chunks, uint32_t* __restrict__ err) {
+    __shared__ unsigned long long s_key[HEAD_WIN];
     const uint32_t p = blockIdx.x;
     if (p >= n_pairs) return;
     const int lane = threadIdx.x;
     const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
     const uint32_t pend = pstart[p + 1];
     uint32_t h = pstart[p], n = 0;
+    uint32_t w0 = h, wn = 0;
+    auto load_window = [&](uint32_t from) {
+        lds_wave_sync();
+        w0 = from; wn = pend - w0 < (uint32_t)HEAD_WIN ? pend - w0 : (uint32_t)HEAD_WIN;
+        for (uint32_t i = lane; i < wn; i += 64) s_key[i] = ((unsigned long long)a_qc[w0 + i] << 32) | a_qp[w0 + i];
+        lds_wave_sync();
+    };
+    if (h < pend) load_window(h);
     while (h < pend) {
-        const uint32_t w0 = h, wn = pend - w0 < (uint32_t)HEAD_WIN ? pend - w0 : (uint32_t)HEAD_WIN;
-        for (uint32_t i = lane; i < wn; i += 64) s_win[i] = nxt[w0 + i];
-        lds_wave_sync();
-        if (lane == 0) {
-            while (h < pend && h - w0 < wn) {
-                uint32_t e = s_win[h - w0];
-                if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, e); else atomicOr(err, 1u);
-                n++; h = e;
-            }
-            s_h = h; s_n = n;
+        const unsigned long long limit = s_key[h - w0] + FRAGMENT_LENGTH;     // h is always inside the window
+        uint32_t sp = h + 1, b = pend;
+        for (;;) {
+            if (sp >= pend) { b = pend; break; }
+            if (sp >= w0 + wn) load_window(sp);
+            const uint32_t idx = sp + lane;
+            const bool over = idx < w0 + wn && s_key[idx - w0] > limit;
+            const unsigned long long bal = __ballot(over);
+            if (bal) { b = sp + (uint32_t)__ffsll((long long)bal) - 1; break; }
+            sp = sp + 64 < w0 + wn ? sp + 64 : w0 + wn;
         }
-        lds_wave_sync();
-        h = s_h; n = s_n;
+        if (lane == 0) { if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, b); else atomicOr(err, 1u); }
+        n++; h = b;
+        if (h < pend && (h < w0 || h >= w0 + wn)) load_window(h);
     }
     if (lane == 0) n_chunks[p] = n < max_chunks ? n : max_chunks;
 }
@@ -380,8 +393,9 @@ struct ChainArgs {
     // serial-path scratch, one entry per anchor
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
     int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state, *c_rc;   // candidate chains, chunk s writes at [s, s + n_cand)
-    uint32_t two_c; int band; int force_serial;
-    uint32_t* stats;   // [0] fast chunks, [1] serial chunks
+    uint32_t two_c; int band; int force_serial; int lane_dp;
+    uint32_t* stats;   // [1] chunks / [3] pairs that took a serial fallback (rare paths only: a counter every wave bumps
+                       // serialises the whole launch on one L2 address)
 };
 
 constexpr int RING = 128;   // power of two > CHAIN_BAND
@@ -437,6 +451,109 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
     return nc;
 }
 
+
+// ---- lane-per-chunk DP ---------------------------------------------------------------------------------------
+// chain_chunk's DP step is a 64-lane affair for a band of ~20 predecessors, and the kernel is VALU-issue bound
+// (profiles/r1d_overlap.md). Here ONE LANE owns one chunk: the last LANE_N anchors (q, r, ref contig|strand, f) live
+// in registers as a shift register, every (anchor, predecessor) pair is ~25 branch-free instructions with no
+// cross-lane traffic, and 64 chunks advance per wave step. Per anchor it leaves f, the tree id and the depth in
+// sc_f / sc_root / sc_depth; chain_chunk_kernel then only aggregates the trees and emits candidates.
+// The register file is laid out for the band: LANE_N >= band (band = 2500/c: 20 at c = 125).
+constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4)
+constexpr int LANE_WAVES = 2;
+constexpr uint32_t LANE_DONE = 0x80000000u;
+
+struct LaneAnchor { uint32_t q, r, m; int32_t f; };
+
+// key of predecessor y for anchor x at distance d (0 = not chainable); same rule as the wave kernel and the oracle
+__device__ __forceinline__ uint32_t lane_eval(uint32_t qx, uint32_t rx, uint32_t mx, uint32_t sg, const LaneAnchor& y, int d) {
+    const int32_t dq = (int32_t)(qx - y.q);
+    const int32_t dr = (int32_t)(((rx - y.r) ^ sg) - sg);                 // strand -: ry - rx
+    const int32_t t = dq - dr, nt = dr - dq;
+    const int32_t gap = t > nt ? t : nt;
+    const int32_t scp = y.f - gap;                                        // score - ANCHOR_SCORE2
+    const uint32_t z = y.m ^ mx;
+    // every requirement as a sign bit: 1 <= dq <= 2500, dr >= 1, gap <= 300, score > 40, same ref contig and strand
+    const uint32_t bad = (uint32_t)(dq - 1) | (uint32_t)(BP_CHAIN_BAND - dq) | (uint32_t)(dr - 1) | (uint32_t)(MAX_GAP_LENGTH - gap) |
+                         (uint32_t)(scp - 1) | z | (0u - z);
+    const uint32_t ok = (uint32_t)((int32_t)~bad >> 31);
+    return ((((uint32_t)scp << 7) + (((uint32_t)ANCHOR_SCORE2 << 7) | (127u - (uint32_t)d)))) & ok;
+}
+
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A, uint32_t rows_per_wave) {
+    __shared__ uint32_t s_rd[LANE_WAVES][32][64];     // tree id << 14 | depth of the last 32 anchors, per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
+    uint32_t s = 0, e = 0;
+    bool mine = false;
+    if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) {
+        const uint32_t pair = find_le(A.cbase, A.n_pairs, slot);
+        if (slot - A.cbase[pair] < A.n_chunks[pair]) {
+            const uint2 se = A.chunks[slot];
+            s = se.x; e = se.y;
+            mine = e > s && e - s < 16384;
+        }
+    }
+    const uint32_t s_al = s & ~3u;
+    const uint32_t len = mine ? e - s_al : 0;          // steps this lane takes part in (the first s - s_al are idle)
+    LaneAnchor P[LANE_N];
+#pragma unroll
+    for (int i = 0; i < LANE_N; i++) { P[i].q = 0; P[i].r = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
+    uint32_t R = 0;
+    uint32_t (*rd)[64] = s_rd[wave];
+    const int band = A.band;
+    for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
+        const uint32_t x0 = s_al + t0;
+        uint4 q4 = make_uint4(0, 0, 0, 0), r4 = q4, m4 = q4;
+        if (t0 < len) {
+            q4 = *reinterpret_cast<const uint4*>(A.a_qp + x0);
+            r4 = *reinterpret_cast<const uint4*>(A.a_rp + x0);
+            m4 = *reinterpret_cast<const uint4*>(A.a_rm + x0);
+        }
+        const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+        LaneAnchor nw[4];
+        uint32_t of[4], orid[4], odep[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t x = x0 + u, t = t0 + u;
+            act[u] = x >= s && x < e && mine;
+            const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
+            const uint32_t sg = 0u - (mx & 1u);
+            uint32_t best = 0;
+#pragma unroll
+            for (int d = 1; d <= LANE_N; d++) {
+                if (d <= band) {
+                    const uint32_t k = d <= u ? lane_eval(qx, rx, mx, sg, nw[u - d], d) : lane_eval(qx, rx, mx, sg, P[d - 1 - u], d);
+                    best = k > best ? k : best;
+                }
+            }
+            int32_t f = ANCHOR_SCORE2; uint32_t rid = R, dep = 1;
+            if (best) {
+                f = (int32_t)(best >> 7);
+                const uint32_t v = rd[(t - (127u - (best & 127u))) & 31u][lane];
+                rid = v >> 14; dep = (v & 16383u) + 1;
+            } else if (act[u]) R++;
+            rd[t & 31u][lane] = (rid << 14) | dep;
+            nw[u].q = qx; nw[u].r = rx; nw[u].m = act[u] ? mx : 0xFFFFFFFFu; nw[u].f = f;
+            of[u] = (uint32_t)f; orid[u] = rid; odep[u] = dep;
+        }
+        // shift the register window by four anchors
+#pragma unroll
+        for (int i = LANE_N - 1; i >= 4; i--) P[i] = P[i - 4];
+        P[0] = nw[3]; P[1] = nw[2]; P[2] = nw[1]; P[3] = nw[0];
+        if (act[0] && act[3]) {
+            *reinterpret_cast<uint4*>(A.sc_f + x0) = make_uint4(of[0], of[1], of[2], of[3]);
+            *reinterpret_cast<uint4*>(A.sc_root + x0) = make_uint4(orid[0], orid[1], orid[2], orid[3]);
+            *reinterpret_cast<uint4*>(A.sc_depth + x0) = make_uint4(odep[0], odep[1], odep[2], odep[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (act[u]) { A.sc_f[x0 + u] = (int32_t)of[u]; A.sc_root[x0 + u] = orid[u]; A.sc_depth[x0 + u] = odep[u]; }
+        }
+    }
+    if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) A.out[slot].anchors = mine ? (LANE_DONE | R) : 0u;
+}
+
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs A) {
     typedef hipcub::WarpReduce<uint32_t, 64> WR;
     __shared__ typename WR::TempStorage s_wr[CHAIN_WAVES];
@@ -455,7 +572,22 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     uint32_t (*ring)[RING] = s_ring[wave];
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
-    if (fast) {
+    const uint32_t lane_state = A.lane_dp ? op->anchors : 0u;
+    if (fast && (lane_state & LANE_DONE)) {
+        // the DP ran one lane per chunk (chain_lane_kernel): fold its per-anchor (f, tree, depth) into the tree tables
+        R = lane_state & ~LANE_DONE;
+        if (R > RMAX) fast = false;
+        else {
+            for (uint32_t r = lane; r < R; r += 64) s_best[wave][r] = 0;
+            lds_wave_sync();
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t f = (uint32_t)A.sc_f[s + i], rid = A.sc_root[s + i], dep = A.sc_depth[s + i];
+                atomicMax(&s_best[wave][rid], ((unsigned long long)f << 28) | ((unsigned long long)(16383u - i) << 14) | dep);
+                if (dep == 1) s_rootx[wave][rid] = i;
+            }
+            lds_wave_sync();
+        }
+    } else if (fast) {
         for (uint32_t base = s; base < e && fast; base += 64) {
             const uint32_t idx = base + lane;
             const bool have = idx < e;
@@ -544,7 +676,6 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
             A.c_r0[s + lane] = s_cand[wave][3][lane]; A.c_r1[s + lane] = s_cand[wave][4][lane]; A.c_n[s + lane] = s_cand[wave][5][lane];
             A.c_rc[s + lane] = s_cand[wave][6][lane];
         }
-        if (lane == 0) atomicAdd(&A.stats[0], 1u);
     }
     if (lane == 0) {
         ChunkOut o{};
@@ -729,7 +860,6 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
             lds_wave_sync();
         }
     }
-    if (lane == 0) atomicAdd(&S.stats[2], 1u);
 }
 
 // ---- pairs with more than CMAX candidate chains (genomes beyond ~10 Mb): the same algorithm on global
@@ -1039,6 +1169,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
         P.r_perm = r->idx ? r->idx->perm + r->idx_off : nullptr;
         P.r_pm = r->idx ? r->store->seed_pm + r->seed_off : nullptr;
         P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
+        P.r_bucket = r->idx ? r->idx->bucket + r->idx_boff : nullptr; P.r_bshift = r->idx ? r->idx_bshift : 0;
         P.q_n = q->idx ? (uint32_t)q->n_seeds : 0;
         P.q_key = q->idx ? q->idx->key + q->idx_off : nullptr;
         P.q_perm = q->idx ? q->idx->perm + q->idx_off : nullptr;
@@ -1103,7 +1234,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     A.a_qp = a_qp; A.a_qc = a_qc; A.a_rp = a_rp; A.a_rm = a_rm;
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
     A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
-    A.c_state = a_nxt;   // nxt is dead once the chunk table exists
+    A.c_state = a_nxt;   // spare per-anchor array
     A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
     A.chunks = d_chunks; A.n_chunks = d_nch; A.cbase = d_cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
     A.pairs = d_pairs;
@@ -1111,10 +1242,21 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)hp[0].q->params.c));
     if (total > 0) {
         hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
-        hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
     }
-    hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+    hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_qp, a_qc, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     ctx->t_begin(K_CHAIN_CHUNK);
+    {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
+        const char* le = getenv("PSK_CHAIN_LANE");
+        A.lane_dp = !force_serial && A.band <= LANE_N && !(le && le[0] == '0');
+        if (A.lane_dp) {
+            // few rows: spread them over more waves (idle lanes cost nothing on an under-filled chip)
+            uint32_t rpw = 64;
+            while (rpw > 16 && n_rows / rpw < 512) rpw >>= 1;
+            if (le && atoi(le) >= 8) rpw = (uint32_t)std::min(64, atoi(le));
+            const uint32_t waves = (uint32_t)((n_rows + rpw - 1) / rpw);
+            hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+        }
+    }
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
     SelArgs SA{};
