@@ -249,7 +249,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // ------------------------------------------------------------------ anchors
 // One (reference, query) pair of a launch. Pairs may mix queries (query_many / all-vs-all).
 struct PairDesc {
-    const uint64_t* r_key; const uint32_t* r_perm; const uint64_t* r_pm;     // ref index slice (key = slot<<32 | kmer, perm into r_pm); r_pm = ref seeds pos<<32|meta, (contig,pos) order
+    const uint64_t* r_key; const uint64_t* r_pms;                             // ref index slice: key = slot<<32 | kmer ascending; r_pms = the seeds' pos<<32|meta in the same order
     const uint64_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
     const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
@@ -277,10 +277,12 @@ __device__ __forceinline__ uint32_t find_le_block(const uint32_t* __restrict__ b
     return p;
 }
 
+struct CountOf { __host__ __device__ uint32_t operator()(const uint2& v) const { return v.y; } };
+
 // one lane per (pair, query seed): range of equal k-mers in the ref index
 __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                            uint32_t n_pairs, uint32_t n_items,
-                                                           uint32_t* __restrict__ lb_out, uint32_t* __restrict__ cnt_out) {
+                                                           uint2* __restrict__ lbcnt_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
     if (i >= n_items) return;
@@ -307,26 +309,27 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
         while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)key[mid] == km) a = mid; else b = mid; }
         cnt = b - lo;
     }
-    lb_out[dst] = lo; cnt_out[dst] = cnt;
+    lbcnt_out[dst] = make_uint2(lo, cnt);      // one 8-byte scattered store per item
 }
 
 __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                           uint32_t n_pairs, uint32_t n_items,
-                                                          const uint32_t* __restrict__ lb, const uint32_t* __restrict__ cnt,
+                                                          const uint2* __restrict__ lbcnt,
                                                           const uint32_t* __restrict__ aoff,
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
                                                           uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
     if (i >= n_items) return;
-    uint32_t c = cnt[i];
+    const uint2 lc = lbcnt[i];
+    const uint32_t c = lc.y;
     if (c == 0) return;
     const PairDesc& P = pairs[p];
     const uint32_t j0 = i - sbase[p];
-    uint32_t l = lb[i], dst = aoff[i];
+    uint32_t l = lc.x, dst = aoff[i];
     uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
     for (uint32_t j = 0; j < c; j++) {
-        uint64_t pm = P.r_pm[P.r_perm[l + j]];
+        uint64_t pm = P.r_pms[l + j];        // (pos, meta) of the ref seed, stored in index order
         uint32_t rmeta = (uint32_t)pm;
         a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
         a_rp[dst + j] = (uint32_t)(pm >> 32);
@@ -369,11 +372,11 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
         for (;;) {
             if (sp >= pend) { b = pend; break; }
             if (sp >= w0 + wn) load_window(sp);
+            const uint32_t wend = w0 + wn;
             const uint32_t idx = sp + lane;
-            const bool over = idx < w0 + wn && s_key[idx - w0] > limit;
-            const unsigned long long bal = __ballot(over);
+            const unsigned long long bal = __ballot(idx < wend && s_key[idx - w0] > limit);
             if (bal) { b = sp + (uint32_t)__ffsll((long long)bal) - 1; break; }
-            sp = sp + 64 < w0 + wn ? sp + 64 : w0 + wn;
+            sp = sp + 64 < wend ? sp + 64 : wend;
         }
         if (lane == 0) { if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, b); else atomicOr(err, 1u); }
         n++; h = b;
@@ -486,8 +489,8 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
     uint32_t s = 0, e = 0;
     bool mine = false;
+    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * LANE_WAVES * rows_per_wave);
     if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) {
-        const uint32_t pair = find_le(A.cbase, A.n_pairs, slot);
         if (slot - A.cbase[pair] < A.n_chunks[pair]) {
             const uint2 se = A.chunks[slot];
             s = se.x; e = se.y;
@@ -563,8 +566,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     __shared__ uint32_t s_cand[CHAIN_WAVES][7][64];          // score, q0, q1, r0, r1, nanch, ref contig
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
+    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * CHAIN_WAVES);
     if (slot >= A.n_rows) return;
-    const uint32_t pair = find_le(A.cbase, A.n_pairs, slot), ck = slot - A.cbase[pair];
+    const uint32_t ck = slot - A.cbase[pair];
     if (ck >= A.n_chunks[pair]) return;
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
@@ -1013,8 +1017,8 @@ __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
 // seeds of the query between the leftmost and rightmost kept anchor of every chunk
 __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, row < A.n_rows ? row : A.n_rows - 1, blockIdx.x * blockDim.x);
     if (row >= A.n_rows) return;
-    const uint32_t pair = find_le(A.cbase, A.n_pairs, row);
     if (row - A.cbase[pair] >= A.n_chunks[pair]) return;
     ChunkOut* o = &A.out[row];
     if (o->n_intervals) o->seeds = seeds_between(A.pairs[pair], A.a_qc[A.chunks[row].x], o->left, o->right);
@@ -1166,8 +1170,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
         const psk_sketch* r = hp[p].r; const psk_sketch* q = hp[p].q;
         PairDesc& P = h_pairs[p];
         P.r_key = r->idx ? r->idx->key + r->idx_off : nullptr;
-        P.r_perm = r->idx ? r->idx->perm + r->idx_off : nullptr;
-        P.r_pm = r->idx ? r->store->seed_pm + r->seed_off : nullptr;
+        P.r_pms = r->idx ? r->idx->pms + r->idx_off : nullptr;
         P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
         P.r_bucket = r->idx ? r->idx->bucket + r->idx_boff : nullptr; P.r_bshift = r->idx ? r->idx_bshift : 0;
         P.q_n = q->idx ? (uint32_t)q->n_seeds : 0;
@@ -1193,7 +1196,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     const size_t n_items = (size_t)items, n_rows = (size_t)rows;
     size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (size_t)(n_pairs + 1)),
            o_pstart = al256(o_cbase + 4 * (size_t)(n_pairs + 1)), o_lb = al256(o_pstart + 4 * (size_t)(n_pairs + 1)),
-           o_cnt = al256(o_lb + 4 * n_items), o_aoff = al256(o_cnt + 4 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
+           o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_end = o_misc + 64;
@@ -1201,22 +1204,23 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     char* B = (char*)ctx->q_b.p;
     PairDesc* d_pairs = (PairDesc*)(B + o_pairs); uint32_t* d_sbase = (uint32_t*)(B + o_sbase); uint32_t* d_cbase = (uint32_t*)(B + o_cbase);
     uint32_t* d_pstart = (uint32_t*)(B + o_pstart);
-    uint32_t* d_lb = (uint32_t*)(B + o_lb); uint32_t* d_cnt = (uint32_t*)(B + o_cnt); uint32_t* d_aoff = (uint32_t*)(B + o_aoff);
+    uint2* d_lbcnt = (uint2*)(B + o_lb); uint32_t* d_aoff = (uint32_t*)(B + o_aoff);   // o_lb..o_aoff: (lower bound, count) per item, +1 zero entry
     uint32_t* d_nch = (uint32_t*)(B + o_nch); uint2* d_chunks = (uint2*)(B + o_chunks); ChunkOut* d_cout = (ChunkOut*)(B + o_cout);
     psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..2] stats
     PSK_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemsetAsync(d_misc, 0, 64, st));
-    PSK_HIP(hipMemsetAsync(d_cnt + n_items, 0, 4, st));
+    PSK_HIP(hipMemsetAsync(d_lbcnt + n_items, 0, 8, st));
     const uint32_t gi = (uint32_t)((n_items + 255) / 256);
     ctx->t_begin(K_ANCHOR);
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt);
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt);
     ctx->t_end();
     size_t tmp = 0;
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_cnt, d_aoff, (int)(n_items + 1), st));
+    hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(d_lbcnt, CountOf());
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
     PSK_TRY(ctx->q_c.reserve(tmp));
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, d_cnt, d_aoff, (int)(n_items + 1), st));
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
     hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, d_aoff, d_sbase, n_pairs, d_pstart);
     void* hpin;
     PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 256, &hpin));
@@ -1241,7 +1245,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     A.out = d_cout; A.two_c = 2u * (uint32_t)hp[0].q->params.c; A.force_serial = force_serial; A.stats = d_misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)hp[0].q->params.c));
     if (total > 0) {
-        hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lb, d_cnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
+        hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
     }
     hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_qp, a_qc, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     ctx->t_begin(K_CHAIN_CHUNK);

@@ -602,7 +602,7 @@ psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d
 
 // ---- reference index, built on first use: ONE device radix sort of (slot<<32 | kmer) over all the
 // sketches that need one; LSD radix sort is stable, so equal k-mers keep their (contig,pos) order ----
-struct IdxSeg { const uint32_t* kmer; uint32_t n; uint32_t out_off; uint32_t bshift, nb, boff; };
+struct IdxSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t out_off; uint32_t bshift, nb, boff; };
 
 __global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const IdxSeg sg = segs[blockIdx.y];
@@ -613,13 +613,14 @@ __global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restr
 }
 
 // bucket[boff + b] = first entry of the sketch's sorted slice whose k-mer >> bshift is >= b (b = 0..nb)
-__global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restrict__ segs, const uint64_t* __restrict__ key, uint32_t total,
-                                                           uint32_t* __restrict__ bucket) {
+__global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restrict__ segs, const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm,
+                                                           uint32_t total, uint32_t* __restrict__ bucket, uint64_t* __restrict__ pms) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const uint64_t k = key[i];
     const IdxSeg sg = segs[(uint32_t)(k >> 32)];
     const uint32_t li = i - sg.out_off, b = (uint32_t)k >> sg.bshift;
+    pms[i] = sg.pm[perm[i]];
     uint32_t from = 0;
     if (li > 0) from = ((uint32_t)key[i - 1] >> sg.bshift) + 1;
     for (uint32_t bb = from; bb <= b; bb++) bucket[sg.boff + bb] = li;
@@ -649,15 +650,16 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
             int kbits = 2 * s->params.k, lb = 4;
             while (lb < 22 && (1ull << (lb + 2)) < s->n_seeds) lb++;
             if (lb > kbits) lb = kbits;
-            segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, (uint32_t)s->n_seeds, off, (uint32_t)(kbits - lb), 1u << lb, (uint32_t)boff};
+            segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, s->store->seed_pm + s->seed_off, (uint32_t)s->n_seeds, off, (uint32_t)(kbits - lb), 1u << lb, (uint32_t)boff};
             off += (uint32_t)s->n_seeds; maxn = std::max(maxn, (uint32_t)s->n_seeds);
             boff += (1ull << lb) + 1;
         }
         auto ix = std::make_shared<IndexStore>();
         ix->ctx = ctx;
         size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256), bb = align_up(4 * (size_t)boff, 256);
-        PSK_TRY(ctx->pool_alloc(kb + vb + bb, &ix->base, &ix->bytes));
-        ix->key = (uint64_t*)ix->base; ix->perm = (uint32_t*)((char*)ix->base + kb); ix->bucket = (uint32_t*)((char*)ix->base + kb + vb);
+        PSK_TRY(ctx->pool_alloc(2 * kb + vb + bb, &ix->base, &ix->bytes));
+        ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
+        ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + vb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
         PSK_TRY(ctx->s_mark.reserve(kb + vb));
         uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint32_t* v_in = (uint32_t*)((char*)ctx->s_mark.p + kb);
@@ -669,7 +671,7 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         PSK_TRY(ctx->s_tmp.reserve(tmp));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
-        hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (uint32_t)T, ix->bucket);
+        hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms);
         ctx->t_end();
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) {
