@@ -39,9 +39,16 @@ db = C.c_void_p(); _capi.check(lib.psk_db_create(ctx, C.byref(params), C.byref(d
 _capi.check(lib.psk_db_add(db, b"ref", out[0]))
 opts = _capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0)
 hits = C.POINTER(_capi.Hit)(); n = C.c_uint64(0)
-t = time.time()
-_capi.check(lib.psk_query(db, out[1], C.byref(opts), C.byref(hits), C.byref(n)))
-print("query: %.3f s, hits %d" % (time.time() - t, n.value))
+_capi.check(lib.psk_ctx_set_timing(ctx, 1))
+for rep in range(2):   # the first query also builds the two k-mer indexes
+    t = time.time()
+    _capi.check(lib.psk_query(db, out[1], C.byref(opts), C.byref(hits), C.byref(n)))
+    print("query %d: %.3f s, hits %d" % (rep, time.time() - t, n.value))
+for k in ("sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce"):
+    ms, cnt = C.c_double(0), C.c_uint64(0)
+    _capi.check(lib.psk_ctx_timing(ctx, k.encode(), C.byref(ms), C.byref(cnt)))
+    print("  %-12s %8.3f ms over %d launches" % (k, ms.value, cnt.value))
+_capi.check(lib.psk_ctx_set_timing(ctx, 0))
 for i in range(n.value):
     h = hits[i]; print(" ani %.5f afq %.4f afr %.4f chunks %d intervals %d anchors %d" % (h.ani, h.af_query, h.af_ref, h.n_chunks, h.n_intervals, h.n_anchors))
 opts2 = _capi.QueryOpts(0, 1, 0, 0, 0.0, 0.0)

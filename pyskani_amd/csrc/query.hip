@@ -385,6 +385,53 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
     if (lane == 0) n_chunks[p] = n < max_chunks ? n : max_chunks;
 }
 
+// nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
+__global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
+                                                          const uint32_t* __restrict__ pstart, uint32_t n_pairs,
+                                                          uint32_t total, uint32_t* __restrict__ nxt) {
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= total) return;
+    const uint32_t p = find_le(pstart, n_pairs, a);
+    uint32_t pend = pstart[p + 1];
+    uint64_t key = ((uint64_t)a_qc[a] << 32) + (uint64_t)a_qp[a] + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
+    uint32_t l = a + 1, h = pend;
+    while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)a_qc[mid] << 32) | a_qp[mid]; if (k2 <= key) l = mid + 1; else h = mid; }
+    nxt[a] = l;
+}
+
+// Alternative for a few very large pairs (Gb-scale genomes), where one wave walking 50 000 heads is the critical
+// path: nxt[] for every anchor in parallel, then one wave per pair follows nxt[] from the pair's first anchor. The walk is serial, so the wave stages a
+// 4 096-entry window of nxt[] in LDS with one round of coalesced loads and lane 0 hops inside it.
+constexpr int HOP_WIN = 4096;
+__global__ __launch_bounds__(64) void chunk_hops_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ cbase,
+                                                         uint32_t n_pairs, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+                                                         uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_win[HOP_WIN];
+    __shared__ uint32_t s_h, s_n;
+    const uint32_t p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const int lane = threadIdx.x;
+    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
+    const uint32_t pend = pstart[p + 1];
+    uint32_t h = pstart[p], n = 0;
+    while (h < pend) {
+        const uint32_t w0 = h, wn = pend - w0 < (uint32_t)HOP_WIN ? pend - w0 : (uint32_t)HOP_WIN;
+        for (uint32_t i = lane; i < wn; i += 64) s_win[i] = nxt[w0 + i];
+        lds_wave_sync();
+        if (lane == 0) {
+            while (h < pend && h - w0 < wn) {
+                uint32_t e = s_win[h - w0];
+                if (n < max_chunks) chunks[(size_t)row0 + n] = make_uint2(h, e); else atomicOr(err, 1u);
+                n++; h = e;
+            }
+            s_h = h; s_n = n;
+        }
+        lds_wave_sync();
+        h = s_h; n = s_n;
+    }
+    if (lane == 0) n_chunks[p] = n < max_chunks ? n : max_chunks;
+}
+
 // ------------------------------------------------------------------ chaining
 struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, right; uint64_t cov_q; };
 
@@ -1247,7 +1294,11 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     if (total > 0) {
         hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
     }
-    hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_qp, a_qc, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+    if (total / n_pairs > (1u << 20)) {   // few huge pairs: parallel nxt[] + pointer chase
+        hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
+        hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+    } else
+        hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_qp, a_qc, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
