@@ -1294,7 +1294,9 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     if (total > 0) {
         hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
     }
-    if (total / n_pairs > (1u << 20)) {   // few huge pairs: parallel nxt[] + pointer chase
+    // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
+    const char* hops_env = getenv("PSK_CHUNK_HOPS");
+    if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || total / n_pairs > (1u << 20))) {
         hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
     } else

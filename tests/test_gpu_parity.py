@@ -190,24 +190,25 @@ def test_query_many_refs_matches_oracle(psk, oracle):
         assert sh == shared[i] and ok == bool(flags[i]), nme
 
 
-def test_serial_chain_path_agrees_with_lds_path(ecoli):
-    """The lane-serial fallback (a transliteration of the oracle) and the LDS fast path must agree."""
+def test_alternative_device_paths_agree(ecoli):
+    """Every switchable device path must give the same integers: the default (lane-per-chunk DP), the wave-per-chunk DP
+    (PSK_CHAIN_LANE=0), both ways of building the chunk table (PSK_CHUNK_HOPS=1 pointer chase, =0 head walk) and the lane-serial transliteration of the oracle (PSK_CHAIN_SERIAL=1)."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from conftest import load_fasta_first_record as L\n"
         "import pyskani_amd\n"
         "db = pyskani_amd.Database(); db.sketch('EC590', L('e.coli-EC590.fasta.gz'))\n"
         "h = db.query('K12', L('e.coli-K12.fasta.gz'), learned_ani=False)[0]\n"
-        "print(h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
+        "print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
-    outs = []
-    for serial in (False, True):
+    outs = {}
+    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
         env = dict(os.environ)
-        env.pop("PSK_CHAIN_SERIAL", None)
-        if serial:
-            env["PSK_CHAIN_SERIAL"] = "1"
-        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip())
-    assert outs[0] == outs[1], outs
+        for k in ("PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS"):
+            env.pop(k, None)
+        env.update(extra)
+        outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip()
+    assert len(set(outs.values())) == 1, outs
 
 
 def test_learned_ani_without_model_raises(psk, ecoli):
