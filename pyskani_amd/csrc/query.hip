@@ -1369,8 +1369,11 @@ psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const p
         if (!refs[i]->has_seeds) { psk_set_error("reference of pair %u was sketched with seed=False; it cannot be chained", i); return PSK_EINVAL; }
         if (refs[i]->params.k != queries[i]->params.k || refs[i]->params.c != queries[i]->params.c) { psk_set_error("pair %u: reference and query were sketched with different parameters", i); return PSK_EINVAL; }
     }
-    PSK_TRY(ensure_index(ctx, refs, n));
-    PSK_TRY(ensure_index(ctx, queries, n));
+    {   // one index build for every sketch of the call that lacks one (references and queries together)
+        std::vector<const psk_sketch*> all(refs, refs + n);
+        all.insert(all.end(), queries, queries + n);
+        PSK_TRY(ensure_index(ctx, all.data(), (uint32_t)all.size()));
+    }
     // bound one launch: lb/cnt/aoff cost 12 B per (pair, query seed); anchors ~64 B each
     const uint64_t MAX_ITEMS = 1ull << 27; const uint32_t MAX_PAIRS = 4096;
     std::vector<HostPair> hp;

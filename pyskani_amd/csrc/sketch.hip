@@ -10,6 +10,7 @@
 // followed by rocPRIM plumbing (scan, segmented radix sorts) for the marker set and the
 // k-mer-sorted reference index. Semantics are normative in oracle/skani_oracle.c.
 #include "common.h"
+#include <unordered_set>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 
@@ -627,19 +628,89 @@ __global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restr
     if (li == sg.n - 1) for (uint32_t bb = b + 1; bb <= sg.nb; bb++) bucket[sg.boff + bb] = sg.n;
 }
 
+// ---- index of one sketch by ONE workgroup (sketches up to IDXB_MAX_SEEDS seeds, i.e. genomes up to ~30 Mb at
+// c = 125): counting sort on the k-mer's top bits in LDS (hash-selected k-mers are uniform, ~2-4 per bucket), then
+// every bucket is put in (k-mer, seed index) order by one thread. The bucket starts ARE the lookup table. One launch
+// replaces gather + 5 radix passes + table build: 100 sketches index in ~30 us instead of ~450.
+constexpr int IDXB_THREADS = 1024;
+constexpr int IDXB_MAX_LB = 14;                       // 16 384 buckets = 64 kB of LDS counters
+constexpr uint32_t IDXB_MAX_SEEDS = 1u << 18;
+
+__global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
+                                                                    uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket) {
+    __shared__ uint32_t s_cnt[1 << IDXB_MAX_LB];
+    __shared__ uint32_t s_part[IDXB_THREADS];
+    const IdxSeg sg = segs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, n = sg.n, nb = sg.nb, sh = sg.bshift;
+    uint64_t* __restrict__ K = key + sg.out_off;
+    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) s_cnt[b] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += IDXB_THREADS) atomicAdd(&s_cnt[sg.kmer[i] >> sh], 1u);
+    __syncthreads();
+    // exclusive scan of the bucket counts: a run of `per` buckets per thread, then a scan of the run totals
+    const uint32_t per = (nb + IDXB_THREADS - 1) / IDXB_THREADS, b0 = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) if (b0 + j < nb) sum += s_cnt[b0 + j];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < IDXB_THREADS; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t j = 0; j < per; j++) if (b0 + j < nb) { const uint32_t c = s_cnt[b0 + j]; s_cnt[b0 + j] = run; run += c; }
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) bucket[sg.boff + b] = s_cnt[b];
+    if (tid == 0) bucket[sg.boff + nb] = n;
+    __syncthreads();
+    // scatter (k-mer, seed index) to the bucket's range; the counters become the bucket ENDS
+    for (uint32_t i = tid; i < n; i += IDXB_THREADS) {
+        const uint32_t km = sg.kmer[i];
+        K[atomicAdd(&s_cnt[km >> sh], 1u)] = ((uint64_t)km << 32) | i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // order every bucket by (k-mer, seed index): equal k-mers keep their (contig, pos) order, like a stable sort
+    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) {
+        const uint32_t lo = b ? s_cnt[b - 1] : 0, hi = s_cnt[b], m = hi - lo;
+        if (m < 2) continue;
+        uint64_t* a = K + lo;
+        if (m <= 32) {
+            for (uint32_t x = 1; x < m; x++) { const uint64_t v = a[x]; uint32_t y = x; while (y > 0 && a[y - 1] > v) { a[y] = a[y - 1]; y--; } a[y] = v; }
+        } else {   // a repeat family: heap sort in place
+            for (uint32_t st0 = m / 2; st0-- > 0;) { uint32_t r = st0; const uint64_t v = a[r]; for (;;) { uint32_t c = 2 * r + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) c++; if (a[c] <= v) break; a[r] = a[c]; r = c; } a[r] = v; }
+            for (uint32_t e = m - 1; e > 0; e--) { const uint64_t v = a[e]; a[e] = a[0]; uint32_t r = 0; for (;;) { uint32_t c = 2 * r + 1; if (c >= e) break; if (c + 1 < e && a[c + 1] > a[c]) c++; if (a[c] <= v) break; a[r] = a[c]; r = c; } a[r] = v; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t p = tid; p < n; p += IDXB_THREADS) {
+        const uint64_t v = K[p];
+        const uint32_t i = (uint32_t)v;
+        K[p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)(v >> 32);
+        perm[sg.out_off + p] = i;
+        pms[sg.out_off + p] = sg.pm[i];
+    }
+}
+
 psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n) {
     hipStream_t st = ctx->stream;
     std::vector<const psk_sketch*> todo;
-    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store) {
-        bool dup = false;
-        for (const psk_sketch* t : todo) if (t == refs[i]) { dup = true; break; }
-        if (!dup) todo.push_back(refs[i]);
-    }
+    std::unordered_set<const psk_sketch*> seen;
+    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store && seen.insert(refs[i]).second)
+        todo.push_back(refs[i]);
     const uint64_t GROUP = 1ull << 26;   // seeds per sort
+    // small sketches first (one workgroup each), large ones after (device radix sort); PSK_INDEX_RADIX=1 forces the latter
+    const bool force_radix = getenv("PSK_INDEX_RADIX") != nullptr;
+    auto is_small = [&](const psk_sketch* s) { return !force_radix && s->n_seeds <= IDXB_MAX_SEEDS; };
+    std::stable_partition(todo.begin(), todo.end(), is_small);
     size_t i0 = 0;
     while (i0 < todo.size()) {
+        const bool small = is_small(todo[i0]);
         size_t i1 = i0; uint64_t T = 0;
-        while (i1 < todo.size() && i1 - i0 < 65535 && (i1 == i0 || T + todo[i1]->n_seeds <= GROUP)) { T += todo[i1]->n_seeds; i1++; }
+        while (i1 < todo.size() && is_small(todo[i1]) == small && i1 - i0 < 65535 && (i1 == i0 || T + todo[i1]->n_seeds <= GROUP)) { T += todo[i1]->n_seeds; i1++; }
         const uint32_t m = (uint32_t)(i1 - i0);
         std::vector<IdxSeg> segs(m);
         uint32_t off = 0, maxn = 0;
@@ -648,7 +719,7 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
             const psk_sketch* s = todo[i0 + j];
             // ~4 entries per bucket; k-mers of hash-selected seeds are spread evenly over the 2k-bit space
             int kbits = 2 * s->params.k, lb = 4;
-            while (lb < 22 && (1ull << (lb + 2)) < s->n_seeds) lb++;
+            while (lb < (small ? IDXB_MAX_LB : 22) && (1ull << (lb + 2)) < s->n_seeds) lb++;
             if (lb > kbits) lb = kbits;
             segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, s->store->seed_pm + s->seed_off, (uint32_t)s->n_seeds, off, (uint32_t)(kbits - lb), 1u << lb, (uint32_t)boff};
             off += (uint32_t)s->n_seeds; maxn = std::max(maxn, (uint32_t)s->n_seeds);
@@ -661,9 +732,21 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
         ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + vb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
+        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
+        if (small) {
+            ctx->t_begin(K_SKETCH_SORT);
+            hipLaunchKernelGGL(index_block_kernel, dim3(m), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, ix->key, ix->perm, ix->pms, ix->bucket);
+            ctx->t_end();
+            PSK_HIP(hipStreamSynchronize(st));
+            for (uint32_t j = 0; j < m; j++) {
+                todo[i0 + j]->idx = ix; todo[i0 + j]->idx_off = segs[j].out_off;
+                todo[i0 + j]->idx_boff = segs[j].boff; todo[i0 + j]->idx_bshift = segs[j].bshift;
+            }
+            i0 = i1;
+            continue;
+        }
         PSK_TRY(ctx->s_mark.reserve(kb + vb));
         uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint32_t* v_in = (uint32_t*)((char*)ctx->s_mark.p + kb);
-        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SKETCH_SORT);
         hipLaunchKernelGGL(index_gather_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, k_in, v_in);
         int slot_bits = 1; while ((1u << slot_bits) < m) slot_bits++;
