@@ -77,12 +77,19 @@ class Engine:
         _capi.check(self.lib.psk_ctx_create(device, C.byref(self.ctx)))
         self.params = _capi.Params(125, 1000, 15)
 
+    def _layout(self, offs, lens, n):
+        """ctypes views of the (constant) genome layout, built once: they describe the resident input"""
+        key = (id(offs), n)
+        if getattr(self, "_layout_key", None) != key:
+            self._layout_key = key
+            self._c_off = (C.c_uint64 * n)(*offs[:n]); self._c_len = (C.c_uint64 * n)(*lens[:n])
+            self._gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        return self._c_off, self._c_len, self._gfc
+
     def step(self, d_ptr, offs, lens, names):
         lib, capi = self.lib, self.capi
         n = len(offs)
-        c_off = (C.c_uint64 * n)(*offs)
-        c_len = (C.c_uint64 * n)(*lens)
-        gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        c_off, c_len, gfc = self._layout(offs, lens, n)
         out = (C.c_void_p * n)()
         capi.check(lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
         db = C.c_void_p()
@@ -94,9 +101,9 @@ class Engine:
             nh = C.c_uint64(0)
             capi.check(lib.psk_query(db, out[n - 1], C.byref(opts), C.byref(hits_p), C.byref(nh)))
             hits = np.zeros((nh.value, 4), dtype=np.float32)
-            for i in range(nh.value):
-                h = hits_p[i]
-                hits[i] = (h.ref_index, h.ani, h.af_query, h.af_ref)
+            if nh.value:   # one structured view of the returned psk_hit array instead of a ctypes loop
+                rec = np.frombuffer((capi.Hit * nh.value).from_address(C.addressof(hits_p.contents)), dtype=np.dtype(capi.Hit))
+                hits[:, 0] = rec["ref_index"]; hits[:, 1] = rec["ani"]; hits[:, 2] = rec["af_query"]; hits[:, 3] = rec["af_ref"]
             if hits_p:
                 lib.psk_free(hits_p)
         finally:
@@ -108,8 +115,7 @@ class Engine:
         """BASELINE configs[2] shape on one GPU: every genome against a database of all of them."""
         lib, capi = self.lib, self.capi
         n = len(offs) - 1                      # the trailing query genome is not used here
-        c_off = (C.c_uint64 * n)(*offs[:n]); c_len = (C.c_uint64 * n)(*lens[:n])
-        gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        c_off, c_len, gfc = self._layout(offs, lens, n)
         out = (C.c_void_p * n)()
         capi.check(lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
         db = C.c_void_p()

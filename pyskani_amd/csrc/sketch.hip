@@ -353,6 +353,111 @@ __global__ void marker_copy_kernel(const uint64_t* __restrict__ uniq, const uint
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = uniq[b + i];
 }
 
+
+
+// LDS hand-off between lanes of ONE wave: order the ds ops, no workgroup barrier
+__device__ __forceinline__ void lds_wave_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// exclusive prefix of one value per thread over a workgroup of NT threads (two barriers); *total = sum over the workgroup
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave /* NT/64 + 1 words */, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
+    __syncthreads();                       // s_wave may still be read from an earlier call
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) { const uint32_t c = s_wave[w]; if ((uint32_t)w < wv) base += c; tot += c; }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---- marker set of one genome by ONE workgroup: gather the tile-local lists into LDS, bitonic sort, distinct values
+// out. Replaces compaction + segmented radix sort + distinct pass (0.30 ms per 1 000 genomes) for genomes with up
+// to MB_CAP raw markers (8 Mb at marker_c = 1000); a larger genome raises `overflow` and the batch is redone on the
+// segmented-sort path.
+constexpr int MB_CAP = 8192;
+constexpr int MB_THREADS = 1024;
+constexpr int MB_TILES = 1024;     // tiles of one genome the LDS tile table holds (16.7 Mb)
+__global__ __launch_bounds__(MB_THREADS) void marker_block_kernel(const uint64_t* __restrict__ stage, const uint32_t* __restrict__ tile_off,
+                                                                  const uint32_t* __restrict__ tile_moff, const uint32_t* __restrict__ gft,
+                                                                  uint64_t* __restrict__ uniq, uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+    __shared__ unsigned long long s_m[MB_CAP];
+    __shared__ uint32_t s_cnt[MB_CAP];
+    __shared__ uint32_t s_tsrc[MB_TILES], s_tdst[MB_TILES + 1];
+    __shared__ uint32_t s_wave[MB_THREADS / 64 + 1];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t t0 = gft[g], nt = gft[g + 1] - t0, m0 = tile_moff[t0], n = tile_moff[t0 + nt] - m0;
+    if (n > (uint32_t)MB_CAP || nt > (uint32_t)MB_TILES) { if (tid == 0) { atomicOr(overflow, 1u); cnt[g] = 0; } return; }
+    // tile table into LDS with one round of loads, then the markers with at most MB_CAP / MB_THREADS independent loads
+    for (uint32_t q = tid; q < nt; q += MB_THREADS) { s_tsrc[q] = tile_off[t0 + q]; s_tdst[q] = tile_moff[t0 + q] - m0; }
+    if (tid == 0) s_tdst[nt] = n;
+    __syncthreads();
+    constexpr int PER = MB_CAP / MB_THREADS;
+    unsigned long long v[PER];
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const uint32_t d = tid + r * MB_THREADS;
+        v[r] = ~0ull;
+        if (d < n) {
+            uint32_t lo = 0, hi = nt;                             // last tile q with s_tdst[q] <= d
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_tdst[mid] <= d) lo = mid; else hi = mid; }
+            v[r] = stage[s_tsrc[lo] + (d - s_tdst[lo])];
+        }
+    }
+    // Counting sort on the marker's top 13 bits (hash-selected 21-mers are uniform: <= 1 marker per bucket on
+    // average), then every bucket is ordered in place. A bitonic network over the same 8 192 slots was bound by LDS
+    // bandwidth (91 stages x 128 kB); this touches each marker a handful of times.
+    constexpr int MB_SHIFT = 2 * K_MARKER - 13;
+#pragma unroll
+    for (int r = 0; r < PER; r++) s_cnt[tid * PER + r] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; r++) if (tid + r * MB_THREADS < n) atomicAdd(&s_cnt[(uint32_t)(v[r] >> MB_SHIFT)], 1u);
+    __syncthreads();
+    uint32_t c8[PER], sum = 0;
+#pragma unroll
+    for (int r = 0; r < PER; r++) { c8[r] = s_cnt[tid * PER + r]; sum += c8[r]; }
+    uint32_t tot_raw;
+    uint32_t run = block_exclusive_scan<MB_THREADS>(sum, s_wave, &tot_raw);
+#pragma unroll
+    for (int r = 0; r < PER; r++) { s_cnt[tid * PER + r] = run; run += c8[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; r++) if (tid + r * MB_THREADS < n) s_m[atomicAdd(&s_cnt[(uint32_t)(v[r] >> MB_SHIFT)], 1u)] = v[r];
+    __syncthreads();
+    // the counters are now the bucket ENDS; thread t orders buckets 8t .. 8t+7
+#pragma unroll 1
+    for (int r = 0; r < PER; r++) {
+        const uint32_t b = tid * PER + r;
+        const uint32_t lo = b ? s_cnt[b - 1] : 0, m = s_cnt[b] - lo;
+        if (m < 2) continue;
+        unsigned long long* a = s_m + lo;
+        for (uint32_t x = 1; x < m; x++) { const unsigned long long w = a[x]; uint32_t y = x; while (y > 0 && a[y - 1] > w) { a[y] = a[y - 1]; y--; } a[y] = w; }
+    }
+    __syncthreads();
+    // distinct values: each thread looks at 8 consecutive elements, one workgroup scan ranks them
+    unsigned long long e[PER + 1];
+    const uint32_t i0 = tid * PER;
+    e[0] = i0 ? s_m[i0 - 1] : 0;
+#pragma unroll
+    for (int r = 0; r < PER; r++) e[r + 1] = s_m[i0 + r];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < PER; r++) mine += (i0 + r < n && (i0 + r == 0 || e[r + 1] != e[r])) ? 1u : 0u;
+    uint32_t total;
+    uint32_t rank = block_exclusive_scan<MB_THREADS>(mine, s_wave, &total);
+#pragma unroll
+    for (int r = 0; r < PER; r++) if (i0 + r < n && (i0 + r == 0 || e[r + 1] != e[r])) uniq[m0 + rank++] = e[r + 1];
+    if (tid == 0) cnt[g] = total;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // One sub-batch of genomes moving through the sketch pipeline on its own stream. The phases are split
@@ -501,20 +606,44 @@ struct SketchJob {
         PSK_TRY(R->s_tmp.reserve(tmp_bytes));
         JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_tmc, d_tmoff, (int)(n_tiles + 1), st));
         hipLaunchKernelGGL(gather_u32_kernel, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, st, d_tmoff, d_gft, d_sbeg, (int)(n_genomes + 1));   // segment g = [sbeg[g], sbeg[g+1])
+        // small genomes (expected raw markers well inside MB_CAP): one workgroup per genome does it all in LDS
+        marker_block = getenv("PSK_MARKER_SEGSORT") == nullptr;
+        for (uint32_t g = 0; g < n_genomes && marker_block; g++)
+            if (sk[g]->total_len / (uint64_t)p->marker_c > (uint64_t)(MB_CAP * 3 / 4)) marker_block = false;
+        if (marker_block) {
+            JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t), st));      // overflow flag
+            hipLaunchKernelGGL(marker_block_kernel, dim3(n_genomes), dim3(MB_THREADS), 0, st, d_mstage, d_toff, d_tmoff, d_gft, d_mdense, d_moff, d_mcnt);
+            JHIP(hipMemcpyAsync(h_moff + n_genomes + 1, d_mcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        } else {
+            PSK_TRY(marker_segsort());
+        }
+        PSK_TRY(marker_offsets());
+        ctx->t_end(st);
+        return PSK_OK;
+    }
+
+    bool marker_block = false;
+    // tile-local lists -> dense per-genome segments -> segmented radix sort -> distinct values (in d_mstage)
+    psk_status marker_segsort() {
+        const size_t ns = h_goff[n_genomes];
+        size_t tmp_bytes = 0;
         hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense);
         if (ns > 0) {
-            tmp_bytes = 0;
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
         }
         hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_moff);
-        tmp_bytes = 0;
+        return PSK_OK;
+    }
+    // distinct counts -> offsets, on their way to the host
+    psk_status marker_offsets() {
+        size_t tmp_bytes = 0;
+        JHIP(hipMemsetAsync(d_moff + n_genomes, 0, sizeof(uint32_t), st));
         JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
         PSK_TRY(R->s_tmp.reserve(tmp_bytes));
         JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_moff, d_moff, (int)(n_genomes + 1), st));
         JHIP(hipMemcpyAsync(h_moff, d_moff, sizeof(uint32_t) * (n_genomes + 1), hipMemcpyDeviceToHost, st));
-        ctx->t_end(st);
         return PSK_OK;
     }
 
@@ -522,10 +651,16 @@ struct SketchJob {
     psk_status phase3() {
         if (empty) return PSK_OK;
         JHIP(hipStreamSynchronize(st));
+        if (marker_block && h_moff[n_genomes + 1]) {   // a genome held more raw markers than the LDS path takes: redo on the sort path
+            marker_block = false;
+            PSK_TRY(marker_segsort());
+            PSK_TRY(marker_offsets());
+            JHIP(hipStreamSynchronize(st));
+        }
         const uint32_t total_markers = h_moff[n_genomes];
         PSK_TRY(ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes));
         store->markers = (uint64_t*)store->mbase;
-        hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, d_mstage, d_sbeg, d_moff, store->markers);
+        hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, marker_block ? d_mdense : d_mstage, d_sbeg, d_moff, store->markers);
         return PSK_OK;
     }
 
@@ -636,48 +771,100 @@ constexpr int IDXB_THREADS = 1024;
 constexpr int IDXB_MAX_LB = 14;                       // 16 384 buckets = 64 kB of LDS counters
 constexpr uint32_t IDXB_MAX_SEEDS = 1u << 18;
 
-__global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg* __restrict__ segs, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
                                                                     uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket) {
+    // `slices` workgroups share one sketch: workgroup (seg, sl) owns buckets [B0, B1) = the sl-th part of the bucket
+    // space and the index positions its k-mers sort to. Every workgroup streams ALL of the sketch's k-mers (coalesced,
+    // cheap) but histograms, scatters, orders and writes only its own part, so the scattered traffic of a sketch
+    // is spread over `slices` CUs; the number of k-mers below B0 gives its base position without any grid sync.
     __shared__ uint32_t s_cnt[1 << IDXB_MAX_LB];
-    __shared__ uint32_t s_part[IDXB_THREADS];
-    const IdxSeg sg = segs[blockIdx.x];
+    __shared__ uint32_t s_part[IDXB_THREADS / 64 + 1];
+    const IdxSeg sg = segs[blockIdx.x / slices];
+    const uint32_t sl = blockIdx.x % slices;
     const uint32_t tid = threadIdx.x, n = sg.n, nb = sg.nb, sh = sg.bshift;
+    const uint32_t B0 = (uint32_t)((uint64_t)nb * sl / slices), B1 = (uint32_t)((uint64_t)nb * (sl + 1) / slices), nbl = B1 - B0;
     uint64_t* __restrict__ K = key + sg.out_off;
-    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) s_cnt[b] = 0;
+    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) s_cnt[b] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += IDXB_THREADS) atomicAdd(&s_cnt[sg.kmer[i] >> sh], 1u);
-    __syncthreads();
-    // exclusive scan of the bucket counts: a run of `per` buckets per thread, then a scan of the run totals
-    const uint32_t per = (nb + IDXB_THREADS - 1) / IDXB_THREADS, b0 = tid * per;
-    uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; j++) if (b0 + j < nb) sum += s_cnt[b0 + j];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < IDXB_THREADS; o <<= 1) {
-        const uint32_t v = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // eight independent loads per thread per round trip, then the dependent LDS atomics
+    uint32_t below = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 8 * IDXB_THREADS) {
+        uint32_t km[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * IDXB_THREADS; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) if (i0 + tid + r * IDXB_THREADS < n) {
+            const uint32_t b = km[r] >> sh;
+            if (b < B0) below++; else if (b < B1) atomicAdd(&s_cnt[b - B0], 1u);
+        }
     }
-    uint32_t run = s_part[tid] - sum;
-    for (uint32_t j = 0; j < per; j++) if (b0 + j < nb) { const uint32_t c = s_cnt[b0 + j]; s_cnt[b0 + j] = run; run += c; }
+    uint32_t base;
+    block_exclusive_scan<IDXB_THREADS>(below, s_part, &base);        // base = k-mers that sort before this part
     __syncthreads();
-    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) bucket[sg.boff + b] = s_cnt[b];
-    if (tid == 0) bucket[sg.boff + nb] = n;
+    // exclusive scan of the bucket counts: a run of `per` buckets per thread, then one workgroup scan of the run totals
+    const uint32_t per = (nbl + IDXB_THREADS - 1) / IDXB_THREADS, b0 = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) if (b0 + j < nbl) sum += s_cnt[b0 + j];
+    uint32_t mine_total;
+    uint32_t run = base + block_exclusive_scan<IDXB_THREADS>(sum, s_part, &mine_total);
+    for (uint32_t j = 0; j < per; j++) if (b0 + j < nbl) { const uint32_t c = s_cnt[b0 + j]; s_cnt[b0 + j] = run; run += c; }
+    __syncthreads();
+    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) bucket[sg.boff + B0 + b] = s_cnt[b];
+    if (tid == 0 && sl == slices - 1) bucket[sg.boff + nb] = n;
     __syncthreads();
     // scatter (k-mer, seed index) to the bucket's range; the counters become the bucket ENDS
-    for (uint32_t i = tid; i < n; i += IDXB_THREADS) {
-        const uint32_t km = sg.kmer[i];
-        K[atomicAdd(&s_cnt[km >> sh], 1u)] = ((uint64_t)km << 32) | i;
+    for (uint32_t i0 = 0; i0 < n; i0 += 8 * IDXB_THREADS) {
+        uint32_t km[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * IDXB_THREADS; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = i0 + tid + r * IDXB_THREADS, b = km[r] >> sh;
+            if (i < n && b >= B0 && b < B1) K[atomicAdd(&s_cnt[b - B0], 1u)] = ((uint64_t)km[r] << 32) | i;
+        }
     }
     __threadfence_block();
     __syncthreads();
     // order every bucket by (k-mer, seed index): equal k-mers keep their (contig, pos) order, like a stable sort
-    for (uint32_t b = tid; b < nb; b += IDXB_THREADS) {
-        const uint32_t lo = b ? s_cnt[b - 1] : 0, hi = s_cnt[b], m = hi - lo;
+    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) {
+        const uint32_t lo = b ? s_cnt[b - 1] : base, hi = s_cnt[b], m = hi - lo;
         if (m < 2) continue;
         uint64_t* a = K + lo;
-        if (m <= 32) {
+        if (m <= 8) {   // the common case: eight independent loads, a sorting network in registers, eight stores
+            uint64_t v[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) v[x] = (uint32_t)x < m ? a[x] : ~0ull;
+#define PSK_CE(p, q) { const uint64_t lo_ = v[p] < v[q] ? v[p] : v[q], hi_ = v[p] < v[q] ? v[q] : v[p]; v[p] = lo_; v[q] = hi_; }
+            PSK_CE(0, 1) PSK_CE(2, 3) PSK_CE(4, 5) PSK_CE(6, 7)
+            PSK_CE(0, 2) PSK_CE(1, 3) PSK_CE(4, 6) PSK_CE(5, 7)
+            PSK_CE(1, 2) PSK_CE(5, 6) PSK_CE(0, 4) PSK_CE(3, 7)
+            PSK_CE(1, 5) PSK_CE(2, 6)
+            PSK_CE(1, 4) PSK_CE(3, 6)
+            PSK_CE(2, 4) PSK_CE(3, 5)
+            PSK_CE(3, 4)
+#undef PSK_CE
+#pragma unroll
+            for (int x = 0; x < 8; x++) if ((uint32_t)x < m) a[x] = v[x];
+        } else if (m <= 16) {   // rare (Poisson tail of the bucket load): same idea, bitonic network on 16 registers
+            uint64_t v[16];
+#pragma unroll
+            for (int x = 0; x < 16; x++) v[x] = (uint32_t)x < m ? a[x] : ~0ull;
+#pragma unroll
+            for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+                    for (int x = 0; x < 16; x++) {
+                        const int y = x ^ j;
+                        if (y > x) {
+                            const bool up = (x & k) == 0;
+                            const uint64_t lo_ = v[x] < v[y] ? v[x] : v[y], hi_ = v[x] < v[y] ? v[y] : v[x];
+                            v[x] = up ? lo_ : hi_; v[y] = up ? hi_ : lo_;
+                        }
+                    }
+#pragma unroll
+            for (int x = 0; x < 16; x++) if ((uint32_t)x < m) a[x] = v[x];
+        } else if (m <= 32) {
             for (uint32_t x = 1; x < m; x++) { const uint64_t v = a[x]; uint32_t y = x; while (y > 0 && a[y - 1] > v) { a[y] = a[y - 1]; y--; } a[y] = v; }
         } else {   // a repeat family: heap sort in place
             for (uint32_t st0 = m / 2; st0-- > 0;) { uint32_t r = st0; const uint64_t v = a[r]; for (;;) { uint32_t c = 2 * r + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) c++; if (a[c] <= v) break; a[r] = a[c]; r = c; } a[r] = v; }
@@ -686,12 +873,18 @@ __global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg*
     }
     __threadfence_block();
     __syncthreads();
-    for (uint32_t p = tid; p < n; p += IDXB_THREADS) {
-        const uint64_t v = K[p];
-        const uint32_t i = (uint32_t)v;
-        K[p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)(v >> 32);
-        perm[sg.out_off + p] = i;
-        pms[sg.out_off + p] = sg.pm[i];
+    const uint32_t pend = base + mine_total;
+    for (uint32_t p0 = base; p0 < pend; p0 += 8 * IDXB_THREADS) {
+        uint64_t v[8], pm[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * IDXB_THREADS; v[r] = p < pend ? K[p] : 0; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * IDXB_THREADS; pm[r] = p < pend ? sg.pm[(uint32_t)v[r]] : 0; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t p = p0 + tid + r * IDXB_THREADS;
+            if (p < pend) { K[p] = ((uint64_t)(blockIdx.x / slices) << 32) | (uint32_t)(v[r] >> 32); perm[sg.out_off + p] = (uint32_t)v[r]; pms[sg.out_off + p] = pm[r]; }
+        }
     }
 }
 
@@ -735,7 +928,12 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         if (small) {
             ctx->t_begin(K_SKETCH_SORT);
-            hipLaunchKernelGGL(index_block_kernel, dim3(m), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, ix->key, ix->perm, ix->pms, ix->bucket);
+            // The kernel can split a sketch over several workgroups (slices of the bucket space). Measured on MI355X with
+            // 101 sketches: 8 slices are no faster than 1 (0.38 vs 0.33 ms for the whole marker + index phase) - the
+            // kernel's time is its chain of dependent round trips, not one CU's scattered traffic. PSK_INDEX_SLICES overrides.
+            uint32_t slices = 1;
+            if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
+            hipLaunchKernelGGL(index_block_kernel, dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket);
             ctx->t_end();
             PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {

@@ -71,6 +71,42 @@ def test_sketch_arbitrary_bytes(psk, oracle, k, c):
     assert_sketch_equal(gs, oracle.Sketch(contigs, c=c, marker_c=4 * c, k=k))
 
 
+def test_marker_paths(psk, oracle):
+    """Marker sets: the one-workgroup-per-genome LDS path (default for genomes up to ~6 Mb at marker_c = 1000), its
+    overflow fallback (a repeat-rich genome with more raw markers than the LDS holds) and the segmented-sort path
+    forced through PSK_MARKER_SEGSORT must all give the oracle's sets."""
+    rng = np.random.default_rng(77)
+    unit = None
+    for _ in range(200):                       # a 1 kb unit that carries at least two marker windows
+        u = random_genome(rng, 1000)
+        if len(oracle.Sketch([u * 3]).markers) >= 2:
+            unit = u
+            break
+    assert unit is not None
+    repeat = unit * 6000                       # 6 Mb: expected 6 000 raw markers, really >= 12 000 -> device overflow flag
+    plain = random_genome(rng, 700000)
+    want_r, want_p = oracle.Sketch([repeat]), oracle.Sketch([plain])
+    db, gs = gpu_sketch(psk, [repeat]); assert_sketch_equal(gs, want_r)
+    db, gs = gpu_sketch(psk, [plain]); assert_sketch_equal(gs, want_p)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import random_genome\n"
+        "import pyskani_amd\n"
+        "rng = np.random.default_rng(78); g = random_genome(rng, 700000)\n"
+        "db = pyskani_amd.Database(); db.sketch('a', g)\n"
+        "import hashlib\n"
+        "sk = db._sketch('x', [g], True); seeds, markers = sk.export()\n"
+        "print(len(seeds), len(markers), hashlib.sha256(markers.tobytes()).hexdigest())\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for force in (False, True):
+        env = dict(os.environ); env.pop("PSK_MARKER_SEGSORT", None)
+        if force:
+            env["PSK_MARKER_SEGSORT"] = "1"
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip())
+    assert outs[0] == outs[1], outs
+
+
 def test_sketch_empty_and_short(psk, oracle):
     db, gs = gpu_sketch(psk, [b"ATGC" * 100])        # 400 bp: below MIN_LENGTH_CONTIG (test_database.py:13)
     seeds, markers = gs.export()
