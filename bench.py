@@ -176,6 +176,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through `python -m torch.distributed.run "
+              f"--nproc-per-node {args.gpus} ...`; measuring {world} GPU(s)", file=sys.stderr)
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
