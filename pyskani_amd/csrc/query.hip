@@ -444,6 +444,7 @@ struct ChainArgs {
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
     int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state, *c_rc;   // candidate chains, chunk s writes at [s, s + n_cand)
     uint32_t two_c; int band; int force_serial; int lane_dp;
+    uint32_t* ovf_list; uint32_t* ovf_count;   // rows the lane kernel hands to the wave kernel (more than LANE_TREES qualifying chain trees, >= 16 384 anchors)
     uint32_t* stats;   // [1] chunks / [3] pairs that took a serial fallback (rare paths only: a counter every wave bumps
                        // serialises the whole launch on one L2 address)
 };
@@ -511,7 +512,7 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
 // The register file is laid out for the band: LANE_N >= band (band = 2500/c: 20 at c = 125).
 constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4)
 constexpr int LANE_WAVES = 2;
-constexpr uint32_t LANE_DONE = 0x80000000u;
+constexpr int LANE_TREES = 4;        // qualifying chain trees per chunk kept in registers
 
 struct LaneAnchor { uint32_t q, r, m; int32_t f; };
 
@@ -535,12 +536,13 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
     uint32_t s = 0, e = 0;
-    bool mine = false;
+    bool mine = false, real = false;     // real: a row of the chunk table that holds a chunk; mine: this lane chains it
     const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * LANE_WAVES * rows_per_wave);
     if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) {
         if (slot - A.cbase[pair] < A.n_chunks[pair]) {
             const uint2 se = A.chunks[slot];
             s = se.x; e = se.y;
+            real = true;
             mine = e > s && e - s < 16384;
         }
     }
@@ -549,8 +551,17 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     LaneAnchor P[LANE_N];
 #pragma unroll
     for (int i = 0; i < LANE_N; i++) { P[i].q = 0; P[i].r = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
-    uint32_t R = 0;
-    uint32_t (*rd)[64] = s_rd[wave];
+    // Chain trees that can yield a candidate, at most LANE_TREES per chunk, keyed by the local index of their ROOT
+    // anchor. A tree gets a slot when its first anchor with score >= MIN_SCORE2 appears (such an anchor has depth >= 3,
+    // and lower-scoring anchors can never be the tree's best once one exists); the many single-anchor trees of
+    // spurious matches never take one. Slot: best anchor key f<<28 | (16383 - local index)<<14 | depth, its (q, r).
+    unsigned long long bk[LANE_TREES];
+    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
+#pragma unroll
+    for (int j = 0; j < LANE_TREES; j++) { bk[j] = 0; sroot[j] = 0xFFFFFFFFu; bq[j] = br[j] = 0; }
+    uint32_t S = 0;
+    bool ovf = false;
+    uint32_t (*rd)[64] = s_rd[wave];      // root index << 14 | depth of the last 32 anchors
     const int band = A.band;
     for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
         const uint32_t x0 = s_al + t0;
@@ -562,12 +573,10 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
         }
         const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
         LaneAnchor nw[4];
-        uint32_t of[4], orid[4], odep[4];
-        bool act[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t x = x0 + u, t = t0 + u;
-            act[u] = x >= s && x < e && mine;
+            const bool act = x >= s && x < e && mine;
             const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
             const uint32_t sg = 0u - (mx & 1u);
             uint32_t best = 0;
@@ -578,67 +587,81 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
                     best = k > best ? k : best;
                 }
             }
-            int32_t f = ANCHOR_SCORE2; uint32_t rid = R, dep = 1;
+            int32_t f = ANCHOR_SCORE2; uint32_t ridx = x - s, dep = 1;
             if (best) {
                 f = (int32_t)(best >> 7);
                 const uint32_t v = rd[(t - (127u - (best & 127u))) & 31u][lane];
-                rid = v >> 14; dep = (v & 16383u) + 1;
-            } else if (act[u]) R++;
-            rd[t & 31u][lane] = (rid << 14) | dep;
-            nw[u].q = qx; nw[u].r = rx; nw[u].m = act[u] ? mx : 0xFFFFFFFFu; nw[u].f = f;
-            of[u] = (uint32_t)f; orid[u] = rid; odep[u] = dep;
+                ridx = v >> 14; dep = (v & 16383u) + 1;
+            }
+            rd[t & 31u][lane] = (ridx << 14) | dep;
+            nw[u].q = qx; nw[u].r = rx; nw[u].m = act ? mx : 0xFFFFFFFFu; nw[u].f = f;
+            if (act && f >= MIN_SCORE2) {
+                const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
+                bool found = false;
+#pragma unroll
+                for (int j = 0; j < LANE_TREES; j++) {
+                    const bool hit = sroot[j] == ridx;
+                    found = found || hit;
+                    if (hit && k64 > bk[j]) { bk[j] = k64; bq[j] = qx; br[j] = rx; }
+                }
+                if (!found) {
+                    if (S >= (uint32_t)LANE_TREES) ovf = true;
+#pragma unroll
+                    for (int j = 0; j < LANE_TREES; j++) if (S == (uint32_t)j) { sroot[j] = ridx; bk[j] = k64; bq[j] = qx; br[j] = rx; }
+                    S++;
+                }
+            }
         }
         // shift the register window by four anchors
 #pragma unroll
         for (int i = LANE_N - 1; i >= 4; i--) P[i] = P[i - 4];
         P[0] = nw[3]; P[1] = nw[2]; P[2] = nw[1]; P[3] = nw[0];
-        if (act[0] && act[3]) {
-            *reinterpret_cast<uint4*>(A.sc_f + x0) = make_uint4(of[0], of[1], of[2], of[3]);
-            *reinterpret_cast<uint4*>(A.sc_root + x0) = make_uint4(orid[0], orid[1], orid[2], orid[3]);
-            *reinterpret_cast<uint4*>(A.sc_depth + x0) = make_uint4(odep[0], odep[1], odep[2], odep[3]);
-        } else {
+    }
+    if ((uint32_t)lane < rows_per_wave && slot < A.n_rows && real) {
+        if (mine && !ovf) {
+            // candidates in ROOT order (slots were taken in order of first qualifying anchor): pick the smallest root left
+            uint32_t nc = 0, last = 0;
+            for (uint32_t c = 0; c < S; c++) {
+                uint32_t pick = 0xFFFFFFFFu; unsigned long long k = 0; uint32_t q1 = 0, rb = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (act[u]) { A.sc_f[x0 + u] = (int32_t)of[u]; A.sc_root[x0 + u] = orid[u]; A.sc_depth[x0 + u] = odep[u]; }
+                for (int j = 0; j < LANE_TREES; j++)
+                    if (sroot[j] != 0xFFFFFFFFu && (c == 0 || sroot[j] > last) && sroot[j] < pick) { pick = sroot[j]; k = bk[j]; q1 = bq[j]; rb = br[j]; }
+                last = pick;
+                const uint32_t xr = s + pick, ra = A.a_rp[xr], o = s + nc;
+                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.a_qp[xr]; A.c_q1[o] = q1;
+                A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
+                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.a_rm[xr] >> 1;
+                nc++;
+            }
+            ChunkOut o{};
+            o.n_cand = nc; o.left = 0xFFFFFFFFu; o.right = 0;
+            A.out[slot] = o;
+        } else {
+            A.ovf_list[atomicAdd(A.ovf_count, 1u)] = slot;       // rare: the wave kernel redoes this chunk
         }
     }
-    if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) A.out[slot].anchors = mine ? (LANE_DONE | R) : 0u;
 }
 
-__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs A) {
+// The wave-per-chunk chaining of ONE row of the chunk table (one wavefront): DP over an LDS ring, per-tree bests,
+// candidate emission. Shared arrays are the calling wave's slices.
+struct ChainWaveLds {
+    hipcub::WarpReduce<uint32_t, 64>::TempStorage wr;
+    uint32_t ring[6][RING];            // qp, rp, rm, f, root id, depth
+    unsigned long long best[RMAX];     // f<<28 | (16383-local idx)<<14 | depth
+    uint32_t rootx[RMAX];              // local index of each tree's root anchor
+    uint32_t cand[7][64];              // score, q0, q1, r0, r1, nanch, ref contig
+};
+
+__device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds& L, int lane) {
     typedef hipcub::WarpReduce<uint32_t, 64> WR;
-    __shared__ typename WR::TempStorage s_wr[CHAIN_WAVES];
-    __shared__ uint32_t s_ring[CHAIN_WAVES][6][RING];        // qp, rp, rm, f, root id, depth
-    __shared__ unsigned long long s_best[CHAIN_WAVES][RMAX]; // f<<28 | (16383-local idx)<<14 | depth
-    __shared__ uint32_t s_rootx[CHAIN_WAVES][RMAX];          // local index of each tree's root anchor
-    __shared__ uint32_t s_cand[CHAIN_WAVES][7][64];          // score, q0, q1, r0, r1, nanch, ref contig
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
-    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * CHAIN_WAVES);
-    if (slot >= A.n_rows) return;
-    const uint32_t ck = slot - A.cbase[pair];
-    if (ck >= A.n_chunks[pair]) return;
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
     ChunkOut* op = &A.out[slot];
-    uint32_t (*ring)[RING] = s_ring[wave];
+    uint32_t (*ring)[RING] = L.ring;
+    unsigned long long* s_best_w = L.best; uint32_t* s_rootx_w = L.rootx; uint32_t (*s_cand_w)[64] = L.cand;
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
-    const uint32_t lane_state = A.lane_dp ? op->anchors : 0u;
-    if (fast && (lane_state & LANE_DONE)) {
-        // the DP ran one lane per chunk (chain_lane_kernel): fold its per-anchor (f, tree, depth) into the tree tables
-        R = lane_state & ~LANE_DONE;
-        if (R > RMAX) fast = false;
-        else {
-            for (uint32_t r = lane; r < R; r += 64) s_best[wave][r] = 0;
-            lds_wave_sync();
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint32_t f = (uint32_t)A.sc_f[s + i], rid = A.sc_root[s + i], dep = A.sc_depth[s + i];
-                atomicMax(&s_best[wave][rid], ((unsigned long long)f << 28) | ((unsigned long long)(16383u - i) << 14) | dep);
-                if (dep == 1) s_rootx[wave][rid] = i;
-            }
-            lds_wave_sync();
-        }
-    } else if (fast) {
+    if (fast) {
         for (uint32_t base = s; base < e && fast; base += 64) {
             const uint32_t idx = base + lane;
             const bool have = idx < e;
@@ -669,7 +692,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
                         }
                     }
                 }
-                uint32_t best = WR(s_wr[wave]).Reduce(key, hipcub::Max());
+                uint32_t best = WR(L.wr).Reduce(key, hipcub::Max());
                 best = __builtin_amdgcn_readfirstlane(best);
                 int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
                 if (best) {
@@ -679,13 +702,13 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
                 } else {
                     rid = R++; dep = 1;
                     if (rid >= RMAX) { fast = false; break; }
-                    if (lane == 0) { s_rootx[wave][rid] = avail; s_best[wave][rid] = 0; }
+                    if (lane == 0) { s_rootx_w[rid] = avail; s_best_w[rid] = 0; }
                 }
                 if (lane == 0) {
                     const uint32_t sl = x & (RING - 1);
                     ring[0][sl] = qx; ring[1][sl] = rx; ring[2][sl] = mx; ring[3][sl] = (uint32_t)f; ring[4][sl] = rid; ring[5][sl] = dep;
                     unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - avail) << 14) | dep;
-                    if (k64 > s_best[wave][rid]) s_best[wave][rid] = k64;
+                    if (k64 > s_best_w[rid]) s_best_w[rid] = k64;
                 }
                 lds_wave_sync();
             }
@@ -698,7 +721,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
             const uint32_t r = r0 + lane;
             bool qual = false; uint32_t f = 0, lx = 0, dep = 0;
             if (r < R) {
-                unsigned long long bk = s_best[wave][r];
+                unsigned long long bk = s_best_w[r];
                 f = (uint32_t)(bk >> 28); lx = 16383u - (uint32_t)((bk >> 14) & 16383u); dep = (uint32_t)(bk & 16383u);
                 qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE2;
             }
@@ -707,11 +730,11 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
             C += __popcll(bal);
             if (C > 64) { fast = false; break; }
             if (qual) {
-                uint32_t xr = s + s_rootx[wave][r], xb = s + lx;
+                uint32_t xr = s + s_rootx_w[r], xb = s + lx;
                 uint32_t ra = A.a_rp[xr], rb = A.a_rp[xb];
-                s_cand[wave][0][ci] = f; s_cand[wave][1][ci] = A.a_qp[xr]; s_cand[wave][2][ci] = A.a_qp[xb];
-                s_cand[wave][3][ci] = ra < rb ? ra : rb; s_cand[wave][4][ci] = ra < rb ? rb : ra; s_cand[wave][5][ci] = dep;
-                s_cand[wave][6][ci] = A.a_rm[xr] >> 1;
+                s_cand_w[0][ci] = f; s_cand_w[1][ci] = A.a_qp[xr]; s_cand_w[2][ci] = A.a_qp[xb];
+                s_cand_w[3][ci] = ra < rb ? ra : rb; s_cand_w[4][ci] = ra < rb ? rb : ra; s_cand_w[5][ci] = dep;
+                s_cand_w[6][ci] = A.a_rm[xr] >> 1;
             }
         }
     }
@@ -723,15 +746,37 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     } else {
         lds_wave_sync();
         if ((uint32_t)lane < C) {
-            A.c_score[s + lane] = (int32_t)s_cand[wave][0][lane]; A.c_q0[s + lane] = s_cand[wave][1][lane]; A.c_q1[s + lane] = s_cand[wave][2][lane];
-            A.c_r0[s + lane] = s_cand[wave][3][lane]; A.c_r1[s + lane] = s_cand[wave][4][lane]; A.c_n[s + lane] = s_cand[wave][5][lane];
-            A.c_rc[s + lane] = s_cand[wave][6][lane];
+            A.c_score[s + lane] = (int32_t)s_cand_w[0][lane]; A.c_q0[s + lane] = s_cand_w[1][lane]; A.c_q1[s + lane] = s_cand_w[2][lane];
+            A.c_r0[s + lane] = s_cand_w[3][lane]; A.c_r1[s + lane] = s_cand_w[4][lane]; A.c_n[s + lane] = s_cand_w[5][lane];
+            A.c_rc[s + lane] = s_cand_w[6][lane];
         }
     }
     if (lane == 0) {
         ChunkOut o{};
         o.n_cand = C; o.left = 0xFFFFFFFFu; o.right = 0;
         *op = o;
+    }
+}
+
+// every row of the chunk table (used when the lane kernel does not run: band > LANE_N, PSK_CHAIN_LANE=0, serial cross-check)
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs A) {
+    __shared__ ChainWaveLds s_lds[CHAIN_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
+    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * CHAIN_WAVES);
+    if (slot >= A.n_rows) return;
+    if (slot - A.cbase[pair] >= A.n_chunks[pair]) return;
+    chain_chunk_row(A, slot, s_lds[wave], lane);
+}
+
+// only the rows the lane kernel listed (fixed grid, waves loop over the list: its length is known on the device only)
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_list_kernel(ChainArgs A) {
+    __shared__ ChainWaveLds s_lds[CHAIN_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_list = *A.ovf_count, n_waves = gridDim.x * CHAIN_WAVES;
+    for (uint32_t k = blockIdx.x * CHAIN_WAVES + wave; k < n_list; k += n_waves) {
+        chain_chunk_row(A, A.ovf_list[k], s_lds[wave], lane);
+        lds_wave_sync();
     }
 }
 
@@ -1246,14 +1291,15 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
-           o_end = o_misc + 64;
+           o_ovf = al256(o_misc + 64), o_end = o_ovf + 4 * n_rows;
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
     PairDesc* d_pairs = (PairDesc*)(B + o_pairs); uint32_t* d_sbase = (uint32_t*)(B + o_sbase); uint32_t* d_cbase = (uint32_t*)(B + o_cbase);
     uint32_t* d_pstart = (uint32_t*)(B + o_pstart);
     uint2* d_lbcnt = (uint2*)(B + o_lb); uint32_t* d_aoff = (uint32_t*)(B + o_aoff);   // o_lb..o_aoff: (lower bound, count) per item, +1 zero entry
     uint32_t* d_nch = (uint32_t*)(B + o_nch); uint2* d_chunks = (uint2*)(B + o_chunks); ChunkOut* d_cout = (ChunkOut*)(B + o_cout);
-    psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..2] stats
+    psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..4] stats, [8] overflow-list length
+    uint32_t* d_ovf = (uint32_t*)(B + o_ovf);
     PSK_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
@@ -1311,9 +1357,14 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
             while (rpw > 16 && n_rows / rpw < 512) rpw >>= 1;
             if (le && atoi(le) >= 8) rpw = (uint32_t)std::min(64, atoi(le));
             const uint32_t waves = (uint32_t)((n_rows + rpw - 1) / rpw);
+            A.ovf_list = d_ovf; A.ovf_count = d_misc + 8;      // d_misc was zeroed above
             hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+            // the few chunks it passes on (more than LANE_TREES trees, >= 16 384 anchors): wave kernel over the list
+            const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
+            hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);
         }
     }
+    if (!A.lane_dp)
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
     SelArgs SA{};
