@@ -178,6 +178,7 @@ struct IndexStore {
     uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
     uint32_t* perm = nullptr;  // index of the seed in the sketch's (contig,pos)-ordered arrays
     uint64_t* pms = nullptr;   // pos<<32 | meta of the seed at each index position (saves the perm -> seed_pm hop)
+    uint32_t* km32 = nullptr;  // the sorted k-mers alone (low word of key): what the join streams, half the bytes
     uint32_t* bucket = nullptr; // per sketch nb+1 offsets: bucket b = entries whose k-mer >> bshift == b (a lookup is one
                                // table read plus a scan of ~4 keys instead of a 15-level binary search)
     ~IndexStore();

@@ -249,8 +249,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // ------------------------------------------------------------------ anchors
 // One (reference, query) pair of a launch. Pairs may mix queries (query_many / all-vs-all).
 struct PairDesc {
-    const uint64_t* r_key; const uint64_t* r_pms;                             // ref index slice: key = slot<<32 | kmer ascending; r_pms = the seeds' pos<<32|meta in the same order
-    const uint64_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
+    const uint32_t* r_key; const uint64_t* r_pms;                             // ref index slice: k-mers ascending; r_pms = the seeds' pos<<32|meta in the same order
+    const uint32_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
     const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
     const uint32_t* q_contig_start;
@@ -287,12 +287,12 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
     const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
     if (i >= n_items) return;
     const PairDesc& P = pairs[p];
-    const uint64_t* __restrict__ key = P.r_key;
+    const uint32_t* __restrict__ key = P.r_key;
     const uint32_t rn = P.r_n;
     // lane i takes the i-th query seed in K-MER order: neighbouring lanes search neighbouring keys, so the first
     // levels of their binary searches read the same words and the last ones the same cache lines
     const uint32_t iq = i - sbase[p];
-    const uint32_t km = (uint32_t)P.q_key[iq];
+    const uint32_t km = P.q_key[iq];
     const uint32_t dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
     // bucket table: the k-mer's top bits give a range of ~4 index entries
     uint32_t lo = 0, hi = 0;
@@ -1261,12 +1261,12 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     for (uint32_t p = 0; p < n_pairs; p++) {
         const psk_sketch* r = hp[p].r; const psk_sketch* q = hp[p].q;
         PairDesc& P = h_pairs[p];
-        P.r_key = r->idx ? r->idx->key + r->idx_off : nullptr;
+        P.r_key = r->idx ? r->idx->km32 + r->idx_off : nullptr;
         P.r_pms = r->idx ? r->idx->pms + r->idx_off : nullptr;
         P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
         P.r_bucket = r->idx ? r->idx->bucket + r->idx_boff : nullptr; P.r_bshift = r->idx ? r->idx_bshift : 0;
         P.q_n = q->idx ? (uint32_t)q->n_seeds : 0;
-        P.q_key = q->idx ? q->idx->key + q->idx_off : nullptr;
+        P.q_key = q->idx ? q->idx->km32 + q->idx_off : nullptr;
         P.q_perm = q->idx ? q->idx->perm + q->idx_off : nullptr;
         P.q_pos = q->store ? q->store->seed_pos + q->seed_off : nullptr;
         P.q_meta = q->store ? q->store->seed_meta + q->seed_off : nullptr;

@@ -750,13 +750,14 @@ __global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restr
 
 // bucket[boff + b] = first entry of the sketch's sorted slice whose k-mer >> bshift is >= b (b = 0..nb)
 __global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restrict__ segs, const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm,
-                                                           uint32_t total, uint32_t* __restrict__ bucket, uint64_t* __restrict__ pms) {
+                                                           uint32_t total, uint32_t* __restrict__ bucket, uint64_t* __restrict__ pms, uint32_t* __restrict__ km32) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const uint64_t k = key[i];
     const IdxSeg sg = segs[(uint32_t)(k >> 32)];
     const uint32_t li = i - sg.out_off, b = (uint32_t)k >> sg.bshift;
     pms[i] = sg.pm[perm[i]];
+    km32[i] = (uint32_t)k;
     uint32_t from = 0;
     if (li > 0) from = ((uint32_t)key[i - 1] >> sg.bshift) + 1;
     for (uint32_t bb = from; bb <= b; bb++) bucket[sg.boff + bb] = li;
@@ -772,7 +773,7 @@ constexpr int IDXB_MAX_LB = 14;                       // 16 384 buckets = 64 kB 
 constexpr uint32_t IDXB_MAX_SEEDS = 1u << 18;
 
 __global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg* __restrict__ segs, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
-                                                                    uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket) {
+                                                                    uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket, uint32_t* __restrict__ km32) {
     // `slices` workgroups share one sketch: workgroup (seg, sl) owns buckets [B0, B1) = the sl-th part of the bucket
     // space and the index positions its k-mers sort to. Every workgroup streams ALL of the sketch's k-mers (coalesced,
     // cheap) but histograms, scatters, orders and writes only its own part, so the scattered traffic of a sketch
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg*
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t p = p0 + tid + r * IDXB_THREADS;
-            if (p < pend) { K[p] = ((uint64_t)(blockIdx.x / slices) << 32) | (uint32_t)(v[r] >> 32); perm[sg.out_off + p] = (uint32_t)v[r]; pms[sg.out_off + p] = pm[r]; }
+            if (p < pend) { K[p] = ((uint64_t)(blockIdx.x / slices) << 32) | (uint32_t)(v[r] >> 32); km32[sg.out_off + p] = (uint32_t)(v[r] >> 32); perm[sg.out_off + p] = (uint32_t)v[r]; pms[sg.out_off + p] = pm[r]; }
         }
     }
 }
@@ -921,9 +922,10 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         auto ix = std::make_shared<IndexStore>();
         ix->ctx = ctx;
         size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256), bb = align_up(4 * (size_t)boff, 256);
-        PSK_TRY(ctx->pool_alloc(2 * kb + vb + bb, &ix->base, &ix->bytes));
+        PSK_TRY(ctx->pool_alloc(2 * kb + 2 * vb + bb, &ix->base, &ix->bytes));
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
-        ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + vb);
+        ix->km32 = (uint32_t*)((char*)ix->base + 2 * kb + vb);
+        ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
         PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         if (small) {
@@ -933,7 +935,7 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
             // kernel's time is its chain of dependent round trips, not one CU's scattered traffic. PSK_INDEX_SLICES overrides.
             uint32_t slices = 1;
             if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
-            hipLaunchKernelGGL(index_block_kernel, dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket);
+            hipLaunchKernelGGL(index_block_kernel, dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
             ctx->t_end();
             PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {
@@ -952,7 +954,7 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         PSK_TRY(ctx->s_tmp.reserve(tmp));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
-        hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms);
+        hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms, ix->km32);
         ctx->t_end();
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) {

@@ -184,6 +184,28 @@ def test_chain_multicontig_repeats_and_strands(psk, oracle):
     check_pair(psk, oracle, ref, [q2, q1, b"ACGT" * 50])
 
 
+def test_chain_many_repeat_copies_per_chunk(psk, oracle):
+    """Seven diverged copies of a 12 kb element in the reference against one copy in the query: the query chunks
+    each carry seven qualifying chain trees, more than the lane-per-chunk kernel keeps in registers, so they go
+    through its overflow list to the wave kernel; plus a tandem case on both strands."""
+    rng = np.random.default_rng(111)
+    elem = random_genome(rng, 12000)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ref = []
+    parts = []
+    for c in range(7):
+        copy = mutate(rng, elem, 0.01 + 0.004 * c)
+        if c % 3 == 2:
+            copy = copy[::-1].translate(comp)
+        parts.append(random_genome(rng, 20000 + 1000 * c) + copy)
+    ref.append(b"".join(parts[:4]) + random_genome(rng, 5000))
+    ref.append(b"".join(parts[4:]) + random_genome(rng, 30000))
+    flank_l, flank_r = random_genome(rng, 60000), random_genome(rng, 60000)
+    query = [flank_l + elem + flank_r, mutate(rng, ref[0][:50000], 0.02)]
+    res = check_pair(psk, oracle, ref, query)
+    assert res and res[0]._raw["n_intervals"] >= 2
+
+
 def test_chain_unrelated_gives_no_hit(psk, oracle):
     rng = np.random.default_rng(12)
     a, b = random_genome(rng, 200000), random_genome(rng, 200000)
