@@ -642,6 +642,138 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     }
 }
 
+// ---- four lanes per chunk, for launches too small to fill the chip with one lane per chunk -----------------
+// (the headline search: 100 pairs = 22 k chunks). Lane j of a quad owns the anchors whose index is j mod 4: ownership
+// never moves, so the 24-deep window becomes four 6-deep ones with static register indices, each lane scores 6
+// predecessors per anchor instead of 24, and two quad DPP exchanges give all four the best key. The step's dependent
+// instruction chain - what a lone wave per SIMD is bound by - is ~2.4 x shorter; throughput per chunk is lower, so
+// the one-lane kernel stays for big launches.
+__device__ __forceinline__ uint32_t lane_eval_d(uint32_t qx, uint32_t rx, uint32_t mx, uint32_t sg, const LaneAnchor& y, uint32_t d, int band) {
+    const int32_t dq = (int32_t)(qx - y.q);
+    const int32_t dr = (int32_t)(((rx - y.r) ^ sg) - sg);
+    const int32_t t = dq - dr, nt = dr - dq;
+    const int32_t gap = t > nt ? t : nt;
+    const int32_t scp = y.f - gap;
+    const uint32_t z = y.m ^ mx;
+    const uint32_t bad = (uint32_t)(dq - 1) | (uint32_t)(BP_CHAIN_BAND - dq) | (uint32_t)(dr - 1) | (uint32_t)(MAX_GAP_LENGTH - gap) |
+                         (uint32_t)(scp - 1) | z | (0u - z) | (uint32_t)(band - (int32_t)d);
+    const uint32_t ok = (uint32_t)((int32_t)~bad >> 31);
+    return ((((uint32_t)scp << 7) + (((uint32_t)ANCHOR_SCORE2 << 7) | 127u) - d)) & ok;
+}
+
+constexpr int QUAD_N = LANE_N / 4;
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A) {
+    __shared__ uint32_t s_rd[LANE_WAVES][32][16];     // root index << 14 | depth of the last 32 anchors, per quad
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2;
+    const uint32_t j = lane & 3;
+    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    uint32_t s = 0, e = 0;
+    bool mine = false, real = false;
+    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * LANE_WAVES * 16);
+    if (slot < A.n_rows && slot - A.cbase[pair] < A.n_chunks[pair]) {
+        const uint2 se = A.chunks[slot];
+        s = se.x; e = se.y;
+        real = true;
+        mine = e > s && e - s < 16384;
+    }
+    const uint32_t s_al = s & ~3u;
+    const uint32_t len = mine ? e - s_al : 0;
+    // window: entry i = the anchor 4 i before this lane's latest one (scalar arrays: a struct array with conditional
+    // whole-struct moves ends up in scratch memory)
+    uint32_t Wq[QUAD_N], Wr[QUAD_N], Wm[QUAD_N]; int32_t Wf[QUAD_N];
+#pragma unroll
+    for (int i = 0; i < QUAD_N; i++) { Wq[i] = 0; Wr[i] = 0; Wm[i] = 0xFFFFFFFFu; Wf[i] = 0; }
+    unsigned long long bk[LANE_TREES];
+    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
+#pragma unroll
+    for (int k = 0; k < LANE_TREES; k++) { bk[k] = 0; sroot[k] = 0xFFFFFFFFu; bq[k] = br[k] = 0; }
+    uint32_t S = 0;
+    bool ovf = false;
+    uint32_t (*rd)[16] = s_rd[wave];
+    const int band = A.band;
+    for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
+        const uint32_t x0 = s_al + t0;
+        uint4 q4 = make_uint4(0, 0, 0, 0), r4 = q4, m4 = q4;
+        if (t0 < len) {
+            q4 = *reinterpret_cast<const uint4*>(A.a_qp + x0);
+            r4 = *reinterpret_cast<const uint4*>(A.a_rp + x0);
+            m4 = *reinterpret_cast<const uint4*>(A.a_rm + x0);
+        }
+        const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t x = x0 + u, t = t0 + u;
+            const bool act = x >= s && x < e && mine;
+            const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
+            const uint32_t sg = 0u - (mx & 1u);
+            // this lane's latest anchor sits d0 = ((u - j) mod 4, 4 if 0) before x
+            const uint32_t d0 = ((((uint32_t)u - j) - 1u) & 3u) + 1u;
+            uint32_t best = 0;
+#pragma unroll
+            for (int i = 0; i < QUAD_N; i++) {
+                LaneAnchor y; y.q = Wq[i]; y.r = Wr[i]; y.m = Wm[i]; y.f = Wf[i];
+                const uint32_t k = lane_eval_d(qx, rx, mx, sg, y, d0 + 4u * i, band);
+                best = k > best ? k : best;
+            }
+            {   // all four lanes of the quad get the maximum
+                uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                best = o > best ? o : best;
+                o = (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0x4E, 0xF, 0xF, true);            // quad_perm [2,3,0,1]
+                best = o > best ? o : best;
+            }
+            int32_t f = ANCHOR_SCORE2; uint32_t ridx = x - s, dep = 1;
+            if (best) {
+                f = (int32_t)(best >> 7);
+                const uint32_t v = rd[(t - (127u - (best & 127u))) & 31u][quad];
+                ridx = v >> 14; dep = (v & 16383u) + 1;
+            }
+            rd[t & 31u][quad] = (ridx << 14) | dep;          // four lanes, one value
+            const bool own = j == (uint32_t)u;               // x is 4-aligned at u = 0, so anchor x belongs to lane u
+#pragma unroll
+            for (int i = QUAD_N - 1; i >= 1; i--) { Wq[i] = own ? Wq[i - 1] : Wq[i]; Wr[i] = own ? Wr[i - 1] : Wr[i]; Wm[i] = own ? Wm[i - 1] : Wm[i]; Wf[i] = own ? Wf[i - 1] : Wf[i]; }
+            Wq[0] = own ? qx : Wq[0]; Wr[0] = own ? rx : Wr[0]; Wm[0] = own ? (act ? mx : 0xFFFFFFFFu) : Wm[0]; Wf[0] = own ? f : Wf[0];
+            if (act && f >= MIN_SCORE2) {
+                const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < LANE_TREES; k++) {
+                    const bool hit = sroot[k] == ridx;
+                    found = found || hit;
+                    if (hit && k64 > bk[k]) { bk[k] = k64; bq[k] = qx; br[k] = rx; }
+                }
+                if (!found) {
+                    if (S >= (uint32_t)LANE_TREES) ovf = true;
+#pragma unroll
+                    for (int k = 0; k < LANE_TREES; k++) if (S == (uint32_t)k) { sroot[k] = ridx; bk[k] = k64; bq[k] = qx; br[k] = rx; }
+                    S++;
+                }
+            }
+        }
+    }
+    if (j == 0 && slot < A.n_rows && real) {
+        if (mine && !ovf) {
+            uint32_t nc = 0, last = 0;
+            for (uint32_t c = 0; c < S; c++) {
+                uint32_t pick = 0xFFFFFFFFu; unsigned long long k = 0; uint32_t q1 = 0, rb = 0;
+#pragma unroll
+                for (int i = 0; i < LANE_TREES; i++)
+                    if (sroot[i] != 0xFFFFFFFFu && (c == 0 || sroot[i] > last) && sroot[i] < pick) { pick = sroot[i]; k = bk[i]; q1 = bq[i]; rb = br[i]; }
+                last = pick;
+                const uint32_t xr = s + pick, ra = A.a_rp[xr], o = s + nc;
+                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.a_qp[xr]; A.c_q1[o] = q1;
+                A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
+                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.a_rm[xr] >> 1;
+                nc++;
+            }
+            ChunkOut o{};
+            o.n_cand = nc; o.left = 0xFFFFFFFFu; o.right = 0;
+            A.out[slot] = o;
+        } else {
+            A.ovf_list[atomicAdd(A.ovf_count, 1u)] = slot;
+        }
+    }
+}
+
 // The wave-per-chunk chaining of ONE row of the chunk table (one wavefront): DP over an LDS ring, per-tree bests,
 // candidate emission. Shared arrays are the calling wave's slices.
 struct ChainWaveLds {
@@ -1358,6 +1490,11 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
             if (le && atoi(le) >= 8) rpw = (uint32_t)std::min(64, atoi(le));
             const uint32_t waves = (uint32_t)((n_rows + rpw - 1) / rpw);
             A.ovf_list = d_ovf; A.ovf_count = d_misc + 8;      // d_misc was zeroed above
+            const bool quad = le && le[0] == 'q' ? true : (le && atoi(le) >= 8 ? false : n_rows < 32 * 1024);
+            if (quad) {   // small launch: four lanes per chunk, 16 chunks per wave
+                const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
+                hipLaunchKernelGGL(chain_quad_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
+            } else
             hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
             // the few chunks it passes on (more than LANE_TREES trees, >= 16 384 anchors): wave kernel over the list
             const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);

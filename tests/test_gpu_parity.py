@@ -261,7 +261,7 @@ def test_alternative_device_paths_agree(ecoli):
         "print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     outs = {}
-    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"})):
+    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"})):
         env = dict(os.environ)
         for k in ("PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX"):
             env.pop(k, None)
