@@ -1454,7 +1454,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     PSK_HIP(hipStreamSynchronize(st));   // also keeps h_pairs/h_sbase/h_cbase alive until copied
     const uint32_t total = h_small[0];
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
-    const size_t na = (size_t)total + 64;
+    const size_t na = ((size_t)total + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
     PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 8 + 1) + 64));   // select_big_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;

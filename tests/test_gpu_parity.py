@@ -297,6 +297,25 @@ def test_full_size_properties(psk):
         assert abs(hits[f"d{j}"].identity - (1 - 0.75 * d)) < 0.003
 
 
+@pytest.mark.parametrize("k,c,mc", [(16, 60, 500), (11, 200, 800), (13, 100, 1000), (15, 250, 1000)])
+def test_chain_other_sketch_parameters(psk, oracle, k, c, mc):
+    """Chaining away from the defaults: look-back bands 41 (wave-per-chunk DP), 12, 25 (one over the lane kernels'
+    window) and 10; k-mer widths 22 to 32 bits through the bucketed index."""
+    rng = np.random.default_rng(900 + k)
+    anc = random_genome(rng, 500000)
+    ref = [anc[:200000], mutate(rng, anc[200000:], 0.004)]
+    qry = [mutate(rng, anc[100000:450000], 0.03, 0.0003)]
+    r, q = oracle.Sketch(ref, c=c, marker_c=mc, k=k), oracle.Sketch(qry, c=c, marker_c=mc, k=k)
+    want = oracle.query([("ref", r)], q)
+    db = psk.Database(compression=c, marker_compression=mc, k=k)
+    db.sketch("ref", *ref)
+    got = db.query("q", *qry, learned_ani=False)
+    assert len(got) == len(want) == 1
+    for f in INT_FIELDS:
+        assert got[0]._raw[f] == getattr(want[0][1], f), f
+    assert abs(got[0].identity - want[0][1].ani) < 1e-6
+
+
 def test_metagenome_mode_short_contigs(psk, oracle):
     """BASELINE configs[3] in miniature: c=30 / marker_c=200, short contigs as separate queries, both
     faster_small settings; every hit list must equal the oracle's."""
