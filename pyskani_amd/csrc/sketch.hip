@@ -316,11 +316,6 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
 }
-__global__ void marker_segments_kernel(const uint32_t* __restrict__ g_off, const uint32_t* __restrict__ marker_count,
-                                       uint32_t* __restrict__ beg, uint32_t* __restrict__ end, int n) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n) { beg[g] = g_off[g]; end[g] = g_off[g] + marker_count[g]; }
-}
 // one block per genome: write the distinct values of the sorted segment, in order, to `uniq` at the same
 // segment offset; cnt[g] = number of distinct markers (cnt[n_genomes] must be pre-zeroed by the caller's scan input)
 __global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __restrict__ sorted, uint64_t* __restrict__ uniq,
