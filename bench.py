@@ -257,6 +257,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_ms_per_step": kernel_ms,
+            # SURVEY.md §8(d) side figures, whole job
+            "extras": {"genomes_sketched_per_s": (n_refs + (0 if args.workload == "allvsall" else 1)) * world * args.steps / dt,
+                       "bases_sketched_per_s": bases * world * args.steps / dt,
+                       "reported_hits_per_step": int(n_hits)},
         }
         if args.cpu_sample > 0 and world == 1 and args.workload == "search":
             ns = min(args.cpu_sample, n_refs)
