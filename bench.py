@@ -255,7 +255,9 @@ def main():
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "priced against HBM as the contract asks; the kernel is integer-VALU-issue bound (one 64-bit mix per base: "
+                                 "15 four-cycle + 7 two-cycle wave instructions per base, DESIGN.md section 4, profiles/micro/valu_rates.hip)"},
             "kernel_ms_per_step": kernel_ms,
             # SURVEY.md §8(d) side figures, whole job
             "extras": {"genomes_sketched_per_s": (n_refs + (0 if args.workload == "allvsall" else 1)) * world * args.steps / dt,
