@@ -1,0 +1,67 @@
+"""GPU: randomised parity sweep. Random parameters (k, c, marker_c), contig structure, divergence, repeats and
+strand flips; every integer intermediate of chaining and both sketches must equal the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import mutate, random_genome
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+@pytest.fixture(scope="module")
+def psk():
+    import pyskani_amd
+    return pyskani_amd
+
+
+def _case(rng):
+    k = int(rng.integers(9, 17))
+    c = int(rng.choice([8, 20, 30, 60, 100, 105, 125, 200, 400]))
+    mc = int(c * rng.choice([2, 4, 8]))
+    L = int(rng.integers(30000, 400000))
+    anc = random_genome(rng, L)
+    if rng.random() < 0.5:                      # plant a repeat family
+        rep = random_genome(rng, int(rng.integers(300, 6000)))
+        pieces, pos = [], 0
+        for _ in range(int(rng.integers(2, 7))):
+            cut = int(rng.integers(pos, L))
+            pieces.append(anc[pos:cut]); pieces.append(mutate(rng, rep, rng.uniform(0, 0.03))); pos = cut
+        pieces.append(anc[pos:])
+        anc = b"".join(pieces)
+    def split(seq):
+        n = int(rng.integers(1, 6))
+        cuts = sorted(int(x) for x in rng.integers(0, len(seq), size=n - 1))
+        parts = [seq[a:b] for a, b in zip([0] + cuts, cuts + [len(seq)])]
+        return [p[::-1].translate(COMP) if rng.random() < 0.3 else p for p in parts]
+    ref = split(mutate(rng, anc, rng.uniform(0, 0.02)))
+    lo = int(rng.integers(0, len(anc) // 2)); hi = int(rng.integers(lo + len(anc) // 4, len(anc)))
+    qry = split(mutate(rng, anc[lo:hi], rng.uniform(0, 0.08), rng.uniform(0, 0.001)))
+    return k, c, mc, ref, qry
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PSK_FUZZ_SEEDS", "24"))))   # PSK_FUZZ_SEEDS=1000 for a long sweep
+def test_random_pairs_match_oracle(psk, oracle, seed):
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(4):
+        k, c, mc, ref, qry = _case(rng)
+        kw = {"median": True} if rng.random() < 0.2 else ({"robust": True} if rng.random() < 0.2 else {})
+        r, q = oracle.Sketch(ref, c=c, marker_c=mc, k=k), oracle.Sketch(qry, c=c, marker_c=mc, k=k)
+        want = oracle.query([("ref", r)], q, **kw)
+        db = psk.Database(compression=c, marker_compression=mc, k=k)
+        db.sketch("ref", *ref)
+        gs = db._sketch("q", qry, True)
+        seeds, markers = gs.export()
+        assert np.array_equal(seeds["kmer"], q.seeds["kmer"]) and np.array_equal(seeds["pos"], q.seeds["pos"]), (seed, k, c)
+        assert np.array_equal(markers, q.markers), (seed, k, c, mc)
+        got = db.query("q", *qry, learned_ani=False, **kw)
+        assert len(got) == len(want), (seed, k, c, mc, kw)
+        if want:
+            for f in INT_FIELDS:
+                assert got[0]._raw[f] == getattr(want[0][1], f), (seed, k, c, mc, kw, f)
+            assert abs(got[0].identity - want[0][1].ani) < 1e-6, (seed, k, c, mc, kw)
+            assert abs(got[0].query_fraction - want[0][1].af_query) < 1e-6 and abs(got[0].reference_fraction - want[0][1].af_ref) < 1e-6
