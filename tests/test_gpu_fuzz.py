@@ -65,3 +65,39 @@ def test_random_pairs_match_oracle(psk, oracle, seed):
                 assert got[0]._raw[f] == getattr(want[0][1], f), (seed, k, c, mc, kw, f)
             assert abs(got[0].identity - want[0][1].ani) < 1e-6, (seed, k, c, mc, kw)
             assert abs(got[0].query_fraction - want[0][1].af_query) < 1e-6 and abs(got[0].reference_fraction - want[0][1].af_ref) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PSK_FUZZ_DB_SEEDS", "6"))))
+def test_random_databases_match_oracle(psk, oracle, seed):
+    """Random small databases (1-3 families, 3-20 members, assorted parameters) against several queries through
+    query_many: hit sets, every chaining integer and ANI / AF must equal the oracle's screen + chain loop."""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.integers(11, 17)); c = int(rng.choice([30, 60, 125, 200])); mc = int(c * rng.choice([4, 8]))
+    fams = [random_genome(rng, int(rng.integers(60000, 250000))) for _ in range(int(rng.integers(1, 4)))]
+    refs = []
+    for i in range(int(rng.integers(3, 21))):
+        a = fams[int(rng.integers(0, len(fams)))]
+        refs.append((f"r{i}", mutate(rng, a, rng.uniform(0, 0.12), rng.uniform(0, 0.0005))))
+    db = psk.Database(compression=c, marker_compression=mc, k=k)
+    for n, sq in refs:
+        db.sketch(n, sq)
+    osk = [(n, oracle.Sketch([sq], c=c, marker_c=mc, k=k)) for n, sq in refs]
+    queries = []
+    for j in range(int(rng.integers(1, 6))):
+        a = fams[int(rng.integers(0, len(fams)))]
+        lo = int(rng.integers(0, len(a) // 2))
+        queries.append((f"q{j}", mutate(rng, a[lo:lo + int(rng.integers(3000, len(a) - lo))], rng.uniform(0, 0.06))))
+    queries.append(("unrelated", random_genome(rng, 50000)))
+    fs = bool(rng.integers(0, 2))
+    cutoff = float(rng.choice([0.0, 0.7, 0.85, 0.95])) or None
+    got_all = db.query_many(queries, learned_ani=False, faster_small=fs, cutoff=cutoff)
+    for (qn, qs), got in zip(queries, got_all):
+        want = {n: r for n, r in oracle.query(osk, oracle.Sketch([qs], c=c, marker_c=mc, k=k), faster_small=fs, cutoff=cutoff)}
+        g = {h.reference_name: h for h in got}
+        assert set(g) == set(want), (seed, qn, sorted(set(g) ^ set(want)))
+        for n, w in want.items():
+            for f in INT_FIELDS:
+                assert g[n]._raw[f] == getattr(w, f), (seed, qn, n, f)
+            assert abs(g[n].identity - w.ani) < 1e-6 and abs(g[n].query_fraction - w.af_query) < 1e-6
+        single = db.query(qn, qs, learned_ani=False, faster_small=fs, cutoff=cutoff)
+        assert [(h.reference_name, h.identity) for h in single] == [(h.reference_name, h.identity) for h in got]
