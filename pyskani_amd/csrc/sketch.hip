@@ -160,6 +160,8 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     const uint32_t kdrop = 32 - 2 * C.k;
     uint32_t mlo = 0, mhi = 0;
     const uint64_t thr = C.thr;
+    // a wave whose 4 096 bases lie wholly past the contig's end has nothing to hash (short contigs, last tiles)
+    if (64u * (uint32_t)(tid & ~63) < n)
 #pragma unroll
     for (int i = 0; i < 64; i++) {
         const int s0 = 28 + i, sw = s0 / 16, so = s0 % 16;
