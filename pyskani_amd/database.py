@@ -368,17 +368,27 @@ class Database:
                    faster_small=False):
         """[(name, contigs...)] -> list of hit lists; equals [self.query(name, *contigs, ...) for ...].
         An addition to the reference API for all-vs-all / many-bin workloads."""
-        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         sketches = [self._sketch(g[0], g[1:], seed) for g in genomes]
+        return self.query_sketches(sketches, learned_ani=learned_ani, median=median, robust=robust, cutoff=cutoff,
+                                   faster_small=faster_small)
+
+    def sketch_only(self, name, *contigs, seed=True):
+        """Sketch a genome WITHOUT adding it: the `Sketch` can be queried (`query_sketches`) or shipped to another
+        rank as a record (`Sketch.to_record().to_bytes()`), e.g. by `parallel.ShardedDatabase.all_vs_all`."""
+        return self._sketch(name, contigs, seed)
+
+    def query_sketches(self, sketches, *, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False):
+        """query_many for genomes that are already sketched (`Sketch` objects made with this database's parameters)."""
+        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         n = len(sketches)
         if not all(self._resident):      # `open`ed database: sketches come from disk per query
-            return [self._query_lazy(g[0], s, opts) for g, s in zip(genomes, sketches)]
+            return [self._query_lazy(s.name, s, opts) for s in sketches]
         arr = (C.c_void_p * max(n, 1))(*[s._h for s in sketches])
         hits_p = C.POINTER(_capi.Hit)()
         offs = (C.c_uint64 * (n + 1))()
         _capi.check(self._lib.psk_query_many(self._h, arr, n, C.byref(opts), C.byref(hits_p), offs))
         try:
-            return [[self._hit(hits_p[j], genomes[i][0]) for j in range(offs[i], offs[i + 1])] for i in range(n)]
+            return [[self._hit(hits_p[j], sketches[i].name) for j in range(offs[i], offs[i + 1])] for i in range(n)]
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)

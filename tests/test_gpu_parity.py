@@ -474,3 +474,45 @@ print("sharded ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_sharded_all_vs_all_two_ranks_share_the_gpu(psk):
+    """ShardedDatabase.all_vs_all with two ranks (gloo, both on this box's one GPU): shards sketch their own genomes,
+    exchange sketch records, query them against the local shard, gather hits. Must equal one Database.query_many."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+from conftest import random_genome, mutate
+import pyskani_amd as psk
+from pyskani_amd.parallel import ShardedDatabase
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.default_rng(17)
+anc = [random_genome(rng, 120000), random_genome(rng, 90000)]
+genomes = [mutate(rng, anc[i %% 2], 0.01 * (i // 2)) for i in range(7)]
+names = ["g%%d" %% i for i in range(7)]
+sdb = ShardedDatabase(dist, device=torch.device("cuda", 0))
+n_local = sdb.sketch_all(names, lambda i: (genomes[i],))
+assert n_local == (4 if rank == 0 else 3)
+got = sdb.all_vs_all(batch=2, learned_ani=False)
+db = psk.Database()
+for n, g in zip(names, genomes): db.sketch(n, g)
+want = db.query_many(list(zip(names, genomes)), learned_ani=False)
+for n, hits in zip(names, want):
+    w = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in hits]
+    g = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in got[n]]
+    assert g == w, (n, g, w)
+assert sum(len(v) for v in got.values()) >= 7 + 12
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "all-vs-all ok")
+''' % (ROOT, ROOT)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("all-vs-all ok" in o for o in outs), outs

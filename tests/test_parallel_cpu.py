@@ -44,6 +44,13 @@ assert fetched == list(range(*shard_bounds(7, rank, world))) and n_local == len(
 hits = sdb.query("q", b"ACGT")
 assert [h.reference_name for h in hits] == ["g0", "g2", "g4", "g6"], hits
 assert all(abs(h.identity - (0.5 + int(h.reference_name[1:]) / 100)) < 1e-6 and h.query_name == "q" for h in hits)
+# ragged byte lists (the sketch exchange of ShardedDatabase.all_vs_all)
+from pyskani_amd.parallel import all_gather_bytes
+mine = [bytes([rank + 1]) * (5 + 3 * i + 7 * rank) for i in range(2 + rank)] if rank == 0 else [b"x" * 11, b"", b"yz"]
+got = all_gather_bytes(mine, dist)
+assert got[rank] == mine and len(got) == world
+assert got[0] == [bytes([1]) * 5, bytes([1]) * 8] and got[1] == [b"x" * 11, b"", b"yz"], got
+assert all_gather_bytes([], dist) == [[], []]
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
