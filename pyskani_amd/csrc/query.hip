@@ -279,12 +279,21 @@ __device__ __forceinline__ uint32_t find_le_block(const uint32_t* __restrict__ b
 
 struct CountOf { __host__ __device__ uint32_t operator()(const uint2& v) const { return v.y; } };
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8, each with its own L2). Renumbering
+// them so that consecutive LOGICAL workgroups share an XCD keeps the ~150 workgroups that join one (ref, query) pair
+// - and re-read the same index slices - on one L2 instead of filling all eight.
+__device__ __forceinline__ uint32_t xcd_block_id() {
+    const uint32_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    return xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+}
+
 // one lane per (pair, query seed): range of equal k-mers in the ref index
 __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                            uint32_t n_pairs, uint32_t n_items,
                                                            uint2* __restrict__ lbcnt_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
+    const uint32_t lb = xcd_block_id();
+    uint32_t i = lb * blockDim.x + threadIdx.x;
+    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
     if (i >= n_items) return;
     const PairDesc& P = pairs[p];
     const uint32_t* __restrict__ key = P.r_key;
@@ -318,8 +327,9 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
                                                           const uint32_t* __restrict__ aoff,
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
                                                           uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, blockIdx.x * blockDim.x);
+    const uint32_t lb = xcd_block_id();
+    uint32_t i = lb * blockDim.x + threadIdx.x;
+    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
     if (i >= n_items) return;
     const uint2 lc = lbcnt[i];
     const uint32_t c = lc.y;
