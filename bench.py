@@ -96,7 +96,7 @@ class Engine:
         capi.check(lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
         try:
             capi.check(lib.psk_db_add_batch(db, names, out, n - 1))
-            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0)
+            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
             hits_p = C.POINTER(capi.Hit)()
             nh = C.c_uint64(0)
             capi.check(lib.psk_query(db, out[n - 1], C.byref(opts), C.byref(hits_p), C.byref(nh)))
@@ -122,7 +122,7 @@ class Engine:
         capi.check(lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
         try:
             capi.check(lib.psk_db_add_batch(db, names, out, n))
-            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0)
+            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
             hits_p = C.POINTER(capi.Hit)()
             offsets = (C.c_uint64 * (n + 1))()
             capi.check(lib.psk_query_many(db, out, n, C.byref(opts), C.byref(hits_p), offsets))
@@ -206,8 +206,8 @@ def main():
             return eng.step_all_vs_all(buf.data_ptr(), offs, lens, names)
         hits = eng.step(buf.data_ptr(), offs, lens, names)
         if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
-            hits[:, 0] += rank * n_refs          # global ref index
-            return all_gather_hits(hits, dist, device=coll_device).shape[0]
+            idx = np.stack([np.zeros(len(hits), np.int64), hits[:, 0].astype(np.int64) + rank * n_refs], axis=1)   # (query, GLOBAL ref index)
+            return all_gather_hits(idx, hits[:, 1:4], dist, device=coll_device)[0].shape[0]
         return hits.shape[0]
 
     def fence():

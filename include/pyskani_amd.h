@@ -14,6 +14,10 @@
  *   psk_query   <- the whole allow_threads closure of Database::query   lib.rs:569-659
  *                  (screen_val default :603-609, learned rule :611-614, ani>0.1 filter :654)
  *   psk_hit     <- the fields of skani::types::AniEstResult that Hit exposes, hit.rs:77-104
+ *   psk_model_* <- skani::regression::{use_learned_ani, get_model}      lib.rs:611-614 and the
+ *                  `&model_opt` argument of map_params_from_sketch      lib.rs:646-651
+ *   psk_db_add  also implements the name-keyed store of lib.rs:51-55: queries shortlist NAMES
+ *                  (lib.rs:616-637), so a name sketched twice yields one hit, against its last sketch
  *
  * Conventions: plain pointers and sizes, opaque handles, no exceptions cross the ABI.
  * Every function returns a psk_status; psk_last_error() gives the thread-local message.
@@ -44,6 +48,7 @@ typedef enum {
 typedef struct psk_ctx psk_ctx;       /* one GPU: device id, stream, scratch arenas         */
 typedef struct psk_sketch psk_sketch; /* one genome's seeds+index+markers, resident in HBM  */
 typedef struct psk_db psk_db;         /* ordered reference set (insertion order = lib.rs:501) */
+typedef struct psk_model psk_model;   /* learned-ANI regression model (gradient-boosted trees), device resident */
 
 /* SketchParams::new(marker_c, c, k, false, false)  lib.rs:416 */
 typedef struct {
@@ -60,6 +65,9 @@ typedef struct {
     int32_t faster_small;    /* rescue_small = !faster_small, lib.rs:597 */
     double cutoff;           /* 0 = SEARCH_ANI_CUTOFF_DEFAULT (0.80), lib.rs:603-609 */
     double min_aligned_frac; /* 0 = D_FRAC_COVER_CUTOFF/100 = 0.15, lib.rs:589-590   */
+    const psk_model* model;  /* `model_opt` of lib.rs:614/:650. The regression runs when learned_ani == 1, or when
+                                learned_ani == -1, c >= 70, !median (lib.rs:611-613) AND a model is given; learned_ani == 1
+                                without a model is PSK_ENOMODEL, learned_ani == -1 without one returns the raw chain ANI */
 } psk_query_opts;
 
 typedef struct {
@@ -70,6 +78,10 @@ typedef struct {
     /* integer intermediates (bit-exact parity checks against the oracle) */
     uint32_t n_chunks, n_intervals;
     uint64_t n_anchors, covered_query, covered_ref, sum_chain_anchors, sum_chunk_seeds;
+    float ani_raw;      /* chain ANI before the regression (== ani when learned == 0)      */
+    float ani_std;      /* sample standard deviation of the per-chunk ANI estimates        */
+    uint32_t learned;   /* 1 iff the regression model produced `ani`                       */
+    uint32_t reserved;
 } psk_hit;
 
 typedef struct { uint32_t kmer, pos, contig, canon; } psk_seed; /* export record (parity tests) */
@@ -119,6 +131,55 @@ psk_status psk_sketch_contig_lens(const psk_sketch* s, uint32_t* lens);
 psk_status psk_sketch_import(psk_ctx* ctx, const psk_params* p, const uint32_t* contig_lens, uint32_t n_contigs,
                              const psk_seed* seeds, uint64_t n_seeds, const uint64_t* markers, uint64_t n_markers,
                              int has_seeds, psk_sketch** out);
+
+/* ---- learned-ANI regression (lib.rs:611-614; skani::regression, crate gbdt 0.1.3 at Cargo.lock:1608) ----
+ * skani embeds its trained GBDT weights inside the crate, which is not part of the reference tree; a model
+ * therefore comes from the caller: either as flat arrays (what a Rust host holding a gbdt::GBDT would pass) or
+ * as the serde-JSON text of a gbdt::gradient_boost::GBDT. Inference runs on the GPU, one lane per hit.
+ * Tree semantics (gbdt 0.1.3 DecisionTree::predict_one): at an inner node go LEFT iff x[feature] < threshold;
+ * a feature equal to PSK_FEATURE_UNKNOWN follows `missing` (-1 left, 0 stop and use this node's value, +1 right);
+ * prediction = bias + shrinkage * sum over trees of the reached node's value, accumulated in tree order in f32. */
+#define PSK_FEATURE_UNKNOWN (-3.402823466e+38F)   /* gbdt VALUE_TYPE_UNKNOWN = f32::MIN */
+typedef struct {
+    int32_t feature;    /* index into the model's feature vector */
+    float threshold;    /* DTNode.feature_value */
+    int32_t left, right;/* node indices relative to the tree's first node */
+    float value;        /* DTNode.pred */
+    int32_t missing;    /* -1 / 0 / +1 */
+    int32_t is_leaf;
+    int32_t reserved;
+} psk_tree_node;
+/* What a model's feature vector is made of. The default vector (features == NULL) is
+ * {ANI100, STD100, Q90_QUERY, Q50_QUERY, Q10_QUERY, Q90_REF, Q50_REF, Q10_REF, AVG_CHAIN_LEN}: the fields skani's
+ * AniEstResult carries beside the three fractions, as recalled — UNVERIFIED against the absent crate; a model file
+ * may name its own order with a top-level "psk_features": ["ani100", "std100", ...] array. */
+typedef enum {
+    PSK_F_ANI100 = 0,       /* raw chain ANI x 100 */
+    PSK_F_STD100 = 1,       /* sample std of the per-chunk ANI estimates x 100 */
+    PSK_F_Q90_QUERY = 2, PSK_F_Q50_QUERY = 3, PSK_F_Q10_QUERY = 4,   /* contig-length quantiles: sorted lengths at n*9/10, n/2, n/10 */
+    PSK_F_Q90_REF = 5, PSK_F_Q50_REF = 6, PSK_F_Q10_REF = 7,
+    PSK_F_AVG_CHAIN_LEN = 8,/* covered bases / kept chains */
+    PSK_F_AF_QUERY = 9, PSK_F_AF_REF = 10, PSK_F_N_CHUNKS = 11,
+    PSK_F_TOTAL_LEN_QUERY = 12, PSK_F_TOTAL_LEN_REF = 13, PSK_F_N_CONTIGS_QUERY = 14, PSK_F_N_CONTIGS_REF = 15,
+    PSK_F_COUNT = 16
+} psk_feature;
+psk_status psk_model_create(psk_ctx* ctx, const psk_tree_node* nodes, uint64_t n_nodes, const uint32_t* tree_first_node,
+                            uint32_t n_trees, float bias, float shrinkage, const int32_t* features, uint32_t n_features,
+                            psk_model** out);
+psk_status psk_model_load_json(psk_ctx* ctx, const char* json, size_t len, psk_model** out);
+psk_status psk_model_load_file(psk_ctx* ctx, const char* path, psk_model** out);
+void psk_model_free(psk_model* m);
+psk_status psk_model_info(const psk_model* m, uint32_t* n_trees, uint64_t* n_nodes, uint32_t* n_features);
+/* evaluate the model on n_rows host rows of n_features floats (GPU evaluation; parity tests and model checks) */
+psk_status psk_model_predict(const psk_model* m, const float* rows, uint32_t n_rows, float* out);
+
+/* ---- device-side sketch records: the exchange step of a multi-GPU all-vs-all. A packed sketch is one
+ * self-contained, 16-byte aligned byte range of HBM that an RCCL all-gather can move between GPUs as it is;
+ * psk_sketch_unpack turns n received records (d_src + offsets[i]) into n sketches sharing one store. Nothing
+ * passes through host memory except the 64-byte headers and the contig tables. */
+psk_status psk_sketch_pack_size(const psk_sketch* s, uint64_t* bytes);
+psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity);
+psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out);
 
 psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out);
 void psk_db_destroy(psk_db* db);

@@ -20,16 +20,45 @@ class _Sketch(C.Structure):
                 ("n_markers", C.c_uint64), ("markers", C.POINTER(C.c_uint64))]
 
 
+class Node(C.Structure):
+    _fields_ = [("feature", C.c_int32), ("threshold", C.c_float), ("left", C.c_int32), ("right", C.c_int32),
+                ("value", C.c_float), ("missing", C.c_int32), ("is_leaf", C.c_int32)]
+
+
+class _Model(C.Structure):
+    _fields_ = [("nodes", C.POINTER(Node)), ("first", C.POINTER(C.c_uint32)), ("n_trees", C.c_uint32),
+                ("n_features", C.c_uint32), ("features", C.POINTER(C.c_int32)), ("bias", C.c_float), ("shrinkage", C.c_float)]
+
+
+class Model:
+    """Flattened regression trees for orc_chain / orc_model_predict. `trees` = list of node lists
+    [(feature, threshold, left, right, value, missing, is_leaf), ...] with children relative to the tree."""
+
+    def __init__(self, trees, bias, shrinkage, features):
+        flat = [n for t in trees for n in t]
+        self._nodes = (Node * max(len(flat), 1))(*[Node(*n) for n in flat])
+        firsts = np.concatenate([[0], np.cumsum([len(t) for t in trees])]).astype(np.uint32)
+        self._first = (C.c_uint32 * len(firsts))(*firsts.tolist())
+        self._feat = (C.c_int32 * len(features))(*features)
+        self.c = _Model(self._nodes, self._first, len(trees), len(features), self._feat, bias, shrinkage)
+
+    def predict(self, row):
+        arr = (C.c_float * len(row))(*row)
+        return lib().orc_model_predict(C.byref(self.c), arr)
+
+
 class QueryOpts(C.Structure):
     _fields_ = [("learned_ani", C.c_int), ("median", C.c_int), ("robust", C.c_int),
-                ("screen_val", C.c_double), ("rescue_small", C.c_int), ("min_aligned_frac", C.c_double)]
+                ("screen_val", C.c_double), ("rescue_small", C.c_int), ("min_aligned_frac", C.c_double),
+                ("model", C.POINTER(_Model))]
 
 
 class Result(C.Structure):
     _fields_ = [("ani", C.c_float), ("af_query", C.c_float), ("af_ref", C.c_float),
                 ("n_anchors", C.c_uint64), ("n_chunks", C.c_uint32), ("n_intervals", C.c_uint32),
                 ("covered_query", C.c_uint64), ("covered_ref", C.c_uint64),
-                ("sum_chain_anchors", C.c_uint64), ("sum_chunk_seeds", C.c_uint64)]
+                ("sum_chain_anchors", C.c_uint64), ("sum_chunk_seeds", C.c_uint64),
+                ("ani_raw", C.c_float), ("ani_std", C.c_float), ("learned", C.c_uint32)]
 
 
 def build():
@@ -55,6 +84,8 @@ def lib():
                                    C.POINTER(Result)]
         _lib.orc_mm_hash64.restype = C.c_uint64
         _lib.orc_mm_hash64.argtypes = [C.c_uint64]
+        _lib.orc_model_predict.restype = C.c_float
+        _lib.orc_model_predict.argtypes = [C.POINTER(_Model), C.POINTER(C.c_float)]
         _lib.orc_last_chunks.restype = C.c_uint32
         _lib.orc_last_chunks.argtypes = [C.POINTER(C.c_void_p)]
     return _lib
@@ -107,8 +138,9 @@ def screen(q, r, screen_val=0.80, rescue_small=True):
     return bool(ok), shared.value
 
 
-def chain(ref, query, median=False, robust=False, min_aligned_frac=0.15):
-    o = QueryOpts(0, int(median), int(robust), 0.0, 1, min_aligned_frac)
+def chain(ref, query, median=False, robust=False, min_aligned_frac=0.15, learned_ani=False, model=None):
+    la = -1 if learned_ani is None else int(bool(learned_ani))
+    o = QueryOpts(la, int(median), int(robust), 0.0, 1, min_aligned_frac, C.pointer(model.c) if model is not None else None)
     res = Result()
     rc = lib().orc_chain(ref._p, query._p, C.byref(o), C.byref(res))
     if rc != 0:
@@ -125,15 +157,21 @@ def last_chunks():
     return np.frombuffer(buf, dtype=chunk_dtype).copy()
 
 
-def query(refs, q, *, median=False, robust=False, cutoff=None, faster_small=False):
-    """The screen + chain loops of Database.query (lib.rs:603-657) over a list of (name, Sketch)."""
+def query(refs, q, *, median=False, robust=False, cutoff=None, faster_small=False, learned_ani=False, model=None):
+    """The screen + chain loops of Database.query (lib.rs:603-657) over a list of (name, Sketch). As in the
+    reference, the marker list keeps every entry while the sketch store is keyed by name (lib.rs:51-55, 501-508):
+    a name is shortlisted when ANY of its entries passes (lib.rs:616-637) and chained once, against its LAST sketch."""
     screen_val = cutoff if cutoff else 0.80
-    hits = []
+    store = {name: r for name, r in refs}              # later sketch of a name replaces the earlier one
+    order = {name: i for i, (name, _) in enumerate(refs)}
+    shortlist = set()
     for name, r in refs:
         ok, _ = screen(q, r, screen_val, not faster_small)
-        if not ok:
-            continue
-        res = chain(r, q, median=median, robust=robust)
+        if ok:
+            shortlist.add(name)
+    hits = []
+    for name in sorted(shortlist, key=order.get):      # the reference's order is HashSet order, i.e. unspecified
+        res = chain(store[name], q, median=median, robust=robust, learned_ani=learned_ani, model=model)
         if res.ani > 0.1:
             hits.append((name, res))
     return hits

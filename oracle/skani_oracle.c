@@ -160,12 +160,49 @@ static uint32_t seeds_between(const orc_sketch* q, const uint64_t* cstart, uint3
     return (uint32_t)(l - first);
 }
 
+/* gbdt 0.1.3 (Cargo.lock:1608) DecisionTree::predict_one / GBDT::predict, SquaredError loss: at an inner node go left
+ * iff x[feature] < threshold; an UNKNOWN feature follows `missing` (-1 left, 0 stop at this node, +1 right);
+ * prediction = bias + shrinkage * sum_t value(reached node of tree t), accumulated in tree order in f32. */
+float orc_model_predict(const orc_model* m, const float* row) {
+    float acc = m->bias;
+    for (uint32_t t = 0; t < m->n_trees; t++) {
+        const orc_node* T = m->nodes + m->first[t];
+        uint32_t tn = m->first[t + 1] - m->first[t], i = 0;
+        float v = 0.0f;
+        for (uint32_t step = 0; step <= tn; step++) {
+            const orc_node* nd = &T[i];
+            v = nd->value;
+            if (nd->is_leaf) break;
+            float x = row[nd->feature];
+            int go = x == ORC_FEATURE_UNKNOWN ? nd->missing : (x < nd->threshold ? -1 : 1);
+            if (go == 0) break;
+            i = (uint32_t)(go < 0 ? nd->left : nd->right);
+        }
+        acc += m->shrinkage * v;
+    }
+    return acc;
+}
+
+static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
+/* contig-length quantiles {q90, q50, q10}: sorted kept-contig lengths at n*9/10, n/2, n/10 */
+static void len_quantiles(const orc_sketch* s, float out[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+    uint32_t n = s->n_contigs;
+    if (!n) return;
+    uint32_t* v = malloc(sizeof(uint32_t) * n);
+    memcpy(v, s->contig_len, sizeof(uint32_t) * n);
+    qsort(v, n, sizeof(uint32_t), cmp_u32);
+    uint64_t i90 = (uint64_t)n * 9 / 10, i50 = n / 2, i10 = n / 10;
+    out[0] = (float)v[i90 < n ? i90 : n - 1]; out[1] = (float)v[i50 < n ? i50 : n - 1]; out[2] = (float)v[i10 < n ? i10 : n - 1];
+    free(v);
+}
+
 /* chain_seeds (lib.rs:652-653) with the MapParams of map_params_from_sketch (lib.rs:646-651). */
 int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_opts* o, orc_result* out) {
     memset(out, 0, sizeof *out);
     out->ani = -1.0f;
     free(g_recs); g_recs = NULL; g_nrecs = 0;
-    if (o->learned_ani) return -2;                    /* GBDT weights live inside the absent crate */
+    if (o->learned_ani == 1 && !o->model) return -2;  /* GBDT weights live inside the absent crate: a model must be supplied */
     const int k = ref->k, c = ref->c;
     uint64_t nq = query->n_seeds, nr = ref->n_seeds;
     if (nq == 0 || nr == 0) return 0;
@@ -301,6 +338,30 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
         double afr = (double)out->covered_query / (double)ref->total_len; if (afr > 1) afr = 1;
         out->af_query = (float)afq; out->af_ref = (float)afr;
         if (afq >= o->min_aligned_frac || afr >= o->min_aligned_frac) out->ani = (float)ani;
+        /* sample standard deviation of all chunk estimates (a regression feature) */
+        double mean_all = 0, ssq = 0;
+        for (uint64_t i = 0; i < nd; i++) mean_all += anis[i];
+        mean_all /= (double)nd;
+        for (uint64_t i = 0; i < nd; i++) ssq += (anis[i] - mean_all) * (anis[i] - mean_all);
+        out->ani_raw = out->ani; out->ani_std = nd > 1 ? (float)sqrt(ssq / (double)(nd - 1)) : 0.0f;
+        /* learned ANI (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median, when a model is present */
+        int learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && c >= 70 && !o->median));
+        if (learned && out->ani > 0.0f) {
+            float fm[ORC_F_COUNT], row[64];
+            float lq[3], lr[3];
+            len_quantiles(query, lq); len_quantiles(ref, lr);
+            fm[ORC_F_ANI100] = out->ani_raw * 100.0f; fm[ORC_F_STD100] = out->ani_std * 100.0f;
+            fm[ORC_F_Q90_QUERY] = lq[0]; fm[ORC_F_Q50_QUERY] = lq[1]; fm[ORC_F_Q10_QUERY] = lq[2];
+            fm[ORC_F_Q90_REF] = lr[0]; fm[ORC_F_Q50_REF] = lr[1]; fm[ORC_F_Q10_REF] = lr[2];
+            fm[ORC_F_AVG_CHAIN_LEN] = out->n_intervals ? (float)out->covered_query / (float)out->n_intervals : 0.0f;
+            fm[ORC_F_AF_QUERY] = out->af_query; fm[ORC_F_AF_REF] = out->af_ref; fm[ORC_F_N_CHUNKS] = (float)out->n_chunks;
+            fm[ORC_F_TOTAL_LEN_QUERY] = (float)query->total_len; fm[ORC_F_TOTAL_LEN_REF] = (float)ref->total_len;
+            fm[ORC_F_N_CONTIGS_QUERY] = (float)query->n_contigs; fm[ORC_F_N_CONTIGS_REF] = (float)ref->n_contigs;
+            for (uint32_t j = 0; j < o->model->n_features && j < 64; j++) row[j] = fm[o->model->features[j]];
+            float pred = orc_model_predict(o->model, row) * 0.01f;
+            out->ani = pred < 0.0f ? 0.0f : (pred > 1.0f ? 1.0f : pred);
+            out->learned = 1;
+        }
     }
     free(A); free(cstart); free(f); free(root); free(depth); free(best); free(cands); free(kept); free(anis);
     free(chunk_qc); free(c_anch); free(c_left); free(c_right); free(c_nint);

@@ -51,12 +51,28 @@ typedef struct {
     uint64_t* markers;
 } orc_sketch;
 
+/* Learned-ANI regression model (skani::regression::get_model, lib.rs:614): gradient-boosted regression trees with
+ * the semantics of crate gbdt 0.1.3 (Cargo.lock:1608). skani's trained weights are embedded in the absent crate, so
+ * a model is always supplied by the test (synthetic trees) — the oracle restates the EVALUATION, not the weights. */
+typedef struct { int32_t feature; float threshold; int32_t left, right; float value; int32_t missing, is_leaf; } orc_node;
 typedef struct {
-    int learned_ani;   /* must be 0: model weights are not available */
+    const orc_node* nodes; const uint32_t* first;   /* first[t]..first[t+1]: nodes of tree t, children relative to first[t] */
+    uint32_t n_trees, n_features;
+    const int32_t* features;                        /* ORC_F_* id of every position of the feature vector */
+    float bias, shrinkage;
+} orc_model;
+enum { ORC_F_ANI100 = 0, ORC_F_STD100, ORC_F_Q90_QUERY, ORC_F_Q50_QUERY, ORC_F_Q10_QUERY, ORC_F_Q90_REF, ORC_F_Q50_REF, ORC_F_Q10_REF,
+       ORC_F_AVG_CHAIN_LEN, ORC_F_AF_QUERY, ORC_F_AF_REF, ORC_F_N_CHUNKS, ORC_F_TOTAL_LEN_QUERY, ORC_F_TOTAL_LEN_REF,
+       ORC_F_N_CONTIGS_QUERY, ORC_F_N_CONTIGS_REF, ORC_F_COUNT };
+#define ORC_FEATURE_UNKNOWN (-3.402823466e+38F)   /* gbdt VALUE_TYPE_UNKNOWN = f32::MIN */
+
+typedef struct {
+    int learned_ani;   /* -1 = default rule (c >= 70 && !median, lib.rs:611-613) when a model is given, 0 = off, 1 = on (needs a model) */
     int median, robust;
     double screen_val; /* 0 -> 0.80 (lib.rs:603-609) */
     int rescue_small;  /* = !faster_small (lib.rs:597) */
     double min_aligned_frac; /* 0.15 (lib.rs:589-590) */
+    const orc_model* model;
 } orc_query_opts;
 
 typedef struct {
@@ -67,7 +83,12 @@ typedef struct {
     uint32_t n_intervals;    /* kept chains */
     uint64_t covered_query, covered_ref;
     uint64_t sum_chain_anchors, sum_chunk_seeds;
+    float ani_raw, ani_std;  /* chain ANI before the regression; sample std of the per-chunk estimates */
+    uint32_t learned;
 } orc_result;
+
+/* gbdt 0.1.3 GBDT::predict for one row of model->n_features floats */
+float orc_model_predict(const orc_model* m, const float* row);
 
 uint64_t orc_mm_hash64(uint64_t key);
 

@@ -18,14 +18,26 @@ class Params(C.Structure):
 
 class QueryOpts(C.Structure):
     _fields_ = [("learned_ani", C.c_int32), ("median", C.c_int32), ("robust", C.c_int32),
-                ("faster_small", C.c_int32), ("cutoff", C.c_double), ("min_aligned_frac", C.c_double)]
+                ("faster_small", C.c_int32), ("cutoff", C.c_double), ("min_aligned_frac", C.c_double),
+                ("model", C.c_void_p)]
 
 
 class Hit(C.Structure):
     _fields_ = [("ani", C.c_float), ("af_query", C.c_float), ("af_ref", C.c_float),
                 ("ref_index", C.c_uint32), ("n_chunks", C.c_uint32), ("n_intervals", C.c_uint32),
                 ("n_anchors", C.c_uint64), ("covered_query", C.c_uint64), ("covered_ref", C.c_uint64),
-                ("sum_chain_anchors", C.c_uint64), ("sum_chunk_seeds", C.c_uint64)]
+                ("sum_chain_anchors", C.c_uint64), ("sum_chunk_seeds", C.c_uint64),
+                ("ani_raw", C.c_float), ("ani_std", C.c_float), ("learned", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class TreeNode(C.Structure):
+    _fields_ = [("feature", C.c_int32), ("threshold", C.c_float), ("left", C.c_int32), ("right", C.c_int32),
+                ("value", C.c_float), ("missing", C.c_int32), ("is_leaf", C.c_int32), ("reserved", C.c_int32)]
+
+
+FEATURE_NAMES = ["ani100", "std100", "q90_query", "q50_query", "q10_query", "q90_ref", "q50_ref", "q10_ref", "avg_chain_len",
+                 "af_query", "af_ref", "n_chunks", "total_len_query", "total_len_ref", "n_contigs_query", "n_contigs_ref"]
+DEFAULT_FEATURES = FEATURE_NAMES[:9]
 
 
 class Seed(C.Structure):
@@ -39,6 +51,8 @@ SYMBOLS = [
     "psk_sketch_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
+    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack",
+    "psk_model_create", "psk_model_load_json", "psk_model_load_file", "psk_model_free", "psk_model_info", "psk_model_predict",
 ]
 
 _lib = None
@@ -90,6 +104,16 @@ def load():
     lib.psk_chain.argtypes = [vp, C.POINTER(vp), u32, vp, C.POINTER(QueryOpts), C.POINTER(Hit)]
     lib.psk_query.argtypes = [vp, vp, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_query_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
+    lib.psk_sketch_pack_size.argtypes = [vp, C.POINTER(u64)]
+    lib.psk_sketch_pack.argtypes = [vp, vp, u64]
+    lib.psk_sketch_unpack.argtypes = [vp, vp, C.POINTER(u64), u32, C.POINTER(vp)]
+    lib.psk_model_create.argtypes = [vp, C.POINTER(TreeNode), u64, C.POINTER(u32), u32, C.c_float, C.c_float, C.POINTER(C.c_int32), u32, C.POINTER(vp)]
+    lib.psk_model_load_json.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    lib.psk_model_load_file.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.psk_model_free.argtypes = [vp]
+    lib.psk_model_free.restype = None
+    lib.psk_model_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u64), C.POINTER(u32)]
+    lib.psk_model_predict.argtypes = [vp, vp, u32, vp]
     _lib = lib
     return lib
 

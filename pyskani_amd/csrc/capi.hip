@@ -279,6 +279,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     std::lock_guard<std::mutex> lk(db->ctx->mu);
     db->refs.push_back(s);
     db->names.emplace_back(name);
+    db->note_added((uint32_t)db->refs.size() - 1);
     db->tables_dirty = true; db->inv_dirty = true;
     return PSK_OK;
 }
@@ -286,18 +287,21 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
 psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* const* sketches, uint32_t n) {
     if (!db || (n && (!names || !sketches))) { psk_set_error("db_add_batch: NULL argument"); return PSK_EINVAL; }
     std::lock_guard<std::mutex> lk(db->ctx->mu);
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = 0; i < n; i++)
         if (!sketches[i] || !names[i] || sketches[i]->ctx != db->ctx) { psk_set_error("db_add_batch: bad entry %u", i); return PSK_EINVAL; }
+    for (uint32_t i = 0; i < n; i++) {
         db->refs.push_back(sketches[i]);
         db->names.emplace_back(names[i]);
+        db->note_added((uint32_t)db->refs.size() - 1);
     }
     db->tables_dirty = true; db->inv_dirty = true;
     return PSK_OK;
 }
 
-uint32_t psk_db_size(const psk_db* db) { return db ? (uint32_t)db->refs.size() : 0; }
-const char* psk_db_name(const psk_db* db, uint32_t i) { return db && i < db->names.size() ? db->names[i].c_str() : nullptr; }
-const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t i) { return db && i < db->refs.size() ? db->refs[i] : nullptr; }
+// the three readers take the context lock: a concurrent psk_db_add may be growing the vectors
+uint32_t psk_db_size(const psk_db* db) { if (!db) return 0; std::lock_guard<std::mutex> lk(db->ctx->mu); return (uint32_t)db->refs.size(); }
+const char* psk_db_name(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::lock_guard<std::mutex> lk(db->ctx->mu); return i < db->names.size() ? db->names[i].c_str() : nullptr; }
+const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::lock_guard<std::mutex> lk(db->ctx->mu); return i < db->refs.size() ? db->refs[i] : nullptr; }
 
 psk_status psk_screen(psk_db* db, const psk_sketch* q, double screen_val, int rescue_small, uint8_t* pass, uint32_t* shared) {
     if (!db || !q || (!pass && !db->refs.empty())) { psk_set_error("screen: NULL argument"); return PSK_EINVAL; }
@@ -319,7 +323,7 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
     psk_ctx* ctx = db->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
-    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
+    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
     const uint32_t n = (uint32_t)db->refs.size();
     if (n == 0) return PSK_OK;
     const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
@@ -327,6 +331,11 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
     PSK_TRY(screen_impl(db, q, screen_val, !o->faster_small, pass.data(), nullptr));
     std::vector<const psk_sketch*> shortlist;
     std::vector<uint32_t> idx;
+    if (db->has_dups) {   // shortlist of NAMES (lib.rs:616-637): a passing entry stands for the name's last sketch
+        std::vector<uint8_t> p2(n, 0);
+        for (uint32_t i = 0; i < n; i++) if (pass[i]) p2[db->canon[i]] = 1;
+        pass.swap(p2);
+    }
     for (uint32_t i = 0; i < n; i++) if (pass[i]) { shortlist.push_back(db->refs[i]); idx.push_back(i); }
     if (shortlist.empty()) return PSK_OK;
     std::vector<psk_hit> res(shortlist.size());
@@ -352,7 +361,7 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     psk_ctx* ctx = db->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
-    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
+    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
     const uint32_t n = (uint32_t)db->refs.size();
     std::vector<psk_hit> all;
     const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
@@ -366,6 +375,11 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
         for (uint32_t i = 0; i < m; i++) if (!queries[b + i]) { psk_set_error("query_many: NULL query %u", b + i); return PSK_EINVAL; }
         pass.assign((size_t)m * n, 0);
         if (n) PSK_TRY(screen_many_impl(db, queries + b, m, screen_val, !o->faster_small, pass.data()));
+        if (db->has_dups)   // names, not entries, are shortlisted (lib.rs:616-637)
+            for (uint32_t i = 0; i < m; i++) {
+                uint8_t* row = pass.data() + (size_t)i * n;
+                for (uint32_t r = 0; r < n; r++) if (row[r] && db->canon[r] != r) { row[db->canon[r]] = 1; row[r] = 0; }
+            }
         pr.clear(); pq.clear(); pri.clear(); pqi.clear();
         for (uint32_t i = 0; i < m; i++) for (uint32_t r = 0; r < n; r++) if (pass[(size_t)i * n + r]) {
             pr.push_back(db->refs[r]); pq.push_back(queries[b + i]); pri.push_back(r); pqi.push_back(i);
@@ -382,6 +396,147 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
     if (!all.empty()) memcpy(outp, all.data(), sizeof(psk_hit) * all.size());
     *hits = outp;
+    return PSK_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ device-side sketch records (multi-GPU exchange)
+// A packed sketch is one self-contained byte range of HBM: what ShardedDatabase.all_vs_all all-gathers over xGMI
+//  without the D2H -> bytes -> H2D hop of psk_sketch_export / psk_sketch_import.
+//   [PackHeader 64 B][contig_len u32 x nc][contig_seed_start u32 x (nc+1)] pad16
+//   [seed_kmer u32 x ns] pad16 [seed_pos u32 x ns] pad16 [seed_meta u32 x ns] pad16 [markers u64 x nm] pad16
+namespace {
+struct PackHeader { uint32_t magic, version; int32_t c, marker_c, k; uint32_t has_seeds, n_contigs, reserved; uint64_t n_seeds, n_markers, total_len, bytes; };
+static_assert(sizeof(PackHeader) == 64, "PackHeader is 64 bytes");
+constexpr uint32_t PACK_MAGIC = 0x4B53504Bu;   // "KPSK"
+inline uint64_t al16(uint64_t x) { return (x + 15) & ~15ull; }
+struct PackLayout { uint64_t o_len, o_cs, o_kmer, o_pos, o_meta, o_mark, end; };
+inline PackLayout pack_layout(uint64_t nc, uint64_t ns, uint64_t nm) {
+    PackLayout L;
+    L.o_len = sizeof(PackHeader); L.o_cs = L.o_len + 4 * nc; L.o_kmer = al16(L.o_cs + 4 * (nc + 1));
+    L.o_pos = al16(L.o_kmer + 4 * ns); L.o_meta = al16(L.o_pos + 4 * ns); L.o_mark = al16(L.o_meta + 4 * ns); L.end = al16(L.o_mark + 8 * nm);
+    return L;
+}
+__global__ void build_pm_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ meta, uint64_t* __restrict__ pm, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pm[i] = ((uint64_t)pos[i] << 32) | meta[i];
+}
+}  // namespace
+
+extern "C" {
+
+psk_status psk_sketch_pack_size(const psk_sketch* s, uint64_t* bytes) {
+    if (!s || !bytes) { psk_set_error("pack_size: NULL argument"); return PSK_EINVAL; }
+    *bytes = pack_layout(s->contig_len.size(), s->n_seeds, s->n_markers).end;
+    return PSK_OK;
+}
+
+psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity) {
+    if (!s || !d_dst) { psk_set_error("pack: NULL argument"); return PSK_EINVAL; }
+    if (((uintptr_t)d_dst & 15) != 0) { psk_set_error("pack: destination must be 16-byte aligned"); return PSK_EINVAL; }
+    psk_ctx* ctx = s->ctx;
+    const uint64_t nc = s->contig_len.size(), ns = s->n_seeds, nm = s->n_markers;
+    const PackLayout L = pack_layout(nc, ns, nm);
+    if (capacity < L.end) { psk_set_error("pack: destination holds %llu bytes, the record needs %llu", (unsigned long long)capacity, (unsigned long long)L.end); return PSK_EINVAL; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    void* hp;
+    PSK_TRY(ctx->pinned(L.o_kmer, &hp));
+    memset(hp, 0, L.o_kmer);
+    PackHeader* H = (PackHeader*)hp;
+    H->magic = PACK_MAGIC; H->version = 1; H->c = s->params.c; H->marker_c = s->params.marker_c; H->k = s->params.k;
+    H->has_seeds = s->has_seeds; H->n_contigs = (uint32_t)nc; H->n_seeds = ns; H->n_markers = nm; H->total_len = s->total_len; H->bytes = L.end;
+    uint32_t* hl = (uint32_t*)((char*)hp + L.o_len);
+    for (uint64_t i = 0; i < nc; i++) hl[i] = s->contig_len[i];
+    uint32_t* hc = (uint32_t*)((char*)hp + L.o_cs);
+    for (uint64_t i = 0; i <= nc; i++) hc[i] = i < s->contig_seed_start.size() ? s->contig_seed_start[i] : (uint32_t)ns;
+    char* d = (char*)d_dst;
+    hipStream_t st = ctx->stream;
+    PSK_HIP(hipMemcpyAsync(d, hp, L.o_kmer, hipMemcpyHostToDevice, st));
+    if (ns) {
+        PSK_HIP(hipMemcpyAsync(d + L.o_kmer, s->store->seed_kmer + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
+        PSK_HIP(hipMemcpyAsync(d + L.o_pos, s->store->seed_pos + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
+        PSK_HIP(hipMemcpyAsync(d + L.o_meta, s->store->seed_meta + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
+    }
+    if (nm) PSK_HIP(hipMemcpyAsync(d + L.o_mark, s->store->markers + s->marker_off, 8 * nm, hipMemcpyDeviceToDevice, st));
+    PSK_HIP(hipStreamSynchronize(st));      // the pinned staging block is reused by the next call
+    return PSK_OK;
+}
+
+/* n records at d_src + offsets[i] -> n device-resident sketches sharing one store. Two host syncs per call. */
+psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out) {
+    if (!ctx || (n && (!d_src || !offsets || !out))) { psk_set_error("unpack: NULL argument"); return PSK_EINVAL; }
+    for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
+    if (!n) return PSK_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const char* src = (const char*)d_src;
+    std::vector<PackHeader> H(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i] & 15) { psk_set_error("unpack: record %u is not 16-byte aligned", i); return PSK_EINVAL; }
+        PSK_HIP(hipMemcpyAsync(&H[i], src + offsets[i], sizeof(PackHeader), hipMemcpyDeviceToHost, st));
+    }
+    PSK_HIP(hipStreamSynchronize(st));
+    uint64_t tot_c = 0, tot_s = 0, tot_m = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const PackHeader& h = H[i];
+        if (h.magic != PACK_MAGIC || h.version != 1 || h.k < 1 || h.k > 16 || h.c < 1 || h.marker_c < 1 ||
+            h.bytes != pack_layout(h.n_contigs, h.n_seeds, h.n_markers).end) { psk_set_error("unpack: record %u is not a packed sketch", i); return PSK_EINVAL; }
+        tot_c += h.n_contigs; tot_s += h.n_seeds; tot_m += h.n_markers;
+    }
+    if (tot_s >= 0x7FFFFFF0ull || tot_m >= 0x7FFFFFF0ull) { psk_set_error("unpack: batch too large for one store; split it"); return PSK_ELIMIT; }
+    std::vector<uint32_t> meta(2 * tot_c + n);      // per record: contig_len[nc], contig_seed_start[nc+1]
+    {
+        uint64_t w = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t nb = 4 * (2 * (uint64_t)H[i].n_contigs + 1);
+            PSK_HIP(hipMemcpyAsync(meta.data() + w, src + offsets[i] + sizeof(PackHeader), nb, hipMemcpyDeviceToHost, st));
+            w += 2 * (uint64_t)H[i].n_contigs + 1;
+        }
+    }
+    auto store = std::make_shared<SketchStore>();
+    store->ctx = ctx;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ns = (size_t)tot_s;
+    const size_t b_kmer = 0, b_pos = al(b_kmer + 4 * ns), b_meta = al(b_pos + 4 * ns), b_pm = al(b_meta + 4 * ns), b_cs = al(b_pm + 8 * ns), b_end = al(b_cs + 4 * (size_t)(tot_c + n));
+    PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
+    char* sb = (char*)store->base;
+    store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
+    store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cs);
+    PSK_TRY(ctx->pool_alloc(8 * ((size_t)tot_m + 1), &store->mbase, &store->mbytes));
+    store->markers = (uint64_t*)store->mbase;
+    PSK_HIP(hipStreamSynchronize(st));              // meta[] is on the host
+    std::vector<uint32_t> cstart(tot_c + n);
+    std::vector<std::unique_ptr<psk_sketch>> sk(n);
+    uint64_t so = 0, mo = 0, co = 0, w = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const PackHeader& h = H[i];
+        const PackLayout L = pack_layout(h.n_contigs, h.n_seeds, h.n_markers);
+        sk[i].reset(new psk_sketch());
+        psk_sketch* s = sk[i].get();
+        s->ctx = ctx; s->params = psk_params{h.c, h.marker_c, h.k}; s->has_seeds = h.has_seeds != 0; s->total_len = h.total_len;
+        s->store = store; s->seed_off = so; s->n_seeds = h.n_seeds; s->marker_off = mo; s->n_markers = h.n_markers; s->contig_off = co;
+        s->contig_len.assign(meta.begin() + w, meta.begin() + w + h.n_contigs);
+        s->contig_seed_start.assign(meta.begin() + w + h.n_contigs, meta.begin() + w + 2 * (uint64_t)h.n_contigs + 1);
+        for (uint64_t c = 0; c <= h.n_contigs; c++) {
+            if (s->contig_seed_start[c] > h.n_seeds || (c && s->contig_seed_start[c] < s->contig_seed_start[c - 1])) { psk_set_error("unpack: record %u has a corrupt contig table", i); return PSK_EINVAL; }
+            cstart[co + c] = (uint32_t)(so + s->contig_seed_start[c]);
+        }
+        const char* r = src + offsets[i];
+        if (h.n_seeds) {
+            PSK_HIP(hipMemcpyAsync(store->seed_kmer + so, r + L.o_kmer, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
+            PSK_HIP(hipMemcpyAsync(store->seed_pos + so, r + L.o_pos, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
+            PSK_HIP(hipMemcpyAsync(store->seed_meta + so, r + L.o_meta, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
+        }
+        if (h.n_markers) PSK_HIP(hipMemcpyAsync(store->markers + mo, r + L.o_mark, 8 * h.n_markers, hipMemcpyDeviceToDevice, st));
+        so += h.n_seeds; mo += h.n_markers; co += (uint64_t)h.n_contigs + 1; w += 2 * (uint64_t)h.n_contigs + 1;
+    }
+    PSK_HIP(hipMemcpyAsync(store->contig_seed_start, cstart.data(), 4 * cstart.size(), hipMemcpyHostToDevice, st));
+    if (ns) hipLaunchKernelGGL(build_pm_kernel, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, st, store->seed_pos, store->seed_meta, store->seed_pm, (uint64_t)ns);
+    PSK_HIP(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < n; i++) out[i] = sk[i].release();
     return PSK_OK;
 }
 

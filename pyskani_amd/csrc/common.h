@@ -5,9 +5,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <memory>
 #include <mutex>
+#include <deque>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/pyskani_amd.h"
 
@@ -216,6 +219,15 @@ struct psk_sketch {
     std::vector<uint32_t> contig_seed_start; // host copy, LOCAL offsets, n_contigs+1
     uint64_t total_len = 0;
     bool has_seeds = true;
+    // contig-length quantiles {q90, q50, q10} (features of the learned-ANI regression): sorted lengths at n*9/10, n/2, n/10
+    void len_quantiles(float out[3]) const {
+        out[0] = out[1] = out[2] = 0.f;
+        if (contig_len.empty()) return;
+        std::vector<uint32_t> v(contig_len);
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        out[0] = (float)v[std::min(n - 1, n * 9 / 10)]; out[1] = (float)v[std::min(n - 1, n / 2)]; out[2] = (float)v[std::min(n - 1, n / 10)];
+    }
     mutable std::shared_ptr<IndexStore> idx;  // built on first chaining use
     mutable uint64_t idx_off = 0;
     mutable uint64_t idx_boff = 0;      // first entry of this sketch's bucket table in idx->bucket
@@ -226,7 +238,19 @@ struct psk_db {
     psk_ctx* ctx = nullptr;
     psk_params params{};
     std::vector<psk_sketch*> refs;
-    std::vector<std::string> names;
+    std::deque<std::string> names;       // deque: psk_db_name() pointers stay valid while sketches are added
+    // lib.rs:51-55 + 616-637: the sketch store is a map keyed by name (a later sketch of a name replaces the earlier
+    // one) while the marker list keeps both entries; a query shortlists NAMES, so every passing entry of a name
+    // stands for the name's LAST sketch and yields one hit. canon[i] = last index holding names[i].
+    std::unordered_map<std::string, uint32_t> last_by_name;
+    std::vector<uint32_t> canon;
+    bool has_dups = false;
+    void note_added(uint32_t i) {
+        auto it = last_by_name.find(names[i]);
+        if (it != last_by_name.end()) { has_dups = true; for (uint32_t j = 0; j < i; j++) if (canon[j] == it->second) canon[j] = i; it->second = i; }
+        else last_by_name.emplace(names[i], i);
+        canon.push_back(i);
+    }
     // device tables for the screen kernel, rebuilt lazily
     bool tables_dirty = true;
     Scratch d_marker_ptr, d_marker_n;
@@ -235,6 +259,23 @@ struct psk_db {
     Scratch inv_key, inv_ref, inv_tmp;
     uint64_t inv_n = 0;
 };
+
+// learned-ANI regression model: flattened trees in HBM
+struct ModelNode { int32_t feature; float threshold; int32_t left, right; float value; int32_t missing, is_leaf, menu; };  // menu = psk_feature id of `feature`
+struct ModelDev { const ModelNode* nodes; const uint32_t* first; uint32_t n_trees; uint32_t n_features; float bias, shrinkage; };
+struct psk_model {
+    psk_ctx* ctx = nullptr;
+    void* base = nullptr;
+    ModelDev dev{};
+    uint64_t n_nodes = 0;
+    std::vector<int32_t> features;   // psk_feature id of every position of the model's feature vector
+    ~psk_model() { if (base) (void)hipFree(base); }
+};
+// per-pair inputs of the regression that the chain kernels do not produce
+struct PairStats { float lq[3], lr[3]; float ncq, ncr; };
+// hits[p].ani <- model(features of pair p) / 100 for every valid hit; launched on st after pair_reduce
+void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const PairStats* d_stats, const uint64_t* d_total_len /* [2p]=query,[2p+1]=ref */,
+                          uint32_t n_pairs, hipStream_t st);
 
 // ---- shared device helpers ----
 __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {

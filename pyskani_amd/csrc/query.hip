@@ -1343,15 +1343,33 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
                 }
                 __syncthreads();
             }
-    } else if (threadIdx.x == 0) {   // very long genomes: stream the mean in chunk order
-        double sum = 0; uint32_t cnt = 0;
-        for (uint32_t i = 0; i < nc; i++) if (co[i].n_intervals) {
-            double ratio = (double)co[i].anchors / (double)(co[i].seeds > 1 ? co[i].seeds - 1 : 1); if (ratio > 1.0) ratio = 1.0;
-            sum += pow(ratio, 1.0 / (double)R.k); cnt++;
-        }
-        mean_serial = sum / (double)cnt;
     }
     __syncthreads();
+    // mean and sample standard deviation of ALL chunk values (feature of the learned-ANI regression; also the mean of
+    // pairs beyond RED_CAP chunks): two block-parallel passes, fixed thread -> element mapping (deterministic)
+    __shared__ double s_red[8];
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    };
+    auto chunk_val = [&](uint32_t i) {
+        double ratio = (double)co[i].anchors / (double)(co[i].seeds > 1 ? co[i].seeds - 1 : 1); if (ratio > 1.0) ratio = 1.0;
+        return pow(ratio, 1.0 / (double)R.k);
+    };
+    double part = 0;
+    if (!overflow) { for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) part += s_v[j]; }
+    else { for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) if (co[i].n_intervals) part += chunk_val(i); }
+    const double mean_all = m ? block_sum(part) / (double)m : 0.0;
+    part = 0;
+    if (!overflow) { for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) { const double d = s_v[j] - mean_all; part += d * d; } }
+    else { for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) if (co[i].n_intervals) { const double d = chunk_val(i) - mean_all; part += d * d; } }
+    const double ssq = block_sum(part);
+    const double std_all = m > 1 ? sqrt(ssq / (double)(m - 1)) : 0.0;
+    mean_serial = mean_all;
     if (threadIdx.x == 0) {
         h.ref_index = p;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
@@ -1383,6 +1401,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
             h.af_query = (float)afq; h.af_ref = (float)afr;
             if (!ok) h.ani = -2.0f;
             else if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
+            h.ani_raw = h.ani; h.ani_std = (float)std_all;
         }
         R.hits[p] = h;
     }
@@ -1544,6 +1563,22 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     ctx->t_begin(K_PAIR_REDUCE);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
     ctx->t_end();
+    // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
+    const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && hp[0].q->params.c >= 70 && !o->median));
+    std::vector<PairStats> h_stats; std::vector<uint64_t> h_tl;
+    if (learned) {
+        h_stats.resize(n_pairs); h_tl.resize(2 * (size_t)n_pairs);
+        for (uint32_t p = 0; p < n_pairs; p++) {
+            hp[p].q->len_quantiles(h_stats[p].lq); hp[p].r->len_quantiles(h_stats[p].lr);
+            h_stats[p].ncq = (float)hp[p].q->contig_len.size(); h_stats[p].ncr = (float)hp[p].r->contig_len.size();
+            h_tl[2 * (size_t)p] = hp[p].q->total_len; h_tl[2 * (size_t)p + 1] = hp[p].r->total_len;
+        }
+        const size_t sb = al256(sizeof(PairStats) * n_pairs);
+        PSK_TRY(ctx->q_h.reserve(sb + 16 * (size_t)n_pairs + 256));
+        PSK_HIP(hipMemcpyAsync(ctx->q_h.p, h_stats.data(), sizeof(PairStats) * n_pairs, hipMemcpyHostToDevice, st));
+        PSK_HIP(hipMemcpyAsync((char*)ctx->q_h.p + sb, h_tl.data(), 16 * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+        learned_apply_launch(o->model, d_hits, (const PairStats*)ctx->q_h.p, (const uint64_t*)((char*)ctx->q_h.p + sb), n_pairs, st);
+    }
     psk_hit* h_hits = (psk_hit*)((char*)hpin + 256);
     PSK_HIP(hipMemcpyAsync(h_hits, d_hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipMemcpyAsync(h_small, d_misc, 16, hipMemcpyDeviceToHost, st));
@@ -1560,7 +1595,8 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
 psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out) {
     if (!ctx || !o || (n && (!refs || !queries || !out))) { psk_set_error("chain: NULL argument"); return PSK_EINVAL; }
-    if (o->learned_ani == 1) { psk_set_error("learned ANI requested but no regression model is loaded (skani's GBDT weights are not redistributable here)"); return PSK_ENOMODEL; }
+    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded (skani's GBDT weights are embedded in the skani crate; supply them with psk_model_load_file)"); return PSK_ENOMODEL; }
+    if (o->model && o->model->ctx != ctx) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
     for (uint32_t i = 0; i < n; i++) {
         if (!refs[i] || !queries[i]) { psk_set_error("chain: NULL sketch in pair %u", i); return PSK_EINVAL; }
         if (!queries[i]->has_seeds) { psk_set_error("query sketch was built with seed=False; it cannot be chained"); return PSK_EINVAL; }

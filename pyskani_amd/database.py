@@ -67,7 +67,7 @@ def _as_bytes(obj):
 class Hit:
     """A single hit found when querying a `Database` with a genome (hit.rs:18-104)."""
 
-    __slots__ = ("_identity", "_query_name", "_query_fraction", "_reference_name", "_reference_fraction", "_raw")
+    __slots__ = ("_identity", "_query_name", "_query_fraction", "_reference_name", "_reference_fraction", "_raw", "_learned")
 
     def __init__(self, identity, query_name, query_fraction, reference_name, reference_fraction):
         identity = float(np.float32(identity))
@@ -85,6 +85,7 @@ class Hit:
         self._reference_name = str(reference_name)
         self._reference_fraction = reference_fraction
         self._raw = None
+        self._learned = False
 
     def __repr__(self):  # hit.rs:61-74
         return ("Hit(identity={!r}, query_name={!r}, query_fraction={!r}, reference_name={!r}, "
@@ -96,6 +97,9 @@ class Hit:
     query_fraction = property(lambda self: self._query_fraction)
     reference_name = property(lambda self: self._reference_name)
     reference_fraction = property(lambda self: self._reference_fraction)
+    # not in the reference: True when `identity` came out of the learned-ANI regression model, False when it is the raw
+    # chain ANI (the reference applies skani's embedded model by default, lib.rs:611-614; this build needs the model file)
+    learned = property(lambda self: self._learned)
 
 
 class Sketch:
@@ -150,6 +154,25 @@ class Sketch:
             0 if markers_only else 1, C.byref(h)))
         return cls(ctx, h, record.name)
 
+    def pack_size(self):
+        """Bytes of this sketch as a packed device record (psk_sketch_pack_size)."""
+        n = C.c_uint64()
+        _capi.check(self._ctx._lib.psk_sketch_pack_size(self._h, C.byref(n)))
+        return n.value
+
+    def pack_into(self, device_ptr, capacity):
+        """Write the packed record at a 16-byte aligned DEVICE address (e.g. inside a torch uint8 tensor)."""
+        _capi.check(self._ctx._lib.psk_sketch_pack(self._h, C.c_void_p(device_ptr), capacity))
+
+    @classmethod
+    def unpack(cls, ctx, device_ptr, offsets, names):
+        """Packed records at device_ptr + offsets[i] -> device-resident sketches (psk_sketch_unpack)."""
+        n = len(offsets)
+        offs = (C.c_uint64 * max(n, 1))(*[int(o) for o in offsets])
+        out = (C.c_void_p * max(n, 1))()
+        _capi.check(ctx._lib.psk_sketch_unpack(ctx._h, C.c_void_p(device_ptr), offs, n, out))
+        return [cls(ctx, C.c_void_p(out[i]), names[i]) for i in range(n)]
+
     def export(self):
         """(seeds, markers) copied back to the host — used by the parity tests."""
         _, ns, nm, _, _ = self._info()
@@ -159,15 +182,77 @@ class Sketch:
         return seeds, markers
 
 
-_warned_no_model = False
+class Model:
+    """Learned-ANI regression model (skani::regression::get_model, lib.rs:614), resident in HBM.
+
+    skani's trained gradient-boosted trees are embedded in the skani crate, which is not part of the reference tree,
+    so the weights must be supplied: `Model.from_file(path)` reads the serde-JSON of a `gbdt::GBDT` (crate gbdt 0.1.3,
+    Cargo.lock:1608); `Model.from_trees` takes explicit trees. Inference runs on the GPU (csrc/model.hip)."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h = ctx, handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._ctx._lib.psk_model_free(self._h)
+            self._h = None
+
+    @classmethod
+    def from_file(cls, path, device=0):
+        ctx = default_context(device)
+        h = C.c_void_p()
+        _capi.check(ctx._lib.psk_model_load_file(ctx._h, os.fsencode(path), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_json(cls, text, device=0):
+        ctx = default_context(device)
+        data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        _capi.check(ctx._lib.psk_model_load_json(ctx._h, data, len(data), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_trees(cls, trees, bias=0.0, shrinkage=1.0, features=None, device=0):
+        """trees: list of node lists [(feature, threshold, left, right, value, missing, is_leaf), ...], children
+        relative to the tree; features: names from _capi.FEATURE_NAMES (default: _capi.DEFAULT_FEATURES)."""
+        ctx = default_context(device)
+        flat = [n for t in trees for n in t]
+        nodes = (_capi.TreeNode * max(len(flat), 1))(*[_capi.TreeNode(*n, 0) for n in flat])
+        first = (C.c_uint32 * max(len(trees), 1))(*np.concatenate([[0], np.cumsum([len(t) for t in trees])])[:len(trees)].astype(int).tolist())
+        feats = None
+        if features is not None:
+            feats = (C.c_int32 * len(features))(*[_capi.FEATURE_NAMES.index(f) for f in features])
+        h = C.c_void_p()
+        _capi.check(ctx._lib.psk_model_create(ctx._h, nodes, len(flat), first, len(trees), bias, shrinkage, feats,
+                                              len(features) if features is not None else 0, C.byref(h)))
+        return cls(ctx, h)
+
+    @property
+    def shape(self):
+        nt, nn, nf = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        _capi.check(self._ctx._lib.psk_model_info(self._h, C.byref(nt), C.byref(nn), C.byref(nf)))
+        return nt.value, nn.value, nf.value
+
+    def predict(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.shape[2])
+        out = np.zeros(len(rows), np.float32)
+        _capi.check(self._ctx._lib.psk_model_predict(self._h, rows.ctypes.data_as(C.c_void_p), len(rows), out.ctypes.data_as(C.c_void_p)))
+        return out
 
 
 class Database:
     """A database storing sketched genomes (lib.rs:132-137, 368-660): sketches live in HBM; with a `path`
     they are also written to a folder in the reference's layout (storage.py)."""
 
-    def __init__(self, path=None, *, compression=125, marker_compression=1000, k=15, format=None, device=0):
+    def __init__(self, path=None, *, compression=125, marker_compression=1000, k=15, format=None, device=0, model=None):
+        """`device` and `model` are additions to the reference signature (lib.rs:369): the GPU to use, and the
+        learned-ANI regression model (a `Model` or a path to a gbdt JSON file; default: $PSK_MODEL_PATH if set)."""
         self._ctx = default_context(device)
+        self._model = None
+        self._warned_no_model = False
+        self._cache_lock = threading.Lock()
+        self._device = device
         self._lib = self._ctx._lib
         self._params = _capi.Params(int(compression), int(marker_compression), int(k))
         self._lock = threading.Lock()   # `sketch` takes &mut self (lib.rs:479)
@@ -198,6 +283,17 @@ class Database:
         h = C.c_void_p()
         _capi.check(self._lib.psk_db_create(self._ctx._h, C.byref(self._params), C.byref(h)))
         self._h = h
+        if model is None and os.environ.get("PSK_MODEL_PATH"):
+            model = os.environ["PSK_MODEL_PATH"]
+        if model is not None:
+            self.load_model(model)
+
+    def load_model(self, model):
+        """Attach the learned-ANI regression model used by `query` (lib.rs:611-614): a `Model`, or the path of a
+        gbdt JSON file. `None` detaches it."""
+        if model is not None and not isinstance(model, Model):
+            model = Model.from_file(model, device=self._device)
+        self._model = model
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -277,13 +373,16 @@ class Database:
         if self._resident[i]:
             return Sketch(self._ctx, C.c_void_p(self._lib.psk_db_sketch(self._h, i)), self._names[i], owned=False)
         name = self._names[i]
-        if name in self._cache:
-            self._cache.move_to_end(name)
-            return self._cache[name]
+        with self._cache_lock:                                              # `query` takes &self: callers may be concurrent
+            sk = self._cache.get(name)
+            if sk is not None:
+                self._cache.move_to_end(name)
+                return sk
         sk = Sketch.from_record(self._ctx, self._storage.load(name))        # KeyError / OSError as lib.rs:95-122
-        self._cache[name] = sk
-        while len(self._cache) > 256:
-            self._cache.popitem(last=False)
+        with self._cache_lock:
+            self._cache[name] = sk
+            while len(self._cache) > 256:
+                self._cache.popitem(last=False)
         return sk
 
     def save(self, path, overwrite=False, format=None):
@@ -300,20 +399,33 @@ class Database:
         if not overwrite and os.path.exists(markers_path):
             raise FileExistsError(markers_path)                              # lib.rs:688-692
         kind = "consolidated" if format is None else format
-        if kind == "consolidated":
-            target = _storage.Consolidated(folder)
-            if overwrite and os.path.exists(os.path.join(folder, "sketches.db")):
-                os.remove(os.path.join(folder, "sketches.db"))
-        elif kind == "separated":
-            target = _storage.Folder(folder)
-        else:
+        if kind not in ("consolidated", "separated"):
             raise ValueError(f"invalid format: {kind}")
-        markers = []
-        for i in range(len(self._names)):
-            rec = self._full_sketch(i).to_record()
+        # a database opened from `folder` reads its sketches lazily from the very files this call replaces: every record
+        # is read BEFORE the target is touched, and sketches.db is rebuilt under a temporary name and renamed at the end
+        last = {name: i for i, name in enumerate(self._names)}             # the store is keyed by name (lib.rs:51-55)
+        records = [self._full_sketch(last[name]).to_record() for name in dict.fromkeys(self._names)]
+        if kind == "consolidated":
+            target = _storage.Consolidated(folder, file_name="sketches.db.tmp")
+            tmp = os.path.join(folder, "sketches.db.tmp")
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        else:
+            target = _storage.Folder(folder)
+        for rec in records:
             target.store(rec)
-            markers.append(rec.markers_only())
+        if kind == "consolidated":
+            if not os.path.exists(tmp):
+                open(tmp, "wb").close()
+            os.replace(tmp, os.path.join(folder, "sketches.db"))
+            target.file_name = "sketches.db"
+        by_name = {rec.name: rec for rec in records}
+        markers = [by_name[name].markers_only() for name in self._names]
         target.flush((self._params.c, self._params.marker_c, self._params.k), markers)
+        if self._storage is not None and os.path.realpath(self._storage.path) == os.path.realpath(folder):
+            self._storage = target      # saved onto its own folder: the old offsets / files are gone
+            with self._cache_lock:
+                self._cache.clear()
 
     # -- the hot path ------------------------------------------------------------------------
     def _sketch(self, name, contigs, seed):
@@ -345,23 +457,31 @@ class Database:
         return None
 
     def _opts(self, learned_ani, median, robust, cutoff, faster_small):
-        global _warned_no_model
         # default rule: learned ANI when c >= 70 and not median (lib.rs:611-613, docstring :522-527)
-        learned = learned_ani if learned_ani is not None else (self._params.c >= 70 and not median)
-        if learned and learned_ani is None:
-            # the GBDT weights live inside the skani crate and are not available to this build: say so
-            if not _warned_no_model:
-                warnings.warn("pyskani_amd: no learned-ANI regression model is available; returning the raw "
-                              "chain ANI (pass learned_ani=False to silence, learned_ani=True raises)", RuntimeWarning, stacklevel=3)
-                _warned_no_model = True
+        learned = bool(learned_ani) if learned_ani is not None else (self._params.c >= 70 and not median)
+        if learned and self._model is None:
+            if learned_ani is not None:       # explicit learned_ani=True without a model
+                raise RuntimeError("learned_ani=True needs a regression model: skani's GBDT weights are embedded in the "
+                                   "skani crate; load them with Database(model=...), Database.load_model() or $PSK_MODEL_PATH")
+            # default call: the reference would apply skani's embedded model here. Say so once per Database and mark
+            # every Hit (Hit.learned is False): identities are the raw chain ANI, ~7e-4 above the regressed value on
+            # the reference's own E. coli test pair (test_ani.py:28-40).
+            if not self._warned_no_model:
+                warnings.warn("pyskani_amd: no learned-ANI regression model is loaded, so identities are the RAW chain ANI "
+                              "(what pyskani returns for learned_ani=False), not pyskani's default regressed value; "
+                              "pass learned_ani=False to accept that explicitly, or load a model "
+                              "(Database(model=...), Database.load_model(), $PSK_MODEL_PATH)", RuntimeWarning, stacklevel=3)
+                self._warned_no_model = True
             learned = False
-        return _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
-                               float(cutoff) if cutoff else 0.0, 0.0)
+        o = _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
+                            float(cutoff) if cutoff else 0.0, 0.0, self._model._h if (learned and self._model is not None) else None)
+        o._keep = self._model
+        return o
 
     def _hit(self, r, qname):
-        ref_name = self._lib.psk_db_name(self._h, r.ref_index).decode("utf-8")
-        hit = Hit(r.ani, qname, r.af_query, ref_name, r.af_ref)
+        hit = Hit(r.ani, qname, r.af_query, self._names[r.ref_index], r.af_ref)
         hit._raw = {f: getattr(r, f) for f, _ in _capi.Hit._fields_}
+        hit._learned = bool(r.learned)
         return hit
 
     def query_many(self, genomes, *, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
@@ -402,7 +522,8 @@ class Database:
         flags = np.zeros(n, np.uint8)
         screen_val = opts.cutoff if opts.cutoff != 0.0 else 0.80
         _capi.check(self._lib.psk_screen(self._h, q._h, screen_val, int(not opts.faster_small), flags.ctypes.data_as(C.c_void_p), None))
-        idx = [i for i in range(n) if flags[i]]
+        last = {nm: i for i, nm in enumerate(self._names)}                 # shortlist of NAMES, lib.rs:616-637
+        idx = sorted({last[self._names[i]] for i in range(n) if flags[i]})
         if not idx:
             return []
         sketches = [self._full_sketch(i) for i in idx]

@@ -5,7 +5,7 @@ nothing else on the data path is collective: every (query, ref) pair is independ
 """
 import numpy as np
 
-HIT_COLS = 4  # global ref index, ani, af_query, af_ref
+HIT_VALS = 3  # ani, af_query, af_ref
 
 
 def shard_bounds(n_items, rank, world):
@@ -15,62 +15,88 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_hits(local_hits, dist, device="cpu", group=None):
+def weighted_shard_cuts(weights, world):
+    """Contiguous shards balanced on `weights` (genome lengths ~ seed counts): cut point r is the first
+    index whose prefix weight reaches r/world of the total. Returns world+1 cut indices; every rank computes the same."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    if n == 0 or w.sum() <= 0:
+        return [shard_bounds(n, r, world)[0] for r in range(world)] + [n]
+    pre = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(pre, pre[-1] * r / world, side="left"))
+        # the genome straddling the target goes to whichever side leaves the smaller imbalance
+        if c > 0 and abs(pre[c - 1] - pre[-1] * r / world) <= abs(pre[min(c, n)] - pre[-1] * r / world):
+            c -= 1
+        cuts.append(min(max(c, cuts[-1]), n))
+    return cuts + [n]
+
+
+def all_gather_hits(idx, vals, dist, device="cpu", group=None):
     """All-gather ragged per-shard hit lists.
 
-    local_hits: float32 array [n_local, HIT_COLS] whose column 0 already holds GLOBAL ref indices.
-    Returns the concatenation over ranks (rank order), identical on every rank. Two collectives:
-    an all-gather of the counts, then one all-gather of lists padded to the largest count.
+    idx:  int64 [n_local, 2] = (global query index, global ref index) — integers travel as integers (exact for any
+          database size); vals: float32 [n_local, 3] = (ani, af_query, af_ref).
+    Returns (idx, vals) concatenated over ranks in rank order, identical on every rank. Three collectives:
+    an all-gather of the counts, then one each of the two lists padded to the largest count.
     """
     import torch
     world = dist.get_world_size(group)
-    local = np.ascontiguousarray(local_hits, dtype=np.float32).reshape(-1, HIT_COLS)
-    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1, 2)
+    vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1, HIT_VALS)
+    assert len(idx) == len(vals)
+    cnt = torch.tensor([idx.shape[0]], dtype=torch.int64, device=device)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
     counts = [int(c.item()) for c in cnts]
     m = max(max(counts), 1)
-    mine = torch.zeros((m, HIT_COLS), dtype=torch.float32, device=device)
-    if local.shape[0]:
-        mine[:local.shape[0]] = torch.from_numpy(local).to(device)
-    parts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    out = [p[:c].cpu().numpy() for p, c in zip(parts, counts)]
-    return np.concatenate(out, axis=0) if out else np.zeros((0, HIT_COLS), np.float32)
+    out = []
+    for local, dtype, cols in ((idx, torch.int64, 2), (vals, torch.float32, HIT_VALS)):
+        mine = torch.zeros((m, cols), dtype=dtype, device=device)
+        if local.shape[0]:
+            mine[:local.shape[0]] = torch.from_numpy(local).to(device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out.append(np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0))
+    return out[0], out[1]
 
 
-def all_gather_bytes(blobs, dist, device="cpu", group=None):
-    """All-gather a list of byte strings per rank: returns, on every rank, the lists of all ranks (rank order).
-    Two collectives: lengths (padded to the longest list), then one padded uint8 all-gather."""
+def all_gather_sketches(sketches, ctx, dist, device, group=None):
+    """The exchange step of an all-vs-all: every rank contributes a list of device-resident sketches
+    and receives everybody's, as device-resident sketches on ITS GPU. Records are packed into one uint8 device tensor
+    (psk_sketch_pack), moved by ONE all-gather of that tensor (RCCL over xGMI with backend "nccl"; no host hop),
+    and unpacked in place (psk_sketch_unpack). A second, small all-gather carries the record sizes.
+    Returns a list over ranks of lists of `Sketch`."""
     import torch
+    from .database import Sketch
     world = dist.get_world_size(group)
-    n = torch.tensor([len(blobs)], dtype=torch.int64, device=device)
+    sizes = [s.pack_size() for s in sketches]
+    n = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
     ns = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(ns, n, group=group)
     counts = [int(x.item()) for x in ns]
     m = max(max(counts), 1)
-    lens = torch.zeros(m, dtype=torch.int64, device=device)
-    if blobs:
-        lens[:len(blobs)] = torch.tensor([len(b) for b in blobs], dtype=torch.int64, device=device)
-    all_lens = [torch.zeros_like(lens) for _ in range(world)]
-    dist.all_gather(all_lens, lens, group=group)
-    all_lens = [l.cpu().numpy() for l in all_lens]
-    width = max(int(max(int(l.sum()) for l in all_lens)), 1)
-    mine = torch.zeros(width, dtype=torch.uint8, device=device)
-    if blobs:
-        flat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
-        mine[:len(flat)] = torch.from_numpy(flat.copy()).to(device)
-    parts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
+    mine = torch.zeros(m, dtype=torch.int64, device=device)
+    if sizes:
+        mine[:len(sizes)] = torch.tensor(sizes, dtype=torch.int64)
+    all_sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    all_sizes = [t.cpu().numpy()[:c] for t, c in zip(all_sizes, counts)]
+    offs = [np.concatenate([[0], np.cumsum(sz)]).astype(np.int64) for sz in all_sizes]     # record sizes are multiples of 16
+    width = max(int(max(o[-1] for o in offs)), 16)
+    buf = torch.zeros(width, dtype=torch.uint8, device=device)
+    rank = dist.get_rank(group)
+    for s, o, sz in zip(sketches, offs[rank][:-1], sizes):
+        s.pack_into(buf.data_ptr() + int(o), int(sz))
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    torch.cuda.synchronize(device)              # the library reads the gathered tensors on its own stream
     out = []
     for r in range(world):
-        buf = parts[r].cpu().numpy().tobytes()
-        pos, lst = 0, []
-        for k in range(counts[r]):
-            ln = int(all_lens[r][k]); lst.append(buf[pos:pos + ln]); pos += ln
-        out.append(lst)
+        names = [f"rank{r}_{j}" for j in range(counts[r])]
+        out.append(Sketch.unpack(ctx, parts[r].data_ptr(), offs[r][:-1], names) if counts[r] else [])
     return out
-
 
 
 class ShardedDatabase:
@@ -95,19 +121,29 @@ class ShardedDatabase:
         self.local = local
         self.names = []          # GLOBAL reference names, identical on every rank
         self._lo = 0
+        self._cuts = None        # shard cut points (world + 1), identical on every rank
+        self.device = device
 
     def __len__(self):
         return len(self.names)
 
     def _shard(self, r):
+        if self._cuts is not None:
+            return self._cuts[r], self._cuts[r + 1]
         return shard_bounds(len(self.names), r, self.world)
 
-    def sketch_all(self, names, fetch):
+    def sketch_all(self, names, fetch, weights=None):
         """Add references `names` (the same list on every rank); `fetch(i)` returns the contigs (a tuple of
-        bytes-like) of global reference i and is called only for this rank's shard."""
+        bytes-like) of global reference i and is called only for this rank's shard. `weights` (one number per
+        reference, the same on every rank — genome length is the natural choice: seeds ~ length / c) balances the
+        contiguous shards on seed count instead of genome count."""
         if self.names:
             raise RuntimeError("ShardedDatabase.sketch_all may be called once: shards are contiguous")
         self.names = list(names)
+        if weights is not None:
+            if len(weights) != len(self.names):
+                raise ValueError("weights must hold one entry per reference")
+            self._cuts = weighted_shard_cuts(weights, self.world)
         self._lo, hi = self._shard(self.rank)
         for i in range(self._lo, hi):
             self.local.sketch(self.names[i], *fetch(i))
@@ -121,39 +157,38 @@ class ShardedDatabase:
         from .database import Hit
         by_name = {n: self._lo + j for j, n in enumerate(self.names[self._lo:self._lo + len(self.local)])}
         local = self.local.query(name, *contigs, **opts)
-        # column 0 travels as float32: exact below 2^24 references per job
-        rows = np.array([[self._global_index(h, by_name), h.identity, h.query_fraction, h.reference_fraction] for h in local],
-                        dtype=np.float32).reshape(-1, HIT_COLS)
-        allh = all_gather_hits(rows, self.dist, device=self.coll_device, group=self.group)
-        return [Hit(float(r[1]), name, float(r[2]), self.names[int(r[0])], float(r[3])) for r in allh]
+        idx = np.array([[0, self._global_index(h, by_name)] for h in local], dtype=np.int64).reshape(-1, 2)
+        vals = np.array([[h.identity, h.query_fraction, h.reference_fraction] for h in local], dtype=np.float32).reshape(-1, HIT_VALS)
+        idx, vals = all_gather_hits(idx, vals, self.dist, device=self.coll_device, group=self.group)
+        return [Hit(float(v[0]), name, float(v[1]), self.names[int(i[1])], float(v[2])) for i, v in zip(idx, vals)]
 
     def all_vs_all(self, batch=256, **opts):
         """Every genome of the job against every other (and itself). Each rank's shard IS its share of the genomes,
-        so the query side is the all-gather of the shards' sketches, `batch` genomes per rank at a time: records are
-        exported from HBM, exchanged as bytes, imported on the receiving GPU, queried against the local shard with
-        `Database.query_sketches`, and the hit lists all-gathered. Returns {query_name: [Hit, ...]}, identical on
-        every rank, hits in global reference order."""
-        from .database import Hit, Sketch
-        from .storage import Record
+        so the query side is the all-gather of the shards' sketches, `batch` genomes per rank at a time, as packed
+        device records (`all_gather_sketches`: HBM -> xGMI -> HBM); each received batch is queried against the local
+        shard with `Database.query_sketches`, and the hit lists are all-gathered at the end. Returns
+        {query_name: [Hit, ...]}, identical on every rank, hits in global reference order."""
+        import torch
+        from .database import Hit
         local = self.local
         n_local = len(local)
         by_name = {n: self._lo + j for j, n in enumerate(self.names[self._lo:self._lo + n_local])}
         sizes = [self._shard(r)[1] - self._shard(r)[0] for r in range(self.world)]
-        rows_q, rows_h = [], []
+        dev = self.device if self.device is not None else torch.device("cuda", local._device)
+        rows_i, rows_v = [], []
         for b in range((max(sizes) + batch - 1) // batch if sizes else 0):
             i0, i1 = min(b * batch, n_local), min((b + 1) * batch, n_local)
-            blobs = [local._full_sketch(i).to_record().to_bytes() for i in range(i0, i1)]
-            for r, lst in enumerate(all_gather_bytes(blobs, self.dist, device=self.coll_device, group=self.group)):
+            mine = [local._full_sketch(i) for i in range(i0, i1)]
+            for r, sketches in enumerate(all_gather_sketches(mine, local._ctx, self.dist, dev, group=self.group)):
                 qbase = self._shard(r)[0] + b * batch
-                sketches = [Sketch.from_record(local._ctx, Record.from_bytes(x)) for x in lst]
                 for j, hits in enumerate(local.query_sketches(sketches, **opts) if sketches else []):
                     for h in hits:
-                        rows_q.append([qbase + j, 0, 0, 0])
-                        rows_h.append([self._global_index(h, by_name), h.identity, h.query_fraction, h.reference_fraction])
-        a = all_gather_hits(np.array(rows_h, dtype=np.float32).reshape(-1, HIT_COLS), self.dist, device=self.coll_device, group=self.group)
-        q = all_gather_hits(np.array(rows_q, dtype=np.float32).reshape(-1, HIT_COLS), self.dist, device=self.coll_device, group=self.group)
+                        rows_i.append([qbase + j, self._global_index(h, by_name)])
+                        rows_v.append([h.identity, h.query_fraction, h.reference_fraction])
+        idx, vals = all_gather_hits(np.array(rows_i, dtype=np.int64).reshape(-1, 2), np.array(rows_v, dtype=np.float32).reshape(-1, HIT_VALS),
+                                    self.dist, device=self.coll_device, group=self.group)
         out = {n: [] for n in self.names}
-        for t in np.lexsort((a[:, 0], q[:, 0])):
-            qn = self.names[int(q[t, 0])]
-            out[qn].append(Hit(float(a[t, 1]), qn, float(a[t, 2]), self.names[int(a[t, 0])], float(a[t, 3])))
+        for t in np.lexsort((idx[:, 1], idx[:, 0])):
+            qn = self.names[int(idx[t, 0])]
+            out[qn].append(Hit(float(vals[t, 0]), qn, float(vals[t, 1]), self.names[int(idx[t, 1])], float(vals[t, 2])))
         return out

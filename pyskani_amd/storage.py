@@ -136,15 +136,16 @@ class Consolidated:
     """DatabaseStorage::Consolidated (lib.rs:64-87, 108-122): records appended to sketches.db + an index."""
     kind = "consolidated"
 
-    def __init__(self, path, index=None):
+    def __init__(self, path, index=None, file_name="sketches.db"):
         self.path = path
         self.index = {} if index is None else index
+        self.file_name = file_name
 
     def store(self, record):
         if record.name in self.index:                              # lib.rs:66-72
             raise ValueError(f"duplicate name in sketches: {record.name!r}")
         data = record.to_bytes()
-        with open(os.path.join(self.path, "sketches.db"), "ab") as f:
+        with open(os.path.join(self.path, self.file_name), "ab") as f:
             f.seek(0, os.SEEK_END)
             offset = f.tell()
             f.write(data)
@@ -154,7 +155,7 @@ class Consolidated:
         if name not in self.index:
             raise KeyError(name)                                   # lib.rs:109-112
         offset, length = self.index[name]
-        with open(os.path.join(self.path, "sketches.db"), "rb") as f:
+        with open(os.path.join(self.path, self.file_name), "rb") as f:
             f.seek(offset)
             return Record.from_bytes(f.read(length))
 

@@ -1,0 +1,226 @@
+"""GPU: learned-ANI regression (lib.rs:611-614), name de-duplication of the shortlist (lib.rs:51-55, 616-637) and the
+round-1 advisor findings, through the C-ABI, against the oracle and the evaluator in tests/gbdt_util.py."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import gbdt_util as G
+from conftest import mutate, random_genome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def psk():
+    import pyskani_amd
+    return pyskani_amd
+
+
+@pytest.fixture(scope="module")
+def trio():
+    rng = np.random.default_rng(41)
+    g = random_genome(rng, 400_000)
+    cuts = [0, 90_000, 150_000, 150_400, 300_000, 400_000]          # one contig < 500 is dropped (lib.rs:156)
+    q = mutate(rng, g, 0.015)
+    return g, [q[a:b] for a, b in zip(cuts, cuts[1:])], mutate(rng, g, 0.04)
+
+
+def test_model_predict_matches_python_evaluator(psk):
+    rng = np.random.default_rng(5)
+    trees = G.random_trees(rng, n_trees=40, depth=5)
+    m = psk.Model.from_trees(trees, bias=98.5, shrinkage=0.1)
+    assert m.shape == (40, 40 * 63, 9)
+    rows = np.array([[rng.uniform(lo, hi) for lo, hi in [(97, 100), (0, 1)] + [(1e3, 6e6)] * 6 + [(1e3, 3e4)]] for _ in range(500)], np.float32)
+    rows[rng.random(rows.shape) < 0.05] = G.UNKNOWN
+    got = m.predict(rows)
+    want = np.array([G.predict(trees, 98.5, 0.1, r) for r in rows], np.float32)
+    assert np.array_equal(got, want)                                  # f32 accumulation in tree order: bit-exact
+
+
+def test_model_json_loader(psk, tmp_path):
+    """The serde-JSON shape of gbdt::GBDT; a custom feature order through "psk_features"."""
+    rng = np.random.default_rng(6)
+    trees = G.random_trees(rng, n_trees=5, depth=3)
+    path = tmp_path / "model.json"
+    path.write_text(G.to_gbdt_json(trees, 97.25, 0.3))
+    m = psk.Model.from_file(str(path))
+    row = np.array([[99.1, 0.4, 5e6, 4e6, 3e6, 5e6, 4e6, 3e6, 2e4]], np.float32)
+    assert m.predict(row)[0] == np.float32(G.predict(trees, 97.25, 0.3, row[0]))
+    feats = ["std100", "ani100", "af_query", "af_ref", "n_chunks", "q50_ref", "q50_query", "total_len_ref", "n_contigs_query"]
+    m2 = psk.Model.from_json(G.to_gbdt_json(trees, 97.25, 0.3, features=feats))
+    assert m2.shape[2] == 9
+    with pytest.raises(ValueError):
+        psk.Model.from_json('{"conf": {}, "trees": [{"tree": {"tree": []}}], "bias": 0}')
+    with pytest.raises(ValueError):
+        psk.Model.from_json(G.to_gbdt_json(trees, 0.0, 1.0, features=["ani100", "nonsense"]))
+    with pytest.raises(ValueError):
+        psk.Model.from_json("not json")
+    with pytest.raises(KeyError):
+        psk.Model.from_file(str(tmp_path / "absent.json"))
+
+
+@pytest.mark.parametrize("features", [None, ["ani100", "std100", "af_query", "af_ref", "n_chunks", "q90_query", "q10_ref", "avg_chain_len",
+                                             "total_len_query", "total_len_ref", "n_contigs_query", "n_contigs_ref"]])
+def test_query_with_model_matches_oracle(psk, oracle, trio, features):
+    ref, qcontigs, other = trio
+    rng = np.random.default_rng(8)
+    nf = len(features) if features else 9
+    scales = None if features is None else [(97, 100), (0, 1), (0, 1), (0, 1), (1, 40), (1e3, 2e5), (1e3, 5e5), (1e3, 3e4), (3e5, 5e5), (3e5, 5e5), (1, 6), (1, 3)]
+    trees = G.random_trees(rng, n_trees=12, depth=4, n_features=nf, scales=scales)
+    model = psk.Model.from_trees(trees, bias=98.0, shrinkage=0.2, features=features)
+    from pyskani_amd import _capi
+    ids = list(range(9)) if features is None else [_capi.FEATURE_NAMES.index(f) for f in features]
+    omodel = oracle.Model(trees, 98.0, 0.2, ids)
+    db = psk.Database(model=model)
+    db.sketch("ref", ref)
+    db.sketch("other", other)
+    orefs = [("ref", oracle.Sketch([ref])), ("other", oracle.Sketch([other]))]
+    oq = oracle.Sketch(qcontigs)
+    for kw in ({}, {"learned_ani": True}, {"learned_ani": False}, {"median": True}, {"robust": True}, {"median": True, "learned_ani": True}):
+        hits = db.query("q", *qcontigs, **kw)
+        want = oracle.query(orefs, oq, median=kw.get("median", False), robust=kw.get("robust", False),
+                            learned_ani=kw.get("learned_ani", None), model=omodel)
+        assert [h.reference_name for h in hits] == [n for n, _ in want]
+        for h, (_, w) in zip(hits, want):
+            assert h.learned == bool(w.learned)
+            assert h._raw["learned"] == w.learned
+            assert abs(h._raw["ani_raw"] - w.ani_raw) < 1e-6 and abs(h._raw["ani_std"] - w.ani_std) < 1e-6
+            assert abs(h.identity - w.ani) < 2e-6, (kw, h.identity, w.ani)
+        # the default rule: c >= 70 and not median (lib.rs:611-613)
+        expect_learned = kw.get("learned_ani", not kw.get("median", False))
+        assert all(h.learned == expect_learned for h in hits)
+    # many-query path shares the stage
+    a = db.query_many([("q", *qcontigs), ("r", ref)])
+    b = [db.query("q", *qcontigs), db.query("r", ref)]
+    assert [[(h.reference_name, h.identity, h.learned) for h in x] for x in a] == [[(h.reference_name, h.identity, h.learned) for h in x] for x in b]
+
+
+def test_default_rule_needs_c_70(psk, trio):
+    ref, qcontigs, _ = trio
+    trees = G.random_trees(np.random.default_rng(2), n_trees=2, depth=2)
+    db = psk.Database(compression=60, marker_compression=500, model=psk.Model.from_trees(trees, bias=98.0))
+    db.sketch("ref", ref)
+    assert [h.learned for h in db.query("q", *qcontigs)] == [False]
+    assert [h.learned for h in db.query("q", *qcontigs, learned_ani=True)] == [True]
+
+
+def test_no_model_behaviour(psk, trio, monkeypatch):
+    """No model: learned_ani=True raises, the default warns once per Database and flags the hits as un-regressed."""
+    monkeypatch.delenv("PSK_MODEL_PATH", raising=False)
+    ref, qcontigs, _ = trio
+    for _ in range(2):                 # every Database warns, not only the first of the process
+        db = psk.Database()
+        db.sketch("ref", ref)
+        with pytest.raises(RuntimeError):
+            db.query("q", *qcontigs, learned_ani=True)
+        with pytest.warns(RuntimeWarning, match="RAW chain ANI"):
+            hits = db.query("q", *qcontigs)
+        assert len(hits) == 1 and hits[0].learned is False
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            db.query("q", *qcontigs)                           # once per Database
+            db.query("q", *qcontigs, learned_ani=False)
+            db.query("q", *qcontigs, median=True)              # default rule: median switches the model off
+
+
+def test_model_from_environment(psk, trio, tmp_path, monkeypatch):
+    ref, qcontigs, _ = trio
+    trees = G.random_trees(np.random.default_rng(12), n_trees=4, depth=3)
+    path = tmp_path / "m.json"
+    path.write_text(G.to_gbdt_json(trees, 98.0, 0.25))
+    monkeypatch.setenv("PSK_MODEL_PATH", str(path))
+    db = psk.Database()
+    db.sketch("ref", ref)
+    hits = db.query("q", *qcontigs)
+    assert hits[0].learned and hits[0]._raw["ani_raw"] != hits[0]._raw["ani"]
+
+
+def test_duplicate_names_give_one_hit(psk, oracle):
+    """lib.rs:51-55 (store keyed by name) + :616-637 (shortlist of names): one hit per NAME, against its last sketch —
+    also when only the EARLIER entry passes the screen."""
+    rng = np.random.default_rng(3)
+    g = random_genome(rng, 150_000)
+    far, near, unrelated = mutate(rng, g, 0.05), mutate(rng, g, 0.01), random_genome(rng, 150_000)
+    db = psk.Database()
+    for name, seq in (("x", far), ("y", near), ("x", near), ("z", near), ("z", unrelated)):
+        db.sketch(name, seq)
+    sk = {n: oracle.Sketch([s]) for n, s in (("far", far), ("near", near), ("unrelated", unrelated))}
+    orefs = [("x", sk["far"]), ("y", sk["near"]), ("x", sk["near"]), ("z", sk["near"]), ("z", sk["unrelated"])]
+    for many in (False, True):
+        hits = db.query_many([("q", g)], learned_ani=False)[0] if many else db.query("q", g, learned_ani=False)
+        want = oracle.query(orefs, oracle.Sketch([g]))
+        # "z": its first entry passes the screen, so the name is shortlisted and chained against the unrelated later sketch -> no hit
+        assert [h.reference_name for h in hits] == [n for n, _ in want] == ["y", "x"]
+        for h, (_, w) in zip(hits, want):
+            assert h._raw["n_anchors"] == w.n_anchors and abs(h.identity - w.ani) < 1e-6
+
+
+def test_duplicate_names_on_disk(psk, tmp_path):
+    rng = np.random.default_rng(4)
+    g = random_genome(rng, 100_000)
+    db = psk.Database(str(tmp_path / "sep"), format="separated")        # Folder.store overwrites silently, lib.rs:57-58
+    db.sketch("x", mutate(rng, g, 0.05)); db.sketch("x", mutate(rng, g, 0.01)); db.flush()
+    opened = psk.Database.open(str(tmp_path / "sep"))
+    hits = opened.query("q", g, learned_ani=False)
+    assert len(hits) == 1 and hits[0].identity > 0.985
+    con = psk.Database(str(tmp_path / "con"))                            # Consolidated.store rejects duplicates, lib.rs:66-72
+    con.sketch("x", g)
+    with pytest.raises(ValueError):
+        con.sketch("x", g)
+
+
+def test_save_onto_own_folder(psk, tmp_path):
+    """save(path, overwrite=True) onto the folder an opened database reads from must not destroy it."""
+    rng = np.random.default_rng(6)
+    g = random_genome(rng, 80_000)
+    folder = str(tmp_path / "db")
+    with psk.Database(folder) as db:
+        db.sketch("a", g); db.sketch("b", mutate(rng, g, 0.02))
+    opened = psk.Database.open(folder)
+    before = [(h.reference_name, h.identity) for h in opened.query("q", g, learned_ani=False)]
+    opened.save(folder, overwrite=True)
+    assert [(h.reference_name, h.identity) for h in opened.query("q", g, learned_ani=False)] == before
+    again = psk.Database.load(folder)
+    assert [(h.reference_name, h.identity) for h in again.query("q", g, learned_ani=False)] == before and len(before) == 2
+    opened.save(folder, overwrite=True, format="separated")
+    assert os.path.exists(os.path.join(folder, "a.sketch"))
+
+
+def test_pack_unpack_device_records(psk, oracle):
+    """psk_sketch_pack / psk_sketch_unpack (the multi-GPU exchange records): unpacked sketches are byte-identical to the
+    originals (seeds, markers, contig tables) and chain to the same result."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(21)
+    g = random_genome(rng, 200_000)
+    genomes = [[g[:70_000], g[70_000:70_300], g[70_300:]], [mutate(rng, g, 0.02)], [b"ACGT" * 50], [random_genome(rng, 30_000)] * 2]
+    db = psk.Database()
+    sketches = [db._sketch(f"s{i}", c, True) for i, c in enumerate(genomes)] + [db._sketch("m", genomes[1], False)]
+    sizes = [s.pack_size() for s in sketches]
+    assert all(sz % 16 == 0 and sz >= 64 for sz in sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    buf = torch.zeros(int(offs[-1]), dtype=torch.uint8, device="cuda")
+    for s, o, sz in zip(sketches, offs, sizes):
+        s.pack_into(buf.data_ptr() + int(o), sz)
+    with pytest.raises(ValueError):
+        sketches[0].pack_into(buf.data_ptr(), sizes[0] - 16)
+    torch.cuda.synchronize()
+    moved = buf.clone()                                    # what an all-gather would deliver
+    torch.cuda.synchronize()
+    got = psk.Sketch.unpack(db._ctx, moved.data_ptr(), offs[:-1], [s.name for s in sketches])
+    for a, b in zip(sketches, got):
+        sa, ma = a.export(); sb, mb = b.export()
+        assert sa.tobytes() == sb.tobytes() and ma.tobytes() == mb.tobytes()
+        assert a.to_record().to_bytes() == b.to_record().to_bytes()
+        assert a._info()[1:] == b._info()[1:]
+    ref = psk.Database()
+    ref.sketch("ref", g)
+    want = [[(h.identity, h._raw["n_anchors"], h._raw["covered_query"]) for h in x] for x in ref.query_sketches(sketches[:4], learned_ani=False)]
+    have = [[(h.identity, h._raw["n_anchors"], h._raw["covered_query"]) for h in x] for x in ref.query_sketches(got[:4], learned_ani=False)]
+    assert want == have and len(want[0]) == 1 and len(want[1]) == 1
+    bad = moved.clone(); bad[int(offs[1])] = 0
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        psk.Sketch.unpack(db._ctx, bad.data_ptr(), offs[:-1], [s.name for s in sketches])

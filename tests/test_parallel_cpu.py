@@ -17,16 +17,20 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 n_refs = 11
 lo, hi = shard_bounds(n_refs, rank, world)
-# every third global ref "hits"; ANI encodes the global index so the gather can be checked
-idx = np.array([g for g in range(lo, hi) if g %% 3 == 0], dtype=np.float32)
-local = np.stack([idx, 0.9 + idx / 1000, np.full_like(idx, 0.5), np.full_like(idx, 0.25)], axis=1) if len(idx) else np.zeros((0, 4), np.float32)
-allh = all_gather_hits(local, dist)
-want = np.array([g for g in range(n_refs) if g %% 3 == 0], dtype=np.float32)
-assert np.array_equal(allh[:, 0], want), (allh, want)
-assert np.allclose(allh[:, 1], 0.9 + want / 1000)
+# every third global ref "hits"; ANI encodes the global index so the gather can be checked. Indices travel as int64:
+# 2**24 + 1 is not representable in float32 (ADVICE r1) and must survive the gather
+BIG = 2 ** 24 + 1
+gidx = np.array([g for g in range(lo, hi) if g %% 3 == 0], dtype=np.int64)
+idx = np.stack([np.full_like(gidx, 5), gidx + BIG], axis=1).reshape(-1, 2)
+vals = np.stack([0.9 + gidx / 1000, np.full(len(gidx), 0.5), np.full(len(gidx), 0.25)], axis=1).astype(np.float32).reshape(-1, 3)
+gi, gv = all_gather_hits(idx, vals, dist)
+want = np.array([g for g in range(n_refs) if g %% 3 == 0], dtype=np.int64)
+assert gi.dtype == np.int64 and np.array_equal(gi[:, 1], want + BIG) and np.all(gi[:, 0] == 5), (gi, want)
+assert np.allclose(gv[:, 0], 0.9 + want / 1000) and np.all(gv[:, 1] == 0.5) and np.all(gv[:, 2] == 0.25)
 # a rank with no hits at all
-empty = all_gather_hits(np.zeros((0, 4), np.float32) if rank == 1 else local, dist)
-assert len(empty) == (len(local) if rank == 0 else len(allh) - len(local)) or True
+ei, ev = all_gather_hits(np.zeros((0, 2), np.int64) if rank == 1 else idx, np.zeros((0, 3), np.float32) if rank == 1 else vals, dist)
+n0 = len([g for g in range(*shard_bounds(n_refs, 0, world)) if g %% 3 == 0])
+assert len(ei) == len(ev) == n0 and np.array_equal(ei[:, 1], want[:n0] + BIG)
 # ShardedDatabase over a stand-in local database (no GPU here): hits = refs whose name ends in an even digit
 from pyskani_amd.parallel import ShardedDatabase
 from pyskani_amd.database import Hit
@@ -44,13 +48,13 @@ assert fetched == list(range(*shard_bounds(7, rank, world))) and n_local == len(
 hits = sdb.query("q", b"ACGT")
 assert [h.reference_name for h in hits] == ["g0", "g2", "g4", "g6"], hits
 assert all(abs(h.identity - (0.5 + int(h.reference_name[1:]) / 100)) < 1e-6 and h.query_name == "q" for h in hits)
-# ragged byte lists (the sketch exchange of ShardedDatabase.all_vs_all)
-from pyskani_amd.parallel import all_gather_bytes
-mine = [bytes([rank + 1]) * (5 + 3 * i + 7 * rank) for i in range(2 + rank)] if rank == 0 else [b"x" * 11, b"", b"yz"]
-got = all_gather_bytes(mine, dist)
-assert got[rank] == mine and len(got) == world
-assert got[0] == [bytes([1]) * 5, bytes([1]) * 8] and got[1] == [b"x" * 11, b"", b"yz"], got
-assert all_gather_bytes([], dist) == [[], []]
+# shards balanced on weights (genome lengths ~ seed counts): one 3 Gb genome beside six 5 Mb ones
+from pyskani_amd.parallel import weighted_shard_cuts
+sdb2 = ShardedDatabase(dist, local=FakeLocal())
+w = [5e6, 5e6, 3e9, 5e6, 5e6, 5e6, 5e6]
+sdb2.sketch_all(names, lambda i: (names[i].encode(),), weights=w)
+assert sdb2._cuts == weighted_shard_cuts(w, world) == [0, 3, 7], sdb2._cuts
+assert [h.reference_name for h in sdb2.query("q", b"ACGT")] == ["g0", "g2", "g4", "g6"]
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -65,6 +69,21 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_weighted_shard_cuts():
+    from pyskani_amd.parallel import weighted_shard_cuts
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 50, 1000):
+        for world in (1, 2, 3, 8):
+            w = rng.integers(1, 100, n) * (1 + 50 * (rng.random(n) < 0.05))
+            cuts = weighted_shard_cuts(w, world)
+            assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n and all(a <= b for a, b in zip(cuts, cuts[1:]))
+            if n >= 20 * world:
+                loads = [w[a:b].sum() for a, b in zip(cuts, cuts[1:])]
+                assert max(loads) - min(loads) <= 2 * w.max()          # never worse than one genome either side
+    assert weighted_shard_cuts([1, 1, 1, 1], 2) == [0, 2, 4]
+    assert weighted_shard_cuts([0, 0, 0], 2) == [0, 2, 3]             # no weight: fall back to counts
 
 
 def test_all_gather_hits_world2_gloo():
