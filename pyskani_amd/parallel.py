@@ -4,6 +4,7 @@ through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo
 nothing else on the data path is collective: every (query, ref) pair is independent (lib.rs:617-657).
 """
 import numpy as np
+import torch  # noqa: F401  (before the HIP library: torch bundles its own HIP runtime, which must initialise first)
 
 HIT_VALS = 3  # ani, af_query, af_ref
 

@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own copy of the HIP runtime; it must initialise BEFORE libpyskani_amd.so brings in /opt/rocm's
+# (the other order leaves torch with "No HIP GPUs are available"). Tests that use both in one process rely on this.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
