@@ -108,6 +108,15 @@ psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* con
                            const uint64_t* lens, uint32_t n_contigs, int want_seeds,
                            psk_sketch** out);
 
+/* Sketch n_genomes genomes from host ASCII in one call: genome g owns contigs [genome_first_contig[g],
+ * genome_first_contig[g+1]) of contigs[]/lens[] (ordinary pageable memory, borrowed for the call). The call is a
+ * three-stage pipeline — worker threads copy into pinned staging slots, a copy stream moves the slots over PCIe, the
+ * sketch kernels run on the previous sub-batch — so the sustained rate is the host->device link's, not one memcpy
+ * thread's ($PSK_INGEST_THREADS, default min(16, cores / 2)). Same result as n_genomes x psk_sketch_host. */
+psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
+                                const uint32_t* genome_first_contig, uint32_t n_genomes, int want_seeds,
+                                psk_sketch** out);
+
 /* Sketch n_genomes genomes whose ASCII already sits in HBM. d_bases is a device pointer;
  * contig i is bytes [contig_off[i], contig_off[i]+contig_len[i]) of it, contig_off[i] % 16 == 0
  * and the allocation must extend 16 bytes past the last contig. genome g owns contigs

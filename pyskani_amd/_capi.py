@@ -48,7 +48,7 @@ class Seed(C.Structure):
 SYMBOLS = [
     "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
     "psk_ctx_synchronize", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
-    "psk_sketch_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
+    "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
     "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack",
@@ -83,6 +83,7 @@ def load():
     lib.psk_device_free.argtypes = [vp, vp]
     lib.psk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.psk_sketch_host.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(vp)]
+    lib.psk_sketch_many_host.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(u32), u32, C.c_int, C.POINTER(vp)]
     lib.psk_sketch_batch_device.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), u32, C.c_int, C.POINTER(vp)]
     lib.psk_sketch_free.argtypes = [vp]
     lib.psk_sketch_free.restype = None

@@ -13,6 +13,8 @@ void psk_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static void ingest_release(psk_ctx* c);   // host-ingest pipeline resources (defined with psk_sketch_many_host)
+
 extern "C" {
 
 const char* psk_last_error(void) { return g_err; }
@@ -45,6 +47,7 @@ void psk_ctx_destroy(psk_ctx* c) {
     Scratch* all[] = {&c->s_desc, &c->s_packed, &c->s_mask, &c->s_counts, &c->s_offs, &c->s_tmp, &c->s_mark, &c->s_flags, &c->s_misc,
                       &c->q_a, &c->q_b, &c->q_c, &c->q_d, &c->q_e, &c->q_f, &c->q_g, &c->q_h, &c->q_i};
     for (Scratch* s : all) s->release();
+    ingest_release(c);
     c->jobs_release();
     c->pool_drain();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -538,6 +541,176 @@ psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* of
     PSK_HIP(hipStreamSynchronize(st));
     for (uint32_t i = 0; i < n; i++) out[i] = sk[i].release();
     return PSK_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ host-ASCII ingest pipeline
+// psk_sketch_many_host: many genomes whose contigs sit in ordinary (pageable) host memory. The boundary of the reference
+// hands over host buffers (lib.rs:485-489), so from ASCII in host memory the path is bound by PCIe, not by the sketch
+// kernels (5 MB per genome against ~4 µs of sketch_scan). Three stages overlap:
+//   worker threads  pageable -> pinned staging slots   (a single memcpy thread moves ~10 GB/s, PCIe Gen5 x16 ~55 GB/s)
+//   copy stream     pinned slot -> device sub-batch buffer (hipMemcpyAsync, one DMA per 32 MB slot)
+//   ctx stream      sketch_batch_impl over the previous sub-batch (double-buffered device ASCII)
+#include <condition_variable>
+#include <functional>
+#include <thread>
+#include <atomic>
+#include <map>
+namespace {
+struct ParallelFor {   // persistent workers; run(n, fn) executes fn(0..n-1) on the workers and the caller
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, cv_done;
+    std::function<void(int)> fn; int n = 0, next = 0, active = 0; uint64_t gen = 0; bool stop = false;
+    explicit ParallelFor(int workers) {
+        for (int i = 0; i < workers; i++) th.emplace_back([this] {
+            uint64_t seen = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (gen != seen && next < n); });
+                if (stop) return;
+                seen = gen;
+                while (next < n) { int i = next++; active++; lk.unlock(); fn(i); lk.lock(); active--; }
+                if (active == 0) cv_done.notify_all();
+            }
+        });
+    }
+    void run(int count, std::function<void(int)> f) {
+        std::unique_lock<std::mutex> lk(mu);
+        fn = std::move(f); n = count; next = 0; gen++;
+        cv.notify_all();
+        while (next < n) { int i = next++; active++; lk.unlock(); fn(i); lk.lock(); active--; }
+        cv_done.wait(lk, [&] { return active == 0 && next >= n; });
+    }
+    ~ParallelFor() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+constexpr size_t INGEST_SLOT = 32u << 20;       // pinned staging slot
+constexpr int INGEST_SLOTS = 4;
+struct IngestRes {   // per-context resources of the pipeline, created on first use
+    hipStream_t copy = nullptr;
+    void* pinned[INGEST_SLOTS] = {nullptr}; hipEvent_t slot_free[INGEST_SLOTS] = {nullptr};
+    Scratch dev[2]; hipEvent_t ready[2] = {nullptr, nullptr};
+    std::unique_ptr<ParallelFor> pool;
+};
+std::mutex g_ingest_mu;
+std::map<psk_ctx*, IngestRes*> g_ingest;
+}  // namespace
+static void ingest_release(psk_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ingest_mu);
+    auto it = g_ingest.find(c);
+    if (it == g_ingest.end()) return;
+    IngestRes* R = it->second;
+    if (R->copy) (void)hipStreamSynchronize(R->copy);
+    for (int i = 0; i < INGEST_SLOTS; i++) { if (R->pinned[i]) (void)hipHostFree(R->pinned[i]); if (R->slot_free[i]) (void)hipEventDestroy(R->slot_free[i]); }
+    for (int i = 0; i < 2; i++) { R->dev[i].release(); if (R->ready[i]) (void)hipEventDestroy(R->ready[i]); }
+    if (R->copy) (void)hipStreamDestroy(R->copy);
+    delete R;
+    g_ingest.erase(it);
+}
+
+extern "C" {
+
+psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
+                                const uint32_t* genome_first_contig, uint32_t n_genomes, int want_seeds, psk_sketch** out) {
+    if (!ctx || !p || !out || (n_genomes && (!genome_first_contig || !lens || !contigs))) { psk_set_error("sketch_many_host: NULL argument"); return PSK_EINVAL; }
+    for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
+    if (!n_genomes) return PSK_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PSK_HIP(hipSetDevice(ctx->device));
+    IngestRes* R;
+    {
+        std::lock_guard<std::mutex> g(g_ingest_mu);
+        IngestRes*& slot = g_ingest[ctx];
+        if (!slot) {
+            slot = new IngestRes();
+            PSK_HIP(hipStreamCreateWithFlags(&slot->copy, hipStreamNonBlocking));
+            for (int i = 0; i < INGEST_SLOTS; i++) {
+                PSK_HIP(hipHostMalloc(&slot->pinned[i], INGEST_SLOT, hipHostMallocDefault));
+                PSK_HIP(hipEventCreateWithFlags(&slot->slot_free[i], hipEventDisableTiming));
+            }
+            for (int i = 0; i < 2; i++) PSK_HIP(hipEventCreateWithFlags(&slot->ready[i], hipEventDisableTiming));
+            const char* env = getenv("PSK_INGEST_THREADS");
+            int nt = env ? atoi(env) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+            slot->pool.reset(new ParallelFor(std::max(0, nt - 1)));
+        }
+        R = slot;
+    }
+    const uint32_t n_contigs = genome_first_contig[n_genomes];
+    // sub-batches of ~192 MB of ASCII (whole genomes); device offsets of the kept contigs, 16-byte aligned
+    const uint64_t SUB = 192ull << 20;
+    struct Sub { uint32_t g0, g1; uint64_t bytes; };
+    std::vector<Sub> subs;
+    std::vector<uint64_t> off(n_contigs, 0), len64(lens, lens + n_contigs);
+    for (uint32_t g = 0; g < n_genomes;) {
+        Sub s{g, g, 0};
+        while (s.g1 < n_genomes) {
+            uint64_t gb = 0;
+            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) if (lens[c] >= MIN_LENGTH_CONTIG) gb += (lens[c] + 15) & ~15ull;
+            if (s.g1 > s.g0 && s.bytes + gb > SUB) break;
+            uint64_t o = s.bytes;
+            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) { off[c] = o; if (lens[c] >= MIN_LENGTH_CONTIG) o += (lens[c] + 15) & ~15ull; }
+            s.bytes += gb; s.g1++;
+        }
+        subs.push_back(s);
+        g = s.g1;
+    }
+    // consumer state shared with the producer thread
+    std::mutex m; std::condition_variable cv;
+    int produced = 0, consumed = 0; psk_status prod_rc = PSK_OK; std::string prod_err;
+    const int device = ctx->device;
+    std::thread producer([&] {
+        (void)hipSetDevice(device);
+        int slot_i = 0;
+        for (size_t b = 0; b < subs.size(); b++) {
+            { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return consumed + 2 > (int)b; }); }     // device buffer b % 2 is free again
+            const Sub& s = subs[b];
+            Scratch& D = R->dev[b & 1];
+            psk_status rc = D.reserve(s.bytes + 64);
+            hipError_t e = hipSuccess;
+            const uint32_t c0 = genome_first_contig[s.g0], c1 = genome_first_contig[s.g1];
+            for (uint64_t lo = 0; lo < s.bytes && rc == PSK_OK && e == hipSuccess; lo += INGEST_SLOT) {
+                const uint64_t hi = std::min<uint64_t>(s.bytes, lo + INGEST_SLOT);
+                char* pin = (char*)R->pinned[slot_i];
+                e = hipEventSynchronize(R->slot_free[slot_i]);      // its previous DMA has drained
+                if (e != hipSuccess) break;
+                const int parts = (int)std::min<uint64_t>(64, (hi - lo + (1u << 20) - 1) >> 20);
+                R->pool->run(parts, [&](int t) {
+                    const uint64_t a = lo + (hi - lo) * (uint64_t)t / parts, z = lo + (hi - lo) * (uint64_t)(t + 1) / parts;
+                    // first contig whose device range ends after a
+                    uint32_t l = c0, r = c1;
+                    while (l < r) { uint32_t mid = (l + r) >> 1; if (off[mid] + (lens[mid] >= MIN_LENGTH_CONTIG ? lens[mid] : 0) <= a) l = mid + 1; else r = mid; }
+                    for (uint32_t c = l; c < c1 && off[c] < z; c++) {
+                        if (lens[c] < MIN_LENGTH_CONTIG) continue;
+                        const uint64_t s0 = std::max(a, off[c]), s1 = std::min(z, off[c] + lens[c]);
+                        if (s0 < s1) memcpy(pin + (s0 - lo), contigs[c] + (s0 - off[c]), s1 - s0);
+                    }
+                });
+                e = hipMemcpyAsync((char*)D.p + lo, pin, hi - lo, hipMemcpyHostToDevice, R->copy);
+                if (e == hipSuccess) e = hipEventRecord(R->slot_free[slot_i], R->copy);
+                slot_i = (slot_i + 1) % INGEST_SLOTS;
+            }
+            if (e == hipSuccess && rc == PSK_OK) e = hipEventRecord(R->ready[b & 1], R->copy);
+            std::lock_guard<std::mutex> l(m);
+            if (rc != PSK_OK || e != hipSuccess) { prod_rc = rc != PSK_OK ? rc : PSK_EHIP; prod_err = e != hipSuccess ? hipGetErrorString(e) : psk_last_error(); produced = (int)subs.size(); cv.notify_all(); return; }
+            produced = (int)b + 1;
+            cv.notify_all();
+        }
+    });
+    psk_status rc = PSK_OK;
+    for (size_t b = 0; b < subs.size() && rc == PSK_OK; b++) {
+        { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return produced > (int)b; }); if (prod_rc != PSK_OK) { rc = prod_rc; psk_set_error("ingest: %s", prod_err.c_str()); break; } }
+        const Sub& s = subs[b];
+        hipError_t e = hipStreamWaitEvent(ctx->stream, R->ready[b & 1], 0);
+        if (e != hipSuccess) { psk_set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); rc = PSK_EHIP; break; }
+        rc = sketch_batch_impl(ctx, p, (const uint8_t*)R->dev[b & 1].p, off.data(), len64.data(), genome_first_contig + s.g0, s.g1 - s.g0, want_seeds, out + s.g0);
+        { std::lock_guard<std::mutex> l(m); consumed = (int)b + 1; }
+        cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> l(m); consumed = (int)subs.size() + 2; }
+    cv.notify_all();
+    producer.join();
+    (void)hipStreamSynchronize(R->copy);
+    if (rc != PSK_OK) for (uint32_t g = 0; g < n_genomes; g++) { delete out[g]; out[g] = nullptr; }
+    return rc;
 }
 
 }  // extern "C"

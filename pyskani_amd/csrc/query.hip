@@ -290,11 +290,13 @@ __device__ __forceinline__ uint32_t xcd_block_id() {
 // one lane per (pair, query seed): range of equal k-mers in the ref index
 __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                            uint32_t n_pairs, uint32_t n_items,
-                                                           uint2* __restrict__ lbcnt_out) {
+                                                           uint2* __restrict__ lbcnt_out, unsigned long long* __restrict__ block_sum) {
+    __shared__ unsigned long long s_ws[4];
     const uint32_t lb = xcd_block_id();
     uint32_t i = lb * blockDim.x + threadIdx.x;
     const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
-    if (i >= n_items) return;
+    uint32_t cnt = 0;
+    if (i < n_items) {
     const PairDesc& P = pairs[p];
     const uint32_t* __restrict__ key = P.r_key;
     const uint32_t rn = P.r_n;
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
         lo = P.r_bucket[bk]; hi = P.r_bucket[bk + 1];
     }
     while (lo < hi && (uint32_t)key[lo] < km) lo++;
-    uint32_t cnt = 0;
     if (lo < rn && (uint32_t)key[lo] == km) {
         uint32_t step = 1;
         while (lo + step < rn && (uint32_t)key[lo + step] == km) step <<= 1;
@@ -319,6 +320,15 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
         cnt = b - lo;
     }
     lbcnt_out[dst] = make_uint2(lo, cnt);      // one 8-byte scattered store per item
+    }
+    // 64-bit anchor total of the workgroup: the offsets the scan produces are 32-bit, the host compares the two totals
+    // (repeat-rich pairs can exceed 2^32 anchors: a k-mer present 10^5 times on both sides already does)
+    unsigned long long c64 = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+    if ((threadIdx.x & 63) == 0) s_ws[threadIdx.x >> 6] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[lb] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
 }
 
 __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
@@ -1452,7 +1462,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
-           o_ovf = al256(o_misc + 64), o_end = o_ovf + 4 * n_rows;
+           o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows), o_end = o_bsum + 8 * ((n_items + 255) / 256 + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
     PairDesc* d_pairs = (PairDesc*)(B + o_pairs); uint32_t* d_sbase = (uint32_t*)(B + o_sbase); uint32_t* d_cbase = (uint32_t*)(B + o_cbase);
@@ -1461,6 +1471,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     uint32_t* d_nch = (uint32_t*)(B + o_nch); uint2* d_chunks = (uint2*)(B + o_chunks); ChunkOut* d_cout = (ChunkOut*)(B + o_cout);
     psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..4] stats, [8] overflow-list length
     uint32_t* d_ovf = (uint32_t*)(B + o_ovf);
+    unsigned long long* d_bsum = (unsigned long long*)(B + o_bsum);
     PSK_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
     PSK_HIP(hipMemcpyAsync(d_cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
@@ -1468,20 +1479,30 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     PSK_HIP(hipMemsetAsync(d_lbcnt + n_items, 0, 8, st));
     const uint32_t gi = (uint32_t)((n_items + 255) / 256);
     ctx->t_begin(K_ANCHOR);
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt);
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_bsum);
     ctx->t_end();
-    size_t tmp = 0;
+    size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(d_lbcnt, CountOf());
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
-    PSK_TRY(ctx->q_c.reserve(tmp));
+    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, d_bsum, d_bsum + gi, (int)gi, st));
+    PSK_TRY(ctx->q_c.reserve(std::max(tmp, tmp2)));
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
+    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, d_bsum, d_bsum + gi, (int)gi, st));      // 64-bit total, beside the 32-bit offsets
     hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, d_aoff, d_sbase, n_pairs, d_pstart);
     void* hpin;
     PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 256, &hpin));
     uint32_t* h_small = (uint32_t*)hpin;
     PSK_HIP(hipMemcpyAsync(h_small, d_aoff + n_items, 4, hipMemcpyDeviceToHost, st));
+    PSK_HIP(hipMemcpyAsync(h_small + 2, d_bsum + gi, 8, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipStreamSynchronize(st));   // also keeps h_pairs/h_sbase/h_cbase alive until copied
     const uint32_t total = h_small[0];
+    {
+        unsigned long long total64; memcpy(&total64, h_small + 2, 8);
+        if (total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
+            psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
+            return PSK_ELIMIT;
+        }
+    }
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)total + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
@@ -1616,7 +1637,20 @@ psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const p
         hp.clear();
         uint64_t items = 0; uint32_t e = b;
         while (e < n && hp.size() < MAX_PAIRS && (hp.empty() || items + queries[e]->n_seeds <= MAX_ITEMS)) { hp.push_back({refs[e], queries[e]}); items += queries[e]->n_seeds; e++; }
-        PSK_TRY(chain_batch(ctx, hp.data(), (uint32_t)hp.size(), o, out + b));
+        psk_status rc = chain_batch(ctx, hp.data(), (uint32_t)hp.size(), o, out + b);
+        if (rc == PSK_ELIMIT && hp.size() > 1) {   // too many anchors for 32-bit offsets: halve the batch until single pairs
+            std::vector<HostPair> todo(hp);
+            size_t step = (todo.size() + 1) / 2;
+            for (size_t s0 = 0; s0 < todo.size();) {
+                const size_t n1 = std::min(step, todo.size() - s0);
+                rc = chain_batch(ctx, todo.data() + s0, (uint32_t)n1, o, out + b + s0);
+                if (rc == PSK_ELIMIT && n1 > 1) { step = (n1 + 1) / 2; continue; }
+                if (rc != PSK_OK) return rc;
+                s0 += n1;
+            }
+            rc = PSK_OK;
+        }
+        PSK_TRY(rc);
         b = e;
     }
     return PSK_OK;

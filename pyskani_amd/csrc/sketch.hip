@@ -456,6 +456,7 @@ __global__ __launch_bounds__(MB_THREADS) void marker_block_kernel(const uint64_t
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+struct ToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 
 // One sub-batch of genomes moving through the sketch pipeline on its own stream. The phases are split
 // at the two points where the host must learn a size (total seeds, total distinct markers).
@@ -473,6 +474,7 @@ struct SketchJob {
     uint4* d_tinfo = nullptr; ContigDesc* d_desc = nullptr; uint64_t* d_mask = nullptr;
     uint64_t *d_mstage = nullptr, *d_msorted = nullptr, *d_mdense = nullptr;
     uint32_t *h_goff = nullptr, *h_coff = nullptr, *h_moff = nullptr;
+    unsigned long long *d_total64 = nullptr, *h_total64 = nullptr;
     bool empty = false;
 
     void drop() { for (auto* x : sk) delete x; sk.clear(); }
@@ -528,9 +530,14 @@ struct SketchJob {
         PSK_TRY(R->s_desc.reserve(sizeof(ContigDesc) * n_desc));
         PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
         PSK_TRY(R->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS));
-        PSK_TRY(R->s_offs.reserve(sizeof(uint32_t) * o_end));
+        size_t red_tmp = 0;
+        hipcub::TransformInputIterator<unsigned long long, ToU64, const uint32_t*> it64_probe((const uint32_t*)nullptr, ToU64());
+        JHIP(hipcub::DeviceReduce::Sum(nullptr, red_tmp, it64_probe, (unsigned long long*)nullptr, (int)n_tiles, st));
+        const size_t o_tot = align_up(sizeof(uint32_t) * o_end, 256);
+        PSK_TRY(R->s_offs.reserve(o_tot + 256 + red_tmp));
         PSK_TRY(R->s_counts.reserve(sizeof(uint4) * ((size_t)n_tiles + 1) + sizeof(uint32_t) * ((size_t)n_tiles + 4)));
         uint32_t* d_offs = (uint32_t*)R->s_offs.p;
+        d_total64 = (unsigned long long*)((char*)R->s_offs.p + o_tot);
         d_cnt = d_offs + o_cnt; d_toff = d_offs + o_toff; d_gft = d_offs + o_gft; d_cft = d_offs + o_cft;
         d_goff = d_offs + o_goff; d_coff = d_offs + o_coff; d_mcnt = d_offs + o_mcnt; d_sbeg = d_offs + o_sbeg;
         d_send = d_offs + o_send; d_moff = d_offs + o_moff; d_tmc = d_offs + o_tmc; d_tmoff = d_offs + o_tmoff;
@@ -538,11 +545,12 @@ struct SketchJob {
         d_desc = (ContigDesc*)R->s_desc.p; d_packed = (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p;
         size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
         void* hp;
-        PSK_TRY(R->pin(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4), &hp));
+        PSK_TRY(R->pin(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4) + 16, &hp));
         ContigDesc* h_desc = (ContigDesc*)hp;
         uint32_t* h_gft = (uint32_t*)(h_desc + n_desc);
         uint32_t* h_cft = h_gft + n_genomes + 1;
         h_goff = h_cft + n_desc + 1; h_coff = h_goff + n_genomes + 1; h_moff = h_coff + n_desc + 1;
+        h_total64 = (unsigned long long*)(((uintptr_t)(h_moff + n_genomes + 1 + 4) + 7) & ~(uintptr_t)7);
         memcpy(h_desc, descs.data(), sizeof(ContigDesc) * n_desc);
         memcpy(h_gft, g_first_tile.data(), sizeof(uint32_t) * (n_genomes + 1));
         for (int i = 0; i < n_desc; i++) h_cft[i] = descs[i].first_tile;
@@ -566,6 +574,13 @@ struct SketchJob {
         JHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
         PSK_TRY(R->s_tmp.reserve(tmp_bytes));
         JHIP(hipcub::DeviceScan::ExclusiveSum(R->s_tmp.p, tmp_bytes, d_cnt, d_toff, (int)(n_tiles + 1), st));
+        {   // the offsets are 32-bit: a 64-bit total of the same counts tells phase2 whether they wrapped (low-complexity
+            // input can make nearly every base a seed)
+            hipcub::TransformInputIterator<unsigned long long, ToU64, const uint32_t*> it64(d_cnt, ToU64());
+            size_t tb = red_tmp;
+            JHIP(hipcub::DeviceReduce::Sum((char*)R->s_offs.p + o_tot + 256, tb, it64, d_total64, (int)n_tiles, st));
+            JHIP(hipMemcpyAsync(h_total64, d_total64, 8, hipMemcpyDeviceToHost, st));
+        }
         int n1 = n_genomes + 1, n2 = n_desc + 1;
         hipLaunchKernelGGL(gather_u32_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_toff, d_gft, d_goff, n1);
         hipLaunchKernelGGL(gather_u32_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, d_toff, d_cft, d_coff, n2);
@@ -579,7 +594,7 @@ struct SketchJob {
         if (empty) return PSK_OK;
         JHIP(hipStreamSynchronize(st));
         const uint32_t total_seeds = h_goff[n_genomes];
-        if (total_seeds >= 0x7FFFFFF0u) { psk_set_error("batch yields >= 2^31 seeds; split it"); return PSK_ELIMIT; }
+        if (*h_total64 >= 0x7FFFFFF0ull) { psk_set_error("batch yields %llu seeds (>= 2^31 per launch); split it", (unsigned long long)*h_total64); return PSK_ELIMIT; }
         store = std::make_shared<SketchStore>();
         size_t ns = total_seeds;
         size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),

@@ -438,6 +438,45 @@ class Database:
         _capi.check(self._lib.psk_sketch_host(self._ctx._h, C.byref(self._params), arr, lens, n, int(bool(seed)), C.byref(h)))
         return Sketch(self._ctx, h, name)
 
+    def _sketch_many(self, genomes, seed):
+        """[(name, contig, ...)] -> [Sketch] through the pipelined host-ingest entry point (psk_sketch_many_host)."""
+        views, first = [], [0]
+        for g in genomes:
+            if not isinstance(g[0], str):
+                raise TypeError("name must be a str")
+            views.extend(_as_bytes(c) for c in g[1:])
+            first.append(len(views))
+        n, nc = len(genomes), len(views)
+        arr = (C.c_char_p * max(nc, 1))(*views)
+        lens = (C.c_uint64 * max(nc, 1))(*[len(v) for v in views])
+        gfc = (C.c_uint32 * (n + 1))(*first)
+        out = (C.c_void_p * max(n, 1))()
+        _capi.check(self._lib.psk_sketch_many_host(self._ctx._h, C.byref(self._params), arr, lens, gfc, n, int(bool(seed)), out))
+        return [Sketch(self._ctx, C.c_void_p(out[i]), genomes[i][0]) for i in range(n)]
+
+    def sketch_many(self, genomes, *, seed=True):
+        """Add many reference genomes in one call: `genomes` = [(name, contig, ...), ...]. Same result as
+        `for g in genomes: db.sketch(*g)` (lib.rs:477-510 applied per genome), but the contigs cross PCIe through a
+        pinned, double-buffered pipeline that overlaps the copies with the sketch kernels — the way to load a large
+        reference set from host memory. An addition to the reference API."""
+        if not self._lock.acquire(blocking=False):
+            raise RuntimeError("Already borrowed")
+        try:
+            sketches = self._sketch_many(genomes, seed)
+            if self._storage is not None:
+                for sk in sketches:
+                    self._storage.store(sk.to_record())
+            names = (C.c_char_p * max(len(sketches), 1))(*[sk.name.encode("utf-8") for sk in sketches])
+            handles = (C.c_void_p * max(len(sketches), 1))(*[sk._h for sk in sketches])
+            _capi.check(self._lib.psk_db_add_batch(self._h, names, handles, len(sketches)))
+            for sk in sketches:
+                sk._owned = False
+                self._names.append(sk.name)
+                self._resident.append(True)
+        finally:
+            self._lock.release()
+        return None
+
     def sketch(self, name, *contigs, seed=True):
         """Add a reference genome to the database (lib.rs:477-510)."""
         if not isinstance(name, str):
@@ -488,7 +527,7 @@ class Database:
                    faster_small=False):
         """[(name, contigs...)] -> list of hit lists; equals [self.query(name, *contigs, ...) for ...].
         An addition to the reference API for all-vs-all / many-bin workloads."""
-        sketches = [self._sketch(g[0], g[1:], seed) for g in genomes]
+        sketches = self._sketch_many(genomes, seed)
         return self.query_sketches(sketches, learned_ani=learned_ani, median=median, robust=robust, cutoff=cutoff,
                                    faster_small=faster_small)
 
