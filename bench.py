@@ -12,7 +12,16 @@ with RCCL (torch.distributed backend "nccl").
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — dominant kernel (sketch_scan) timed with HIP events on the library's stream
-  cpu_baseline — the CPU oracle (oracle/, a port) on a bounded sample of the same workload
+  cpu_baseline — the CPU oracle (oracle/, a port) on a bounded sample of the same workload: one core (what a
+                 pyskani call uses, lib.rs:493,569) and all host cores (one query / reference per thread)
+  extras       — at N=1: the same workload through the pyskani-shaped API from HOST memory
+                 (api_pairs_per_s: 1 000 x Database.sketch(bytes) + Database.query(bytes);
+                  host_ascii_pairs_per_s: Database.sketch_many + query, the pipelined ingest)
+
+Other workloads (not the headline; `--workload`):
+  allvsall    BASELINE configs[2] shape on one GPU: every genome against all (families of 100)
+  metagenome  BASELINE configs[3] shape: short contigs (2-50 kb) against a resident database of 5 Mb references,
+              c=30 marker_c=200
 """
 import argparse
 import ctypes as C
@@ -30,6 +39,16 @@ N_REFS = 1000            # per GPU
 N_FAMILIES = 10
 DIVERGENCE = (0.0005, 0.002, 0.005, 0.01, 0.02, 0.04, 0.07, 0.10)   # SURVEY.md §8(d) family model
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def make_genomes(torch, device, seed_shared, seed_members, n_refs, n_families):
@@ -76,6 +95,32 @@ class Engine:
         self.ctx = C.c_void_p()
         _capi.check(self.lib.psk_ctx_create(device, C.byref(self.ctx)))
         self.params = _capi.Params(125, 1000, 15)
+
+    def set_params(self, c, marker_c, k=15):
+        self.params = self.capi.Params(c, marker_c, k)
+
+    def sketch_device(self, d_ptr, offs, lens):
+        n = len(offs)
+        c_off = (C.c_uint64 * n)(*offs); c_len = (C.c_uint64 * n)(*lens); gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        out = (C.c_void_p * n)()
+        self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
+        return out
+
+    def make_db(self, names, handles, n):
+        db = C.c_void_p()
+        self.capi.check(self.lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
+        self.capi.check(self.lib.psk_db_add_batch(db, names, handles, n))
+        return db
+
+    def query_many(self, db, handles, n, faster_small=False):
+        opts = self.capi.QueryOpts(0, 0, 0, int(faster_small), 0.0, 0.0, None)
+        hits_p = C.POINTER(self.capi.Hit)()
+        offsets = (C.c_uint64 * (n + 1))()
+        self.capi.check(self.lib.psk_query_many(db, handles, n, C.byref(opts), C.byref(hits_p), offsets))
+        nh = int(offsets[n])
+        if hits_p:
+            self.lib.psk_free(hits_p)
+        return nh
 
     def _layout(self, offs, lens, n):
         """ctypes views of the (constant) genome layout, built once: they describe the resident input"""
@@ -139,22 +184,78 @@ class Engine:
         return ms.value, n.value
 
 
-def cpu_baseline(fetch, n_sample):
-    """The CPU oracle (a port of the restated skani path, single thread like one pyskani call) on
-    1 query vs the first n_sample references of this rank's shard. `fetch(i)` returns genome i's bytes
-    (i = -1: the query); only oracle time is counted, not the D2H copies that feed it."""
+def cpu_baseline(fetch, n_sample, threads):
+    """The CPU oracle (a port of the restated skani path) on 1 query vs the first n_sample references of this rank's
+    shard. `fetch(i)` returns genome i's bytes (i = -1: the query); only oracle time is counted, not the D2H copies
+    that feed it. Two figures: ONE core (a pyskani call is single-threaded, lib.rs:493,569) and ALL host cores with one
+    reference per thread (what a user gets from the GIL release) — ctypes drops the GIL, so plain threads scale."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
-    secs = 0.0
-    g = fetch(-1)
-    t0 = time.perf_counter(); q = O.Sketch([g]); secs += time.perf_counter() - t0
-    refs = []
-    for i in range(n_sample):
-        g = fetch(i)
-        t0 = time.perf_counter(); refs.append((str(i), O.Sketch([g]))); secs += time.perf_counter() - t0
-    del g
-    t0 = time.perf_counter(); hits = O.query(refs, q); secs += time.perf_counter() - t0
-    return n_sample / secs, secs, len(hits)
+    genomes = [fetch(i) for i in range(n_sample)]
+    gq = fetch(-1)
+    t0 = time.perf_counter()
+    q = O.Sketch([gq])
+    refs = [(str(i), O.Sketch([g])) for i, g in enumerate(genomes)]
+    hits = O.query(refs, q)
+    secs1 = time.perf_counter() - t0
+    del refs
+
+    def one(i):
+        r = O.Sketch([genomes[i]])
+        ok, _ = O.screen(q, r, 0.80, True)
+        return bool(ok and O.chain(r, q).ani > 0.1)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        nh = sum(ex.map(one, range(n_sample)))
+    secs_all = time.perf_counter() - t0
+    assert nh == len(hits)
+    return n_sample / secs1, secs1, len(hits), n_sample / secs_all, secs_all
+
+
+def api_rates(psk, genomes, query):
+    """The drop-in path a pyskani user calls, from ASCII in HOST memory (SURVEY.md §8d 'Metric'):
+    (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query."""
+    out = {}
+    n = len(genomes)
+    for label, bulk in (("api", False), ("host_ascii", True), ("api", False), ("host_ascii", True)):   # second pass = warm
+        db = psk.Database()
+        t0 = time.perf_counter()
+        if bulk:
+            db.sketch_many([(f"r{i}", g) for i, g in enumerate(genomes)])
+        else:
+            for i, g in enumerate(genomes):
+                db.sketch(f"r{i}", g)
+        t1 = time.perf_counter()
+        hits = db.query("q", query, learned_ani=False)
+        t2 = time.perf_counter()
+        out[label] = {"pairs_per_s": n / (t2 - t0), "sketch_s": t1 - t0, "query_ms": (t2 - t1) * 1e3, "hits": len(hits),
+                      "host_GBps": sum(len(g) for g in genomes) / (t1 - t0) / 1e9}
+        del db
+    return out
+
+
+def make_contigs(torch, device, buf, offs, lens, n_refs, n_contigs, seed):
+    """BASELINE configs[3] / SURVEY.md §8(d) config 4: query contigs = substrings of random references, length
+    log-uniform in [2 kb, 50 kb], extra divergence U[0, 5 %]. Built on the GPU; 16-byte aligned offsets."""
+    rng = np.random.default_rng(seed)
+    clen = np.exp(rng.uniform(np.log(2000), np.log(50000), n_contigs)).astype(np.int64)
+    src = rng.integers(0, n_refs, n_contigs)
+    div = rng.uniform(0, 0.05, n_contigs)
+    coffs, total = [], 0
+    for L in clen:
+        coffs.append(total); total += (int(L) + 15 + 16) & ~15
+    out = torch.zeros(total + 64, dtype=torch.uint8, device=device)
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    inv = torch.zeros(256, dtype=torch.uint8, device=device); inv[list(b"ACGT")] = torch.arange(4, dtype=torch.uint8, device=device)
+    for i in range(n_contigs):
+        L = int(clen[i]); r = int(src[i]); st = int(rng.integers(0, lens[r] - L))
+        piece = inv[buf[offs[r] + st: offs[r] + st + L].long()]
+        mut = torch.rand(L, generator=g, device=device) < float(div[i])
+        shift = torch.randint(1, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+        out[coffs[i]:coffs[i] + L] = lut[torch.where(mut, (piece + shift) & 3, piece).long()]
+    return out, coffs, [int(x) for x in clen]
 
 
 def main():
@@ -162,12 +263,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--refs", type=int, default=N_REFS, help="references per GPU (BASELINE configs[1]: 1000)")
-    ap.add_argument("--workload", choices=["search", "allvsall"], default="search",
-                    help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes (extra, not the headline)")
+    ap.add_argument("--refs", type=int, default=None, help="references per GPU (search / allvsall default 1000 = BASELINE configs[1]; metagenome default 5000)")
+    ap.add_argument("--workload", choices=["search", "allvsall", "metagenome"], default="search",
+                    help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes; metagenome = configs[3] shape (extras, not the headline)")
+    ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
+    ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
     ap.add_argument("--cpu-sample", type=int, default=1000, help="references in the CPU-baseline sample (0 = skip); 1000 = the whole workload, ~10-20 s")
+    ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
     args = ap.parse_args()
 
     import torch
@@ -193,17 +297,36 @@ def main():
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    n_refs = args.refs
-    buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=N_FAMILIES)
+    n_refs = args.refs if args.refs is not None else (5000 if args.workload == "metagenome" else N_REFS)
+    n_families = N_FAMILIES if args.workload == "search" else max(1, n_refs // 100)     # families of 100 for configs 3-4
+    buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=n_families)
     torch.cuda.synchronize()
 
     from pyskani_amd.parallel import all_gather_hits
     eng = Engine(local_rank)
     names = (C.c_char_p * n_refs)(*[f"r{rank}_{i}".encode() for i in range(n_refs)])
+    meta_state = {}
+    if args.workload == "metagenome":
+        eng.set_params(30, 200)
+        t0 = time.perf_counter()
+        handles = eng.sketch_device(buf.data_ptr(), offs[:n_refs], lens[:n_refs])
+        meta_state["db"] = eng.make_db(names, handles, n_refs)
+        eng.capi.check(eng.lib.psk_ctx_synchronize(eng.ctx))
+        meta_state["db_build_s"] = time.perf_counter() - t0
+        cbuf, coffs, clens = make_contigs(torch, device, buf, offs, lens, n_refs, args.queries, seed=4 + rank)
+        torch.cuda.synchronize()
+        meta_state.update(cbuf=cbuf, coffs=coffs, clens=clens)
 
     def step():
         if args.workload == "allvsall":
             return eng.step_all_vs_all(buf.data_ptr(), offs, lens, names)
+        if args.workload == "metagenome":   # sketch every contig, query them all against the resident database
+            qh = eng.sketch_device(meta_state["cbuf"].data_ptr(), meta_state["coffs"], meta_state["clens"])
+            try:
+                return eng.query_many(meta_state["db"], qh, len(meta_state["coffs"]), args.faster_small)
+            finally:
+                for h in qh:
+                    eng.lib.psk_sketch_free(h)
         hits = eng.step(buf.data_ptr(), offs, lens, names)
         if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
             idx = np.stack([np.zeros(len(hits), np.int64), hits[:, 0].astype(np.int64) + rank * n_refs], axis=1)   # (query, GLOBAL ref index)
@@ -235,41 +358,81 @@ def main():
     eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
 
     if rank == 0:
-        pairs = (n_refs * n_refs if args.workload == "allvsall" else n_refs) * world * args.steps
-        value = pairs / dt
+        if args.workload == "allvsall":
+            pairs_per_step, sketched = n_refs * n_refs, n_refs
+            bases = float(sum(lens[:n_refs]))
+            wl = f"all-vs-all {n_refs} x {n_refs} synthetic ~5 Mb genomes per GPU ({n_families} families x {n_refs // n_families}), c=125 marker_c=1000 k=15"
+        elif args.workload == "metagenome":
+            pairs_per_step, sketched = args.queries * n_refs, args.queries
+            bases = float(sum(meta_state["clens"]))
+            wl = (f"metagenome: {args.queries} contigs (2-50 kb, log-uniform, 0-5 % divergence) vs a resident database of {n_refs} synthetic ~5 Mb refs "
+                  f"({n_families} families), c=30 marker_c=200 k=15, faster_small={args.faster_small}")
+        else:
+            pairs_per_step, sketched = n_refs, n_refs + 1
+            bases = float(sum(lens))
+            wl = f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15"
+        value = pairs_per_step * world * args.steps / dt
         # sketch_scan: ALGORITHMIC bytes per launch = sum over the launch's genomes of
         # L (ASCII read) + L/4 (2-bit packed write)   [SURVEY.md §8(d) B_sk, first two terms; DESIGN.md §4]
-        bases = float(sum(lens))
         alg_bytes = bases * 1.25 * args.steps / max(1, scan_n)   # per launch (a step may split into sub-batches)
         avg_s = (scan_ms / max(1, scan_n)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
+        traffic = valu = None
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_sketch_scan.json")
-        if os.path.exists(pmc):   # PMC pass is offline (rocprofv3 --pmc, separate runs); scaled by this launch's bases
+        if os.path.exists(pmc) and args.workload != "metagenome":
+            # OFFLINE counters (rocprofv3 --pmc in separate passes, profiles/r1_pmc_traffic.md), scaled by this launch's bases:
+            # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) and VALU wave-instructions (SQ_INSTS_VALU = 26.8 per 64 bases, 61 % of them
+            # four-cycle and 39 % two-cycle by profiles/micro/valu_rates.hip = 3.2 cycles on average)
             traffic = json.load(open(pmc))["traffic_bytes_per_base"] * bases * args.steps / max(1, scan_n)
+            insts = 2.069e9 / 4926656976.0 * bases * args.steps / max(1, scan_n)
+            simd_cycles_peak = avg_s * 2.4e9 * 1024          # 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock
+            valu = {"valu_issue_frac": insts * 3.2 / simd_cycles_peak if avg_s > 0 else None,
+                    "valu_issue_frac_at_1p93GHz": insts * 3.2 / (avg_s * 1.93e9 * 1024) if avg_s > 0 else None,
+                    "valu_wave_instructions_per_launch": insts,
+                    "source": "SQ_INSTS_VALU measured offline (profiles/r1_pmc_traffic.md), cycle classes from profiles/micro/valu_rates.hip; "
+                              "launch duration measured live; 1.93 GHz = GRBM_GUI_ACTIVE clock of the profiled launch"}
         line = {
             "metric": "genome-pairs/sec (sketch+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": (f"all-vs-all {n_refs} x {n_refs} synthetic ~5 Mb genomes per GPU" if args.workload == "allvsall" else f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU") + f" (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
-                       "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
+            "config": {"workload": wl, "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "priced against HBM as the contract asks; the kernel is integer-VALU-issue bound (one 64-bit mix per base: "
-                                 "15 four-cycle + 7 two-cycle wave instructions per base, DESIGN.md section 4, profiles/micro/valu_rates.hip)"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc pass (profiles/r1_pmc_traffic.md), scaled by bases" if traffic else None,
+                         "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
+                         "note": "priced against HBM as the contract asks; the kernel's real roof is integer VALU issue (one 64-bit mix per base: "
+                                 "15 four-cycle + 7 two-cycle wave instructions per base, DESIGN.md section 4): see valu.valu_issue_frac"},
             "kernel_ms_per_step": kernel_ms,
             # SURVEY.md §8(d) side figures, whole job
-            "extras": {"genomes_sketched_per_s": (n_refs + (0 if args.workload == "allvsall" else 1)) * world * args.steps / dt,
+            "extras": {"genomes_sketched_per_s": sketched * world * args.steps / dt,
                        "bases_sketched_per_s": bases * world * args.steps / dt,
                        "reported_hits_per_step": int(n_hits)},
         }
-        if args.cpu_sample > 0 and world == 1 and args.workload == "search":
-            ns = min(args.cpu_sample, n_refs)
-            v, secs, nh = cpu_baseline(lambda i: bytes(buf[offs[i]:offs[i] + lens[i]].cpu().numpy()), ns)
-            line["cpu_baseline"] = {"value": v, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
-                                    "sample": f"1 query vs the first {ns} of {n_refs} refs of the same workload (sketch {ns + 1} genomes + {ns} screens + {nh} chained hits), {secs:.1f} s of oracle time"}
+        if args.workload == "metagenome":
+            line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
+        if world == 1 and args.workload == "search" and (args.cpu_sample > 0 or not args.no_api):
+            host = buf.cpu().numpy()
+            fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
+            if not args.no_api:
+                import pyskani_amd as psk
+                r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
+                line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"],
+                                      api_detail=r["api"], host_ascii_detail=r["host_ascii"],
+                                      api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
+                                               "api = n x sketch() + query(); host_ascii = sketch_many() (pinned, double-buffered H2D pipeline) + query()")
+            if args.cpu_sample > 0:
+                ns = min(args.cpu_sample, n_refs)
+                threads = os.cpu_count() or 1
+                v1, secs1, nh, vall, secs_all = cpu_baseline(fetch, ns, threads)
+                line["cpu_baseline"] = {"value": v1, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                                        "sample": f"1 query vs the first {ns} of {n_refs} refs of the same workload (sketch {ns + 1} genomes + {ns} screens + {nh} chained hits), {secs1:.1f} s of oracle time",
+                                        "all_cores": {"value": vall, "cores": threads, "seconds": secs_all,
+                                                      "how": "same sample, one reference (sketch + screen + chain) per thread over every hardware thread of the host"},
+                                        "note": "the repo's own C restatement (the Rust reference cannot be built here); it keeps seeds in flat arrays where skani inserts "
+                                                "into hash maps, so it is if anything faster than the Rust path: a conservative floor for the speed-up"}
         print(json.dumps(line), flush=True)
+    if meta_state.get("db"):
+        eng.lib.psk_db_destroy(meta_state["db"])
     if world > 1:
         dist.destroy_process_group()
 
