@@ -273,6 +273,7 @@ void psk_db_destroy(psk_db* db) {
     for (psk_sketch* s : db->refs) delete s;
     db->d_marker_ptr.release(); db->d_marker_n.release();
     db->inv_key.release(); db->inv_ref.release(); db->inv_tmp.release();
+    db->d_refdesc.release(); db->d_canon.release();
     delete db;
 }
 
@@ -283,7 +284,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     db->refs.push_back(s);
     db->names.emplace_back(name);
     db->note_added((uint32_t)db->refs.size() - 1);
-    db->tables_dirty = true; db->inv_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true;
     return PSK_OK;
 }
 
@@ -297,7 +298,7 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
         db->names.emplace_back(names[i]);
         db->note_added((uint32_t)db->refs.size() - 1);
     }
-    db->tables_dirty = true; db->inv_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true;
     return PSK_OK;
 }
 
@@ -320,42 +321,30 @@ psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_ref
     return chain_impl(ctx, refs, n_refs, q, o, out);
 }
 
+static psk_status hits_out(const std::vector<psk_hit>& all, psk_hit** hits) {
+    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (all.size() ? all.size() : 1));
+    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+    if (!all.empty()) memcpy(outp, all.data(), sizeof(psk_hit) * all.size());
+    *hits = outp;
+    return PSK_OK;
+}
+
 psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, psk_hit** hits, uint64_t* n_hits) {
     if (!db || !q || !o || !hits || !n_hits) { psk_set_error("query: NULL argument"); return PSK_EINVAL; }
     *hits = nullptr; *n_hits = 0;
     psk_ctx* ctx = db->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
-    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
-    const uint32_t n = (uint32_t)db->refs.size();
-    if (n == 0) return PSK_OK;
-    const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
-    std::vector<uint8_t> pass(n);
-    PSK_TRY(screen_impl(db, q, screen_val, !o->faster_small, pass.data(), nullptr));
-    std::vector<const psk_sketch*> shortlist;
-    std::vector<uint32_t> idx;
-    if (db->has_dups) {   // shortlist of NAMES (lib.rs:616-637): a passing entry stands for the name's last sketch
-        std::vector<uint8_t> p2(n, 0);
-        for (uint32_t i = 0; i < n; i++) if (pass[i]) p2[db->canon[i]] = 1;
-        pass.swap(p2);
-    }
-    for (uint32_t i = 0; i < n; i++) if (pass[i]) { shortlist.push_back(db->refs[i]); idx.push_back(i); }
-    if (shortlist.empty()) return PSK_OK;
-    std::vector<psk_hit> res(shortlist.size());
-    PSK_TRY(chain_impl(ctx, shortlist.data(), (uint32_t)shortlist.size(), q, o, res.data()));
-    size_t m = 0;
-    for (size_t i = 0; i < res.size(); i++) if (res[i].ani > 0.1f) m++;   // lib.rs:654
-    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (m ? m : 1));
-    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
-    m = 0;
-    for (size_t i = 0; i < res.size(); i++) if (res[i].ani > 0.1f) { outp[m] = res[i]; outp[m].ref_index = idx[i]; m++; }
-    *hits = outp; *n_hits = m;
+    std::vector<psk_hit> all;
+    uint64_t offs[2];
+    PSK_TRY(query_many_impl(db, &q, 1, o, all, offs));
+    PSK_TRY(hits_out(all, hits));
+    *n_hits = all.size();
     return PSK_OK;
 }
 
 /* Many queries against one database. Same result as n_queries x psk_query; hits of query i are
- * hits[offsets[i] .. offsets[i+1]). Queries are screened in one launch per batch (one workgroup per
- * (ref, query)) and all surviving pairs are chained in shared launches (chain_pairs_impl). */
+ * hits[offsets[i] .. offsets[i+1]). */
 psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                           psk_hit** hits, uint64_t* offsets) {
     if (!db || (!queries && n_queries) || !o || !hits || !offsets) { psk_set_error("query_many: NULL argument"); return PSK_EINVAL; }
@@ -364,42 +353,9 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     psk_ctx* ctx = db->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
-    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
-    const uint32_t n = (uint32_t)db->refs.size();
     std::vector<psk_hit> all;
-    const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
-    const uint32_t QB = n ? std::max<uint32_t>(1, std::min<uint32_t>(4096, (1u << 26) / n)) : 1;   // queries per round
-    std::vector<uint8_t> pass;
-    std::vector<const psk_sketch*> pr, pq;
-    std::vector<uint32_t> pri, pqi;
-    std::vector<psk_hit> res;
-    for (uint32_t b = 0; b < n_queries; b += QB) {
-        const uint32_t m = std::min(QB, n_queries - b);
-        for (uint32_t i = 0; i < m; i++) if (!queries[b + i]) { psk_set_error("query_many: NULL query %u", b + i); return PSK_EINVAL; }
-        pass.assign((size_t)m * n, 0);
-        if (n) PSK_TRY(screen_many_impl(db, queries + b, m, screen_val, !o->faster_small, pass.data()));
-        if (db->has_dups)   // names, not entries, are shortlisted (lib.rs:616-637)
-            for (uint32_t i = 0; i < m; i++) {
-                uint8_t* row = pass.data() + (size_t)i * n;
-                for (uint32_t r = 0; r < n; r++) if (row[r] && db->canon[r] != r) { row[db->canon[r]] = 1; row[r] = 0; }
-            }
-        pr.clear(); pq.clear(); pri.clear(); pqi.clear();
-        for (uint32_t i = 0; i < m; i++) for (uint32_t r = 0; r < n; r++) if (pass[(size_t)i * n + r]) {
-            pr.push_back(db->refs[r]); pq.push_back(queries[b + i]); pri.push_back(r); pqi.push_back(i);
-        }
-        res.resize(pr.size());
-        if (!pr.empty()) PSK_TRY(chain_pairs_impl(ctx, pr.data(), pq.data(), (uint32_t)pr.size(), o, res.data()));
-        size_t k = 0;
-        for (uint32_t i = 0; i < m; i++) {
-            for (; k < pr.size() && pqi[k] == i; k++) if (res[k].ani > 0.1f) { res[k].ref_index = pri[k]; all.push_back(res[k]); }   // lib.rs:654
-            offsets[b + i + 1] = all.size();
-        }
-    }
-    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (all.size() ? all.size() : 1));
-    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
-    if (!all.empty()) memcpy(outp, all.data(), sizeof(psk_hit) * all.size());
-    *hits = outp;
-    return PSK_OK;
+    PSK_TRY(query_many_impl(db, queries, n_queries, o, all, offsets));
+    return hits_out(all, hits);
 }
 
 }  // extern "C"

@@ -208,6 +208,19 @@ struct SketchStore {
     }
 };
 
+// device-side description of one sketch: what either side of a (query, reference) pair contributes to the chain kernels,
+// plus the per-sketch inputs of the learned-ANI regression. Pairs are assembled from two of these ON THE DEVICE.
+struct SketchDesc {
+    const uint32_t* key; const uint64_t* pms; const uint32_t* perm; const uint32_t* bucket;   // k-mer index (null until built)
+    const uint32_t* pos; const uint32_t* meta; const uint32_t* seed_pos_base; const uint32_t* contig_start;
+    uint64_t total_len;
+    uint32_t n;             // seeds, once the k-mer index exists (0 before)
+    uint32_t bshift, rows;  // bucket shift; rows of the chunk table a pair with this sketch as the query needs
+    uint32_t n_contigs;
+    float lenq[3];          // contig-length quantiles {q90, q50, q10}
+    uint32_t pad;
+};
+
 struct psk_sketch {
     psk_ctx* ctx = nullptr;
     psk_params params{};
@@ -223,6 +236,7 @@ struct psk_sketch {
     void len_quantiles(float out[3]) const {
         out[0] = out[1] = out[2] = 0.f;
         if (contig_len.empty()) return;
+        if (contig_len.size() == 1) { out[0] = out[1] = out[2] = (float)contig_len[0]; return; }
         std::vector<uint32_t> v(contig_len);
         std::sort(v.begin(), v.end());
         const size_t n = v.size();
@@ -258,6 +272,11 @@ struct psk_db {
     bool inv_dirty = true;
     Scratch inv_key, inv_ref, inv_tmp;
     uint64_t inv_n = 0;
+    // device table of SketchDesc, one per reference (refreshed when references are added or indexed)
+    bool desc_dirty = true;
+    uint64_t desc_indexed = 0; uint32_t desc_n = 0;
+    Scratch d_refdesc, d_canon;
+    std::vector<SketchDesc> h_refdesc;
 };
 
 // learned-ANI regression model: flattened trees in HBM
@@ -271,10 +290,9 @@ struct psk_model {
     std::vector<int32_t> features;   // psk_feature id of every position of the model's feature vector
     ~psk_model() { if (base) (void)hipFree(base); }
 };
-// per-pair inputs of the regression that the chain kernels do not produce
-struct PairStats { float lq[3], lr[3]; float ncq, ncr; };
-// hits[p].ani <- model(features of pair p) / 100 for every valid hit; launched on st after pair_reduce
-void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const PairStats* d_stats, const uint64_t* d_total_len /* [2p]=query,[2p+1]=ref */,
+// hits[p].ani <- model(features of pair p) / 100 for every valid hit; launched on st after pair_reduce.
+// pair_qr[p] = (index into qd, index into rd) of pair p.
+void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const uint2* pair_qr, const SketchDesc* qd, const SketchDesc* rd,
                           uint32_t n_pairs, hipStream_t st);
 
 // ---- shared device helpers ----
@@ -324,7 +342,8 @@ psk_status screen_impl(psk_db* db, const psk_sketch* query, double screen_val, i
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out);
-psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, double screen_val, int rescue_small,
-                            uint8_t* pass /* [n_queries][n_refs] */);
+// Database.query for n_queries sketches (lib.rs:569-659): hits of query i are all[offsets[i] .. offsets[i+1]), ref insertion order
+psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                           std::vector<psk_hit>& all, uint64_t* offsets);
 psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);

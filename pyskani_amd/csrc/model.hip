@@ -43,31 +43,31 @@ __global__ __launch_bounds__(256) void model_predict_kernel(ModelDev M, const fl
 }
 
 // one lane per hit: assemble the feature menu in LDS, evaluate, overwrite ani (kept in ani_raw)
-__global__ __launch_bounds__(128) void learned_ani_kernel(ModelDev M, psk_hit* __restrict__ hits, const PairStats* __restrict__ stats,
-                                                          const uint64_t* __restrict__ total_len, uint32_t n_pairs) {
+__global__ __launch_bounds__(128) void learned_ani_kernel(ModelDev M, psk_hit* __restrict__ hits, const uint2* __restrict__ pair_qr,
+                                                          const SketchDesc* __restrict__ qd, const SketchDesc* __restrict__ rd, uint32_t n_pairs) {
     __shared__ float s_f[128][PSK_F_COUNT + 1];
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     psk_hit h = hits[p];
     if (!(h.ani > 0.f)) return;            // invalid result (aligned fraction below the cut-off): left as it is
     float* f = s_f[threadIdx.x];
-    const PairStats st = stats[p];
+    const SketchDesc& Q = qd[pair_qr[p].x]; const SketchDesc& R = rd[pair_qr[p].y];
     f[PSK_F_ANI100] = h.ani_raw * 100.f; f[PSK_F_STD100] = h.ani_std * 100.f;
-    f[PSK_F_Q90_QUERY] = st.lq[0]; f[PSK_F_Q50_QUERY] = st.lq[1]; f[PSK_F_Q10_QUERY] = st.lq[2];
-    f[PSK_F_Q90_REF] = st.lr[0]; f[PSK_F_Q50_REF] = st.lr[1]; f[PSK_F_Q10_REF] = st.lr[2];
+    f[PSK_F_Q90_QUERY] = Q.lenq[0]; f[PSK_F_Q50_QUERY] = Q.lenq[1]; f[PSK_F_Q10_QUERY] = Q.lenq[2];
+    f[PSK_F_Q90_REF] = R.lenq[0]; f[PSK_F_Q50_REF] = R.lenq[1]; f[PSK_F_Q10_REF] = R.lenq[2];
     f[PSK_F_AVG_CHAIN_LEN] = h.n_intervals ? (float)h.covered_query / (float)h.n_intervals : 0.f;
     f[PSK_F_AF_QUERY] = h.af_query; f[PSK_F_AF_REF] = h.af_ref; f[PSK_F_N_CHUNKS] = (float)h.n_chunks;
-    f[PSK_F_TOTAL_LEN_QUERY] = (float)total_len[2 * (size_t)p]; f[PSK_F_TOTAL_LEN_REF] = (float)total_len[2 * (size_t)p + 1];
-    f[PSK_F_N_CONTIGS_QUERY] = st.ncq; f[PSK_F_N_CONTIGS_REF] = st.ncr;
+    f[PSK_F_TOTAL_LEN_QUERY] = (float)Q.total_len; f[PSK_F_TOTAL_LEN_REF] = (float)R.total_len;
+    f[PSK_F_N_CONTIGS_QUERY] = (float)Q.n_contigs; f[PSK_F_N_CONTIGS_REF] = (float)R.n_contigs;
     float pred = gbdt_eval(M, [&](const ModelNode& nd) { return f[nd.menu]; }) * 0.01f;
     pred = pred < 0.f ? 0.f : (pred > 1.f ? 1.f : pred);
     h.ani = pred; h.learned = 1;
     hits[p] = h;
 }
 
-void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const PairStats* d_stats, const uint64_t* d_total_len, uint32_t n_pairs, hipStream_t st) {
+void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const uint2* pair_qr, const SketchDesc* qd, const SketchDesc* rd, uint32_t n_pairs, hipStream_t st) {
     if (!m || !n_pairs) return;
-    hipLaunchKernelGGL(learned_ani_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, m->dev, d_hits, d_stats, d_total_len, n_pairs);
+    hipLaunchKernelGGL(learned_ani_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, m->dev, d_hits, pair_qr, qd, rd, n_pairs);
 }
 
 // ------------------------------------------------------------------ minimal JSON reader (objects, arrays, numbers, strings, literals)

@@ -8,6 +8,8 @@
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <algorithm>
+#include <deque>
+#include <unordered_map>
 
 // ------------------------------------------------------------------ screen
 static inline size_t al256s(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -188,7 +190,11 @@ static psk_status build_inverted(psk_db* db) {
     return PSK_OK;
 }
 
-psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small, uint8_t* pass) {
+// Screens nq queries against every reference of the db; the pass matrix [nq][n_refs] STAYS ON THE DEVICE (d_pass, caller-owned).
+// `keep` holds the host staging of the async uploads until the caller's next stream synchronisation.
+struct ScreenStaging { std::deque<std::vector<MarkerSet>> hq; std::deque<std::vector<uint32_t>> qoff; };
+static psk_status screen_many_device(psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small,
+                                     uint8_t* d_pass, ScreenStaging& keep) {
     psk_ctx* ctx = db->ctx;
     const uint32_t n = (uint32_t)db->refs.size();
     if (n == 0 || nq == 0) return PSK_OK;
@@ -200,11 +206,15 @@ psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32
     const bool use_inv = force ? !strcmp(force, "inv") : ((uint64_t)n * nq >= (1ull << 18));
     if (use_inv) PSK_TRY(build_inverted(db));
     const uint32_t per = std::max<uint32_t>(1, std::min<uint32_t>(65535, (use_inv ? (1u << 26) : (1u << 24)) / n));   // queries per launch
-    std::vector<MarkerSet> hq;
-    std::vector<uint32_t> qoff;
-    for (uint32_t b = 0; b < nq; b += per) {
+    // per sub-launch: query marker table + offsets (+ the count matrix of the inverted-index path), side by side in q_a
+    const size_t slot_bytes = al256s(sizeof(MarkerSet) * per) + al256s(4 * (size_t)(per + 1));
+    const uint32_t n_sub = (nq + per - 1) / per;
+    PSK_TRY(ctx->q_a.reserve(slot_bytes * n_sub + (use_inv ? 4 * (size_t)per * n : 0) + 512));
+    uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_a.p + al256s(slot_bytes * n_sub));
+    for (uint32_t b = 0, sub = 0; b < nq; b += per, sub++) {
         const uint32_t m = std::min(per, nq - b);
-        hq.resize(m); qoff.assign(m + 1, 0);
+        keep.hq.emplace_back(m); keep.qoff.emplace_back(m + 1, 0u);
+        std::vector<MarkerSet>& hq = keep.hq.back(); std::vector<uint32_t>& qoff = keep.qoff.back();
         uint64_t items = 0;
         for (uint32_t i = 0; i < m; i++) {
             const psk_sketch* q = queries[b + i];
@@ -213,12 +223,9 @@ psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32
         }
         qoff[m] = (uint32_t)items;
         if (items >= 0xFFFFFFF0ull) { psk_set_error("too many query markers in one screen launch"); return PSK_ELIMIT; }
-        const size_t o_q = 0, o_off = al256s(sizeof(MarkerSet) * m), o_pass = al256s(o_off + 4 * (size_t)(m + 1)),
-                     o_cnt = al256s(o_pass + (size_t)m * n), o_end = o_cnt + (use_inv ? 4 * (size_t)m * n : 0);
-        PSK_TRY(ctx->q_a.reserve(o_end + 256));
-        char* Bq = (char*)ctx->q_a.p;
-        MarkerSet* d_q = (MarkerSet*)(Bq + o_q); uint32_t* d_qoff = (uint32_t*)(Bq + o_off);
-        uint8_t* d_pass = (uint8_t*)(Bq + o_pass); uint32_t* d_cnt = (uint32_t*)(Bq + o_cnt);
+        char* Bq = (char*)ctx->q_a.p + slot_bytes * sub;
+        MarkerSet* d_q = (MarkerSet*)Bq; uint32_t* d_qoff = (uint32_t*)(Bq + al256s(sizeof(MarkerSet) * per));
+        uint8_t* pass_b = d_pass + (size_t)b * n;
         PSK_HIP(hipMemcpyAsync(d_q, hq.data(), sizeof(MarkerSet) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SCREEN);
         if (use_inv) {
@@ -228,13 +235,11 @@ psk_status screen_many_impl(psk_db* db, const psk_sketch* const* queries, uint32
                 hipLaunchKernelGGL(inv_lookup_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, st, d_q, d_qoff, m, (uint32_t)items,
                                    (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (uint32_t)db->inv_n, n, d_cnt);
             const size_t cells = (size_t)m * n;
-            hipLaunchKernelGGL(inv_decide_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, m, d_cnt, thresh, rescue_small, d_pass);
+            hipLaunchKernelGGL(inv_decide_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, m, d_cnt, thresh, rescue_small, pass_b);
         } else {
-            hipLaunchKernelGGL(screen_many_kernel, dim3(n, m), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, thresh, rescue_small, d_pass);
+            hipLaunchKernelGGL(screen_many_kernel, dim3(n, m), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, thresh, rescue_small, pass_b);
         }
         ctx->t_end();
-        PSK_HIP(hipMemcpyAsync(pass + (size_t)b * n, d_pass, (size_t)m * n, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipStreamSynchronize(st));
     }
     return PSK_OK;
 }
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
                                                           const uint2* __restrict__ lbcnt,
                                                           const uint32_t* __restrict__ aoff,
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
-                                                          uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm) {
+                                                          uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err) {
     const uint32_t lb = xcd_block_id();
     uint32_t i = lb * blockDim.x + threadIdx.x;
     const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
     const PairDesc& P = pairs[p];
     const uint32_t j0 = i - sbase[p];
     uint32_t l = lc.x, dst = aoff[i];
+    if ((uint64_t)dst + c > cap) { atomicOr(err, 2u); return; }   // beyond the optimistic capacity: the host reruns the batch with the true total
     uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
     for (uint32_t j = 0; j < c; j++) {
         uint64_t pm = P.r_pms[l + j];        // (pos, meta) of the ref seed, stored in index order
@@ -358,9 +364,9 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
 }
 
 // pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
-__global__ void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart) {
+__global__ void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= n_pairs) pstart[p] = aoff[sbase[p]];
+    if (p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = a < cap ? a : cap; }   // inside the (optimistically sized) anchor arrays whatever the counts were
 }
 
 // Chunk table of one pair, one wave per pair. A chunk starts at anchor h and ends before the first anchor b of the
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
     const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
     const uint32_t pend = pstart[p + 1];
     uint32_t h = pstart[p], n = 0;
+    if (pend - h < MIN_ANCHORS) { if (lane == 0) n_chunks[p] = 0; return; }   // no chain can form (>= MIN_ANCHORS anchors): no chunk table, every later kernel skips the pair
     uint32_t w0 = h, wn = 0;
     auto load_window = [&](uint32_t from) {
         lds_wave_sync();
@@ -408,9 +415,9 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
 // nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
 __global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
                                                           const uint32_t* __restrict__ pstart, uint32_t n_pairs,
-                                                          uint32_t total, uint32_t* __restrict__ nxt) {
+                                                          uint32_t* __restrict__ nxt) {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= total) return;
+    if (a >= pstart[n_pairs]) return;      // the grid covers the capacity, the device knows the total
     const uint32_t p = find_le(pstart, n_pairs, a);
     uint32_t pend = pstart[p + 1];
     uint64_t key = ((uint64_t)a_qc[a] << 32) + (uint64_t)a_qp[a] + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(64) void chunk_hops_kernel(const uint32_t* __restri
     const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
     const uint32_t pend = pstart[p + 1];
     uint32_t h = pstart[p], n = 0;
+    if (pend - h < MIN_ANCHORS) { if (lane == 0) n_chunks[p] = 0; return; }   // as in chunk_heads_kernel
     while (h < pend) {
         const uint32_t w0 = h, wn = pend - w0 < (uint32_t)HOP_WIN ? pend - w0 : (uint32_t)HOP_WIN;
         for (uint32_t i = lane; i < wn; i += 64) s_win[i] = nxt[w0 + i];
@@ -1272,6 +1280,7 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
 struct ReduceArgs {
     const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
     const uint32_t* pstart; const PairDesc* pairs;
+    const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
     int k, median, robust; double min_af;
     psk_hit* hits;
     double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
@@ -1284,6 +1293,16 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     __shared__ unsigned long long s_acc[5];
     const uint32_t p = blockIdx.x;
     const uint32_t nc = R.n_chunks[p];
+    if (nc == 0) {   // no chunk table: fewer than MIN_ANCHORS anchors (every rescued short contig against an unrelated reference)
+        if (threadIdx.x == 0) {
+            psk_hit h{};
+            h.ani = -1.0f; h.ani_raw = -1.0f;
+            h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            R.hits[p] = h;
+        }
+        return;
+    }
     const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
     if (threadIdx.x == 0) { s_n = 0; for (int i = 0; i < 5; i++) s_acc[i] = 0; }
     __syncthreads();
@@ -1381,7 +1400,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
     const double std_all = m > 1 ? sqrt(ssq / (double)(m - 1)) : 0.0;
     mean_serial = mean_all;
     if (threadIdx.x == 0) {
-        h.ref_index = p;
+        h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
         h.n_anchors = R.pstart[p + 1] - R.pstart[p];
         h.covered_query = s_acc[0]; h.covered_ref = s_acc[1]; h.sum_chain_anchors = s_acc[2]; h.sum_chunk_seeds = s_acc[3];
@@ -1409,8 +1428,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
             double afq = (double)s_acc[0] / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
             double afr = (double)s_acc[0] / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;   // one covered-bases count serves both
             h.af_query = (float)afq; h.af_ref = (float)afr;
-            if (!ok) h.ani = -2.0f;
-            else if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
+            if (ok && (afq >= R.min_af || afr >= R.min_af)) h.ani = (float)ani;
             h.ani_raw = h.ani; h.ani_std = (float)std_all;
         }
         R.hits[p] = h;
@@ -1420,91 +1438,145 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
 // ------------------------------------------------------------------ host orchestration
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct HostPair { const psk_sketch* r; const psk_sketch* q; };
+static SketchDesc make_desc(const psk_sketch* s) {
+    SketchDesc d{};
+    const bool ix = s->idx != nullptr;
+    d.key = ix ? s->idx->km32 + s->idx_off : nullptr; d.pms = ix ? s->idx->pms + s->idx_off : nullptr;
+    d.perm = ix ? s->idx->perm + s->idx_off : nullptr; d.bucket = ix ? s->idx->bucket + s->idx_boff : nullptr;
+    d.bshift = ix ? s->idx_bshift : 0; d.n = ix ? (uint32_t)s->n_seeds : 0;
+    d.pos = s->store ? s->store->seed_pos + s->seed_off : nullptr; d.meta = s->store ? s->store->seed_meta + s->seed_off : nullptr;
+    d.seed_pos_base = s->store ? s->store->seed_pos : nullptr;
+    d.contig_start = s->store ? s->store->contig_seed_start + s->contig_off : nullptr;
+    d.total_len = s->total_len; d.n_contigs = (uint32_t)s->contig_len.size();
+    uint64_t rows = 0;      // chunk heads on one contig are more than FRAGMENT_LENGTH apart
+    if (d.n) for (uint32_t len : s->contig_len) rows += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
+    d.rows = (uint32_t)std::min<uint64_t>(rows, 0xFFFFFFFFu);
+    s->len_quantiles(d.lenq);
+    return d;
+}
 
-// one launch sequence over n_pairs (ref, query) pairs; out[p] in pair order
-static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs, const psk_query_opts* o, psk_hit* out) {
-    hipStream_t st = ctx->stream;
-    const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
-    std::vector<PairDesc> h_pairs(n_pairs);
-    std::vector<uint32_t> h_sbase(n_pairs + 1), h_cbase(n_pairs + 1);
-    uint64_t items = 0, rows = 0;
-    for (uint32_t p = 0; p < n_pairs; p++) {
-        const psk_sketch* r = hp[p].r; const psk_sketch* q = hp[p].q;
-        PairDesc& P = h_pairs[p];
-        P.r_key = r->idx ? r->idx->km32 + r->idx_off : nullptr;
-        P.r_pms = r->idx ? r->idx->pms + r->idx_off : nullptr;
-        P.r_n = r->idx ? (uint32_t)r->n_seeds : 0;
-        P.r_bucket = r->idx ? r->idx->bucket + r->idx_boff : nullptr; P.r_bshift = r->idx ? r->idx_bshift : 0;
-        P.q_n = q->idx ? (uint32_t)q->n_seeds : 0;
-        P.q_key = q->idx ? q->idx->km32 + q->idx_off : nullptr;
-        P.q_perm = q->idx ? q->idx->perm + q->idx_off : nullptr;
-        P.q_pos = q->store ? q->store->seed_pos + q->seed_off : nullptr;
-        P.q_meta = q->store ? q->store->seed_meta + q->seed_off : nullptr;
-        P.q_seed_pos_base = q->store ? q->store->seed_pos : nullptr;
-        P.q_contig_start = q->store ? q->store->contig_seed_start + q->contig_off : nullptr;
-        P.q_total_len = q->total_len; P.r_total_len = r->total_len;
-        h_sbase[p] = (uint32_t)items; h_cbase[p] = (uint32_t)rows;
-        items += P.q_n;
-        // chunk heads on one contig are more than FRAGMENT_LENGTH apart
-        uint64_t mc = 0;
-        if (P.q_n && P.r_n) for (uint32_t len : q->contig_len) mc += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
-        rows += mc;
+__device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
+    PairDesc P;
+    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
+    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta;
+    P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
+    P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
+    return P;
+}
+
+// pairs from an explicit (query desc, ref desc) index list; sbase / cbase come from the host
+__global__ __launch_bounds__(256) void pair_build_list_kernel(const uint2* __restrict__ qr, const SketchDesc* __restrict__ qd, const SketchDesc* __restrict__ rd,
+                                                              uint32_t n_pairs, PairDesc* __restrict__ pairs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pairs) pairs[p] = combine_desc(qd[qr[p].x], rd[qr[p].y]);
+}
+
+// Device-side shortlist: one workgroup per batch entry walks its query's row of the pass matrix and turns the passing
+// references with rank in [rank_lo, rank_hi) into pairs. Every pair of one query has the same item and row count, so the
+// item / row offsets follow from the rank: no scan, no pass[] on the host (lib.rs:617-637 + 640-645 in one kernel).
+struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
+__global__ __launch_bounds__(256) void pair_build_rows_kernel(const BatchQ* __restrict__ bq, const uint8_t* __restrict__ pass, uint32_t n_refs,
+                                                              const SketchDesc* __restrict__ qd, const SketchDesc* __restrict__ rd,
+                                                              PairDesc* __restrict__ pairs, uint32_t* __restrict__ sbase, uint32_t* __restrict__ cbase,
+                                                              uint2* __restrict__ pair_qr, uint32_t n_pairs, uint32_t n_items, uint32_t n_rows) {
+    __shared__ uint32_t s_w[4];
+    const BatchQ B = bq[blockIdx.x];
+    const SketchDesc Q = qd[B.q];
+    const uint8_t* __restrict__ row = pass + (size_t)B.q * n_refs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < n_refs && running < B.rank_hi; base += 256) {
+        const uint32_t r = base + threadIdx.x;
+        const bool f = r < n_refs && row[r];
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += s_w[w];
+        const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const uint32_t rank = running + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1));
+        if (f && rank >= B.rank_lo && rank < B.rank_hi) {
+            const uint32_t j = rank - B.rank_lo, slot = B.pair_off + j;
+            pairs[slot] = combine_desc(Q, rd[r]);
+            sbase[slot] = B.item_off + j * Q.n; cbase[slot] = B.row_off + j * Q.rows;
+            pair_qr[slot] = make_uint2(B.q, r);
+        }
+        running += tot;
+        __syncthreads();
     }
-    h_sbase[n_pairs] = (uint32_t)items; h_cbase[n_pairs] = (uint32_t)rows;
-    if (items == 0 || rows == 0) {
-        for (uint32_t p = 0; p < n_pairs; p++) { out[p] = psk_hit{}; out[p].ani = -1.0f; }
-        return PSK_OK;
-    }
-    const size_t n_items = (size_t)items, n_rows = (size_t)rows;
-    size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (size_t)(n_pairs + 1)),
-           o_pstart = al256(o_cbase + 4 * (size_t)(n_pairs + 1)), o_lb = al256(o_pstart + 4 * (size_t)(n_pairs + 1)),
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { sbase[n_pairs] = n_items; cbase[n_pairs] = n_rows; }
+}
+
+// rows of the pass matrix: per-query pass counts and per-reference "passed somewhere" flags (what the host needs to plan batches
+// and to index the references that will be chained); with duplicate names, a passing entry first moves to the name's last sketch
+__global__ __launch_bounds__(256) void pass_canon_kernel(uint8_t* __restrict__ pass, uint32_t n_refs, const uint32_t* __restrict__ canon) {
+    uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (row[r] && canon[r] != r) { row[canon[r]] = 1; row[r] = 0; }   // canon[r] > r and canon[canon[r]] == canon[r]
+}
+__global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restrict__ pass, uint32_t n_refs, uint32_t* __restrict__ row_count, uint8_t* __restrict__ col_flag) {
+    __shared__ uint32_t s_c[4];
+    const uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
+    uint32_t c = 0;
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (row[r]) { c++; col_flag[r] = 1; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const { return h.ani > 0.1f; } };   // lib.rs:654
+
+// device arrays of one chain launch sequence, carved from ctx->q_b
+struct ChainBufs {
+    PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
+    psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
+    uint32_t gi;
+};
+static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
+    const size_t gi = (n_items + 255) / 256;
+    size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (n_pairs + 1)),
+           o_pstart = al256(o_cbase + 4 * (n_pairs + 1)), o_lb = al256(o_pstart + 4 * (n_pairs + 1)),
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
-           o_chunks = al256(o_nch + 4 * (size_t)n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
-           o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_misc = al256(o_hits + sizeof(psk_hit) * n_pairs),
-           o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows), o_end = o_bsum + 8 * ((n_items + 255) / 256 + 1);
+           o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
+           o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
+           o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows),
+           o_qr = al256(o_bsum + 8 * (gi + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_end = o_bq + sizeof(BatchQ) * (n_bq + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
-    PairDesc* d_pairs = (PairDesc*)(B + o_pairs); uint32_t* d_sbase = (uint32_t*)(B + o_sbase); uint32_t* d_cbase = (uint32_t*)(B + o_cbase);
-    uint32_t* d_pstart = (uint32_t*)(B + o_pstart);
-    uint2* d_lbcnt = (uint2*)(B + o_lb); uint32_t* d_aoff = (uint32_t*)(B + o_aoff);   // o_lb..o_aoff: (lower bound, count) per item, +1 zero entry
-    uint32_t* d_nch = (uint32_t*)(B + o_nch); uint2* d_chunks = (uint2*)(B + o_chunks); ChunkOut* d_cout = (ChunkOut*)(B + o_cout);
-    psk_hit* d_hits = (psk_hit*)(B + o_hits); uint32_t* d_misc = (uint32_t*)(B + o_misc);   // [0] err, [1..4] stats, [8] overflow-list length
-    uint32_t* d_ovf = (uint32_t*)(B + o_ovf);
-    unsigned long long* d_bsum = (unsigned long long*)(B + o_bsum);
-    PSK_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, st));
-    PSK_HIP(hipMemcpyAsync(d_sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
-    PSK_HIP(hipMemcpyAsync(d_cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
-    PSK_HIP(hipMemsetAsync(d_misc, 0, 64, st));
-    PSK_HIP(hipMemsetAsync(d_lbcnt + n_items, 0, 8, st));
-    const uint32_t gi = (uint32_t)((n_items + 255) / 256);
+    L->pairs = (PairDesc*)(B + o_pairs); L->sbase = (uint32_t*)(B + o_sbase); L->cbase = (uint32_t*)(B + o_cbase); L->pstart = (uint32_t*)(B + o_pstart);
+    L->lbcnt = (uint2*)(B + o_lb); L->aoff = (uint32_t*)(B + o_aoff); L->nch = (uint32_t*)(B + o_nch); L->chunks = (uint2*)(B + o_chunks);
+    L->cout = (ChunkOut*)(B + o_cout); L->hits = (psk_hit*)(B + o_hits); L->hits_sel = (psk_hit*)(B + o_sel); L->misc = (uint32_t*)(B + o_misc);
+    L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
+    L->gi = (uint32_t)gi;
+    return PSK_OK;
+}
+
+// Everything between "pairs / sbase / cbase are on the device" and "hits are on the device": no host synchronisation.
+// Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
+// reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
+static psk_status chain_run(psk_ctx* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
+                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap) {
+    hipStream_t st = ctx->stream;
+    const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
+    PSK_HIP(hipMemsetAsync(L.misc, 0, 64, st));
+    PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
+    const uint32_t gi = L.gi;
     ctx->t_begin(K_ANCHOR);
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_bsum);
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum);
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
-    hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(d_lbcnt, CountOf());
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, d_bsum, d_bsum + gi, (int)gi, st));
-    PSK_TRY(ctx->q_c.reserve(std::max(tmp, tmp2)));
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, d_aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, d_bsum, d_bsum + gi, (int)gi, st));      // 64-bit total, beside the 32-bit offsets
-    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, d_aoff, d_sbase, n_pairs, d_pstart);
-    void* hpin;
-    PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 256, &hpin));
-    uint32_t* h_small = (uint32_t*)hpin;
-    PSK_HIP(hipMemcpyAsync(h_small, d_aoff + n_items, 4, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipMemcpyAsync(h_small + 2, d_bsum + gi, 8, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipStreamSynchronize(st));   // also keeps h_pairs/h_sbase/h_cbase alive until copied
-    const uint32_t total = h_small[0];
-    {
-        unsigned long long total64; memcpy(&total64, h_small + 2, 8);
-        if (total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
-            psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
-            return PSK_ELIMIT;
-        }
-    }
+    hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
+    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.bsum + gi, (int)gi, st));
+    size_t tmp3 = 0;
+    PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
+    PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
+    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
+    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)gi, st));      // 64-bit total, beside the 32-bit offsets
+    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
-    const size_t na = ((size_t)total + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
+    const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
     PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 8 + 1) + 64));   // select_big_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
@@ -1515,20 +1587,18 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
     A.c_state = a_nxt;   // spare per-anchor array
     A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
-    A.chunks = d_chunks; A.n_chunks = d_nch; A.cbase = d_cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
-    A.pairs = d_pairs;
-    A.out = d_cout; A.two_c = 2u * (uint32_t)hp[0].q->params.c; A.force_serial = force_serial; A.stats = d_misc + 1;
-    A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)hp[0].q->params.c));
-    if (total > 0) {
-        hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, d_pairs, d_sbase, n_pairs, (uint32_t)n_items, d_lbcnt, d_aoff, a_qp, a_qc, a_rp, a_rm);
-    }
+    A.chunks = L.chunks; A.n_chunks = L.nch; A.cbase = L.cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
+    A.pairs = L.pairs;
+    A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
+    A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
+    hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
-    if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || total / n_pairs > (1u << 20))) {
-        hipLaunchKernelGGL(anchor_next_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a_qp, a_qc, d_pstart, n_pairs, total, a_nxt);
-        hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_nxt, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+    if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
+        hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, a_qp, a_qc, L.pstart, n_pairs, a_nxt);
+        hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else
-        hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, d_pstart, a_qp, a_qc, d_cbase, n_pairs, d_chunks, d_nch, d_misc);
+        hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_qp, a_qc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
@@ -1539,7 +1609,7 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
             while (rpw > 16 && n_rows / rpw < 512) rpw >>= 1;
             if (le && atoi(le) >= 8) rpw = (uint32_t)std::min(64, atoi(le));
             const uint32_t waves = (uint32_t)((n_rows + rpw - 1) / rpw);
-            A.ovf_list = d_ovf; A.ovf_count = d_misc + 8;      // d_misc was zeroed above
+            A.ovf_list = L.ovf; A.ovf_count = L.misc + 8;      // misc was zeroed above
             const bool quad = le && le[0] == 'q' ? true : (le && atoi(le) >= 8 ? false : n_rows < 32 * 1024);
             if (quad) {   // small launch: four lanes per chunk, 16 chunks per wave
                 const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
@@ -1555,15 +1625,15 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
     SelArgs SA{};
-    SA.chunks = d_chunks; SA.n_chunks = d_nch; SA.cbase = d_cbase; SA.n_pairs = n_pairs;
+    SA.chunks = L.chunks; SA.n_chunks = L.nch; SA.cbase = L.cbase; SA.n_pairs = n_pairs;
     SA.c_score = A.c_score; SA.c_q0 = A.c_q0; SA.c_q1 = A.c_q1; SA.c_r0 = A.c_r0; SA.c_r1 = A.c_r1; SA.c_n = A.c_n; SA.c_rc = A.c_rc; SA.c_state = A.c_state;
-    SA.out = d_cout; SA.two_c = A.two_c; SA.force_serial = force_serial; SA.stats = d_misc + 1;
+    SA.out = L.cout; SA.two_c = A.two_c; SA.force_serial = force_serial; SA.stats = L.misc + 1;
     ctx->t_begin(K_SELECT);
     hipLaunchKernelGGL(select_kernel, dim3(n_pairs), dim3(64), 0, st, SA);
     {   // pairs whose candidates do not fit the LDS kernel (large genomes); workgroups of small pairs exit at once
         if (!force_serial) {
             BigArgs BA{};
-            BA.S = SA; BA.pstart = d_pstart;
+            BA.S = SA; BA.pstart = L.pstart;
             char* E = (char*)ctx->q_e.p;
             BA.key = (unsigned long long*)E; uint32_t* U = (uint32_t*)(E + 8 * na);
             BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na; BA.kept = U + 7 * na;
@@ -1574,9 +1644,9 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     ctx->t_end();
     hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
-    R.chunks = d_cout; R.n_chunks = d_nch; R.cbase = d_cbase; R.pstart = d_pstart; R.pairs = d_pairs;
-    R.k = hp[0].q->params.k; R.median = o->median; R.robust = o->robust;
-    R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = d_hits;
+    R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
+    R.k = prm.k; R.median = o->median; R.robust = o->robust;
+    R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = L.hits;
     if (o->median || o->robust) {
         PSK_TRY(ctx->q_f.reserve(sizeof(double) * (2 * n_rows + 1024 * (size_t)n_pairs + 1024)));
         R.big_vals = (double*)ctx->q_f.p;
@@ -1585,30 +1655,79 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
     ctx->t_end();
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
-    const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && hp[0].q->params.c >= 70 && !o->median));
-    std::vector<PairStats> h_stats; std::vector<uint64_t> h_tl;
-    if (learned) {
-        h_stats.resize(n_pairs); h_tl.resize(2 * (size_t)n_pairs);
-        for (uint32_t p = 0; p < n_pairs; p++) {
-            hp[p].q->len_quantiles(h_stats[p].lq); hp[p].r->len_quantiles(h_stats[p].lr);
-            h_stats[p].ncq = (float)hp[p].q->contig_len.size(); h_stats[p].ncr = (float)hp[p].r->contig_len.size();
-            h_tl[2 * (size_t)p] = hp[p].q->total_len; h_tl[2 * (size_t)p + 1] = hp[p].r->total_len;
-        }
-        const size_t sb = al256(sizeof(PairStats) * n_pairs);
-        PSK_TRY(ctx->q_h.reserve(sb + 16 * (size_t)n_pairs + 256));
-        PSK_HIP(hipMemcpyAsync(ctx->q_h.p, h_stats.data(), sizeof(PairStats) * n_pairs, hipMemcpyHostToDevice, st));
-        PSK_HIP(hipMemcpyAsync((char*)ctx->q_h.p + sb, h_tl.data(), 16 * (size_t)n_pairs, hipMemcpyHostToDevice, st));
-        learned_apply_launch(o->model, d_hits, (const PairStats*)ctx->q_h.p, (const uint64_t*)((char*)ctx->q_h.p + sb), n_pairs, st);
+    const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
+    if (learned) learned_apply_launch(o->model, L.hits, L.pair_qr, d_qd, d_rd, n_pairs, st);
+    return PSK_OK;
+}
+
+static uint64_t anchor_cap_for(psk_ctx* ctx, size_t n_items) {
+    const uint64_t have = ctx->q_d.cap / 64 > 128 ? ctx->q_d.cap / 64 - 128 : 0;     // anchors the per-anchor arrays already hold
+    const uint64_t want = (uint64_t)n_items + n_items / 4 + 65536;                  // non-repetitive genomes: at most ~one anchor per query seed
+    return std::min<uint64_t>(std::max(have, want), 0x7FFFFF00ull);
+}
+
+// outcome of a launch sequence, read back with the hits
+struct ChainTail { uint32_t misc[16]; unsigned long long total64; };
+static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* retry) {
+    *retry = false;
+    if (T.total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
+        psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, T.total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
+        return PSK_ELIMIT;
     }
-    psk_hit* h_hits = (psk_hit*)((char*)hpin + 256);
-    PSK_HIP(hipMemcpyAsync(h_hits, d_hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipMemcpyAsync(h_small, d_misc, 16, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipStreamSynchronize(st));
-    if (h_small[0]) { psk_set_error("internal: chunk table overflow"); return PSK_EHIP; }
+    if (T.total64 > *cap) { *cap = std::min<uint64_t>(T.total64 + T.total64 / 8 + 65536, 0x7FFFFF00ull); *retry = true; return PSK_OK; }
+    if (T.misc[0] & 1u) { psk_set_error("internal: chunk table overflow"); return PSK_EHIP; }
+    return PSK_OK;
+}
+
+struct HostPair { const psk_sketch* r; const psk_sketch* q; };
+
+// one launch sequence over an explicit list of (ref, query) pairs; out[p] in pair order
+static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs, const psk_query_opts* o, psk_hit* out) {
+    hipStream_t st = ctx->stream;
+    // descriptor table: one entry per distinct sketch
+    std::unordered_map<const psk_sketch*, uint32_t> slot;
+    std::vector<SketchDesc> descs;
+    std::vector<uint2> qr(n_pairs);
+    std::vector<uint32_t> h_sbase(n_pairs + 1), h_cbase(n_pairs + 1);
+    uint64_t items = 0, rows = 0;
+    auto desc_of = [&](const psk_sketch* s) { auto it = slot.find(s); if (it != slot.end()) return it->second; uint32_t i = (uint32_t)descs.size(); slot.emplace(s, i); descs.push_back(make_desc(s)); return i; };
     for (uint32_t p = 0; p < n_pairs; p++) {
-        out[p] = h_hits[p];
-        if (out[p].ani == -2.0f) { psk_set_error("median/robust ANI needs <= %d chunks per pair (genome too long)", RED_CAP); return PSK_ELIMIT; }
+        const uint32_t qi = desc_of(hp[p].q), ri = desc_of(hp[p].r);
+        qr[p] = make_uint2(qi, ri);
+        h_sbase[p] = (uint32_t)items; h_cbase[p] = (uint32_t)rows;
+        items += descs[qi].n; rows += descs[qi].rows;
     }
+    h_sbase[n_pairs] = (uint32_t)items; h_cbase[n_pairs] = (uint32_t)rows;
+    if (items == 0 || rows == 0) {
+        for (uint32_t p = 0; p < n_pairs; p++) { out[p] = psk_hit{}; out[p].ani = -1.0f; out[p].ani_raw = -1.0f; }
+        return PSK_OK;
+    }
+    if (items >= 0xFFFFFF00ull || rows >= 0xFFFFFF00ull) { psk_set_error("batch of %u pairs exceeds the per-launch limits", n_pairs); return PSK_ELIMIT; }
+    ChainBufs L;
+    PSK_TRY(chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, 0, &L));
+    PSK_TRY(ctx->q_h.reserve(al256(sizeof(SketchDesc) * descs.size()) + 256));
+    SketchDesc* d_desc = (SketchDesc*)ctx->q_h.p;
+    PSK_HIP(hipMemcpyAsync(d_desc, descs.data(), sizeof(SketchDesc) * descs.size(), hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(L.pair_qr, qr.data(), 8 * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(L.sbase, h_sbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
+    PSK_HIP(hipMemcpyAsync(L.cbase, h_cbase.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pair_build_list_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, L.pair_qr, d_desc, d_desc, n_pairs, L.pairs);
+    void* hpin;
+    PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 512, &hpin));
+    ChainTail* T = (ChainTail*)hpin; psk_hit* h_hits = (psk_hit*)((char*)hpin + 256);
+    uint64_t cap = anchor_cap_for(ctx, (size_t)items);
+    for (int attempt = 0;; attempt++) {
+        PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, hp[0].q->params, o, d_desc, d_desc, cap));
+        PSK_HIP(hipMemcpyAsync(h_hits, L.hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a launch sequence (also keeps the host staging above alive)
+        bool retry;
+        PSK_TRY(chain_check(*T, n_pairs, &cap, &retry));
+        if (!retry) break;
+        if (attempt >= 2) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+    }
+    for (uint32_t p = 0; p < n_pairs; p++) { out[p] = h_hits[p]; out[p].reserved = 0; }
     return PSK_OK;
 }
 
@@ -1630,7 +1749,7 @@ psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const p
         PSK_TRY(ensure_index(ctx, all.data(), (uint32_t)all.size()));
     }
     // bound one launch: lb/cnt/aoff cost 12 B per (pair, query seed); anchors ~64 B each
-    const uint64_t MAX_ITEMS = 1ull << 27; const uint32_t MAX_PAIRS = 4096;
+    const uint64_t MAX_ITEMS = 1ull << 27; const uint32_t MAX_PAIRS = 1u << 18;
     std::vector<HostPair> hp;
     uint32_t b = 0;
     while (b < n) {
@@ -1662,5 +1781,163 @@ psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_re
     std::vector<const psk_sketch*> qs(n_refs, q);
     PSK_TRY(chain_pairs_impl(ctx, refs, qs.data(), n_refs, o, out));
     for (uint32_t i = 0; i < n_refs; i++) out[i].ref_index = i;
+    return PSK_OK;
+}
+
+// ------------------------------------------------------------------ Database.query / query_many (lib.rs:569-659)
+// n_queries x (screen every reference, chain the shortlist, keep ani > 0.1). The pass matrix, the shortlist, the pair
+// table and the ani > 0.1 filter all stay on the device; the host sees, per round, the per-query pass counts and the
+// per-reference flags (ONE synchronisation: it sizes the batches and indexes the references about to be chained), and per
+// batch of up to 2^20 pairs the surviving hits (ONE synchronisation).
+static psk_status refresh_ref_descs(psk_db* db) {
+    psk_ctx* ctx = db->ctx;
+    const uint32_t n = (uint32_t)db->refs.size();
+    uint64_t indexed = 0;
+    for (const psk_sketch* r : db->refs) indexed += r->idx != nullptr;
+    if (!db->desc_dirty && db->desc_indexed == indexed && db->desc_n == n) return PSK_OK;
+    std::vector<SketchDesc>& h = db->h_refdesc;     // stays alive until the copy has drained (every query ends with a synchronisation)
+    h.resize(n);
+    for (uint32_t i = 0; i < n; i++) h[i] = make_desc(db->refs[i]);
+    PSK_TRY(db->d_refdesc.reserve(sizeof(SketchDesc) * (size_t)n + 256));
+    PSK_HIP(hipMemcpyAsync(db->d_refdesc.p, h.data(), sizeof(SketchDesc) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    db->desc_dirty = false; db->desc_indexed = indexed; db->desc_n = n;
+    return PSK_OK;
+}
+
+psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                           std::vector<psk_hit>& all, uint64_t* offsets) {
+    psk_ctx* ctx = db->ctx;
+    hipStream_t st = ctx->stream;
+    offsets[0] = 0;
+    if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
+    if (o->model && o->model->ctx != ctx) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
+    const uint32_t n = (uint32_t)db->refs.size();
+    for (uint32_t i = 0; i < n_queries; i++) if (!queries[i]) { psk_set_error("query_many: NULL query %u", i); return PSK_EINVAL; }
+    if (n == 0) { for (uint32_t i = 0; i < n_queries; i++) offsets[i + 1] = 0; return PSK_OK; }
+    const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
+    const uint32_t QB = std::max<uint32_t>(1, std::min<uint32_t>(16384, (uint32_t)((1ull << 30) / n)));   // queries per round (pass matrix <= 1 GiB)
+    if (db->has_dups) {
+        PSK_TRY(db->d_canon.reserve(4 * (size_t)n));
+        PSK_HIP(hipMemcpyAsync(db->d_canon.p, db->canon.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+        PSK_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<uint32_t> h_cnt; std::vector<uint8_t> h_flag;
+    std::vector<SketchDesc> h_qd;
+    std::vector<BatchQ> bqs;
+    for (uint32_t b = 0; b < n_queries; b += QB) {
+        const uint32_t m = std::min(QB, n_queries - b);
+        // ---- screen: pass matrix on the device, counts + flags to the host
+        const size_t o_pass = 0, o_cnt = al256((size_t)m * n), o_flag = al256(o_cnt + 4 * (size_t)m), o_end = o_flag + n;
+        PSK_TRY(ctx->q_i.reserve(o_end + 256));
+        uint8_t* d_pass = (uint8_t*)ctx->q_i.p + o_pass; uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_i.p + o_cnt); uint8_t* d_flag = (uint8_t*)ctx->q_i.p + o_flag;
+        ScreenStaging keep;
+        PSK_TRY(screen_many_device(db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
+        if (db->has_dups) hipLaunchKernelGGL(pass_canon_kernel, dim3(m), dim3(256), 0, st, d_pass, n, (const uint32_t*)db->d_canon.p);
+        PSK_HIP(hipMemsetAsync(d_flag, 0, n, st));
+        hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag);
+        void* hpin;
+        PSK_TRY(ctx->pinned(4 * (size_t)m + n + 64, &hpin));
+        PSK_HIP(hipMemcpyAsync(hpin, d_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipMemcpyAsync((char*)hpin + 4 * (size_t)m, d_flag, n, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipStreamSynchronize(st));
+        h_cnt.assign((uint32_t*)hpin, (uint32_t*)hpin + m);
+        h_flag.assign((uint8_t*)hpin + 4 * (size_t)m, (uint8_t*)hpin + 4 * (size_t)m + n);
+        // ---- the references and queries about to be chained: validate, index, describe
+        std::vector<const psk_sketch*> need;
+        for (uint32_t r = 0; r < n; r++) if (h_flag[r]) {
+            const psk_sketch* rs = db->refs[r];
+            if (!rs->has_seeds) { psk_set_error("reference %u ('%s') was sketched with seed=False; it cannot be chained", r, db->names[r].c_str()); return PSK_EINVAL; }
+            need.push_back(rs);
+        }
+        uint64_t round_pairs = 0;
+        for (uint32_t i = 0; i < m; i++) if (h_cnt[i]) {
+            const psk_sketch* q = queries[b + i];
+            if (!q->has_seeds) { psk_set_error("query sketch was built with seed=False; it cannot be chained"); return PSK_EINVAL; }
+            if (q->params.k != db->params.k || q->params.c != db->params.c) { psk_set_error("query %u and the database were sketched with different parameters", b + i); return PSK_EINVAL; }
+            need.push_back(q);
+            round_pairs += h_cnt[i];
+        }
+        for (const psk_sketch* rs : need) if (rs->params.k != db->params.k || rs->params.c != db->params.c) { psk_set_error("a reference and the database were sketched with different parameters"); return PSK_EINVAL; }
+        if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
+        PSK_TRY(ensure_index(ctx, need.data(), (uint32_t)need.size()));
+        PSK_TRY(refresh_ref_descs(db));
+        h_qd.resize(m);
+        for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
+        PSK_TRY(ctx->q_h.reserve(sizeof(SketchDesc) * (size_t)m + 256));
+        SketchDesc* d_qd = (SketchDesc*)ctx->q_h.p;
+        PSK_HIP(hipMemcpyAsync(d_qd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
+        // ---- batches: consecutive (query, rank range) entries under the per-launch limits
+        uint64_t max_items = 1ull << 27, max_pairs = 1ull << 20, max_rows = 1ull << 26;
+        uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
+        std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
+        while (qi < m) {
+            if (rank >= h_cnt[qi]) { qi++; rank = 0; continue; }
+            // plan one batch from (qi, rank)
+            bqs.clear();
+            uint64_t pairs = 0, items = 0, rows = 0;
+            uint32_t pq = qi, pr = rank;
+            while (pq < m) {
+                const uint32_t left = h_cnt[pq] - pr;
+                if (left == 0) { pq++; pr = 0; continue; }
+                const uint64_t qn = h_qd[pq].n, qrows = h_qd[pq].rows;
+                uint64_t take = std::min<uint64_t>(left, max_pairs - pairs);
+                if (qn) take = std::min<uint64_t>(take, (max_items - items) / qn);
+                if (qrows) take = std::min<uint64_t>(take, (max_rows - rows) / qrows);
+                if (take == 0) { if (pairs == 0) take = 1; else break; }      // a single pair always goes through (chain_check refuses what cannot fit)
+                bqs.push_back(BatchQ{pq, pr, pr + (uint32_t)take, (uint32_t)pairs, (uint32_t)items, (uint32_t)rows});
+                pairs += take; items += take * qn; rows += take * qrows;
+                pr += (uint32_t)take;
+                if (pairs >= max_pairs || items >= max_items || rows >= max_rows) break;
+            }
+            const uint32_t n_pairs = (uint32_t)pairs;
+            if (items >= 0xFFFFFF00ull || rows >= 0xFFFFFF00ull) { psk_set_error("a single pair exceeds the per-launch limits (%llu query seeds)", (unsigned long long)items); return PSK_ELIMIT; }
+            uint32_t n_sel = 0;
+            psk_hit* h_sel = nullptr;
+            if (items == 0 || rows == 0) {
+                // nothing to chain (queries without seeds): no hits
+            } else {
+                ChainBufs L;
+                PSK_TRY(chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L));
+                PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(pair_build_rows_kernel, dim3((uint32_t)bqs.size()), dim3(256), 0, st, L.bq, d_pass, n, d_qd, (const SketchDesc*)db->d_refdesc.p,
+                                   L.pairs, L.sbase, L.cbase, L.pair_qr, n_pairs, (uint32_t)items, (uint32_t)rows);
+                const uint32_t spec = std::min<uint32_t>(n_pairs, 1u << 16);      // hits copied back speculatively with the count
+                PSK_TRY(ctx->pinned(sizeof(psk_hit) * (size_t)n_pairs + 512, &hpin));
+                ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
+                uint64_t cap = anchor_cap_for(ctx, (size_t)items);
+                bool too_big = false;
+                for (int attempt = 0;; attempt++) {
+                    PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap));
+                    size_t tmp3 = 0;
+                    PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
+                    PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
+                    PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipMemcpyAsync(h_sel, L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
+                    bool retry;
+                    psk_status rc = chain_check(*T, n_pairs, &cap, &retry);
+                    if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
+                    PSK_TRY(rc);
+                    if (!retry) break;
+                    if (attempt >= 2) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+                }
+                if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
+                n_sel = T->misc[12];
+                if (n_sel > spec) {
+                    PSK_HIP(hipMemcpyAsync(h_sel + spec, L.hits_sel + spec, sizeof(psk_hit) * (size_t)(n_sel - spec), hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipStreamSynchronize(st));
+                }
+            }
+            // hits arrive in (query, ref) order; pair_reduce left the round-local query index in `reserved`
+            for (uint32_t i = 0; i < n_sel; i++) {
+                q_hits[h_sel[i].reserved]++;
+                all.push_back(h_sel[i]);
+                all.back().reserved = 0;
+            }
+            qi = pq; rank = pr;
+        }
+        for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i] + q_hits[i];
+    }
     return PSK_OK;
 }
