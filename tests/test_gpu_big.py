@@ -1,0 +1,65 @@
+"""GPU: BASELINE configs[4] at reduced count — mammalian-scale genomes (24 contigs; 2 genomes instead of 50) sketched and
+chained pairwise, every integer of the chain against the oracle. Default size 300 Mb per genome (a few seconds);
+PSK_BIG_MB=3000 runs the real 3 Gb shape (24 x 125 Mb contigs, ~24 M seeds per genome; minutes, mostly the CPU oracle)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+INT_FIELDS = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+
+
+def big_pair(total_mb, n_contigs=24, divergence=0.01, seed=5):
+    """Two genomes of n_contigs equal contigs: an iid ancestor and a copy with substitutions, two contigs reversed-
+    complemented and the contig order rotated (strands and cross-contig chains are exercised). Built on the GPU."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    L = total_mb * 1_000_000 // n_contigs
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    a_contigs, b_contigs = [], []
+    for i in range(n_contigs):
+        a = torch.randint(0, 4, (L,), generator=g, device=dev, dtype=torch.uint8)
+        mut = torch.rand((L,), generator=g, device=dev) < divergence
+        b = torch.where(mut, (a + torch.randint(1, 4, (L,), generator=g, device=dev, dtype=torch.uint8)) & 3, a)
+        if i in (3, 17):
+            b = (3 - b).flip(0)
+        a_contigs.append(lut[a.long()].cpu().numpy().tobytes())
+        b_contigs.append(lut[b.long()].cpu().numpy().tobytes())
+        del a, b, mut
+    b_contigs = b_contigs[5:] + b_contigs[:5]
+    return a_contigs, b_contigs
+
+
+def test_mammalian_scale_pair_matches_oracle(oracle):
+    import pyskani_amd as psk
+    mb = int(os.environ.get("PSK_BIG_MB", "300"))
+    ref, qry = big_pair(mb)
+    t0 = time.time()
+    db = psk.Database()
+    db.sketch("ref", *ref)
+    t1 = time.time()
+    hits = db.query("qry", *qry, learned_ani=False)
+    t2 = time.time()
+    hits_m = db.query("qry", *qry, learned_ani=False, median=True)
+    hits_r = db.query("qry", *qry, learned_ani=False, robust=True)
+    t3 = time.time()
+    print(f"\n[{mb} Mb x 2] sketch ref {t1 - t0:.2f} s, sketch query + chain {t2 - t1:.2f} s, median + robust {t3 - t2:.2f} s")
+    osr, osq = oracle.Sketch(ref), oracle.Sketch(qry)
+    gs, gm = db._sketch("q", qry, True).export()
+    assert len(gs) == len(osq.seeds)
+    for f in ("kmer", "pos", "contig", "canon"):
+        assert np.array_equal(gs[f], osq.seeds[f]), f
+    assert np.array_equal(gm, osq.markers)
+    for got, kw in ((hits, {}), (hits_m, {"median": True}), (hits_r, {"robust": True})):
+        want = oracle.chain(osr, osq, **kw)
+        assert len(got) == 1
+        for f in INT_FIELDS:
+            assert got[0]._raw[f] == getattr(want, f), (kw, f, got[0]._raw[f], getattr(want, f))
+        assert abs(got[0].identity - want.ani) < 1e-6 and abs(got[0].query_fraction - want.af_query) < 1e-6
+        assert abs(got[0]._raw["ani_std"] - want.ani_std) < 1e-6
+    assert abs(hits[0].identity - 0.99) < 0.002 and hits[0].query_fraction > 0.9
+    if mb >= 1000:
+        assert hits[0]._raw["n_chunks"] > 4096 and len(gs) > (1 << 18)      # beyond the LDS paths of select / pair_reduce / index_block
