@@ -86,6 +86,9 @@ def lib():
         _lib.orc_mm_hash64.argtypes = [C.c_uint64]
         _lib.orc_model_predict.restype = C.c_float
         _lib.orc_model_predict.argtypes = [C.POINTER(_Model), C.POINTER(C.c_float)]
+        _lib.orc_query_refs.restype = C.c_uint32
+        _lib.orc_query_refs.argtypes = [C.POINTER(C.POINTER(_Sketch)), C.c_uint32, C.POINTER(_Sketch), C.POINTER(QueryOpts),
+                                        C.POINTER(C.c_uint32), C.POINTER(Result), C.c_uint32]
         _lib.orc_last_chunks.restype = C.c_uint32
         _lib.orc_last_chunks.argtypes = [C.POINTER(C.c_void_p)]
     return _lib
@@ -146,6 +149,13 @@ def chain(ref, query, median=False, robust=False, min_aligned_frac=0.15, learned
     if rc != 0:
         raise RuntimeError("orc_chain failed: %d" % rc)
     return res
+
+
+def query_count(ref_sketches, q, faster_small=False):
+    """Number of hits of `q` against a list of Sketch objects; the whole screen + chain loop runs in C (no GIL held)."""
+    arr = (C.POINTER(_Sketch) * len(ref_sketches))(*[r._p for r in ref_sketches])
+    o = QueryOpts(0, 0, 0, 0.0, int(not faster_small), 0.15, None)
+    return lib().orc_query_refs(arr, len(ref_sketches), q._p, C.byref(o), None, None, 0)
 
 
 def last_chunks():

@@ -367,3 +367,22 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
     free(chunk_qc); free(c_anch); free(c_left); free(c_right); free(c_nint);
     return 0;
 }
+
+/* The screen + chain loops of Database.query (lib.rs:617-657) for one query against n references, entirely in C so that a
+ * multi-threaded CPU baseline (one query per thread) does not serialise on the Python interpreter lock. Returns the number of
+ * hits (ani > 0.1, lib.rs:654); hits_out (may be NULL) receives up to max_hits (reference index, result) records. */
+uint32_t orc_query_refs(const orc_sketch* const* refs, uint32_t n, const orc_sketch* q, const orc_query_opts* o,
+                        uint32_t* hit_ref, orc_result* hit_res, uint32_t max_hits) {
+    double screen_val = o->screen_val > 0 ? o->screen_val : 0.80;
+    uint32_t nh = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!orc_screen(q, refs[i], screen_val, o->rescue_small, NULL)) continue;
+        orc_result res;
+        if (orc_chain(refs[i], q, o, &res) != 0) continue;
+        if (res.ani > 0.1f) {
+            if (nh < max_hits) { if (hit_ref) hit_ref[nh] = i; if (hit_res) hit_res[nh] = res; }
+            nh++;
+        }
+    }
+    return nh;
+}

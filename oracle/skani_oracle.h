@@ -104,6 +104,10 @@ int orc_screen(const orc_sketch* q, const orc_sketch* r, double screen_val, int 
 /* chain_seeds(ref, query, map_params_from_sketch(ref, ...)) */
 int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_opts* o, orc_result* out);
 
+/* screen + chain of one query against n references in one call (multi-threaded CPU baselines: no interpreter lock inside) */
+uint32_t orc_query_refs(const orc_sketch* const* refs, uint32_t n, const orc_sketch* q, const orc_query_opts* o,
+                        uint32_t* hit_ref, orc_result* hit_res, uint32_t max_hits);
+
 /* debug dumps for GPU parity tests: per-chunk records of the last orc_chain call on this thread */
 typedef struct { uint32_t contig, left, right, anchors, seeds, n_intervals; } orc_chunk_rec;
 uint32_t orc_last_chunks(const orc_chunk_rec** recs);

@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 from pyskani_amd import _capi
 lib = _capi.load()
@@ -37,7 +38,7 @@ if not DO_QUERY:
     sys.exit(0)
 db = C.c_void_p(); _capi.check(lib.psk_db_create(ctx, C.byref(params), C.byref(db)))
 _capi.check(lib.psk_db_add(db, b"ref", out[0]))
-opts = _capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0)
+opts = _capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
 hits = C.POINTER(_capi.Hit)(); n = C.c_uint64(0)
 _capi.check(lib.psk_ctx_set_timing(ctx, 1))
 for rep in range(2):   # the first query also builds the two k-mer indexes
@@ -51,6 +52,6 @@ for k in ("sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_redu
 _capi.check(lib.psk_ctx_set_timing(ctx, 0))
 for i in range(n.value):
     h = hits[i]; print(" ani %.5f afq %.4f afr %.4f chunks %d intervals %d anchors %d" % (h.ani, h.af_query, h.af_ref, h.n_chunks, h.n_intervals, h.n_anchors))
-opts2 = _capi.QueryOpts(0, 1, 0, 0, 0.0, 0.0)
+opts2 = _capi.QueryOpts(0, 1, 0, 0, 0.0, 0.0, None)
 rc = lib.psk_query(db, out[1], C.byref(opts2), C.byref(hits), C.byref(n))
 print("median on 50k chunks ->", rc, lib.psk_last_error())

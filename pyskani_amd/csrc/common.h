@@ -213,6 +213,7 @@ struct SketchStore {
 struct SketchDesc {
     const uint32_t* key; const uint64_t* pms; const uint32_t* perm; const uint32_t* bucket;   // k-mer index (null until built)
     const uint32_t* pos; const uint32_t* meta; const uint32_t* seed_pos_base; const uint32_t* contig_start;
+    const uint32_t* kmer;   // seed k-mers in (contig,pos) order
     uint64_t total_len;
     uint32_t n;             // seeds, once the k-mer index exists (0 before)
     uint32_t bshift, rows;  // bucket shift; rows of the chunk table a pair with this sketch as the query needs

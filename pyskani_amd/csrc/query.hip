@@ -163,6 +163,35 @@ __global__ __launch_bounds__(256) void inv_decide_kernel(const MarkerSet* __rest
     pass[t] = (uint8_t)ok;
 }
 
+// The same screen with the query's row of the count matrix kept in LDS: one workgroup per query, shared-marker counts per
+// reference by LDS atomics, the pass rule applied in place. No count matrix in HBM, no memset, no decide pass (n_refs * 4 B of
+// LDS per workgroup: databases up to INV_LDS_REFS references).
+constexpr uint32_t INV_LDS_REFS = 36 * 1024;
+__global__ __launch_bounds__(512) void inv_screen_lds_kernel(const MarkerSet* __restrict__ refs, const MarkerSet* __restrict__ queries,
+                                                             const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t n_inv,
+                                                             uint32_t n_refs, double thresh, int rescue_small, uint8_t* __restrict__ pass) {
+    extern __shared__ uint32_t s_count[];
+    const MarkerSet q = queries[blockIdx.x];
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) s_count[r] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < q.n; i += blockDim.x) {
+        const uint64_t m = q.p[i];
+        uint32_t l = 0, h = n_inv;
+        while (l < h) { uint32_t mid = (l + h) >> 1; if (key[mid] < m) l = mid + 1; else h = mid; }
+        for (; l < n_inv && key[l] == m; l++) atomicAdd(&s_count[val[l]], 1u);
+    }
+    __syncthreads();
+    uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) {
+        const uint32_t b = refs[r].n, small = q.n < b ? q.n : b;
+        int ok;
+        if (rescue_small && small < SMALL_MARKER_COUNT) ok = 1;
+        else if (small == 0) ok = 0;
+        else ok = ((double)s_count[r] / (double)small) > thresh;
+        row[r] = (uint8_t)ok;
+    }
+}
+
 static psk_status build_inverted(psk_db* db) {
     if (!db->inv_dirty) return PSK_OK;
     psk_ctx* ctx = db->ctx; hipStream_t st = ctx->stream;
@@ -228,7 +257,12 @@ static psk_status screen_many_device(psk_db* db, const psk_sketch* const* querie
         uint8_t* pass_b = d_pass + (size_t)b * n;
         PSK_HIP(hipMemcpyAsync(d_q, hq.data(), sizeof(MarkerSet) * m, hipMemcpyHostToDevice, st));
         ctx->t_begin(K_SCREEN);
-        if (use_inv) {
+        if (use_inv && n <= INV_LDS_REFS && !getenv("PSK_SCREEN_GLOBAL")) {
+            static bool lds_attr = false;
+            if (!lds_attr) { PSK_HIP(hipFuncSetAttribute((const void*)inv_screen_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * INV_LDS_REFS))); lds_attr = true; }
+            hipLaunchKernelGGL(inv_screen_lds_kernel, dim3(m), dim3(512), 4 * (size_t)n, st, (const MarkerSet*)db->d_marker_ptr.p, d_q,
+                               (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (uint32_t)db->inv_n, n, thresh, rescue_small, pass_b);
+        } else if (use_inv) {
             PSK_HIP(hipMemcpyAsync(d_qoff, qoff.data(), 4 * (size_t)(m + 1), hipMemcpyHostToDevice, st));
             PSK_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)m * n, st));
             if (items && db->inv_n)
@@ -257,6 +291,7 @@ struct PairDesc {
     const uint32_t* r_key; const uint64_t* r_pms;                             // ref index slice: k-mers ascending; r_pms = the seeds' pos<<32|meta in the same order
     const uint32_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
     const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
+    const uint32_t* q_kmer;                                                   // their k-mers, same order
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
     const uint32_t* q_contig_start;
     uint64_t q_total_len, r_total_len;
@@ -271,13 +306,19 @@ __device__ __forceinline__ uint32_t find_le(const uint32_t* __restrict__ base, u
     return lo;
 }
 
-// find_le for a whole workgroup of consecutive x: one search by thread 0, then a short forward walk per thread
-// (a pair holds far more items than a workgroup has threads, so the walk is zero or one step)
-__device__ __forceinline__ uint32_t find_le_block(const uint32_t* __restrict__ base, uint32_t n, uint32_t x, uint32_t x_block0) {
-    __shared__ uint32_t s_p0;
-    if (threadIdx.x == 0) s_p0 = find_le(base, n, x_block0);
-    __syncthreads();
-    uint32_t p = s_p0;
+// The pair of a workgroup's first item (or of a chunk-table row) comes from a table filled once per launch sequence
+// (pair_table_kernel): a per-workgroup binary search over up to 2^20 pair offsets was a chain of ~20 DEPENDENT global
+// loads in front of every workgroup of every kernel below — with nothing else to overlap, that latency was their run time.
+__global__ __launch_bounds__(256) void pair_table_kernel(const uint32_t* __restrict__ base, uint32_t n, uint32_t count, uint32_t stride, uint32_t limit,
+                                                         uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t x = (uint64_t)t * stride;
+    out[t] = find_le(base, n, x < limit ? (uint32_t)x : limit - 1);
+}
+// pair of item x given the pair of the workgroup's first item: a short forward walk (a pair usually holds far more items
+// than a workgroup has threads; pairs without items are stepped over)
+__device__ __forceinline__ uint32_t pair_from_hint(const uint32_t* __restrict__ base, uint32_t n, uint32_t x, uint32_t p) {
     while (p + 1 < n && base[p + 1] <= x) p++;
     return p;
 }
@@ -292,42 +333,30 @@ __device__ __forceinline__ uint32_t xcd_block_id() {
     return xcd * q + (xcd < r ? xcd : r) + (b >> 3);
 }
 
-// one lane per (pair, query seed): range of equal k-mers in the ref index
-__global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
-                                                           uint32_t n_pairs, uint32_t n_items,
-                                                           uint2* __restrict__ lbcnt_out, unsigned long long* __restrict__ block_sum) {
-    __shared__ unsigned long long s_ws[4];
-    const uint32_t lb = xcd_block_id();
-    uint32_t i = lb * blockDim.x + threadIdx.x;
-    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
-    uint32_t cnt = 0;
-    if (i < n_items) {
-    const PairDesc& P = pairs[p];
-    const uint32_t* __restrict__ key = P.r_key;
-    const uint32_t rn = P.r_n;
-    // lane i takes the i-th query seed in K-MER order: neighbouring lanes search neighbouring keys, so the first
-    // levels of their binary searches read the same words and the last ones the same cache lines
-    const uint32_t iq = i - sbase[p];
-    const uint32_t km = P.q_key[iq];
-    const uint32_t dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
-    // bucket table: the k-mer's top bits give a range of ~4 index entries
-    uint32_t lo = 0, hi = 0;
+// range of index entries of `key` equal to km: bucket table (the k-mer's top bits give ~4 entries), short scan, galloping
+// upper bound for repeats
+__device__ __forceinline__ void lookup_lane(const uint32_t* __restrict__ key, uint32_t rn, const uint32_t* __restrict__ bucket, uint32_t bshift,
+                                            uint32_t km, uint32_t& lo, uint32_t& cnt) {
+    lo = 0; cnt = 0;
+    uint32_t hi = 0;
     if (rn) {
-        const uint32_t bk = km >> P.r_bshift;
-        lo = P.r_bucket[bk]; hi = P.r_bucket[bk + 1];
+        const uint32_t bk = km >> bshift;
+        lo = bucket[bk]; hi = bucket[bk + 1];
     }
-    while (lo < hi && (uint32_t)key[lo] < km) lo++;
-    if (lo < rn && (uint32_t)key[lo] == km) {
+    while (lo < hi && key[lo] < km) lo++;
+    if (lo < rn && key[lo] == km) {
         uint32_t step = 1;
-        while (lo + step < rn && (uint32_t)key[lo + step] == km) step <<= 1;
+        while (lo + step < rn && key[lo + step] == km) step <<= 1;
         uint32_t a = lo + (step >> 1), b = lo + step < rn ? lo + step : rn;   // key[a]==km, key[b]!=km or b==n
-        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if ((uint32_t)key[mid] == km) a = mid; else b = mid; }
+        while (a + 1 < b) { uint32_t mid = (a + b) >> 1; if (key[mid] == km) a = mid; else b = mid; }
         cnt = b - lo;
     }
-    lbcnt_out[dst] = make_uint2(lo, cnt);      // one 8-byte scattered store per item
-    }
-    // 64-bit anchor total of the workgroup: the offsets the scan produces are 32-bit, the host compares the two totals
-    // (repeat-rich pairs can exceed 2^32 anchors: a k-mer present 10^5 times on both sides already does)
+}
+
+// 64-bit anchor total of the workgroup: the offsets the scan produces are 32-bit, the host compares the two totals
+// (repeat-rich pairs can exceed 2^32 anchors: a k-mer present 10^5 times on both sides already does)
+__device__ __forceinline__ void block_total(uint32_t cnt, uint32_t lb, unsigned long long* __restrict__ block_sum) {
+    __shared__ unsigned long long s_ws[4];
     unsigned long long c64 = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
@@ -336,16 +365,144 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
     if (threadIdx.x == 0) block_sum[lb] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
 }
 
+// WIDE join format (fallback): one lane per (pair, query seed), (lower bound, count) per item
+__global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                           uint32_t n_pairs, uint32_t n_items,
+                                                           uint2* __restrict__ lbcnt_out, unsigned long long* __restrict__ block_sum,
+                                                           const uint32_t* __restrict__ blk_pair) {
+    const uint32_t lb = xcd_block_id();
+    uint32_t i = lb * blockDim.x + threadIdx.x;
+    const uint32_t p = pair_from_hint(sbase, n_pairs, i < n_items ? i : n_items - 1, blk_pair[lb]);
+    uint32_t cnt = 0;
+    if (i < n_items) {
+        const PairDesc& P = pairs[p];
+        // lane i takes the i-th query seed in K-MER order: neighbouring lanes search neighbouring keys
+        const uint32_t iq = i - sbase[p];
+        const uint32_t km = P.q_key[iq];
+        const uint32_t dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
+        uint32_t lo;
+        lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km, lo, cnt);
+        lbcnt_out[dst] = make_uint2(lo, cnt);      // one 8-byte scattered store per item
+    }
+    block_total(cnt, lb, block_sum);
+}
+
+// PACKED join format (default): per (pair, query seed) x = reference position of the FIRST match, y = (ref contig << 1 | ref
+// strand bit) | count << 24. An item with one match - nearly all of them - then needs no further look at the reference: the
+// emit kernel reads nothing at random. Counts >= 255 or reference contig numbers >= 2^23 raise `need_wide` and the host
+// reruns the batch in the wide format.
+// The lookup itself is a MERGE: a wave's 64 query k-mers are consecutive in k-mer order, so their matches sit in one short
+// stretch of the reference's sorted k-mers. The wave reads the bucket table twice (its first and last k-mer), stages that
+// stretch in LDS with coalesced loads and every lane searches it there; only waves whose stretch exceeds JOIN_WIN entries
+// (a sparse query against a dense reference) or that straddle two pairs fall back to one independent lookup per lane.
+constexpr int JOIN_WIN = 256;
+struct PackedCount { __host__ __device__ uint32_t operator()(const uint2& v) const { return v.y >> 24; } };
+__global__ __launch_bounds__(256) void anchor_join_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                          uint32_t n_pairs, uint32_t n_items,
+                                                          uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
+                                                          uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair) {
+    __shared__ uint32_t s_key[4][JOIN_WIN];
+    const uint32_t lb = xcd_block_id();
+    const uint32_t i = lb * blockDim.x + threadIdx.x;
+    const uint32_t p = pair_from_hint(sbase, n_pairs, i < n_items ? i : n_items - 1, blk_pair[lb]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = i < n_items;
+    uint32_t km = 0, dst = 0, lo = 0, cnt = 0;
+    if (valid) {
+        const PairDesc& P = pairs[p];
+        const uint32_t iq = i - sbase[p];
+        km = P.q_key[iq];
+        dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
+    }
+    const unsigned long long vm = __ballot(valid);
+    bool done = false;
+    if (vm) {
+        const int l0 = __ffsll((long long)vm) - 1, l1 = 63 - __clzll((long long)vm);
+        const uint32_t p0 = __shfl(p, l0);
+        if (__all(!valid || p == p0)) {          // the whole wave joins one pair
+            const PairDesc& P0 = pairs[p0];
+            if (P0.r_n == 0) done = true;
+            else {
+                const uint32_t km_a = __shfl(km, l0), km_b = __shfl(km, l1);
+                const uint32_t w_lo = P0.r_bucket[km_a >> P0.r_bshift], w_hi = P0.r_bucket[(km_b >> P0.r_bshift) + 1];
+                const uint32_t wn = w_hi - w_lo;
+                if (wn <= (uint32_t)JOIN_WIN) {
+                    done = true;
+                    uint32_t* sk = s_key[wave];
+                    for (uint32_t j = lane; j < wn; j += 64) sk[j] = P0.r_key[w_lo + j];
+                    lds_wave_sync();
+                    if (valid) {
+                        uint32_t a = 0, b = wn;
+                        while (a < b) { const uint32_t mid = (a + b) >> 1; if (sk[mid] < km) a = mid + 1; else b = mid; }
+                        lo = w_lo + a;
+                        uint32_t e = a;
+                        while (e < wn && sk[e] == km) e++;      // equal k-mers share a bucket: the run ends inside the stretch
+                        cnt = e - a;
+                    }
+                }
+            }
+        }
+    }
+    if (!done && valid) { const PairDesc& P = pairs[p]; lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km, lo, cnt); }
+    if (valid) {
+        uint32_t x = 0, y = 0;
+        if (cnt) {
+            const uint64_t pm = pairs[p].r_pms[lo];
+            const uint32_t rmeta = (uint32_t)pm;
+            x = (uint32_t)(pm >> 32);
+            if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
+            else y = rmeta | (cnt << 24);
+        }
+        item_out[dst] = make_uint2(x, y);      // one 8-byte scattered store per item
+    }
+    block_total(cnt, lb, block_sum);
+}
+
+__global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                                 uint32_t n_pairs, uint32_t n_items,
+                                                                 const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
+                                                                 uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
+                                                                 uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                                 const uint32_t* __restrict__ blk_pair) {
+    const uint32_t lb = xcd_block_id();
+    uint32_t i = lb * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[lb]);
+    const uint2 it = item[i];
+    const uint32_t c = it.y >> 24;
+    if (c == 0) return;
+    const PairDesc& P = pairs[p];
+    const uint32_t j0 = i - sbase[p];
+    const uint32_t dst = aoff[i];
+    if ((uint64_t)dst + c > cap) { atomicOr(err, 2u); return; }   // beyond the optimistic capacity: the host reruns the batch with the true total
+    const uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
+    if (c == 1) {
+        a_qp[dst] = qp; a_qc[dst] = qm >> 1; a_rp[dst] = it.x;
+        a_rm[dst] = (it.y & 0xFFFFFEu) | ((it.y ^ qm) & 1u);   // ref contig << 1 | reverse_match
+        return;
+    }
+    uint32_t l, c2;     // a repeat: find its run in the reference index again (rare)
+    lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[j0], l, c2);
+    for (uint32_t j = 0; j < c; j++) {
+        const uint64_t pm = P.r_pms[l + j];
+        const uint32_t rmeta = (uint32_t)pm;
+        a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
+        a_rp[dst + j] = (uint32_t)(pm >> 32);
+        a_rm[dst + j] = (rmeta & ~1u) | ((rmeta ^ qm) & 1u);
+    }
+}
+
 __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                           uint32_t n_pairs, uint32_t n_items,
                                                           const uint2* __restrict__ lbcnt,
                                                           const uint32_t* __restrict__ aoff,
                                                           uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
-                                                          uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err) {
+                                                          uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                          const uint32_t* __restrict__ blk_pair) {
     const uint32_t lb = xcd_block_id();
     uint32_t i = lb * blockDim.x + threadIdx.x;
-    const uint32_t p = find_le_block(sbase, n_pairs, i < n_items ? i : n_items - 1, lb * blockDim.x);
     if (i >= n_items) return;
+    const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[lb]);
     const uint2 lc = lbcnt[i];
     const uint32_t c = lc.y;
     if (c == 0) return;
@@ -466,6 +623,7 @@ struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, r
 struct ChainArgs {
     const uint32_t *a_qp, *a_qc, *a_rp, *a_rm;
     const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs, n_rows;
+    const uint32_t* row_pair;   // pair of every row of the chunk table
     const PairDesc* pairs;
     ChunkOut* out;
     // serial-path scratch, one entry per anchor
@@ -565,7 +723,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
     uint32_t s = 0, e = 0;
     bool mine = false, real = false;     // real: a row of the chunk table that holds a chunk; mine: this lane chains it
-    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * LANE_WAVES * rows_per_wave);
+    const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
     if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) {
         if (slot - A.cbase[pair] < A.n_chunks[pair]) {
             const uint2 se = A.chunks[slot];
@@ -697,7 +855,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
     uint32_t s = 0, e = 0;
     bool mine = false, real = false;
-    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * LANE_WAVES * 16);
+    const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
     if (slot < A.n_rows && slot - A.cbase[pair] < A.n_chunks[pair]) {
         const uint2 se = A.chunks[slot];
         s = se.x; e = se.y;
@@ -923,7 +1081,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_kernel(ChainArgs
     __shared__ ChainWaveLds s_lds[CHAIN_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
-    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, slot < A.n_rows ? slot : A.n_rows - 1, blockIdx.x * CHAIN_WAVES);
+    const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
     if (slot >= A.n_rows) return;
     if (slot - A.cbase[pair] >= A.n_chunks[pair]) return;
     chain_chunk_row(A, slot, s_lds[wave], lane);
@@ -983,15 +1141,19 @@ __device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
     }
 }
 
+// (A 512-candidate instantiation with half the LDS - six waves per CU instead of three - was measured and is no faster:
+// the kernel's time is each wave's own chain of LDS round trips, not occupancy.)
+constexpr int CM = CMAX;
 __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
-    __shared__ int32_t l_sc[CMAX];
-    __shared__ uint32_t l_q0[CMAX], l_q1[CMAX], l_r0[CMAX], l_r1[CMAX], l_rc[CMAX], l_row[CMAX], l_n[CMAX];
-    __shared__ unsigned long long l_key[CMAX];     // priority keys, then (ref contig, r0) keys
-    __shared__ uint32_t l_pm[CMAX];                // running max of r1 in reference order
-    __shared__ uint16_t l_ord[CMAX];               // candidate index by priority rank
-    __shared__ uint16_t l_idx[CMAX];               // payload of the reference-order sort, then the conflicted list
-    __shared__ uint16_t l_kept[CMAX];
-    __shared__ uint8_t l_conf[CMAX];
+    const uint32_t c_lo = 0;
+    __shared__ int32_t l_sc[CM];
+    __shared__ uint32_t l_q0[CM], l_q1[CM], l_r0[CM], l_r1[CM], l_rc[CM], l_row[CM], l_n[CM];
+    __shared__ unsigned long long l_key[CM];     // priority keys, then (ref contig, r0) keys
+    __shared__ uint32_t l_pm[CM];                // running max of r1 in reference order
+    __shared__ uint16_t l_ord[CM];               // candidate index by priority rank
+    __shared__ uint16_t l_idx[CM];               // payload of the reference-order sort, then the conflicted list
+    __shared__ uint16_t l_kept[CM];
+    __shared__ uint8_t l_conf[CM];
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
@@ -1005,7 +1167,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
         uint32_t off = C + incl - cnt;
         uint32_t tot = __shfl(incl, 63);
-        if (!S.force_serial && C + tot <= CMAX && cnt) {
+        if (!S.force_serial && C + tot <= (uint32_t)CM && cnt) {
             uint32_t s = S.chunks[row0 + r].x;
             for (uint32_t i = 0; i < cnt; i++) {
                 l_sc[off + i] = S.c_score[s + i]; l_q0[off + i] = S.c_q0[s + i]; l_q1[off + i] = S.c_q1[s + i];
@@ -1016,11 +1178,11 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         C += tot;
     }
     if (C == 0) return;
-    if (S.force_serial) {   // cross-check path: O(C^2) by one lane
-        if (lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
+    if (S.force_serial) {   // cross-check path: O(C^2) by one lane (run by the CMAX instantiation only)
+        if (CM == CMAX && lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
         return;
     }
-    if (C > CMAX) return;   // select_big_kernel takes pairs that do not fit in LDS
+    if (C <= c_lo || C > (uint32_t)CM) return;   // another instantiation, or select_big_kernel, takes the pair
     uint32_t P = 64; while (P < C) P <<= 1;
     // ---- priority order: (score desc, generation order asc) ----
     for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
@@ -1269,7 +1431,7 @@ __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
 // seeds of the query between the leftmost and rightmost kept anchor of every chunk
 __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pair = find_le_block(A.cbase, A.n_pairs, row < A.n_rows ? row : A.n_rows - 1, blockIdx.x * blockDim.x);
+    const uint32_t pair = A.row_pair[row < A.n_rows ? row : A.n_rows - 1];
     if (row >= A.n_rows) return;
     if (row - A.cbase[pair] >= A.n_chunks[pair]) return;
     ChunkOut* o = &A.out[row];
@@ -1445,6 +1607,7 @@ static SketchDesc make_desc(const psk_sketch* s) {
     d.perm = ix ? s->idx->perm + s->idx_off : nullptr; d.bucket = ix ? s->idx->bucket + s->idx_boff : nullptr;
     d.bshift = ix ? s->idx_bshift : 0; d.n = ix ? (uint32_t)s->n_seeds : 0;
     d.pos = s->store ? s->store->seed_pos + s->seed_off : nullptr; d.meta = s->store ? s->store->seed_meta + s->seed_off : nullptr;
+    d.kmer = s->store ? s->store->seed_kmer + s->seed_off : nullptr;
     d.seed_pos_base = s->store ? s->store->seed_pos : nullptr;
     d.contig_start = s->store ? s->store->contig_seed_start + s->contig_off : nullptr;
     d.total_len = s->total_len; d.n_contigs = (uint32_t)s->contig_len.size();
@@ -1458,7 +1621,7 @@ static SketchDesc make_desc(const psk_sketch* s) {
 __device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
     PairDesc P;
     P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
-    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta;
+    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer;
     P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
     P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
     return P;
@@ -1531,6 +1694,7 @@ struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const {
 struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
+    uint32_t *blk_pair, *row_pair;
     uint32_t gi;
 };
 static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -1541,13 +1705,15 @@ static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, siz
            o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows),
-           o_qr = al256(o_bsum + 8 * (gi + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_end = o_bq + sizeof(BatchQ) * (n_bq + 1);
+           o_qr = al256(o_bsum + 8 * (gi + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
+           o_rp = al256(o_bp + 4 * (gi + 1)), o_end = o_rp + 4 * (n_rows + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
     L->pairs = (PairDesc*)(B + o_pairs); L->sbase = (uint32_t*)(B + o_sbase); L->cbase = (uint32_t*)(B + o_cbase); L->pstart = (uint32_t*)(B + o_pstart);
     L->lbcnt = (uint2*)(B + o_lb); L->aoff = (uint32_t*)(B + o_aoff); L->nch = (uint32_t*)(B + o_nch); L->chunks = (uint2*)(B + o_chunks);
     L->cout = (ChunkOut*)(B + o_cout); L->hits = (psk_hit*)(B + o_hits); L->hits_sel = (psk_hit*)(B + o_sel); L->misc = (uint32_t*)(B + o_misc);
     L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
+    L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp);
     L->gi = (uint32_t)gi;
     return PSK_OK;
 }
@@ -1556,23 +1722,28 @@ static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, siz
 // Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
 // reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
 static psk_status chain_run(psk_ctx* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
-                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap) {
+                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
     PSK_HIP(hipMemsetAsync(L.misc, 0, 64, st));
     PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
     const uint32_t gi = L.gi;
+    hipLaunchKernelGGL(pair_table_kernel, dim3((gi + 255) / 256), dim3(256), 0, st, L.sbase, n_pairs, gi, 256u, (uint32_t)n_items, L.blk_pair);
+    hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.cbase, n_pairs, (uint32_t)n_rows, 1u, (uint32_t)n_rows, L.row_pair);
     ctx->t_begin(K_ANCHOR);
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum);
+    if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
+    else hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
+    hipcub::TransformInputIterator<uint32_t, PackedCount, const uint2*> pcnt_it(L.lbcnt, PackedCount());
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.bsum + gi, (int)gi, st));
     size_t tmp3 = 0;
     PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
-    PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
+    if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
+    else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)gi, st));      // 64-bit total, beside the 32-bit offsets
     hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
@@ -1588,10 +1759,12 @@ static psk_status chain_run(psk_ctx* ctx, const ChainBufs& L, uint32_t n_pairs, 
     A.c_state = a_nxt;   // spare per-anchor array
     A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
     A.chunks = L.chunks; A.n_chunks = L.nch; A.cbase = L.cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
+    A.row_pair = L.row_pair;
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
-    hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc);
+    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
+    else hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
@@ -1668,8 +1841,10 @@ static uint64_t anchor_cap_for(psk_ctx* ctx, size_t n_items) {
 
 // outcome of a launch sequence, read back with the hits
 struct ChainTail { uint32_t misc[16]; unsigned long long total64; };
-static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* retry) {
+static bool join_wide_default() { const char* e = getenv("PSK_JOIN"); return e && !strcmp(e, "wide"); }
+static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry) {
     *retry = false;
+    if (!*wide && T.misc[5]) { *wide = true; *retry = true; return PSK_OK; }   // a count or contig number the packed join format cannot hold: rerun in the wide format
     if (T.total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
         psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, T.total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
         return PSK_ELIMIT;
@@ -1716,16 +1891,17 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
     PSK_TRY(ctx->pinned(sizeof(psk_hit) * n_pairs + 512, &hpin));
     ChainTail* T = (ChainTail*)hpin; psk_hit* h_hits = (psk_hit*)((char*)hpin + 256);
     uint64_t cap = anchor_cap_for(ctx, (size_t)items);
+    bool wide = join_wide_default();
     for (int attempt = 0;; attempt++) {
-        PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, hp[0].q->params, o, d_desc, d_desc, cap));
+        PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, hp[0].q->params, o, d_desc, d_desc, cap, wide));
         PSK_HIP(hipMemcpyAsync(h_hits, L.hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a launch sequence (also keeps the host staging above alive)
         bool retry;
-        PSK_TRY(chain_check(*T, n_pairs, &cap, &retry));
+        PSK_TRY(chain_check(*T, n_pairs, &cap, &wide, &retry));
         if (!retry) break;
-        if (attempt >= 2) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+        if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
     }
     for (uint32_t p = 0; p < n_pairs; p++) { out[p] = h_hits[p]; out[p].reserved = 0; }
     return PSK_OK;
@@ -1905,9 +2081,9 @@ psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_
                 PSK_TRY(ctx->pinned(sizeof(psk_hit) * (size_t)n_pairs + 512, &hpin));
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
-                bool too_big = false;
+                bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
-                    PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap));
+                    PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide));
                     size_t tmp3 = 0;
                     PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
                     PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
@@ -1916,11 +2092,11 @@ psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_
                     PSK_HIP(hipMemcpyAsync(h_sel, L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     bool retry;
-                    psk_status rc = chain_check(*T, n_pairs, &cap, &retry);
+                    psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
                     if (!retry) break;
-                    if (attempt >= 2) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+                    if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
                 n_sel = T->misc[12];

@@ -251,7 +251,8 @@ def test_query_many_refs_matches_oracle(psk, oracle):
 def test_alternative_device_paths_agree(ecoli):
     """Every switchable device path must give the same integers: the default (lane-per-chunk DP), the wave-per-chunk DP
     (PSK_CHAIN_LANE=0), both ways of building the chunk table (PSK_CHUNK_HOPS=1 pointer chase, =0 head walk) the lane-serial transliteration of the oracle (PSK_CHAIN_SERIAL=1), and the radix-sorted k-mer index
-    (PSK_INDEX_RADIX=1) against the one-workgroup-per-sketch builder."""
+    (PSK_INDEX_RADIX=1) against the one-workgroup-per-sketch builder, and the wide (lower bound, count) join format
+    (PSK_JOIN=wide) against the packed merge join."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from conftest import load_fasta_first_record as L\n"
@@ -261,9 +262,9 @@ def test_alternative_device_paths_agree(ecoli):
         "print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     outs = {}
-    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"})):
+    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"}), ("wide_join", {"PSK_JOIN": "wide"})):
         env = dict(os.environ)
-        for k in ("PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX"):
+        for k in ("PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX", "PSK_JOIN"):
             env.pop(k, None)
         env.update(extra)
         outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip()
@@ -360,15 +361,19 @@ def test_all_vs_all_query_many_matches_oracle(psk, oracle):
     db = psk.Database()
     for n, contigs in genomes:
         db.sketch(n, *contigs)
-    # the batched screen has two implementations (workgroup per pair / inverted marker index): both must agree
+    # the batched screen has three implementations (workgroup per pair / inverted marker index with the count row in LDS /
+    # the same with a count matrix in HBM): all must agree
     per_mode = {}
-    for mode in ("brute", "inv"):
-        os.environ["PSK_SCREEN"] = mode
+    for mode in ("brute", "inv", "inv_global"):
+        os.environ["PSK_SCREEN"] = mode.split("_")[0]
+        if mode == "inv_global":
+            os.environ["PSK_SCREEN_GLOBAL"] = "1"
         try:
             per_mode[mode] = db.query_many([(n, *contigs) for n, contigs in genomes], learned_ani=False)
         finally:
-            os.environ.pop("PSK_SCREEN", None)
-    assert [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["brute"]] == [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["inv"]]
+            os.environ.pop("PSK_SCREEN", None); os.environ.pop("PSK_SCREEN_GLOBAL", None)
+    for mode in ("inv", "inv_global"):
+        assert [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["brute"]] == [[(h.reference_name, h.identity) for h in hs] for hs in per_mode[mode]], mode
     got_all = per_mode["inv"]
     osk = [(n, oracle.Sketch(contigs)) for n, contigs in genomes]
     n_hits = 0
