@@ -304,6 +304,7 @@ def main():
     ap.add_argument("--workload", choices=["search", "allvsall", "metagenome"], default="search",
                     help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes; metagenome = configs[3] shape (extras, not the headline)")
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
+    ap.add_argument("--api-queries", type=int, default=2000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
@@ -447,6 +448,31 @@ def main():
         }
         if args.workload == "metagenome":
             line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
+            if world == 1 and args.api_queries > 0:
+                # the same contigs ONE AT A TIME through the pyskani-shaped API, from host bytes: Database.query(name, contig)
+                import pyskani_amd as psk
+                host = buf.cpu().numpy()
+                pdb = psk.Database(compression=30, marker_compression=200)
+                t0 = time.perf_counter()
+                pdb.sketch_many([(f"r{i}", host[offs[i]:offs[i] + lens[i]].tobytes()) for i in range(n_refs)])
+                t_load = time.perf_counter() - t0
+                del host
+                chost = meta_state["cbuf"].cpu().numpy()
+                nq = min(args.api_queries, args.queries)
+                contigs = [chost[meta_state["coffs"][i]:meta_state["coffs"][i] + meta_state["clens"][i]].tobytes() for i in range(nq)]
+                for c in contigs[:20]:
+                    pdb.query("w", c, learned_ani=False, faster_small=args.faster_small)
+                t0 = time.perf_counter()
+                nh = sum(len(pdb.query(f"c{i}", c, learned_ani=False, faster_small=args.faster_small)) for i, c in enumerate(contigs))
+                t_q = time.perf_counter() - t0
+                many = pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
+                assert sum(len(h) for h in many) == nh
+                t0 = time.perf_counter()
+                pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
+                t_many = time.perf_counter() - t0
+                line["extras"].update(api_queries_per_s=nq / t_q, api_query_ms=t_q / nq * 1e3, api_query_many_per_s=nq / t_many,
+                                      api_db_load_s=t_load, api_hits=nh,
+                                      api_note=f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig, and one Database.query_many() for all of them")
         if world == 1 and args.workload == "search" and (args.cpu_sample > 0 or not args.no_api):
             host = buf.cpu().numpy()
             fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()

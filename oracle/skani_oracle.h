@@ -18,7 +18,9 @@
  *   - aligned fractions and raw ANI (learned_ani=False): match pyskani's KATs
  *     (test_ani.py:28-61) to the reference's own 4 decimals;
  *   - median ANI: within 9e-5 of the KAT (inside BASELINE.json's 1e-4, outside 4 decimals);
- *   - learned-ANI KATs: unreachable (GBDT weights live in the absent crate);
+ *   - learned-ANI KATs: unreachable (GBDT weights live in the absent crate); the regression STAGE is restated and
+ *     runs with a supplied model (orc_model_predict);
+ *   - round 2: no natural median / trimmed-mean variant pins the median or robust KAT to 5e-5 (oracle/README.md);
  *   - seed / marker sets: "parity unpinned" (the reference exposes none).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.

@@ -1,15 +1,7 @@
-# INTEGRATION — binding pyskani to `libpyskani_amd.so`
-
-pyskani today has no FFI: `src/pyskani/_skani/lib.rs` calls the Rust crate `skani` directly. To put the
-MI355X path behind pyskani's existing PyO3 classes a maintainer adds one `extern "C"` block and swaps
-four call sites. None of this can be compiled in this repository's build image (no Rust toolchain); the
-Python package `pyskani_amd` is the working host side meanwhile and exposes the same classes.
-
-## 1. The FFI block (new file `src/pyskani/_skani/ffi.rs`)
-
-The block below is kept as a file, `rust/ffi.rs`.
-
-```rust
+// rust/ffi.rs — the `extern "C"` binding a pyskani maintainer adds as src/pyskani/_skani/ffi.rs to put
+// libpyskani_amd.so behind the existing PyO3 classes (INTEGRATION.md section 2 lists the four call sites to swap in lib.rs).
+// NOT compiled in this repository: the build image has no Rust toolchain. tests/test_api_cpu.py
+// checks that this file declares exactly the symbols of include/pyskani_amd.h.
 // Every symbol of include/pyskani_amd.h (tests/test_api_cpu.py holds the header, this block's Python twin
 // pyskani_amd/_capi.py and the built library to the same symbol set).
 use std::os::raw::{c_char, c_int, c_void};
@@ -125,55 +117,3 @@ pub fn check(status: c_int) -> pyo3::PyResult<()> {
         _ => PyRuntimeError::new_err(msg),    // PSK_EHIP, PSK_ENOMODEL
     })
 }
-```
-
-## 2. Call sites to swap in `src/pyskani/_skani/lib.rs`
-
-| today | becomes |
-|---|---|
-| `struct Database { params, markers: RwLock<Vec<Sketch>>, sketches: RwLock<DatabaseStorage> }` (`:132-137`) | add `gpu: *mut PskDb` (created in `__init__` `:413-417` with `psk_ctx_create(0)` + `psk_db_create`); `Memory` storage keeps only names |
-| `Database::_sketch` body (`:140-185`: `Sketch::new`, contig filter, `fmh_seeds` per contig) | one `psk_sketch_host(ctx, &params, ptrs, lens, n, seed as c_int, &mut handle)`; the contig filter (`:156`) and `{name}_{i}` bookkeeping happen inside the library; `Sketch` newtype (`sketch.rs:4-8`) wraps the handle and frees it in `Drop` |
-| `get_markers_only` + `markers.push` + `sketches.store` (`:495-508`) | `psk_db_add(gpu, name, handle)` (ownership moves, as the `store` call moves the sketch today) |
-| the whole `py.allow_threads(move || { … })` closure of `query` (`:569-659`): `CommandParams` literal, `screen_val`, `get_model`, `check_markers_quickly` loop, `chain_seeds` loop, `ani > 0.1` | `let q = self._sketch(..)?; psk_query(gpu, q.handle, &PskQueryOpts{ learned_ani: learned_ani.map_or(-1, \|b\| b as i32), median, robust, faster_small, cutoff: cutoff.unwrap_or(0.0), min_aligned_frac: 0.0 }, &mut hits, &mut n)` still inside `allow_threads`; each `PskHit` becomes an `AniEstResult { ani, align_fraction_query, align_fraction_ref, ref_file: psk_db_name(gpu, ref_index), query_file: name, ..Default::default() }` and then `Hit::from` (`hit.rs:119-123`) unchanged |
-
-`Hit`, the getters, `__repr__`, the constructor validation (`hit.rs:26-104`) and the Python facade
-(`src/pyskani/__init__.py`) need no change. Threading contract is preserved: `sketch` stays `&mut self`
-(`:479`), `query` stays `&self` (`:551`) with the GIL released; the library serialises calls per context
-on its HIP stream. `build.rs` gains `println!("cargo:rustc-link-lib=dylib=pyskani_amd")` and a search
-path; the wheel ships `libpyskani_amd.so` next to the extension module.
-
-Differences a maintainer must know: (i) hits come back in reference insertion order (today: `HashSet`
-order, `:616,640`); a name sketched twice yields one hit against its later sketch, as the `HashMap` store
-(`:51-55`) and the name shortlist (`:616-637`) make it today; (ii) the learned-ANI model: skani embeds its
-GBDT weights in the crate (`regression::get_model`, `:614`). The Rust side still links `skani` for that
-one call, so it hands the weights over instead of evaluating them: flatten the `gbdt::GBDT` it gets from
-`get_model(c, learned)` into `PskTreeNode`s (node = `DTNode{feature_index, feature_value, pred, missing,
-is_leaf}` + the `BinaryTreeNode` child indices), call `psk_model_create(ctx, nodes, n, first, n_trees,
-gbdt.bias, conf.shrinkage, features, n_features, &mut model)` once per `(c, learned)` and pass
-`PskQueryOpts.model`; or serialise it (`serde_json::to_string(&gbdt)`) into `psk_model_load_json`. The
-feature order is `psk_feature` in the header — it must be checked against
-`skani::regression::predict_from_ani_res`, which this repository could not read. Without a model,
-`learned_ani = 1` is `PSK_ENOMODEL` and `learned_ani = -1` returns the raw chain ANI; (iii) disk-backed storage (`Folder`/`Consolidated`, `:42-123`) can either keep skani's bincode files and feed
-`psk_sketch_import` after deserialising, or adopt `pyskani_amd/storage.py`'s format; either way the markers stay
-resident (`psk_db_add` of a markers-only sketch) and `query` becomes `psk_screen` + load + `psk_chain`; (iv) without a GPU the library fails
-(`PSK_EHIP`) rather than falling back.
-
-## 3. Python today (`ctypes`, shipped in this repo)
-
-`pyskani_amd/_capi.py` is the complete ctypes stub (argtypes for every symbol of the header, status →
-exception mapping); `pyskani_amd/database.py` mirrors `Database`, `Hit`, `Sketch`:
-
-```python
-import pyskani_amd as pyskani          # same names as `import pyskani`
-db = pyskani.Database()                 # compression=125, marker_compression=1000, k=15
-db.sketch("EC590", ref_bytes)           # lib.rs:477
-hits = db.query("K12", query_bytes, learned_ani=False)   # lib.rs:549
-hits[0].identity, hits[0].query_fraction, hits[0].reference_fraction
-```
-
-Additions behind the same handles: `Database.sketch_many` / `psk_sketch_many_host` (pipelined host ingest),
-`Database.query_many` / `psk_query_many`, `Database(model=...)` / `load_model` / `$PSK_MODEL_PATH` (learned-ANI
-model from a gbdt JSON file), device-resident batches (`psk_sketch_batch_device`, `psk_db_add_batch`) and multi-GPU
-sharding (`pyskani_amd/parallel.py`: `psk_sketch_pack/unpack` records all-gathered over RCCL); `bench.py` shows their use.
-A process that also uses PyTorch must `import torch` BEFORE `pyskani_amd` creates its first context: torch bundles its
-own HIP runtime and fails to see the GPU if `/opt/rocm`'s was initialised first.

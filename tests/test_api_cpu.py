@@ -18,6 +18,16 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.psk_version()
 
 
+def test_rust_binding_and_integration_doc_list_every_symbol():
+    """the FFI block must mirror the header, not a subset of it."""
+    header = open(os.path.join(ROOT, "include", "pyskani_amd.h")).read()
+    declared = set(re.findall(r"\b(psk_[a-z0-9_]+)\s*\(", header))
+    for rel in ("rust/ffi.rs", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, rel)).read()
+        bound = set(re.findall(r"pub fn (psk_[a-z0-9_]+)\s*\(", text))
+        assert bound == declared, (rel, bound ^ declared)
+
+
 def test_no_gpu_fails_loudly():
     import pyskani_amd
     try:
