@@ -34,56 +34,71 @@ psk_status psk_ctx_create(int device, psk_ctx** out) {
     PSK_HIP(hipSetDevice(device));
     psk_ctx* c = new psk_ctx();
     c->device = device;
-    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (se != hipSuccess) { delete c; psk_set_error("hipStreamCreate failed: %s", hipGetErrorString(se)); return PSK_EHIP; }
+    if (const char* ml = getenv("PSK_LANES")) c->max_lanes = std::max(1, std::min(16, atoi(ml)));
+    { LaneGuard first(c); if (!first.lane) { delete c; psk_set_error("hipStreamCreate failed"); return PSK_EHIP; } }   // the first lane exists from the start
     *out = c;
     return PSK_OK;
+}
+
+// every lane idle and held: for operations on the whole context
+namespace {
+struct AllLanes {
+    psk_ctx* c; size_t n = 0;
+    explicit AllLanes(psk_ctx* ctx) : c(ctx) {
+        std::unique_lock<std::mutex> lk(c->lanes_mu);
+        c->lanes_cv.wait(lk, [&] { for (char b : c->busy) if (b) return false; return true; });
+        n = c->lanes.size();
+        for (size_t i = 0; i < n; i++) c->busy[i] = 1;
+    }
+    ~AllLanes() { { std::lock_guard<std::mutex> lk(c->lanes_mu); for (size_t i = 0; i < n; i++) c->busy[i] = 0; } c->lanes_cv.notify_all(); }
+};
 }
 
 void psk_ctx_destroy(psk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    Scratch* all[] = {&c->s_desc, &c->s_packed, &c->s_mask, &c->s_counts, &c->s_offs, &c->s_tmp, &c->s_mark, &c->s_flags, &c->s_misc,
-                      &c->q_a, &c->q_b, &c->q_c, &c->q_d, &c->q_e, &c->q_f, &c->q_g, &c->q_h, &c->q_i};
-    for (Scratch* s : all) s->release();
-    ingest_release(c);
-    c->jobs_release();
+    {
+        AllLanes all(c);
+        for (Lane* L : c->lanes) { if (L->stream) (void)hipStreamSynchronize(L->stream); }
+        ingest_release(c);
+        for (Lane* L : c->lanes) { L->release_all(); delete L; }
+        c->lanes.clear(); c->busy.clear(); all.n = 0;
+    }
     c->pool_drain();
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 psk_status psk_ctx_synchronize(psk_ctx* c) {
     if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
     PSK_HIP(hipSetDevice(c->device));
-    PSK_HIP(hipStreamSynchronize(c->stream));
+    AllLanes all(c);
+    for (Lane* L : c->lanes) PSK_HIP(hipStreamSynchronize(L->stream));
     return PSK_OK;
 }
 
 psk_status psk_ctx_set_timing(psk_ctx* c, int on) {
     if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(c->mu);
+    AllLanes all(c);
     c->timing = on != 0;
     return PSK_OK;
 }
 
 psk_status psk_ctx_timing(psk_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
     if (!c || !kernel) { psk_set_error("ctx_timing: NULL argument"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(c->mu);
     PSK_HIP(hipSetDevice(c->device));
-    PSK_HIP(hipStreamSynchronize(c->stream));
-    for (TimerRec& r : c->pending) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.id] += ms; c->acc_n[r.id]++; }
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    AllLanes all(c);
+    for (Lane* L : c->lanes) {
+        PSK_HIP(hipStreamSynchronize(L->stream));
+        for (TimerRec& r : L->pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.id] += ms; c->acc_n[r.id]++; }
+            (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        }
+        L->pending.clear();
     }
-    c->pending.clear();
     for (int i = 0; i < K_COUNT; i++) if (!strcmp(kernel, KERNEL_NAMES[i])) {
         if (total_ms) *total_ms = c->acc_ms[i];
         if (launches) *launches = c->acc_n[i];
-        if (!strcmp(kernel, "reset")) break;
         return PSK_OK;
     }
     if (!strcmp(kernel, "reset")) { for (int i = 0; i < K_COUNT; i++) { c->acc_ms[i] = 0; c->acc_n[i] = 0; } return PSK_OK; }
@@ -105,9 +120,9 @@ psk_status psk_device_free(psk_ctx* c, void* dptr) {
 }
 psk_status psk_memcpy_h2d(psk_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (!dst && bytes) || (!src && bytes)) { psk_set_error("memcpy_h2d: NULL argument"); return PSK_EINVAL; }
-    PSK_HIP(hipSetDevice(c->device));
-    PSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    PSK_HIP(hipStreamSynchronize(c->stream));
+    PSK_LANE(lg, c);
+    PSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, lg.lane->stream));
+    PSK_HIP(hipStreamSynchronize(lg.lane->stream));
     return PSK_OK;
 }
 
@@ -115,8 +130,8 @@ psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint
                                    const uint64_t* contig_len, const uint32_t* genome_first_contig, uint32_t n_genomes,
                                    int want_seeds, psk_sketch** out) {
     if (!ctx || !out || (n_genomes && (!genome_first_contig || !contig_off || !contig_len))) { psk_set_error("sketch_batch: NULL argument"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, ctx);
+    Lane* lane = lg.lane;
     // seed offsets are 32-bit per launch: size sub-batches so that the expected seed count
     // (bases / c) stays far below 2^31; if a launch still overflows (PSK_ELIMIT) halve and retry
     const uint64_t c_eff = p && p->c > 0 ? (uint64_t)p->c : 1;
@@ -131,7 +146,7 @@ psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint
             if (g1 > g0 && bases + gb > limit) break;
             bases += gb; g1++;
         }
-        psk_status rc = sketch_batch_impl(ctx, p, d_bases, contig_off, contig_len, genome_first_contig + g0, g1 - g0, want_seeds, out + g0);
+        psk_status rc = sketch_batch_impl(lane, p, d_bases, contig_off, contig_len, genome_first_contig + g0, g1 - g0, want_seeds, out + g0);
         if (rc == PSK_ELIMIT && g1 - g0 > 1) { limit = bases / 2; continue; }
         if (rc != PSK_OK) {
             for (uint32_t g = 0; g < g0; g++) { delete out[g]; out[g] = nullptr; }
@@ -145,8 +160,8 @@ psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint
 psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
                            uint32_t n_contigs, int want_seeds, psk_sketch** out) {
     if (!ctx || !p || !out || (n_contigs && (!contigs || !lens))) { psk_set_error("sketch_host: NULL argument"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, ctx);
+    Lane* lane = lg.lane;
     // stage the contigs in HBM at 16-byte aligned offsets (short contigs are dropped later, lib.rs:156)
     std::vector<uint64_t> off(n_contigs), len(n_contigs);
     uint64_t total = 0;
@@ -154,12 +169,12 @@ psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* con
         off[i] = total; len[i] = lens[i];
         if (lens[i] >= MIN_LENGTH_CONTIG) total += (lens[i] + 15) & ~15ull;
     }
-    PSK_TRY(ctx->s_misc.reserve(total + 64));
-    uint8_t* d = (uint8_t*)ctx->s_misc.p;
+    PSK_TRY(lane->s_misc.reserve(total + 64));
+    uint8_t* d = (uint8_t*)lane->s_misc.p;
     for (uint32_t i = 0; i < n_contigs; i++)
-        if (lens[i] >= MIN_LENGTH_CONTIG) PSK_HIP(hipMemcpyAsync(d + off[i], contigs[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+        if (lens[i] >= MIN_LENGTH_CONTIG) PSK_HIP(hipMemcpyAsync(d + off[i], contigs[i], lens[i], hipMemcpyHostToDevice, lane->stream));
     uint32_t gfc[2] = {0, n_contigs};
-    return sketch_batch_impl(ctx, p, d, off.data(), len.data(), gfc, 1, want_seeds, out);
+    return sketch_batch_impl(lane, p, d, off.data(), len.data(), gfc, 1, want_seeds, out);
 }
 
 void psk_sketch_free(psk_sketch* s) { delete s; }
@@ -176,9 +191,8 @@ psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds
 
 psk_status psk_sketch_export(const psk_sketch* s, psk_seed* seeds, uint64_t* markers) {
     if (!s) { psk_set_error("NULL sketch"); return PSK_EINVAL; }
-    psk_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, s->ctx);
+    Lane* ctx = lg.lane;
     if (seeds && s->n_seeds) {
         size_t n = s->n_seeds;
         std::vector<uint32_t> kmer(n), pos(n), meta(n);
@@ -209,8 +223,8 @@ psk_status psk_sketch_import(psk_ctx* ctx, const psk_params* p, const uint32_t* 
     if (p->k < 1 || p->k > 16 || p->c < 1 || p->marker_c < 1) { psk_set_error("invalid sketch parameters"); return PSK_EINVAL; }
     if (n_seeds >= 0x7FFFFFF0ull || n_markers >= 0x7FFFFFF0ull) { psk_set_error("sketch too large to import"); return PSK_ELIMIT; }
     *out = nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, ctx);
+    Lane* lane = lg.lane;
     std::unique_ptr<psk_sketch> s(new psk_sketch());
     s->ctx = ctx; s->params = *p; s->has_seeds = has_seeds != 0;
     s->contig_len.assign(contig_lens, contig_lens + n_contigs);
@@ -242,7 +256,7 @@ psk_status psk_sketch_import(psk_ctx* ctx, const psk_params* p, const uint32_t* 
     store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cs);
     PSK_TRY(ctx->pool_alloc(8 * ((size_t)n_markers + 1), &store->mbase, &store->mbytes));
     store->markers = (uint64_t*)store->mbase;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = lane->stream;
     if (ns) {
         PSK_HIP(hipMemcpyAsync(store->seed_kmer, kmer.data(), 4 * ns, hipMemcpyHostToDevice, st));
         PSK_HIP(hipMemcpyAsync(store->seed_pos, pos.data(), 4 * ns, hipMemcpyHostToDevice, st));
@@ -280,7 +294,7 @@ void psk_db_destroy(psk_db* db) {
 psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     if (!db || !name || !s) { delete s; psk_set_error("db_add: NULL argument"); return PSK_EINVAL; }
     if (s->ctx != db->ctx) { delete s; psk_set_error("db_add: sketch belongs to another context"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(db->ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(db->rw);      // exclusive, as `&mut self` makes Database::sketch (lib.rs:479)
     db->refs.push_back(s);
     db->names.emplace_back(name);
     db->note_added((uint32_t)db->refs.size() - 1);
@@ -290,7 +304,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
 
 psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* const* sketches, uint32_t n) {
     if (!db || (n && (!names || !sketches))) { psk_set_error("db_add_batch: NULL argument"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(db->ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(db->rw);
     for (uint32_t i = 0; i < n; i++)
         if (!sketches[i] || !names[i] || sketches[i]->ctx != db->ctx) { psk_set_error("db_add_batch: bad entry %u", i); return PSK_EINVAL; }
     for (uint32_t i = 0; i < n; i++) {
@@ -302,23 +316,21 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
     return PSK_OK;
 }
 
-// the three readers take the context lock: a concurrent psk_db_add may be growing the vectors
-uint32_t psk_db_size(const psk_db* db) { if (!db) return 0; std::lock_guard<std::mutex> lk(db->ctx->mu); return (uint32_t)db->refs.size(); }
-const char* psk_db_name(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::lock_guard<std::mutex> lk(db->ctx->mu); return i < db->names.size() ? db->names[i].c_str() : nullptr; }
-const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::lock_guard<std::mutex> lk(db->ctx->mu); return i < db->refs.size() ? db->refs[i] : nullptr; }
+// the three readers take the database lock shared: a concurrent psk_db_add may be growing the vectors
+uint32_t psk_db_size(const psk_db* db) { if (!db) return 0; std::shared_lock<std::shared_mutex> lk(db->rw); return (uint32_t)db->refs.size(); }
+const char* psk_db_name(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::shared_lock<std::shared_mutex> lk(db->rw); return i < db->names.size() ? db->names[i].c_str() : nullptr; }
+const psk_sketch* psk_db_sketch(const psk_db* db, uint32_t i) { if (!db) return nullptr; std::shared_lock<std::shared_mutex> lk(db->rw); return i < db->refs.size() ? db->refs[i] : nullptr; }
 
 psk_status psk_screen(psk_db* db, const psk_sketch* q, double screen_val, int rescue_small, uint8_t* pass, uint32_t* shared) {
-    if (!db || !q || (!pass && !db->refs.empty())) { psk_set_error("screen: NULL argument"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(db->ctx->mu);
-    PSK_HIP(hipSetDevice(db->ctx->device));
-    return screen_impl(db, q, screen_val, rescue_small, pass, shared);
+    if (!db || !q || !pass) { psk_set_error("screen: NULL argument"); return PSK_EINVAL; }
+    PSK_LANE(lg, db->ctx);
+    return screen_impl(lg.lane, db, q, screen_val, rescue_small, pass, shared);
 }
 
 psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs, const psk_sketch* q, const psk_query_opts* o, psk_hit* out) {
     if (!ctx) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
-    return chain_impl(ctx, refs, n_refs, q, o, out);
+    PSK_LANE(lg, ctx);
+    return chain_impl(lg.lane, refs, n_refs, q, o, out);
 }
 
 static psk_status hits_out(const std::vector<psk_hit>& all, psk_hit** hits) {
@@ -332,12 +344,10 @@ static psk_status hits_out(const std::vector<psk_hit>& all, psk_hit** hits) {
 psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, psk_hit** hits, uint64_t* n_hits) {
     if (!db || !q || !o || !hits || !n_hits) { psk_set_error("query: NULL argument"); return PSK_EINVAL; }
     *hits = nullptr; *n_hits = 0;
-    psk_ctx* ctx = db->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, db->ctx);
     std::vector<psk_hit> all;
     uint64_t offs[2];
-    PSK_TRY(query_many_impl(db, &q, 1, o, all, offs));
+    PSK_TRY(query_many_impl(lg.lane, db, &q, 1, o, all, offs));
     PSK_TRY(hits_out(all, hits));
     *n_hits = all.size();
     return PSK_OK;
@@ -350,11 +360,9 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     if (!db || (!queries && n_queries) || !o || !hits || !offsets) { psk_set_error("query_many: NULL argument"); return PSK_EINVAL; }
     *hits = nullptr;
     offsets[0] = 0;
-    psk_ctx* ctx = db->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, db->ctx);
     std::vector<psk_hit> all;
-    PSK_TRY(query_many_impl(db, queries, n_queries, o, all, offsets));
+    PSK_TRY(query_many_impl(lg.lane, db, queries, n_queries, o, all, offsets));
     return hits_out(all, hits);
 }
 
@@ -398,10 +406,10 @@ psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity) 
     const uint64_t nc = s->contig_len.size(), ns = s->n_seeds, nm = s->n_markers;
     const PackLayout L = pack_layout(nc, ns, nm);
     if (capacity < L.end) { psk_set_error("pack: destination holds %llu bytes, the record needs %llu", (unsigned long long)capacity, (unsigned long long)L.end); return PSK_EINVAL; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, ctx);
+    Lane* lane = lg.lane;
     void* hp;
-    PSK_TRY(ctx->pinned(L.o_kmer, &hp));
+    PSK_TRY(lane->pinned(L.o_kmer, &hp));
     memset(hp, 0, L.o_kmer);
     PackHeader* H = (PackHeader*)hp;
     H->magic = PACK_MAGIC; H->version = 1; H->c = s->params.c; H->marker_c = s->params.marker_c; H->k = s->params.k;
@@ -411,7 +419,7 @@ psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity) 
     uint32_t* hc = (uint32_t*)((char*)hp + L.o_cs);
     for (uint64_t i = 0; i <= nc; i++) hc[i] = i < s->contig_seed_start.size() ? s->contig_seed_start[i] : (uint32_t)ns;
     char* d = (char*)d_dst;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = lane->stream;
     PSK_HIP(hipMemcpyAsync(d, hp, L.o_kmer, hipMemcpyHostToDevice, st));
     if (ns) {
         PSK_HIP(hipMemcpyAsync(d + L.o_kmer, s->store->seed_kmer + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
@@ -428,9 +436,8 @@ psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* of
     if (!ctx || (n && (!d_src || !offsets || !out))) { psk_set_error("unpack: NULL argument"); return PSK_EINVAL; }
     for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
     if (!n) return PSK_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    PSK_LANE(lg, ctx);
+    hipStream_t st = lg.lane->stream;
     const char* src = (const char*)d_src;
     std::vector<PackHeader> H(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -546,6 +553,7 @@ struct IngestRes {   // per-context resources of the pipeline, created on first 
     void* pinned[INGEST_SLOTS] = {nullptr}; hipEvent_t slot_free[INGEST_SLOTS] = {nullptr};
     Scratch dev[2]; hipEvent_t ready[2] = {nullptr, nullptr};
     std::unique_ptr<ParallelFor> pool;
+    std::mutex mu;
 };
 std::mutex g_ingest_mu;
 std::map<psk_ctx*, IngestRes*> g_ingest;
@@ -570,8 +578,8 @@ psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t
     if (!ctx || !p || !out || (n_genomes && (!genome_first_contig || !lens || !contigs))) { psk_set_error("sketch_many_host: NULL argument"); return PSK_EINVAL; }
     for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
     if (!n_genomes) return PSK_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, ctx);
+    Lane* lane = lg.lane;
     IngestRes* R;
     {
         std::lock_guard<std::mutex> g(g_ingest_mu);
@@ -590,6 +598,7 @@ psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t
         }
         R = slot;
     }
+    std::lock_guard<std::mutex> ingest_lock(R->mu);     // one pipelined ingest per context at a time (its staging slots are shared)
     const uint32_t n_contigs = genome_first_contig[n_genomes];
     // sub-batches of ~192 MB of ASCII (whole genomes); device offsets of the kept contigs, 16-byte aligned
     const uint64_t SUB = 192ull << 20;
@@ -655,9 +664,9 @@ psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t
     for (size_t b = 0; b < subs.size() && rc == PSK_OK; b++) {
         { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return produced > (int)b; }); if (prod_rc != PSK_OK) { rc = prod_rc; psk_set_error("ingest: %s", prod_err.c_str()); break; } }
         const Sub& s = subs[b];
-        hipError_t e = hipStreamWaitEvent(ctx->stream, R->ready[b & 1], 0);
+        hipError_t e = hipStreamWaitEvent(lane->stream, R->ready[b & 1], 0);
         if (e != hipSuccess) { psk_set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); rc = PSK_EHIP; break; }
-        rc = sketch_batch_impl(ctx, p, (const uint8_t*)R->dev[b & 1].p, off.data(), len64.data(), genome_first_contig + s.g0, s.g1 - s.g0, want_seeds, out + s.g0);
+        rc = sketch_batch_impl(lane, p, (const uint8_t*)R->dev[b & 1].p, off.data(), len64.data(), genome_first_contig + s.g0, s.g1 - s.g0, want_seeds, out + s.g0);
         { std::lock_guard<std::mutex> l(m); consumed = (int)b + 1; }
         cv.notify_all();
     }

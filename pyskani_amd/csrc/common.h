@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
+#include <condition_variable>
 #include <deque>
 #include <string>
 #include <unordered_map>
@@ -72,21 +74,65 @@ enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANC
 static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce"};
 struct TimerRec { int id; hipEvent_t a, b; };
 
+// One GPU (the public psk_ctx handle): the HBM block pool and the execution lanes. A LANE is what a call runs on: its own HIP
+// stream, scratch buffers and pinned staging, so that calls from different host threads overlap on the device (the reference's
+// `query` takes &self and releases the GIL, lib.rs:551,569: concurrent queries are its only route to parallelism).
+struct Lane;
 struct psk_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<TimerRec> pending;
+    std::mutex stat_mu;
     double acc_ms[K_COUNT] = {0};
     uint64_t acc_n[K_COUNT] = {0};
+    // lanes: created on demand, at most max_lanes; a call takes a free one (LaneGuard) and gives it back
+    std::mutex lanes_mu;
+    std::condition_variable lanes_cv;
+    std::vector<Lane*> lanes;
+    std::vector<char> busy;
+    int max_lanes = 4;
+    std::mutex index_mu;           // k-mer index builds mutate sketches: one at a time
+    // device block pool: sketch stores are recycled instead of hipMalloc/hipFree'd per batch
+    struct PoolBlock { void* p; size_t bytes; };
+    std::vector<PoolBlock> pool;
+    std::mutex pool_mu;
+    psk_status pool_alloc(size_t bytes, void** out, size_t* got) {
+        {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            int best = -1;
+            for (int i = 0; i < (int)pool.size(); i++)
+                if (pool[i].bytes >= bytes && pool[i].bytes <= bytes + bytes / 4 + (1 << 20) && (best < 0 || pool[i].bytes < pool[best].bytes)) best = i;
+            if (best >= 0) { *out = pool[best].p; *got = pool[best].bytes; pool.erase(pool.begin() + best); return PSK_OK; }
+        }
+        size_t want = bytes + bytes / 16 + 256;
+        PSK_HIP(hipMalloc(out, want));
+        *got = want;
+        return PSK_OK;
+    }
+    void pool_release(void* p, size_t bytes) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(pool_mu);
+        size_t held = 0;
+        for (auto& b : pool) held += b.bytes;
+        if (held + bytes > (size_t)64 << 30 || pool.size() >= 16) { (void)hipFree(p); return; }   // cap what the pool keeps
+        pool.push_back({p, bytes});
+    }
+    void pool_drain() { std::lock_guard<std::mutex> lk(pool_mu); for (auto& b : pool) (void)hipFree(b.p); pool.clear(); }
+};
+
+struct Lane {
+    psk_ctx* dev = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<TimerRec> pending;
     void t_begin(int id, hipStream_t st = nullptr) {
-        if (!timing) return;
+        if (!dev->timing) return;
         TimerRec r{id, nullptr, nullptr};
         (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, st ? st : stream);
         pending.push_back(r);
     }
-    void t_end(hipStream_t st = nullptr) { if (timing && !pending.empty()) (void)hipEventRecord(pending.back().b, st ? st : stream); }
+    void t_end(hipStream_t st = nullptr) { if (dev->timing && !pending.empty()) (void)hipEventRecord(pending.back().b, st ? st : stream); }
+    psk_status pool_alloc(size_t bytes, void** out, size_t* got) { return dev->pool_alloc(bytes, out, got); }
     // resources of one in-flight sketch sub-batch: own stream + scratch, so that sketch_emit / sorts of
     // sub-batch j overlap sketch_scan of sub-batch j+1
     struct JobRes {
@@ -129,35 +175,8 @@ struct psk_ctx {
         }
         jobs.clear();
     }
-    std::mutex mu;                 // one stream per ctx: calls are serialised
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
-    // device block pool: sketch stores are recycled instead of hipMalloc/hipFree'd per batch
-    struct PoolBlock { void* p; size_t bytes; };
-    std::vector<PoolBlock> pool;
-    std::mutex pool_mu;
-    psk_status pool_alloc(size_t bytes, void** out, size_t* got) {
-        {
-            std::lock_guard<std::mutex> lk(pool_mu);
-            int best = -1;
-            for (int i = 0; i < (int)pool.size(); i++)
-                if (pool[i].bytes >= bytes && pool[i].bytes <= bytes + bytes / 4 + (1 << 20) && (best < 0 || pool[i].bytes < pool[best].bytes)) best = i;
-            if (best >= 0) { *out = pool[best].p; *got = pool[best].bytes; pool.erase(pool.begin() + best); return PSK_OK; }
-        }
-        size_t want = bytes + bytes / 16 + 256;
-        PSK_HIP(hipMalloc(out, want));
-        *got = want;
-        return PSK_OK;
-    }
-    void pool_release(void* p, size_t bytes) {
-        if (!p) return;
-        std::lock_guard<std::mutex> lk(pool_mu);
-        size_t held = 0;
-        for (auto& b : pool) held += b.bytes;
-        if (held + bytes > (size_t)64 << 30 || pool.size() >= 16) { (void)hipFree(p); return; }   // cap what the pool keeps
-        pool.push_back({p, bytes});
-    }
-    void pool_drain() { std::lock_guard<std::mutex> lk(pool_mu); for (auto& b : pool) (void)hipFree(b.p); pool.clear(); }
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
     size_t h_pinned_cap = 0;
     psk_status pinned(size_t bytes, void** out) {
@@ -171,7 +190,45 @@ struct psk_ctx {
         *out = h_pinned;
         return PSK_OK;
     }
+    void release_all() {
+        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i};
+        for (Scratch* s : all) s->release();
+        jobs_release();
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        h_pinned = nullptr; h_pinned_cap = 0;
+        for (TimerRec& r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        pending.clear();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
 };
+
+// takes a free lane of the context for the duration of one call (creates one if all are busy and fewer than max_lanes exist)
+struct LaneGuard {
+    psk_ctx* c; Lane* lane = nullptr; int idx = -1;
+    explicit LaneGuard(psk_ctx* ctx) : c(ctx) {
+        std::unique_lock<std::mutex> lk(c->lanes_mu);
+        for (;;) {
+            for (size_t i = 0; i < c->lanes.size(); i++) if (!c->busy[i]) { idx = (int)i; break; }
+            if (idx >= 0) break;
+            if ((int)c->lanes.size() < c->max_lanes) {
+                (void)hipSetDevice(c->device);
+                Lane* L = new Lane();
+                L->dev = c; L->device = c->device;
+                if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { delete L; if (c->lanes.empty()) return; }
+                else { c->lanes.push_back(L); c->busy.push_back(0); idx = (int)c->lanes.size() - 1; break; }
+            }
+            c->lanes_cv.wait(lk);
+        }
+        c->busy[idx] = 1; lane = c->lanes[idx];
+        lk.unlock();
+        (void)hipSetDevice(c->device);
+    }
+    ~LaneGuard() { if (idx >= 0) { { std::lock_guard<std::mutex> lk(c->lanes_mu); c->busy[idx] = 0; } c->lanes_cv.notify_one(); } }
+    LaneGuard(const LaneGuard&) = delete;
+    LaneGuard& operator=(const LaneGuard&) = delete;
+};
+#define PSK_LANE(guard, ctx) LaneGuard guard(ctx); if (!guard.lane) { psk_set_error("no execution lane (hipStreamCreate failed)"); return PSK_EHIP; }
 
 // k-mer-sorted reference index of a group of sketches, built on first chaining use (ensure_index)
 struct IndexStore {
@@ -251,6 +308,9 @@ struct psk_sketch {
 
 struct psk_db {
     psk_ctx* ctx = nullptr;
+    // queries hold it shared while they compute; adding references and (re)building the shared device tables
+    // (marker table, inverted index, k-mer indexes of references, descriptor table) take it exclusively
+    mutable std::shared_mutex rw;
     psk_params params{};
     std::vector<psk_sketch*> refs;
     std::deque<std::string> names;       // deque: psk_db_name() pointers stay valid while sketches are added
@@ -259,8 +319,9 @@ struct psk_db {
     // stands for the name's LAST sketch and yields one hit. canon[i] = last index holding names[i].
     std::unordered_map<std::string, uint32_t> last_by_name;
     std::vector<uint32_t> canon;
-    bool has_dups = false;
+    bool has_dups = false, canon_dirty = false;
     void note_added(uint32_t i) {
+        canon_dirty = true;
         auto it = last_by_name.find(names[i]);
         if (it != last_by_name.end()) { has_dups = true; for (uint32_t j = 0; j < i; j++) if (canon[j] == it->second) canon[j] = i; it->second = i; }
         else last_by_name.emplace(names[i], i);
@@ -333,18 +394,18 @@ __device__ __forceinline__ uint64_t mm_hash64_u32(uint32_t key) {
 }
 
 // host-side entry points implemented across the translation units
-psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
+psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
                              int want_seeds, psk_sketch** out);
 // sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
-psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n);
-psk_status screen_impl(psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
+psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
+psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
-psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
+psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out);
 // Database.query for n_queries sketches (lib.rs:569-659): hits of query i are all[offsets[i] .. offsets[i+1]), ref insertion order
-psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                            std::vector<psk_hit>& all, uint64_t* offsets);
-psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs,
+psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);

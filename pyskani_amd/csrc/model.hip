@@ -177,7 +177,6 @@ psk_status psk_model_create(psk_ctx* ctx, const psk_tree_node* nodes, uint64_t n
     first[n_trees] = (uint32_t)n_nodes;
     std::unique_ptr<psk_model> m(new psk_model());
     m->ctx = ctx; m->n_nodes = n_nodes; m->features.assign(features, features + n_features);
-    std::lock_guard<std::mutex> lk(ctx->mu);
     PSK_HIP(hipSetDevice(ctx->device));
     const size_t nb = sizeof(ModelNode) * h.size(), fb = sizeof(uint32_t) * first.size();
     PSK_HIP(hipMalloc(&m->base, nb + fb + 256));
@@ -263,9 +262,8 @@ psk_status psk_model_info(const psk_model* m, uint32_t* n_trees, uint64_t* n_nod
 psk_status psk_model_predict(const psk_model* m, const float* rows, uint32_t n_rows, float* out) {
     if (!m || (n_rows && (!rows || !out))) { psk_set_error("model_predict: NULL argument"); return PSK_EINVAL; }
     if (!n_rows) return PSK_OK;
-    psk_ctx* ctx = m->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    PSK_HIP(hipSetDevice(ctx->device));
+    PSK_LANE(lg, m->ctx);
+    Lane* ctx = lg.lane;
     const size_t rb = sizeof(float) * (size_t)n_rows * m->dev.n_features, ob = sizeof(float) * (size_t)n_rows;
     PSK_TRY(ctx->q_g.reserve(rb + ob + 256));
     float* d_rows = (float*)ctx->q_g.p; float* d_out = (float*)((char*)ctx->q_g.p + ((rb + 255) & ~(size_t)255));

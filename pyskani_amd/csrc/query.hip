@@ -43,23 +43,17 @@ __global__ __launch_bounds__(256) void screen_kernel(const MarkerSet* __restrict
     }
 }
 
-psk_status screen_impl(psk_db* db, const psk_sketch* q, double screen_val, int rescue_small, uint8_t* pass, uint32_t* shared) {
-    psk_ctx* ctx = db->ctx;
+static psk_status upload_marker_table(Lane* ctx, psk_db* db);
+psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* q, double screen_val, int rescue_small, uint8_t* pass, uint32_t* shared) {
+    std::shared_lock<std::shared_mutex> sh(db->rw);
+    if (db->tables_dirty) {      // shared device tables are (re)built under the exclusive lock: no other lane is reading them
+        sh.unlock();
+        { std::unique_lock<std::shared_mutex> ex(db->rw); PSK_TRY(upload_marker_table(ctx, db)); }
+        sh.lock();
+    }
     const uint32_t n = (uint32_t)db->refs.size();
     if (n == 0) return PSK_OK;
     hipStream_t st = ctx->stream;
-    if (db->tables_dirty) {
-        std::vector<MarkerSet> h(n);
-        for (uint32_t i = 0; i < n; i++) {
-            const psk_sketch* r = db->refs[i];
-            h[i].p = r->store ? r->store->markers + r->marker_off : nullptr;
-            h[i].n = (uint32_t)r->n_markers; h[i].pad = 0;
-        }
-        PSK_TRY(db->d_marker_ptr.reserve(sizeof(MarkerSet) * n));
-        PSK_HIP(hipMemcpyAsync(db->d_marker_ptr.p, h.data(), sizeof(MarkerSet) * n, hipMemcpyHostToDevice, st));
-        PSK_HIP(hipStreamSynchronize(st));
-        db->tables_dirty = false;
-    }
     PSK_TRY(ctx->q_a.reserve((size_t)n * 8));
     uint8_t* d_pass = (uint8_t*)ctx->q_a.p;
     uint32_t* d_shared = (uint32_t*)((char*)ctx->q_a.p + (((size_t)n + 3) & ~(size_t)3));
@@ -111,8 +105,7 @@ __global__ __launch_bounds__(256) void screen_many_kernel(const MarkerSet* __res
     }
 }
 
-static psk_status upload_marker_table(psk_db* db) {
-    psk_ctx* ctx = db->ctx;
+static psk_status upload_marker_table(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
     if (!db->tables_dirty) return PSK_OK;
     std::vector<MarkerSet> h(n);
@@ -192,9 +185,9 @@ __global__ __launch_bounds__(512) void inv_screen_lds_kernel(const MarkerSet* __
     }
 }
 
-static psk_status build_inverted(psk_db* db) {
+static psk_status build_inverted(Lane* ctx, psk_db* db) {
     if (!db->inv_dirty) return PSK_OK;
-    psk_ctx* ctx = db->ctx; hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)db->refs.size();
     std::vector<uint32_t> roff(n + 1, 0);
     uint64_t tot = 0;
@@ -222,18 +215,17 @@ static psk_status build_inverted(psk_db* db) {
 // Screens nq queries against every reference of the db; the pass matrix [nq][n_refs] STAYS ON THE DEVICE (d_pass, caller-owned).
 // `keep` holds the host staging of the async uploads until the caller's next stream synchronisation.
 struct ScreenStaging { std::deque<std::vector<MarkerSet>> hq; std::deque<std::vector<uint32_t>> qoff; };
-static psk_status screen_many_device(psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small,
+static psk_status screen_many_device(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t nq, double screen_val, int rescue_small,
                                      uint8_t* d_pass, ScreenStaging& keep) {
-    psk_ctx* ctx = db->ctx;
     const uint32_t n = (uint32_t)db->refs.size();
     if (n == 0 || nq == 0) return PSK_OK;
     hipStream_t st = ctx->stream;
-    PSK_TRY(upload_marker_table(db));
+    PSK_TRY(upload_marker_table(ctx, db));
     const double thresh = pow(screen_val, (double)K_MARKER);
     // small jobs: one workgroup per (ref, query). Large jobs: inverted index + count matrix.
     const char* force = getenv("PSK_SCREEN");    // "inv" / "brute" for tests
     const bool use_inv = force ? !strcmp(force, "inv") : ((uint64_t)n * nq >= (1ull << 18));
-    if (use_inv) PSK_TRY(build_inverted(db));
+    if (use_inv) PSK_TRY(build_inverted(ctx, db));
     const uint32_t per = std::max<uint32_t>(1, std::min<uint32_t>(65535, (use_inv ? (1u << 26) : (1u << 24)) / n));   // queries per launch
     // per sub-launch: query marker table + offsets (+ the count matrix of the inverted-index path), side by side in q_a
     const size_t slot_bytes = al256s(sizeof(MarkerSet) * per) + al256s(4 * (size_t)(per + 1));
@@ -1697,7 +1689,7 @@ struct ChainBufs {
     uint32_t *blk_pair, *row_pair;
     uint32_t gi;
 };
-static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
+static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
     const size_t gi = (n_items + 255) / 256;
     size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (n_pairs + 1)),
            o_pstart = al256(o_cbase + 4 * (n_pairs + 1)), o_lb = al256(o_pstart + 4 * (n_pairs + 1)),
@@ -1721,7 +1713,7 @@ static psk_status chain_layout(psk_ctx* ctx, size_t n_pairs, size_t n_items, siz
 // Everything between "pairs / sbase / cbase are on the device" and "hits are on the device": no host synchronisation.
 // Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
 // reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
-static psk_status chain_run(psk_ctx* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
+static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
                             const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
@@ -1833,7 +1825,7 @@ static psk_status chain_run(psk_ctx* ctx, const ChainBufs& L, uint32_t n_pairs, 
     return PSK_OK;
 }
 
-static uint64_t anchor_cap_for(psk_ctx* ctx, size_t n_items) {
+static uint64_t anchor_cap_for(Lane* ctx, size_t n_items) {
     const uint64_t have = ctx->q_d.cap / 64 > 128 ? ctx->q_d.cap / 64 - 128 : 0;     // anchors the per-anchor arrays already hold
     const uint64_t want = (uint64_t)n_items + n_items / 4 + 65536;                  // non-repetitive genomes: at most ~one anchor per query seed
     return std::min<uint64_t>(std::max(have, want), 0x7FFFFF00ull);
@@ -1857,7 +1849,7 @@ static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* ca
 struct HostPair { const psk_sketch* r; const psk_sketch* q; };
 
 // one launch sequence over an explicit list of (ref, query) pairs; out[p] in pair order
-static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs, const psk_query_opts* o, psk_hit* out) {
+static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, const psk_query_opts* o, psk_hit* out) {
     hipStream_t st = ctx->stream;
     // descriptor table: one entry per distinct sketch
     std::unordered_map<const psk_sketch*, uint32_t> slot;
@@ -1908,11 +1900,11 @@ static psk_status chain_batch(psk_ctx* ctx, const HostPair* hp, uint32_t n_pairs
 }
 
 // chain an arbitrary list of (ref, query) pairs; out[i] belongs to pair i (ref_index is left to the caller)
-psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
+psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out) {
     if (!ctx || !o || (n && (!refs || !queries || !out))) { psk_set_error("chain: NULL argument"); return PSK_EINVAL; }
     if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded (skani's GBDT weights are embedded in the skani crate; supply them with psk_model_load_file)"); return PSK_ENOMODEL; }
-    if (o->model && o->model->ctx != ctx) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
+    if (o->model && o->model->ctx != ctx->dev) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
     for (uint32_t i = 0; i < n; i++) {
         if (!refs[i] || !queries[i]) { psk_set_error("chain: NULL sketch in pair %u", i); return PSK_EINVAL; }
         if (!queries[i]->has_seeds) { psk_set_error("query sketch was built with seed=False; it cannot be chained"); return PSK_EINVAL; }
@@ -1951,7 +1943,7 @@ psk_status chain_pairs_impl(psk_ctx* ctx, const psk_sketch* const* refs, const p
     return PSK_OK;
 }
 
-psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_refs, const psk_sketch* q,
+psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs, const psk_sketch* q,
                       const psk_query_opts* o, psk_hit* out) {
     if (!q) { psk_set_error("chain: NULL query"); return PSK_EINVAL; }
     std::vector<const psk_sketch*> qs(n_refs, q);
@@ -1965,8 +1957,7 @@ psk_status chain_impl(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_re
 // table and the ani > 0.1 filter all stay on the device; the host sees, per round, the per-query pass counts and the
 // per-reference flags (ONE synchronisation: it sizes the batches and indexes the references about to be chained), and per
 // batch of up to 2^20 pairs the surviving hits (ONE synchronisation).
-static psk_status refresh_ref_descs(psk_db* db) {
-    psk_ctx* ctx = db->ctx;
+static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
     uint64_t indexed = 0;
     for (const psk_sketch* r : db->refs) indexed += r->idx != nullptr;
@@ -1980,22 +1971,47 @@ static psk_status refresh_ref_descs(psk_db* db) {
     return PSK_OK;
 }
 
-psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                            std::vector<psk_hit>& all, uint64_t* offsets) {
-    psk_ctx* ctx = db->ctx;
     hipStream_t st = ctx->stream;
     offsets[0] = 0;
     if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
-    if (o->model && o->model->ctx != ctx) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
+    if (o->model && o->model->ctx != ctx->dev) { psk_set_error("the regression model belongs to another context"); return PSK_EINVAL; }
+    // Locking: the call holds the database SHARED while it computes, so queries from several host threads overlap on their
+    // lanes; whatever rebuilds device state other lanes may be reading (marker table, inverted index, the references' k-mer
+    // indexes and descriptor table) is done EXCLUSIVELY, synchronised before the lock is handed back.
+    std::shared_lock<std::shared_mutex> sh(db->rw);
     const uint32_t n = (uint32_t)db->refs.size();
+    auto exclusive = [&](auto&& fn) -> psk_status {
+        sh.unlock();
+        psk_status rc;
+        {
+            std::unique_lock<std::shared_mutex> ex(db->rw);
+            rc = db->refs.size() == n ? fn() : PSK_EINVAL;
+            if (rc == PSK_OK && hipStreamSynchronize(st) != hipSuccess) rc = PSK_EHIP;
+        }
+        sh.lock();
+        if (db->refs.size() != n) { psk_set_error("the database was modified while it was being queried"); return PSK_EINVAL; }
+        return rc;
+    };
     for (uint32_t i = 0; i < n_queries; i++) if (!queries[i]) { psk_set_error("query_many: NULL query %u", i); return PSK_EINVAL; }
     if (n == 0) { for (uint32_t i = 0; i < n_queries; i++) offsets[i + 1] = 0; return PSK_OK; }
     const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
     const uint32_t QB = std::max<uint32_t>(1, std::min<uint32_t>(16384, (uint32_t)((1ull << 30) / n)));   // queries per round (pass matrix <= 1 GiB)
-    if (db->has_dups) {
-        PSK_TRY(db->d_canon.reserve(4 * (size_t)n));
-        PSK_HIP(hipMemcpyAsync(db->d_canon.p, db->canon.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
-        PSK_HIP(hipStreamSynchronize(st));
+    {
+        const char* force = getenv("PSK_SCREEN");
+        const bool want_inv = force ? !strcmp(force, "inv") : ((uint64_t)n * std::min(QB, n_queries) >= (1ull << 18));
+        if (db->tables_dirty || (want_inv && db->inv_dirty) || (db->has_dups && db->canon_dirty))
+            PSK_TRY(exclusive([&]() -> psk_status {
+                PSK_TRY(upload_marker_table(ctx, db));
+                if (want_inv) PSK_TRY(build_inverted(ctx, db));
+                if (db->has_dups && db->canon_dirty) {
+                    PSK_TRY(db->d_canon.reserve(4 * (size_t)n));
+                    PSK_HIP(hipMemcpyAsync(db->d_canon.p, db->canon.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+                    db->canon_dirty = false;
+                }
+                return PSK_OK;
+            }));
     }
     std::vector<uint32_t> h_cnt; std::vector<uint8_t> h_flag;
     std::vector<SketchDesc> h_qd;
@@ -2007,7 +2023,7 @@ psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_
         PSK_TRY(ctx->q_i.reserve(o_end + 256));
         uint8_t* d_pass = (uint8_t*)ctx->q_i.p + o_pass; uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_i.p + o_cnt); uint8_t* d_flag = (uint8_t*)ctx->q_i.p + o_flag;
         ScreenStaging keep;
-        PSK_TRY(screen_many_device(db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
+        PSK_TRY(screen_many_device(ctx, db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
         if (db->has_dups) hipLaunchKernelGGL(pass_canon_kernel, dim3(m), dim3(256), 0, st, d_pass, n, (const uint32_t*)db->d_canon.p);
         PSK_HIP(hipMemsetAsync(d_flag, 0, n, st));
         hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag);
@@ -2025,6 +2041,7 @@ psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_
             if (!rs->has_seeds) { psk_set_error("reference %u ('%s') was sketched with seed=False; it cannot be chained", r, db->names[r].c_str()); return PSK_EINVAL; }
             need.push_back(rs);
         }
+        const size_t n_need_refs = need.size();
         uint64_t round_pairs = 0;
         for (uint32_t i = 0; i < m; i++) if (h_cnt[i]) {
             const psk_sketch* q = queries[b + i];
@@ -2035,8 +2052,19 @@ psk_status query_many_impl(psk_db* db, const psk_sketch* const* queries, uint32_
         }
         for (const psk_sketch* rs : need) if (rs->params.k != db->params.k || rs->params.c != db->params.c) { psk_set_error("a reference and the database were sketched with different parameters"); return PSK_EINVAL; }
         if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
-        PSK_TRY(ensure_index(ctx, need.data(), (uint32_t)need.size()));
-        PSK_TRY(refresh_ref_descs(db));
+        {   // references first (shared state: exclusive), then this call's own query sketches
+            bool refs_stale = db->desc_dirty || db->desc_n != n;
+            uint64_t indexed = 0;
+            for (const psk_sketch* rs : db->refs) indexed += rs->idx != nullptr;
+            refs_stale = refs_stale || indexed != db->desc_indexed;
+            for (size_t i = 0; i < n_need_refs && !refs_stale; i++) refs_stale = !need[i]->idx && need[i]->n_seeds && need[i]->store;
+            if (refs_stale)
+                PSK_TRY(exclusive([&]() -> psk_status {
+                    PSK_TRY(ensure_index(ctx, need.data(), (uint32_t)n_need_refs));
+                    return refresh_ref_descs(ctx, db);
+                }));
+            if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
+        }
         h_qd.resize(m);
         for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
         PSK_TRY(ctx->q_h.reserve(sizeof(SketchDesc) * (size_t)m + 256));

@@ -461,7 +461,7 @@ struct ToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) con
 // One sub-batch of genomes moving through the sketch pipeline on its own stream. The phases are split
 // at the two points where the host must learn a size (total seeds, total distinct markers).
 struct SketchJob {
-    psk_ctx* ctx; psk_ctx::JobRes* R; hipStream_t st;
+    Lane* ctx; Lane::JobRes* R; hipStream_t st;
     const psk_params* p; const uint8_t* d_bases; int want_seeds;
     uint32_t n_genomes = 0, n_tiles = 0; int n_desc = 0;
     std::vector<ContigDesc> descs;
@@ -490,7 +490,7 @@ struct SketchJob {
             g_first_desc[g] = (uint32_t)descs.size();
             g_first_tile[g] = (uint32_t)n_tiles64;
             psk_sketch* s = new psk_sketch();
-            s->ctx = ctx; s->params = *p; s->has_seeds = want_seeds != 0;
+            s->ctx = ctx->dev; s->params = *p; s->has_seeds = want_seeds != 0;
             sk[g] = s;
             for (uint32_t ci = gfc[g]; ci < gfc[g + 1]; ci++) {
                 uint64_t len = contig_len[ci];
@@ -599,7 +599,7 @@ struct SketchJob {
         size_t ns = total_seeds;
         size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
                b_pm = align_up(b_meta + 4 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
-        store->ctx = ctx;
+        store->ctx = ctx->dev;
         PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
         char* sb = (char*)store->base;
         store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
@@ -700,7 +700,7 @@ struct SketchJob {
 #undef JHIP
 };
 
-psk_status sketch_batch_impl(psk_ctx* ctx, const psk_params* p, const uint8_t* d_bases,
+psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
                              int want_seeds, psk_sketch** out) {
@@ -901,7 +901,8 @@ __global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg*
     }
 }
 
-psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n) {
+psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
+    std::lock_guard<std::mutex> index_lock(ctx->dev->index_mu);   // index builds mutate the sketches they index
     hipStream_t st = ctx->stream;
     std::vector<const psk_sketch*> todo;
     std::unordered_set<const psk_sketch*> seen;
@@ -932,7 +933,7 @@ psk_status ensure_index(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n)
             boff += (1ull << lb) + 1;
         }
         auto ix = std::make_shared<IndexStore>();
-        ix->ctx = ctx;
+        ix->ctx = ctx->dev;
         size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256), bb = align_up(4 * (size_t)boff, 256);
         PSK_TRY(ctx->pool_alloc(2 * kb + 2 * vb + bb, &ix->base, &ix->bytes));
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);

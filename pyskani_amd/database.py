@@ -255,7 +255,12 @@ class Database:
         self._device = device
         self._lib = self._ctx._lib
         self._params = _capi.Params(int(compression), int(marker_compression), int(k))
-        self._lock = threading.Lock()   # `sketch` takes &mut self (lib.rs:479)
+        # PyO3 borrow rules of the reference: `sketch` takes &mut self (lib.rs:479), `query` takes &self (lib.rs:551).
+        # Concurrent queries are fine (they overlap on the GPU's execution lanes); a sketch while anything else runs, or
+        # anything while a sketch runs, raises the same RuntimeError PyO3 raises.
+        self._borrow_lock = threading.Lock()
+        self._readers = 0
+        self._writer = False
         self._names = []                # insertion order = markers Vec (lib.rs:501-504)
         self._resident = []             # per ref: True when the full sketch (not only its markers) sits in HBM
         self._cache = collections.OrderedDict()   # lazily loaded sketches of a disk-backed database
@@ -299,6 +304,31 @@ class Database:
         if getattr(self, "_h", None):
             self._lib.psk_db_destroy(self._h)
             self._h = None
+
+    class _Borrow:
+        def __init__(self, db, mutable):
+            self.db, self.mutable = db, mutable
+
+        def __enter__(self):
+            db = self.db
+            with db._borrow_lock:
+                if self.mutable:
+                    if db._writer or db._readers:
+                        raise RuntimeError("Already borrowed")
+                    db._writer = True
+                else:
+                    if db._writer:
+                        raise RuntimeError("Already mutably borrowed")
+                    db._readers += 1
+
+        def __exit__(self, *exc):
+            db = self.db
+            with db._borrow_lock:
+                if self.mutable:
+                    db._writer = False
+                else:
+                    db._readers -= 1
+            return False
 
     def __enter__(self):
         return self
@@ -459,9 +489,7 @@ class Database:
         `for g in genomes: db.sketch(*g)` (lib.rs:477-510 applied per genome), but the contigs cross PCIe through a
         pinned, double-buffered pipeline that overlaps the copies with the sketch kernels — the way to load a large
         reference set from host memory. An addition to the reference API."""
-        if not self._lock.acquire(blocking=False):
-            raise RuntimeError("Already borrowed")
-        try:
+        with Database._Borrow(self, True):
             sketches = self._sketch_many(genomes, seed)
             if self._storage is not None:
                 for sk in sketches:
@@ -473,17 +501,13 @@ class Database:
                 sk._owned = False
                 self._names.append(sk.name)
                 self._resident.append(True)
-        finally:
-            self._lock.release()
         return None
 
     def sketch(self, name, *contigs, seed=True):
         """Add a reference genome to the database (lib.rs:477-510)."""
         if not isinstance(name, str):
             raise TypeError("name must be a str")
-        if not self._lock.acquire(blocking=False):
-            raise RuntimeError("Already borrowed")   # PyO3's &mut self borrow error
-        try:
+        with Database._Borrow(self, True):          # PyO3's &mut self borrow
             sk = self._sketch(name, contigs, seed)
             if self._storage is not None:              # lib.rs:505-508: written at once, markers only on flush
                 self._storage.store(sk.to_record())
@@ -491,8 +515,6 @@ class Database:
             _capi.check(self._lib.psk_db_add(self._h, name.encode("utf-8"), sk._h))
             self._names.append(name)
             self._resident.append(True)
-        finally:
-            self._lock.release()
         return None
 
     def _opts(self, learned_ani, median, robust, cutoff, faster_small):
@@ -540,6 +562,10 @@ class Database:
         """query_many for genomes that are already sketched (`Sketch` objects made with this database's parameters)."""
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         n = len(sketches)
+        with Database._Borrow(self, False):
+            return self._query_sketches(sketches, opts, n)
+
+    def _query_sketches(self, sketches, opts, n):
         if not all(self._resident):      # `open`ed database: sketches come from disk per query
             return [self._query_lazy(s.name, s, opts) for s in sketches]
         arr = (C.c_void_p * max(n, 1))(*[s._h for s in sketches])
@@ -581,6 +607,10 @@ class Database:
         """Query the database with a genome (lib.rs:549-660); returns a list of `Hit`."""
         if not isinstance(name, str):
             raise TypeError("name must be a str")
+        with Database._Borrow(self, False):
+            return self._query(name, contigs, seed, learned_ani, median, robust, cutoff, faster_small)
+
+    def _query(self, name, contigs, seed, learned_ani, median, robust, cutoff, faster_small):
         q = self._sketch(name, contigs, seed)
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         if not all(self._resident):
