@@ -2058,12 +2058,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             for (const psk_sketch* rs : db->refs) indexed += rs->idx != nullptr;
             refs_stale = refs_stale || indexed != db->desc_indexed;
             for (size_t i = 0; i < n_need_refs && !refs_stale; i++) refs_stale = !need[i]->idx && need[i]->n_seeds && need[i]->store;
-            if (refs_stale)
+            if (refs_stale)     // one index launch for the references AND this call's queries (a fresh database: the headline step)
                 PSK_TRY(exclusive([&]() -> psk_status {
-                    PSK_TRY(ensure_index(ctx, need.data(), (uint32_t)n_need_refs));
+                    PSK_TRY(ensure_index(ctx, need.data(), (uint32_t)need.size()));
                     return refresh_ref_descs(ctx, db);
                 }));
-            if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
+            else if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
         }
         h_qd.resize(m);
         for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
