@@ -484,6 +484,166 @@ __global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc*
     }
 }
 
+// The join kernels are bound by the LATENCY of their chain of dependent loads (pair table -> pair descriptor -> query k-mer ->
+// bucket table -> reference k-mers -> reference position) and by instruction issue, at a wave residency the register file
+// already caps (profiles/r2/r2e_pmc_join_kernels_sq.txt: 79 % of residency waiting, 7 waves per SIMD). The *4 variants put
+// JT = 4 tiles of 256 items through every stage TOGETHER - four independent chains in flight per wave instead of one - and
+// amortise the pair lookup over 1 024 items (emit: 37.7 -> 26.1 ms, join: 40.7 -> 38.6 ms per 10^5 pairs).
+constexpr int JT = 4;
+__global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                           uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
+                                                           uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
+                                                           uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair) {
+    __shared__ uint32_t s_key[JT][4][JOIN_WIN];
+    const uint32_t lb = xcd_block_id();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t it[JT], p[JT], km[JT], dst[JT], lo[JT], cnt[JT], w_lo[JT], wn[JT];
+    bool valid[JT], coop[JT], done[JT];
+    uint32_t hint[JT];
+#pragma unroll
+    for (int t = 0; t < JT; t++) { const uint32_t tile = lb * JT + t; hint[t] = blk_pair[tile < n_tiles ? tile : n_tiles - 1]; }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        it[t] = (lb * JT + t) * 256u + threadIdx.x;
+        valid[t] = it[t] < n_items;
+        p[t] = pair_from_hint(sbase, n_pairs, valid[t] ? it[t] : n_items - 1, hint[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        km[t] = 0; dst[t] = 0; lo[t] = 0; cnt[t] = 0; coop[t] = false; done[t] = false; w_lo[t] = 0; wn[t] = 0;
+        if (valid[t]) {
+            const PairDesc& P = pairs[p[t]];
+            const uint32_t iq = it[t] - sbase[p[t]];
+            km[t] = P.q_key[iq];
+            dst[t] = sbase[p[t]] + P.q_perm[iq];     // results are stored in (contig,pos) order
+        }
+    }
+    // bucket reads of every tile whose wave joins one pair
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        const unsigned long long vm = __ballot(valid[t]);
+        if (vm) {
+            const int l0 = __ffsll((long long)vm) - 1, l1 = 63 - __clzll((long long)vm);
+            const uint32_t p0 = __shfl(p[t], l0);
+            if (__all(!valid[t] || p[t] == p0)) {
+                const PairDesc& P0 = pairs[p0];
+                if (P0.r_n == 0) done[t] = true;
+                else {
+                    const uint32_t km_a = __shfl(km[t], l0), km_b = __shfl(km[t], l1);
+                    w_lo[t] = P0.r_bucket[km_a >> P0.r_bshift];
+                    wn[t] = P0.r_bucket[(km_b >> P0.r_bshift) + 1] - w_lo[t];
+                    coop[t] = wn[t] <= (uint32_t)JOIN_WIN;
+                }
+            }
+        }
+    }
+    // the stretches of reference k-mers, staged in LDS
+#pragma unroll
+    for (int t = 0; t < JT; t++) if (coop[t]) {
+        const uint32_t* __restrict__ rk = pairs[__shfl(p[t], __ffsll((long long)__ballot(valid[t])) - 1)].r_key;
+        for (uint32_t j = lane; j < wn[t]; j += 64) s_key[t][wave][j] = rk[w_lo[t] + j];
+    }
+    lds_wave_sync();
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        if (coop[t]) {
+            done[t] = true;
+            if (valid[t]) {      // (starting from the lane's own bucket entry instead of a binary search was measured: slower)
+                const uint32_t* sk = s_key[t][wave];
+                uint32_t a = 0, b = wn[t];
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if (sk[mid] < km[t]) a = mid + 1; else b = mid; }
+                lo[t] = w_lo[t] + a;
+                uint32_t e = a;
+                while (e < wn[t] && sk[e] == km[t]) e++;      // equal k-mers share a bucket: the run ends inside the stretch
+                cnt[t] = e - a;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++)
+        if (!done[t] && valid[t]) { const PairDesc& P = pairs[p[t]]; lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km[t], lo[t], cnt[t]); }
+    uint64_t pm[JT];
+#pragma unroll
+    for (int t = 0; t < JT; t++) pm[t] = (valid[t] && cnt[t]) ? pairs[p[t]].r_pms[lo[t]] : 0ull;
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        if (valid[t]) {
+            uint32_t x = 0, y = 0;
+            if (cnt[t]) {
+                const uint32_t rmeta = (uint32_t)pm[t];
+                x = (uint32_t)(pm[t] >> 32);
+                if (cnt[t] >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
+                else y = rmeta | (cnt[t] << 24);
+            }
+            item_out[dst[t]] = make_uint2(x, y);      // one 8-byte scattered store per item
+        }
+    }
+    {   // 64-bit anchor total of the workgroup (the host compares it with the 32-bit offsets the scan produces)
+        __shared__ unsigned long long s_ws[4];
+        unsigned long long c64 = 0;
+#pragma unroll
+        for (int t = 0; t < JT; t++) c64 += cnt[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+        if (lane == 0) s_ws[wave] = c64;
+        __syncthreads();
+        if (threadIdx.x == 0) block_sum[lb] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                                  uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
+                                                                  const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
+                                                                  uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
+                                                                  uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                                  const uint32_t* __restrict__ blk_pair) {
+    const uint32_t lb = xcd_block_id();
+    uint32_t i[JT], p[JT], c[JT], dst[JT], qp[JT], qm[JT], hint[JT];
+    uint2 rec[JT];
+    bool act[JT];
+#pragma unroll
+    for (int t = 0; t < JT; t++) { const uint32_t tile = lb * JT + t; hint[t] = blk_pair[tile < n_tiles ? tile : n_tiles - 1]; }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        i[t] = (lb * JT + t) * 256u + threadIdx.x;
+        act[t] = i[t] < n_items;
+        rec[t] = act[t] ? item[i[t]] : make_uint2(0, 0);
+        dst[t] = act[t] ? aoff[i[t]] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        c[t] = rec[t].y >> 24;
+        act[t] = act[t] && c[t] != 0;
+        p[t] = pair_from_hint(sbase, n_pairs, i[t] < n_items ? i[t] : n_items - 1, hint[t]);
+        if (act[t] && (uint64_t)dst[t] + c[t] > cap) { atomicOr(err, 2u); act[t] = false; }   // beyond the optimistic capacity: the host reruns the batch
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        qp[t] = 0; qm[t] = 0;
+        if (act[t]) { const PairDesc& P = pairs[p[t]]; const uint32_t j0 = i[t] - sbase[p[t]]; qp[t] = P.q_pos[j0]; qm[t] = P.q_meta[j0]; }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        if (!act[t]) continue;
+        if (c[t] == 1) {
+            const uint32_t d = dst[t];
+            a_qp[d] = qp[t]; a_qc[d] = qm[t] >> 1; a_rp[d] = rec[t].x;
+            a_rm[d] = (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u);   // ref contig << 1 | reverse_match
+        } else {      // a repeat: find its run in the reference index again (rare)
+            const PairDesc& P = pairs[p[t]];
+            uint32_t l, c2;
+            lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[i[t] - sbase[p[t]]], l, c2);
+            for (uint32_t j = 0; j < c[t]; j++) {
+                const uint64_t pm = P.r_pms[l + j];
+                const uint32_t rmeta = (uint32_t)pm;
+                a_qp[dst[t] + j] = qp[t]; a_qc[dst[t] + j] = qm[t] >> 1;
+                a_rp[dst[t] + j] = (uint32_t)(pm >> 32);
+                a_rm[dst[t] + j] = (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                           uint32_t n_pairs, uint32_t n_items,
                                                           const uint2* __restrict__ lbcnt,
@@ -1724,7 +1884,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.cbase, n_pairs, (uint32_t)n_rows, 1u, (uint32_t)n_rows, L.row_pair);
     ctx->t_begin(K_ANCHOR);
     if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
-    else hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
+    static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
+    const uint32_t gi4 = (gi + JT - 1) / JT;
+    uint32_t n_sum = gi;
+    if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
+    else if (!wide) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair); n_sum = gi4; }
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
@@ -1736,7 +1900,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
     if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)gi, st));      // 64-bit total, beside the 32-bit offsets
+    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
     hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
@@ -1756,7 +1920,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
     if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
-    else hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
+    else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
+    else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
