@@ -539,11 +539,32 @@ class Database:
         o._keep = self._model
         return o
 
+    _HIT_DTYPE = np.dtype(_capi.Hit)
+
     def _hit(self, r, qname):
-        hit = Hit(r.ani, qname, r.af_query, self._names[r.ref_index], r.af_ref)
-        hit._raw = {f: getattr(r, f) for f, _ in _capi.Hit._fields_}
-        hit._learned = bool(r.learned)
-        return hit
+        """One psk_hit (ctypes struct) -> Hit (the lazy path: a handful of hits)."""
+        return self._hits(np.frombuffer(bytes(r), dtype=self._HIT_DTYPE), qname)[0]
+
+    def _hits(self, recs, qname):
+        """A numpy array of psk_hit records -> [Hit]. Values come from the library and are valid by construction, so the range
+        checks of Hit.__init__ are skipped; the integer intermediates stay reachable as `hit._raw[field]` without a dict per hit."""
+        names = self._names
+        out = []
+        new = Hit.__new__
+        for rec, ani, afq, ri, afr, learned in zip(recs, recs["ani"].tolist(), recs["af_query"].tolist(), recs["ref_index"].tolist(),
+                                                   recs["af_ref"].tolist(), recs["learned"].tolist()):
+            h = new(Hit)
+            h._identity = ani; h._query_name = qname; h._query_fraction = afq
+            h._reference_name = names[ri]; h._reference_fraction = afr
+            h._raw = rec; h._learned = bool(learned)
+            out.append(h)
+        return out
+
+    def _hits_from_ptr(self, hits_p, lo, hi, qname):
+        if hi <= lo:
+            return []
+        buf = (_capi.Hit * (hi - lo)).from_address(C.addressof(hits_p.contents) + lo * C.sizeof(_capi.Hit))
+        return self._hits(np.frombuffer(buf, dtype=self._HIT_DTYPE).copy(), qname)
 
     def query_many(self, genomes, *, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
                    faster_small=False):
@@ -573,7 +594,7 @@ class Database:
         offs = (C.c_uint64 * (n + 1))()
         _capi.check(self._lib.psk_query_many(self._h, arr, n, C.byref(opts), C.byref(hits_p), offs))
         try:
-            return [[self._hit(hits_p[j], sketches[i].name) for j in range(offs[i], offs[i + 1])] for i in range(n)]
+            return [self._hits_from_ptr(hits_p, offs[i], offs[i + 1], sketches[i].name) for i in range(n)]
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)
@@ -618,11 +639,8 @@ class Database:
         hits_p = C.POINTER(_capi.Hit)()
         n = C.c_uint64(0)
         _capi.check(self._lib.psk_query(self._h, q._h, C.byref(opts), C.byref(hits_p), C.byref(n)))
-        out = []
         try:
-            for i in range(n.value):
-                out.append(self._hit(hits_p[i], name))
+            return self._hits_from_ptr(hits_p, 0, n.value, name)
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)
-        return out

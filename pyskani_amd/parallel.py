@@ -152,7 +152,7 @@ class ShardedDatabase:
 
     def _global_index(self, h, by_name):
         raw = getattr(h, "_raw", None)        # the library's own reference index when the hit carries it; else by name
-        return self._lo + raw["ref_index"] if raw else by_name[h.reference_name]
+        return self._lo + int(raw["ref_index"]) if raw is not None else by_name[h.reference_name]
 
     def query(self, name, *contigs, **opts):
         from .database import Hit
