@@ -14,6 +14,8 @@ void psk_set_error(const char* fmt, ...) {
 }
 
 static void ingest_release(psk_ctx* c);   // host-ingest pipeline resources (defined with psk_sketch_many_host)
+static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
+                              const uint32_t* genome_first_contig, uint32_t n_genomes, int want_seeds, psk_sketch** out);
 
 extern "C" {
 
@@ -168,6 +170,11 @@ psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* con
     for (uint32_t i = 0; i < n_contigs; i++) {
         off[i] = total; len[i] = lens[i];
         if (lens[i] >= MIN_LENGTH_CONTIG) total += (lens[i] + 15) & ~15ull;
+    }
+    if (total >= (64u << 20)) {   // a large genome: through the pinned staging pipeline (a plain copy from pageable memory moves 12-20 GB/s, the pipeline ~50).
+                                  // Measured for 5 MB genomes: the pipeline's start-up (producer thread, staging hand-offs) costs more than it saves (0.43 vs 0.26 ms)
+        const uint32_t gfc[2] = {0, n_contigs};
+        return ingest_impl(ctx, lane, p, contigs, lens, gfc, 1, want_seeds, out);
     }
     PSK_TRY(lane->s_misc.reserve(total + 64));
     uint8_t* d = (uint8_t*)lane->s_misc.p;
@@ -579,7 +586,14 @@ psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t
     for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
     if (!n_genomes) return PSK_OK;
     PSK_LANE(lg, ctx);
-    Lane* lane = lg.lane;
+    return ingest_impl(ctx, lg.lane, p, contigs, lens, genome_first_contig, n_genomes, want_seeds, out);
+}
+
+}  // extern "C"
+
+static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
+                              const uint32_t* genome_first_contig, uint32_t n_genomes, int want_seeds, psk_sketch** out) {
+    for (uint32_t g = 0; g < n_genomes; g++) out[g] = nullptr;
     IngestRes* R;
     {
         std::lock_guard<std::mutex> g(g_ingest_mu);
@@ -677,5 +691,3 @@ psk_status psk_sketch_many_host(psk_ctx* ctx, const psk_params* p, const uint8_t
     if (rc != PSK_OK) for (uint32_t g = 0; g < n_genomes; g++) { delete out[g]; out[g] = nullptr; }
     return rc;
 }
-
-}  // extern "C"
