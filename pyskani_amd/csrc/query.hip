@@ -852,13 +852,16 @@ constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4
 constexpr int LANE_WAVES = 2;
 constexpr int LANE_TREES = 4;        // qualifying chain trees per chunk kept in registers
 
-struct LaneAnchor { uint32_t q, r, m; int32_t f; };
+// u = q - r', r' the strand-signed reference position (-r on the reverse strand): the anchor's diagonal. With it the gap of a
+// pair is |ux - uy| and dr = dq - (ux - uy): three instructions fewer per (anchor, predecessor) pair than from q and r.
+struct LaneAnchor { uint32_t q, u, m; int32_t f; };
+__device__ __forceinline__ uint32_t lane_diag(uint32_t qx, uint32_t rx, uint32_t sg) { return qx - ((rx ^ sg) - sg); }
 
 // key of predecessor y for anchor x at distance d (0 = not chainable); same rule as the wave kernel and the oracle
-__device__ __forceinline__ uint32_t lane_eval(uint32_t qx, uint32_t rx, uint32_t mx, uint32_t sg, const LaneAnchor& y, int d) {
+__device__ __forceinline__ uint32_t lane_eval(uint32_t qx, uint32_t ux, uint32_t mx, const LaneAnchor& y, int d) {
     const int32_t dq = (int32_t)(qx - y.q);
-    const int32_t dr = (int32_t)(((rx - y.r) ^ sg) - sg);                 // strand -: ry - rx
-    const int32_t t = dq - dr, nt = dr - dq;
+    const int32_t t = (int32_t)(ux - y.u), nt = (int32_t)(y.u - ux);    // dq - dr (strand -: dr = ry - rx)
+    const int32_t dr = dq - t;
     const int32_t gap = t > nt ? t : nt;
     const int32_t scp = y.f - gap;                                        // score - ANCHOR_SCORE2
     const uint32_t z = y.m ^ mx;
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     const uint32_t len = mine ? e - s_al : 0;          // steps this lane takes part in (the first s - s_al are idle)
     LaneAnchor P[LANE_N];
 #pragma unroll
-    for (int i = 0; i < LANE_N; i++) { P[i].q = 0; P[i].r = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
+    for (int i = 0; i < LANE_N; i++) { P[i].q = 0; P[i].u = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
     // Chain trees that can yield a candidate, at most LANE_TREES per chunk, keyed by the local index of their ROOT
     // anchor. A tree gets a slot when its first anchor with score >= MIN_SCORE2 appears (such an anchor has depth >= 3,
     // and lower-scoring anchors can never be the tree's best once one exists); the many single-anchor trees of
@@ -916,12 +919,12 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
             const uint32_t x = x0 + u, t = t0 + u;
             const bool act = x >= s && x < e && mine;
             const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
-            const uint32_t sg = 0u - (mx & 1u);
+            const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
             uint32_t best = 0;
 #pragma unroll
             for (int d = 1; d <= LANE_N; d++) {
                 if (d <= band) {
-                    const uint32_t k = d <= u ? lane_eval(qx, rx, mx, sg, nw[u - d], d) : lane_eval(qx, rx, mx, sg, P[d - 1 - u], d);
+                    const uint32_t k = d <= u ? lane_eval(qx, ux, mx, nw[u - d], d) : lane_eval(qx, ux, mx, P[d - 1 - u], d);
                     best = k > best ? k : best;
                 }
             }
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
                 ridx = v >> 14; dep = (v & 16383u) + 1;
             }
             rd[t & 31u][lane] = (ridx << 14) | dep;
-            nw[u].q = qx; nw[u].r = rx; nw[u].m = act ? mx : 0xFFFFFFFFu; nw[u].f = f;
+            nw[u].q = qx; nw[u].u = ux; nw[u].m = act ? mx : 0xFFFFFFFFu; nw[u].f = f;
             if (act && f >= MIN_SCORE2) {
                 const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
                 bool found = false;
@@ -986,10 +989,10 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
 // predecessors per anchor instead of 24, and two quad DPP exchanges give all four the best key. The step's dependent
 // instruction chain - what a lone wave per SIMD is bound by - is ~2.4 x shorter; throughput per chunk is lower, so
 // the one-lane kernel stays for big launches.
-__device__ __forceinline__ uint32_t lane_eval_d(uint32_t qx, uint32_t rx, uint32_t mx, uint32_t sg, const LaneAnchor& y, uint32_t d, int band) {
+__device__ __forceinline__ uint32_t lane_eval_d(uint32_t qx, uint32_t ux, uint32_t mx, const LaneAnchor& y, uint32_t d, int band) {
     const int32_t dq = (int32_t)(qx - y.q);
-    const int32_t dr = (int32_t)(((rx - y.r) ^ sg) - sg);
-    const int32_t t = dq - dr, nt = dr - dq;
+    const int32_t t = (int32_t)(ux - y.u), nt = (int32_t)(y.u - ux);
+    const int32_t dr = dq - t;
     const int32_t gap = t > nt ? t : nt;
     const int32_t scp = y.f - gap;
     const uint32_t z = y.m ^ mx;
@@ -1043,14 +1046,14 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
             const uint32_t x = x0 + u, t = t0 + u;
             const bool act = x >= s && x < e && mine;
             const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
-            const uint32_t sg = 0u - (mx & 1u);
+            const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
             // this lane's latest anchor sits d0 = ((u - j) mod 4, 4 if 0) before x
             const uint32_t d0 = ((((uint32_t)u - j) - 1u) & 3u) + 1u;
             uint32_t best = 0;
 #pragma unroll
             for (int i = 0; i < QUAD_N; i++) {
-                LaneAnchor y; y.q = Wq[i]; y.r = Wr[i]; y.m = Wm[i]; y.f = Wf[i];
-                const uint32_t k = lane_eval_d(qx, rx, mx, sg, y, d0 + 4u * i, band);
+                LaneAnchor y; y.q = Wq[i]; y.u = Wr[i]; y.m = Wm[i]; y.f = Wf[i];
+                const uint32_t k = lane_eval_d(qx, ux, mx, y, d0 + 4u * i, band);
                 best = k > best ? k : best;
             }
             {   // all four lanes of the quad get the maximum
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
             const bool own = j == (uint32_t)u;               // x is 4-aligned at u = 0, so anchor x belongs to lane u
 #pragma unroll
             for (int i = QUAD_N - 1; i >= 1; i--) { Wq[i] = own ? Wq[i - 1] : Wq[i]; Wr[i] = own ? Wr[i - 1] : Wr[i]; Wm[i] = own ? Wm[i - 1] : Wm[i]; Wf[i] = own ? Wf[i - 1] : Wf[i]; }
-            Wq[0] = own ? qx : Wq[0]; Wr[0] = own ? rx : Wr[0]; Wm[0] = own ? (act ? mx : 0xFFFFFFFFu) : Wm[0]; Wf[0] = own ? f : Wf[0];
+            Wq[0] = own ? qx : Wq[0]; Wr[0] = own ? ux : Wr[0]; Wm[0] = own ? (act ? mx : 0xFFFFFFFFu) : Wm[0]; Wf[0] = own ? f : Wf[0];   // Wr holds diagonals
             if (act && f >= MIN_SCORE2) {
                 const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
                 bool found = false;
