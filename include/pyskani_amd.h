@@ -23,8 +23,11 @@
  * Every function returns a psk_status; psk_last_error() gives the thread-local message.
  * Inputs are borrowed for the duration of the call only. Outputs returned through `**`
  * are library-allocated and released with the matching psk_*_free / psk_free.
- * Threading: psk_query/psk_screen/psk_chain on one db/ctx are serialised internally
- * (one HIP stream per ctx); psk_db_add is exclusive, as `&mut self` makes it in lib.rs:479.
+ * Threading: every call runs on one of the context's execution lanes (own HIP stream, scratch and pinned
+ * staging; at most $PSK_LANES = 4 at a time, further callers wait), so psk_query / psk_screen / psk_chain /
+ * psk_sketch_host from different host threads overlap on the device, as `&self` + the released GIL allow in
+ * lib.rs:551,569. A database is held shared by queries and exclusively by psk_db_add (`&mut self`, lib.rs:479)
+ * and by whatever (re)builds its device tables.
  * A missing GPU is an error (PSK_EHIP) — there is no CPU fallback in this library.
  */
 #ifndef PYSKANI_AMD_H

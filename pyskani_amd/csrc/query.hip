@@ -105,6 +105,30 @@ __global__ __launch_bounds__(256) void screen_many_kernel(const MarkerSet* __res
     }
 }
 
+// The same for marker sets too large for one workgroup per pair (a 3 Gb genome holds 3 M markers: 60 ms in one workgroup): the
+// query's markers are cut into slices of SCREEN_SLICE, one workgroup per (reference, query, slice) adds its shared-marker count
+// to the pair's cell, inv_decide_kernel applies the pass rule.
+constexpr uint32_t SCREEN_SLICE = 16384;
+__global__ __launch_bounds__(256) void screen_slice_kernel(const MarkerSet* __restrict__ refs, const MarkerSet* __restrict__ queries,
+                                                           uint32_t n_refs, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_cnt[4];
+    const MarkerSet r = refs[blockIdx.x];
+    const MarkerSet q = queries[blockIdx.y];
+    const uint32_t i0 = blockIdx.z * SCREEN_SLICE, i1 = i0 + SCREEN_SLICE < q.n ? i0 + SCREEN_SLICE : q.n;
+    uint32_t cnt = 0;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const uint64_t m = q.p[i];
+        uint32_t lo = 0, hi = r.n;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (r.p[mid] < m) lo = mid + 1; else hi = mid; }
+        cnt += (lo < r.n && r.p[lo] == m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (t) atomicAdd(&count[(size_t)blockIdx.y * n_refs + blockIdx.x], t); }
+}
+
 static psk_status upload_marker_table(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
     if (!db->tables_dirty) return PSK_OK;
@@ -230,17 +254,19 @@ static psk_status screen_many_device(Lane* ctx, psk_db* db, const psk_sketch* co
     // per sub-launch: query marker table + offsets (+ the count matrix of the inverted-index path), side by side in q_a
     const size_t slot_bytes = al256s(sizeof(MarkerSet) * per) + al256s(4 * (size_t)(per + 1));
     const uint32_t n_sub = (nq + per - 1) / per;
-    PSK_TRY(ctx->q_a.reserve(slot_bytes * n_sub + (use_inv ? 4 * (size_t)per * n : 0) + 512));
+    PSK_TRY(ctx->q_a.reserve(slot_bytes * n_sub + 4 * (size_t)std::min<uint64_t>((uint64_t)per * n, use_inv ? ~0ull : (1ull << 22)) + 512));
     uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_a.p + al256s(slot_bytes * n_sub));
     for (uint32_t b = 0, sub = 0; b < nq; b += per, sub++) {
         const uint32_t m = std::min(per, nq - b);
         keep.hq.emplace_back(m); keep.qoff.emplace_back(m + 1, 0u);
         std::vector<MarkerSet>& hq = keep.hq.back(); std::vector<uint32_t>& qoff = keep.qoff.back();
         uint64_t items = 0;
+        uint32_t max_qm = 0;
         for (uint32_t i = 0; i < m; i++) {
             const psk_sketch* q = queries[b + i];
             hq[i].p = q->store ? q->store->markers + q->marker_off : nullptr; hq[i].n = (uint32_t)q->n_markers; hq[i].pad = 0;
             qoff[i] = (uint32_t)items; items += q->n_markers;
+            max_qm = std::max(max_qm, (uint32_t)q->n_markers);
         }
         qoff[m] = (uint32_t)items;
         if (items >= 0xFFFFFFF0ull) { psk_set_error("too many query markers in one screen launch"); return PSK_ELIMIT; }
@@ -260,6 +286,11 @@ static psk_status screen_many_device(Lane* ctx, psk_db* db, const psk_sketch* co
             if (items && db->inv_n)
                 hipLaunchKernelGGL(inv_lookup_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, st, d_q, d_qoff, m, (uint32_t)items,
                                    (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (uint32_t)db->inv_n, n, d_cnt);
+            const size_t cells = (size_t)m * n;
+            hipLaunchKernelGGL(inv_decide_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, m, d_cnt, thresh, rescue_small, pass_b);
+        } else if (max_qm > 4 * SCREEN_SLICE && (uint64_t)m * n <= (1u << 22)) {   // few pairs of very large marker sets: slice the queries
+            PSK_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)m * n, st));
+            hipLaunchKernelGGL(screen_slice_kernel, dim3(n, m, (max_qm + SCREEN_SLICE - 1) / SCREEN_SLICE), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, d_cnt);
             const size_t cells = (size_t)m * n;
             hipLaunchKernelGGL(inv_decide_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_q, n, m, d_cnt, thresh, rescue_small, pass_b);
         } else {
