@@ -20,7 +20,7 @@ def main(steps=10):
         T("sketch_batch", lambda: capi.check(lib.psk_sketch_batch_device(eng.ctx, C.byref(eng.params), C.c_void_p(buf.data_ptr()), c_off, c_len, gfc, n, 1, out)))
         db = C.c_void_p(); T("db_create", lambda: capi.check(lib.psk_db_create(eng.ctx, C.byref(eng.params), C.byref(db))))
         T("db_add_batch", lambda: capi.check(lib.psk_db_add_batch(db, names, out, n - 1)))
-        opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0); hits_p = C.POINTER(capi.Hit)(); nh = C.c_uint64(0)
+        opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None) if len(capi.QueryOpts._fields_) > 6 else capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0); hits_p = C.POINTER(capi.Hit)(); nh = C.c_uint64(0)
         T("query", lambda: capi.check(lib.psk_query(db, out[n - 1], C.byref(opts), C.byref(hits_p), C.byref(nh))))
         T("free", lambda: (lib.psk_free(hits_p), lib.psk_sketch_free(out[n - 1]), lib.psk_db_destroy(db)))
     print({k: round(v / steps * 1e3, 3) for k, v in acc.items()}, "ms per step; sum", round(sum(acc.values()) / steps * 1e3, 3))

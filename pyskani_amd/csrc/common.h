@@ -230,6 +230,22 @@ struct LaneGuard {
 };
 #define PSK_LANE(guard, ctx) LaneGuard guard(ctx); if (!guard.lane) { psk_set_error("no execution lane (hipStreamCreate failed)"); return PSK_EHIP; }
 
+// grow-only device buffer taken from (and returned to) the context's block pool: for the per-database tables, which a
+// benchmark step or a short-lived Database would otherwise hipMalloc / hipFree every time (30-40 us each)
+struct PoolScratch {
+    psk_ctx* dev = nullptr;
+    void* p = nullptr;
+    size_t cap = 0;
+    psk_status reserve(psk_ctx* d, size_t bytes) {
+        if (bytes <= cap) return PSK_OK;
+        release();
+        dev = d;
+        PSK_TRY(dev->pool_alloc(bytes + bytes / 4 + 256, &p, &cap));
+        return PSK_OK;
+    }
+    void release() { if (p && dev) dev->pool_release(p, cap); p = nullptr; cap = 0; }
+};
+
 // k-mer-sorted reference index of a group of sketches, built on first chaining use (ensure_index)
 struct IndexStore {
     psk_ctx* ctx = nullptr;
@@ -317,27 +333,36 @@ struct psk_db {
     // lib.rs:51-55 + 616-637: the sketch store is a map keyed by name (a later sketch of a name replaces the earlier
     // one) while the marker list keeps both entries; a query shortlists NAMES, so every passing entry of a name
     // stands for the name's LAST sketch and yields one hit. canon[i] = last index holding names[i].
-    std::unordered_map<std::string, uint32_t> last_by_name;
+    std::vector<uint32_t> name_slot;     // open-addressed table over names: slot = (last index holding the name) + 1, 0 = empty
     std::vector<uint32_t> canon;
     bool has_dups = false, canon_dirty = false;
+    static uint32_t name_hash(const std::string& s) { uint32_t h = 2166136261u; for (unsigned char c : s) h = (h ^ c) * 16777619u; return h; }
     void note_added(uint32_t i) {
         canon_dirty = true;
-        auto it = last_by_name.find(names[i]);
-        if (it != last_by_name.end()) { has_dups = true; for (uint32_t j = 0; j < i; j++) if (canon[j] == it->second) canon[j] = i; it->second = i; }
-        else last_by_name.emplace(names[i], i);
+        if (name_slot.size() < 2 * (size_t)(i + 1) + 2) {      // keep the load below 1/2
+            size_t cap = 64; while (cap < 4 * (size_t)(i + 1)) cap <<= 1;
+            std::vector<uint32_t> grown(cap, 0);
+            for (uint32_t v : name_slot) if (v) { size_t k = name_hash(names[v - 1]) & (cap - 1); while (grown[k]) k = (k + 1) & (cap - 1); grown[k] = v; }
+            name_slot.swap(grown);
+        }
+        const size_t mask = name_slot.size() - 1;
+        size_t k = name_hash(names[i]) & mask;
+        while (name_slot[k] && names[name_slot[k] - 1] != names[i]) k = (k + 1) & mask;
+        if (name_slot[k]) { has_dups = true; const uint32_t prev = name_slot[k] - 1; for (uint32_t j = 0; j < i; j++) if (canon[j] == prev) canon[j] = i; }
+        name_slot[k] = i + 1;
         canon.push_back(i);
     }
     // device tables for the screen kernel, rebuilt lazily
     bool tables_dirty = true;
-    Scratch d_marker_ptr, d_marker_n;
+    PoolScratch d_marker_ptr, d_marker_n;
     // inverted marker index for many-query screens: every (marker, ref) of the db sorted by marker
     bool inv_dirty = true;
-    Scratch inv_key, inv_ref, inv_tmp;
+    PoolScratch inv_key, inv_ref, inv_tmp;
     uint64_t inv_n = 0;
     // device table of SketchDesc, one per reference (refreshed when references are added or indexed)
     bool desc_dirty = true;
     uint64_t desc_indexed = 0; uint32_t desc_n = 0;
-    Scratch d_refdesc, d_canon;
+    PoolScratch d_refdesc, d_canon;
     std::vector<SketchDesc> h_refdesc;
 };
 

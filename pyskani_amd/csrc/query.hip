@@ -138,7 +138,7 @@ static psk_status upload_marker_table(Lane* ctx, psk_db* db) {
         h[i].p = r->store ? r->store->markers + r->marker_off : nullptr;
         h[i].n = (uint32_t)r->n_markers; h[i].pad = 0;
     }
-    PSK_TRY(db->d_marker_ptr.reserve(sizeof(MarkerSet) * n));
+    PSK_TRY(db->d_marker_ptr.reserve(ctx->dev, sizeof(MarkerSet) * n));
     PSK_HIP(hipMemcpyAsync(db->d_marker_ptr.p, h.data(), sizeof(MarkerSet) * n, hipMemcpyHostToDevice, ctx->stream));
     PSK_HIP(hipStreamSynchronize(ctx->stream));
     db->tables_dirty = false;
@@ -219,9 +219,9 @@ static psk_status build_inverted(Lane* ctx, psk_db* db) {
     roff[n] = (uint32_t)tot;
     if (tot >= 0x7FFFFFF0ull) { psk_set_error("database holds too many markers for one inverted index"); return PSK_ELIMIT; }
     db->inv_n = tot;
-    PSK_TRY(db->inv_key.reserve(8 * (tot + 1)));
-    PSK_TRY(db->inv_ref.reserve(4 * (tot + 1)));
-    PSK_TRY(db->inv_tmp.reserve(12 * (tot + 1) + 4 * (size_t)(n + 1)));
+    PSK_TRY(db->inv_key.reserve(ctx->dev, 8 * (tot + 1)));
+    PSK_TRY(db->inv_ref.reserve(ctx->dev, 4 * (tot + 1)));
+    PSK_TRY(db->inv_tmp.reserve(ctx->dev, 12 * (tot + 1) + 4 * (size_t)(n + 1)));
     uint64_t* k_in = (uint64_t*)db->inv_tmp.p; uint32_t* v_in = (uint32_t*)(k_in + tot + 1); uint32_t* d_roff = v_in + tot + 1;
     PSK_HIP(hipMemcpyAsync(d_roff, roff.data(), 4 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(inv_gather_kernel, dim3(n), dim3(256), 0, st, (const MarkerSet*)db->d_marker_ptr.p, d_roff, k_in, v_in);
@@ -332,12 +332,16 @@ __device__ __forceinline__ uint32_t find_le(const uint32_t* __restrict__ base, u
 // The pair of a workgroup's first item (or of a chunk-table row) comes from a table filled once per launch sequence
 // (pair_table_kernel): a per-workgroup binary search over up to 2^20 pair offsets was a chain of ~20 DEPENDENT global
 // loads in front of every workgroup of every kernel below — with nothing else to overlap, that latency was their run time.
-__global__ __launch_bounds__(256) void pair_table_kernel(const uint32_t* __restrict__ base, uint32_t n, uint32_t count, uint32_t stride, uint32_t limit,
-                                                         uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void pair_table_kernel(const uint32_t* __restrict__ sbase, const uint32_t* __restrict__ cbase, uint32_t n,
+                                                         uint32_t n_tiles, uint32_t n_items, uint32_t n_rows,
+                                                         uint32_t* __restrict__ blk_pair, uint32_t* __restrict__ row_pair) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const uint64_t x = (uint64_t)t * stride;
-    out[t] = find_le(base, n, x < limit ? (uint32_t)x : limit - 1);
+    if (t < n_tiles) {                        // pair of the first item of every 256-item tile
+        const uint64_t x = (uint64_t)t * 256u;
+        blk_pair[t] = find_le(sbase, n, x < n_items ? (uint32_t)x : n_items - 1);
+    } else if (t - n_tiles < n_rows) {        // pair of every chunk-table row
+        row_pair[t - n_tiles] = find_le(cbase, n, t - n_tiles);
+    }
 }
 // pair of item x given the pair of the workgroup's first item: a short forward walk (a pair usually holds far more items
 // than a workgroup has threads; pairs without items are stepped over)
@@ -704,9 +708,20 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
 }
 
 // pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
-__global__ void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
+__global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap,
+                                                         const unsigned long long* __restrict__ bsum, uint32_t n_sum, unsigned long long* __restrict__ total64) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = a < cap ? a : cap; }   // inside the (optimistically sized) anchor arrays whatever the counts were
+    if (n_sum && blockIdx.x == 0) {   // small launches: the 64-bit anchor total here instead of a device-wide reduction (two launches fewer)
+        __shared__ unsigned long long s_t[4];
+        unsigned long long t = 0;
+        for (uint32_t i = threadIdx.x; i < n_sum; i += blockDim.x) t += bsum[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) *total64 = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+    }
 }
 
 // Chunk table of one pair, one wave per pair. A chunk starts at anchor h and ends before the first anchor b of the
@@ -1914,8 +1929,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     PSK_HIP(hipMemsetAsync(L.misc, 0, 64, st));
     PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
     const uint32_t gi = L.gi;
-    hipLaunchKernelGGL(pair_table_kernel, dim3((gi + 255) / 256), dim3(256), 0, st, L.sbase, n_pairs, gi, 256u, (uint32_t)n_items, L.blk_pair);
-    hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.cbase, n_pairs, (uint32_t)n_rows, 1u, (uint32_t)n_rows, L.row_pair);
+    hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair);
     ctx->t_begin(K_ANCHOR);
     if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
     static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
@@ -1934,8 +1948,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
     if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
-    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap);
+    const bool small_sum = n_sum <= 16384;
+    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
+    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
+                       L.bsum, small_sum ? n_sum : 0u, L.bsum + gi);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
@@ -2164,7 +2180,7 @@ static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     std::vector<SketchDesc>& h = db->h_refdesc;     // stays alive until the copy has drained (every query ends with a synchronisation)
     h.resize(n);
     for (uint32_t i = 0; i < n; i++) h[i] = make_desc(db->refs[i]);
-    PSK_TRY(db->d_refdesc.reserve(sizeof(SketchDesc) * (size_t)n + 256));
+    PSK_TRY(db->d_refdesc.reserve(ctx->dev, sizeof(SketchDesc) * (size_t)n + 256));
     PSK_HIP(hipMemcpyAsync(db->d_refdesc.p, h.data(), sizeof(SketchDesc) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     db->desc_dirty = false; db->desc_indexed = indexed; db->desc_n = n;
     return PSK_OK;
@@ -2205,7 +2221,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 PSK_TRY(upload_marker_table(ctx, db));
                 if (want_inv) PSK_TRY(build_inverted(ctx, db));
                 if (db->has_dups && db->canon_dirty) {
-                    PSK_TRY(db->d_canon.reserve(4 * (size_t)n));
+                    PSK_TRY(db->d_canon.reserve(ctx->dev, 4 * (size_t)n));
                     PSK_HIP(hipMemcpyAsync(db->d_canon.p, db->canon.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
                     db->canon_dirty = false;
                 }
@@ -2224,15 +2240,24 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         ScreenStaging keep;
         PSK_TRY(screen_many_device(ctx, db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
         if (db->has_dups) hipLaunchKernelGGL(pass_canon_kernel, dim3(m), dim3(256), 0, st, d_pass, n, (const uint32_t*)db->d_canon.p);
-        PSK_HIP(hipMemsetAsync(d_flag, 0, n, st));
-        hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag);
         void* hpin;
-        PSK_TRY(ctx->pinned(4 * (size_t)m + n + 64, &hpin));
-        PSK_HIP(hipMemcpyAsync(hpin, d_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipMemcpyAsync((char*)hpin + 4 * (size_t)m, d_flag, n, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipStreamSynchronize(st));
-        h_cnt.assign((uint32_t*)hpin, (uint32_t*)hpin + m);
-        h_flag.assign((uint8_t*)hpin + 4 * (size_t)m, (uint8_t*)hpin + 4 * (size_t)m + n);
+        if ((size_t)m * n <= 65536) {     // a handful of queries: the pass rows themselves cross (<= 64 kB), counted on the host (two launches fewer)
+            PSK_TRY(ctx->pinned((size_t)m * n + 64, &hpin));
+            PSK_HIP(hipMemcpyAsync(hpin, d_pass, (size_t)m * n, hipMemcpyDeviceToHost, st));
+            PSK_HIP(hipStreamSynchronize(st));
+            h_cnt.assign(m, 0); h_flag.assign(n, 0);
+            const uint8_t* hp = (const uint8_t*)hpin;
+            for (uint32_t i = 0; i < m; i++) for (uint32_t r = 0; r < n; r++) if (hp[(size_t)i * n + r]) { h_cnt[i]++; h_flag[r] = 1; }
+        } else {
+            PSK_HIP(hipMemsetAsync(d_flag, 0, n, st));
+            hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag);
+            PSK_TRY(ctx->pinned(4 * (size_t)m + n + 64, &hpin));
+            PSK_HIP(hipMemcpyAsync(hpin, d_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+            PSK_HIP(hipMemcpyAsync((char*)hpin + 4 * (size_t)m, d_flag, n, hipMemcpyDeviceToHost, st));
+            PSK_HIP(hipStreamSynchronize(st));
+            h_cnt.assign((uint32_t*)hpin, (uint32_t*)hpin + m);
+            h_flag.assign((uint8_t*)hpin + 4 * (size_t)m, (uint8_t*)hpin + 4 * (size_t)m + n);
+        }
         // ---- the references and queries about to be chained: validate, index, describe
         std::vector<const psk_sketch*> need;
         for (uint32_t r = 0; r < n; r++) if (h_flag[r]) {
@@ -2311,12 +2336,15 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
                     PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide));
-                    size_t tmp3 = 0;
-                    PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
-                    PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
+                    const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
+                    if (!host_filter) {
+                        size_t tmp3 = 0;
+                        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
+                        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
+                    }
                     PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
-                    PSK_HIP(hipMemcpyAsync(h_sel, L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipMemcpyAsync(h_sel, host_filter ? L.hits : L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     bool retry;
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
@@ -2327,6 +2355,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
                 n_sel = T->misc[12];
+                if (n_pairs <= 4096) {      // host-side filter of a small batch (lib.rs:654), order kept
+                    uint32_t w = 0;
+                    for (uint32_t i = 0; i < n_pairs; i++) if (h_sel[i].ani > 0.1f) h_sel[w++] = h_sel[i];
+                    n_sel = w;
+                }
                 if (n_sel > spec) {
                     PSK_HIP(hipMemcpyAsync(h_sel + spec, L.hits_sel + spec, sizeof(psk_hit) * (size_t)(n_sel - spec), hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipStreamSynchronize(st));
