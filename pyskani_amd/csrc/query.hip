@@ -1309,6 +1309,8 @@ struct SelArgs {
     const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs;
     const int32_t* c_score; const uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_rc; uint32_t* c_state;
     ChunkOut* out; uint32_t two_c; int force_serial; uint32_t* stats;
+    const uint32_t* live; const uint32_t* n_live;      // pairs that have a chunk table (every other pair has no candidate chain)
+    uint32_t* big_list; uint32_t* big_count;           // pairs with more than CMAX candidates, for select_big_kernel
 };
 
 __device__ __forceinline__ void sel_commit(const SelArgs& S, uint32_t row, uint32_t q0, uint32_t q1, uint32_t n) {
@@ -1345,8 +1347,7 @@ __device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
 // (A 512-candidate instantiation with half the LDS - six waves per CU instead of three - was measured and is no faster:
 // the kernel's time is each wave's own chain of LDS round trips, not occupancy.)
 constexpr int CM = CMAX;
-__global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
-    const uint32_t c_lo = 0;
+__device__ void select_pair(const SelArgs& S, const uint32_t p) {
     __shared__ int32_t l_sc[CM];
     __shared__ uint32_t l_q0[CM], l_q1[CM], l_r0[CM], l_r1[CM], l_rc[CM], l_row[CM], l_n[CM];
     __shared__ unsigned long long l_key[CM];     // priority keys, then (ref contig, r0) keys
@@ -1355,7 +1356,6 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
     __shared__ uint16_t l_idx[CM];               // payload of the reference-order sort, then the conflicted list
     __shared__ uint16_t l_kept[CM];
     __shared__ uint8_t l_conf[CM];
-    const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
     // candidates in generation order (rows, then slots)
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
         if (CM == CMAX && lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
         return;
     }
-    if (C <= c_lo || C > (uint32_t)CM) return;   // another instantiation, or select_big_kernel, takes the pair
+    if (C > (uint32_t)CM) { if (lane == 0) S.big_list[atomicAdd(S.big_count, 1u)] = p; return; }   // select_big_kernel takes the pairs that do not fit in LDS (rare: an append per such pair)
     uint32_t P = 64; while (P < C) P <<= 1;
     // ---- priority order: (score desc, generation order asc) ----
     for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
@@ -1481,6 +1481,17 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
     }
 }
 
+// one wave per LIVE pair (pairs without a chunk table - every rescued short contig against an unrelated reference - never reach
+// the selection): a fixed grid walks the device-side list, so a batch of 10^6 pairs of which 10^5 are live does not schedule
+// 10^6 workgroups of 51 KB of LDS each to find that out
+__global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
+    const uint32_t n = S.live ? *S.n_live : S.n_pairs;      // small launches skip the list: every pair is visited
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        select_pair(S, S.live ? S.live[k] : k);
+        lds_wave_sync();
+    }
+}
+
 // ---- pairs with more than CMAX candidate chains (genomes beyond ~10 Mb): the same algorithm on global
 // scratch, one 1024-thread workgroup per pair. Scratch is indexed from the pair's first anchor: a pair with n
 // anchors has at most n/3 candidates, and the padded sort length stays below n.
@@ -1512,24 +1523,13 @@ __device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, 
         }
 }
 
-__global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
+__device__ void select_big_pair(const BigArgs& B, const uint32_t p) {
     __shared__ uint32_t s_scan[BIG_T];
     __shared__ uint32_t s_carry, s_nk, s_flag;
     const SelArgs& S = B.S;
-    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
     const uint32_t base = B.pstart[p];
-    if (S.force_serial) return;
-    // cheap exit for the common case: this pair fits the LDS kernel
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    {
-        uint32_t part = 0;
-        for (uint32_t r = tid; r < nrows; r += BIG_T) part += S.out[row0 + r].n_cand;
-        if (part) atomicAdd(&s_carry, part);
-    }
-    __syncthreads();
-    if (s_carry <= (uint32_t)CMAX) return;
     __syncthreads();
     // ---- candidates in generation order: block scan over the rows' candidate counts ----
     if (tid == 0) s_carry = 0;
@@ -1628,6 +1628,15 @@ __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
     }
     if (tid == 0) atomicAdd(&S.stats[3], 1u);
 }
+// the few pairs select_kernel listed (more than CMAX candidates): a small fixed grid walks the list
+__global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
+    if (B.S.force_serial) return;
+    const uint32_t n = *B.S.big_count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        select_big_pair(B, B.S.big_list[k]);
+        __syncthreads();
+    }
+}
 
 // seeds of the query between the leftmost and rightmost kept anchor of every chunk
 __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
@@ -1644,19 +1653,31 @@ struct ReduceArgs {
     const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
     const uint32_t* pstart; const PairDesc* pairs;
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
+    const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
     int k, median, robust; double min_af;
     psk_hit* hits;
     double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
 };
 constexpr int RED_CAP = 4096;   // chunk ANI values sortable in LDS (genomes up to ~80 Mb at 20 kb chunks)
 
-__global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
+// pairs without a chunk table (fewer than MIN_ANCHORS anchors: every rescued short contig against an unrelated reference): one
+// empty record each, one lane per pair
+__global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t n_pairs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs || R.n_chunks[p] != 0) return;
+    psk_hit h{};
+    h.ani = -1.0f; h.ani_raw = -1.0f;
+    h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+    R.hits[p] = h;
+}
+
+__device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     __shared__ double s_v[RED_CAP];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_acc[5];
-    const uint32_t p = blockIdx.x;
     const uint32_t nc = R.n_chunks[p];
-    if (nc == 0) {   // no chunk table: fewer than MIN_ANCHORS anchors (every rescued short contig against an unrelated reference)
+    if (nc == 0) {      // only reached when the launch visits every pair (no live list): the empty record of pair_empty_kernel
         if (threadIdx.x == 0) {
             psk_hit h{};
             h.ani = -1.0f; h.ani_raw = -1.0f;
@@ -1797,6 +1818,15 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R) {
         R.hits[p] = h;
     }
 }
+__global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R, uint32_t n_pairs) {      // one workgroup per LIVE pair, fixed grid over the list
+    const uint32_t n = R.live ? *R.n_live : n_pairs;        // small launches skip the list: every pair is visited
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        pair_reduce_pair(R, R.live ? R.live[k] : k);
+        __syncthreads();
+    }
+}
+
+struct IsLivePair { const uint32_t* nch; __host__ __device__ bool operator()(const uint32_t& p) const { return nch[p] != 0; } };
 
 // ------------------------------------------------------------------ host orchestration
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1895,7 +1925,7 @@ struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const {
 struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
-    uint32_t *blk_pair, *row_pair;
+    uint32_t *blk_pair, *row_pair, *live, *big_list;
     uint32_t gi;
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -1907,14 +1937,15 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows),
            o_qr = al256(o_bsum + 8 * (gi + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
-           o_rp = al256(o_bp + 4 * (gi + 1)), o_end = o_rp + 4 * (n_rows + 1);
+           o_rp = al256(o_bp + 4 * (gi + 1)), o_live = al256(o_rp + 4 * (n_rows + 1)), o_big = al256(o_live + 4 * (n_pairs + 1)),
+           o_end = o_big + 4 * (n_pairs + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
     L->pairs = (PairDesc*)(B + o_pairs); L->sbase = (uint32_t*)(B + o_sbase); L->cbase = (uint32_t*)(B + o_cbase); L->pstart = (uint32_t*)(B + o_pstart);
     L->lbcnt = (uint2*)(B + o_lb); L->aoff = (uint32_t*)(B + o_aoff); L->nch = (uint32_t*)(B + o_nch); L->chunks = (uint2*)(B + o_chunks);
     L->cout = (ChunkOut*)(B + o_cout); L->hits = (psk_hit*)(B + o_hits); L->hits_sel = (psk_hit*)(B + o_sel); L->misc = (uint32_t*)(B + o_misc);
     L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
-    L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp);
+    L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp); L->live = (uint32_t*)(B + o_live); L->big_list = (uint32_t*)(B + o_big);
     L->gi = (uint32_t)gi;
     return PSK_OK;
 }
@@ -2008,8 +2039,18 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     SA.chunks = L.chunks; SA.n_chunks = L.nch; SA.cbase = L.cbase; SA.n_pairs = n_pairs;
     SA.c_score = A.c_score; SA.c_q0 = A.c_q0; SA.c_q1 = A.c_q1; SA.c_r0 = A.c_r0; SA.c_r1 = A.c_r1; SA.c_n = A.c_n; SA.c_rc = A.c_rc; SA.c_state = A.c_state;
     SA.out = L.cout; SA.two_c = A.two_c; SA.force_serial = force_serial; SA.stats = L.misc + 1;
+    // the pairs that have a chunk table, in pair order (misc[9] = their number, misc[10] = pairs listed for select_big_kernel)
+    const bool use_live = n_pairs > 4096;      // below that the list costs more launches than it saves workgroups
+    SA.live = use_live ? L.live : nullptr; SA.n_live = L.misc + 9; SA.big_list = L.big_list; SA.big_count = L.misc + 10;
+    if (use_live) {
+        hipcub::CountingInputIterator<uint32_t> ids(0);
+        size_t tl = 0;
+        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tl, ids, L.live, L.misc + 9, (int)n_pairs, IsLivePair{L.nch}, st));
+        PSK_TRY(ctx->q_c.reserve(std::max(tl, std::max(tmp, std::max(tmp2, tmp3)))));
+        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tl, ids, L.live, L.misc + 9, (int)n_pairs, IsLivePair{L.nch}, st));
+    }
     ctx->t_begin(K_SELECT);
-    hipLaunchKernelGGL(select_kernel, dim3(n_pairs), dim3(64), 0, st, SA);
+    hipLaunchKernelGGL(select_kernel, dim3(std::min<uint32_t>(n_pairs, 16384u)), dim3(64), 0, st, SA);
     {   // pairs whose candidates do not fit the LDS kernel (large genomes); workgroups of small pairs exit at once
         if (!force_serial) {
             BigArgs BA{};
@@ -2018,7 +2059,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             BA.key = (unsigned long long*)E; uint32_t* U = (uint32_t*)(E + 8 * na);
             BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na; BA.kept = U + 7 * na;
             BA.conf = (uint8_t*)(U + 8 * na);
-            hipLaunchKernelGGL(select_big_kernel, dim3(n_pairs), dim3(BIG_T), 0, st, BA);
+            hipLaunchKernelGGL(select_big_kernel, dim3(std::min<uint32_t>(n_pairs, 64u)), dim3(BIG_T), 0, st, BA);
         }
     }
     ctx->t_end();
@@ -2032,7 +2073,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         R.big_vals = (double*)ctx->q_f.p;
     }
     ctx->t_begin(K_PAIR_REDUCE);
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3(n_pairs), dim3(256), 0, st, R);
+    R.live = use_live ? L.live : nullptr; R.n_live = L.misc + 9;
+    if (use_live) hipLaunchKernelGGL(pair_empty_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, R, n_pairs);
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
     ctx->t_end();
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
     const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
