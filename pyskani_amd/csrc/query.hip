@@ -626,6 +626,44 @@ __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __res
     }
 }
 
+// Batches of many SMALL pairs (metagenome contigs, every short one rescued against every reference): the records' positions
+// do not depend on the order the pairs are joined in, so the join alone runs REFERENCE-major - one wave per pair, pairs visited
+// in the order of `order[]` (pair ids sorted by reference) - and the ~2 000 contigs that probe one reference's 1.3 MB index find
+// it in L2 instead of each fetching its hundred scattered lines from HBM. Everything downstream keeps the query-major layout.
+__global__ __launch_bounds__(256) void anchor_join_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                                const uint32_t* __restrict__ order, uint32_t n_pairs,
+                                                                uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
+                                                                uint32_t* __restrict__ need_wide) {
+    const uint32_t lb = xcd_block_id();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = lb * 4 + wave;
+    uint32_t total = 0;
+    if (w < n_pairs) {
+        const uint32_t p = order[w];
+        const PairDesc P = pairs[p];
+        const uint32_t base = sbase[p];
+        for (uint32_t i0 = 0; i0 < P.q_n; i0 += 64) {
+            const uint32_t iq = i0 + lane;
+            if (iq < P.q_n) {
+                const uint32_t km = P.q_key[iq];
+                uint32_t lo, cnt;
+                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km, lo, cnt);
+                uint32_t x = 0, y = 0;
+                if (cnt) {
+                    const uint64_t pm = P.r_pms[lo];
+                    const uint32_t rmeta = (uint32_t)pm;
+                    x = (uint32_t)(pm >> 32);
+                    if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
+                    else y = rmeta | (cnt << 24);
+                }
+                item_out[base + P.q_perm[iq]] = make_uint2(x, y);
+                total += cnt;
+            }
+        }
+    }
+    block_total(total, lb, block_sum);
+}
+
 __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                                   uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
                                                                   const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
@@ -1826,6 +1864,11 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R, uint32_t
     }
 }
 
+__global__ __launch_bounds__(256) void pair_ref_keys_kernel(const uint2* __restrict__ pair_qr, uint32_t n_pairs, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pairs) { keys[p] = pair_qr[p].y; ids[p] = p; }
+}
+
 struct IsLivePair { const uint32_t* nch; __host__ __device__ bool operator()(const uint32_t& p) const { return nch[p] != 0; } };
 
 // ------------------------------------------------------------------ host orchestration
@@ -1926,17 +1969,17 @@ struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
     uint32_t *blk_pair, *row_pair, *live, *big_list;
-    uint32_t gi;
+    uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum (the 64-bit total sits at bsum[gi_sum])
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
-    const size_t gi = (n_items + 255) / 256;
+    const size_t gi = (n_items + 255) / 256, gi_sum = std::max(gi, (n_pairs + 3) / 4);
     size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (n_pairs + 1)),
            o_pstart = al256(o_cbase + 4 * (n_pairs + 1)), o_lb = al256(o_pstart + 4 * (n_pairs + 1)),
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows),
-           o_qr = al256(o_bsum + 8 * (gi + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
+           o_qr = al256(o_bsum + 8 * (gi_sum + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
            o_rp = al256(o_bp + 4 * (gi + 1)), o_live = al256(o_rp + 4 * (n_rows + 1)), o_big = al256(o_live + 4 * (n_pairs + 1)),
            o_end = o_big + 4 * (n_pairs + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
@@ -1946,7 +1989,7 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
     L->cout = (ChunkOut*)(B + o_cout); L->hits = (psk_hit*)(B + o_hits); L->hits_sel = (psk_hit*)(B + o_sel); L->misc = (uint32_t*)(B + o_misc);
     L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
     L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp); L->live = (uint32_t*)(B + o_live); L->big_list = (uint32_t*)(B + o_big);
-    L->gi = (uint32_t)gi;
+    L->gi = (uint32_t)gi; L->gi_sum = (uint32_t)gi_sum;
     return PSK_OK;
 }
 
@@ -1966,23 +2009,40 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
-    if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
+    const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
+    const bool join_pairs = !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
+    if (join_pairs) {
+        // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys
+        size_t ts = 0;
+        uint32_t* keys_in = L.big_list;                     // free until select runs
+        uint32_t* vals_in = L.live;                         // free until the live list is built
+        uint32_t* keys_out = (uint32_t*)L.hits_sel;         // free until the hits are selected
+        uint32_t* order = keys_out + n_pairs;
+        hipLaunchKernelGGL(pair_ref_keys_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, L.pair_qr, n_pairs, keys_in, vals_in);
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
+        PSK_TRY(ctx->q_g.reserve(ts + 256));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_g.p, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
+        const uint32_t nb = (n_pairs + 3) / 4;
+        hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
+        n_sum = nb;
+    }
+    else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
     else if (!wide) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair); n_sum = gi4; }
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
     hipcub::TransformInputIterator<uint32_t, PackedCount, const uint2*> pcnt_it(L.lbcnt, PackedCount());
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.bsum + gi, (int)gi, st));
+    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.bsum + L.gi_sum, (int)L.gi_sum, st));
     size_t tmp3 = 0;
     PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
     if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
-    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + gi, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
+    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + L.gi_sum, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
     hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
-                       L.bsum, small_sum ? n_sum : 0u, L.bsum + gi);
+                       L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
@@ -2146,7 +2206,7 @@ static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, c
         PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, hp[0].q->params, o, d_desc, d_desc, cap, wide));
         PSK_HIP(hipMemcpyAsync(h_hits, L.hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a launch sequence (also keeps the host staging above alive)
         bool retry;
         PSK_TRY(chain_check(*T, n_pairs, &cap, &wide, &retry));
@@ -2386,7 +2446,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                         PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
                     }
                     PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
-                    PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi, 8, hipMemcpyDeviceToHost, st));
+                    PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipMemcpyAsync(h_sel, host_filter ? L.hits : L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     bool retry;
