@@ -224,3 +224,31 @@ def test_pack_unpack_device_records(psk, oracle):
     torch.cuda.synchronize()
     with pytest.raises(ValueError):
         psk.Sketch.unpack(db._ctx, bad.data_ptr(), offs[:-1], [s.name for s in sketches])
+
+
+def test_query_edge_cases(psk):
+    """Empty database, no query, queries without a hit / without seeds / sketched with seed=False, references sketched
+    with seed=False: the errors and empty results the reference's loop structure implies (lib.rs:617-657)."""
+    rng = np.random.default_rng(77)
+    g = random_genome(rng, 60_000)
+    empty = psk.Database()
+    assert empty.query("q", g, learned_ani=False) == [] and empty.query_many([("q", g)], learned_ani=False) == [[]]
+    assert empty.query_many([], learned_ani=False) == []
+    db = psk.Database()
+    db.sketch("a", g)
+    db.sketch("short", b"ACGT" * 100)                       # below MIN_LENGTH_CONTIG: a reference without seeds or markers
+    assert db.query_many([], learned_ani=False) == []
+    assert db.query("unrelated", random_genome(rng, 60_000), learned_ani=False) == []
+    assert db.query("tiny", b"ACGT" * 50, learned_ani=False) == []              # query without seeds: no hits, no error
+    res = db.query_many([("self", g), ("tiny", b"ACGT" * 50), ("none", random_genome(rng, 50_000)), ("again", g)], learned_ani=False)
+    assert [len(r) for r in res] == [1, 0, 0, 1] and res[0][0].identity == 1.0 and res[3][0].reference_name == "a"
+    with pytest.raises(ValueError, match="seed=False"):
+        db.query("noseed", g, seed=False, learned_ani=False)                     # passes the screen, cannot be chained
+    db2 = psk.Database()
+    db2.sketch("markers_only", g, seed=False)
+    with pytest.raises(ValueError, match="seed=False"):
+        db2.query("q", g, learned_ani=False)
+    assert db2.query("unrelated", random_genome(rng, 60_000), learned_ani=False) == []   # nothing shortlisted: no error
+    other = psk.Database(compression=60)
+    with pytest.raises(ValueError, match="different parameters"):
+        db.query_sketches([other.sketch_only("x", g)], learned_ani=False)
