@@ -1692,6 +1692,7 @@ struct ReduceArgs {
     const uint32_t* pstart; const PairDesc* pairs;
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
     const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
+    int small_done;                                 // chunk tables of <= 64 rows are reduced by pair_reduce_small_kernel
     int k, median, robust; double min_af;
     psk_hit* hits;
     double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
@@ -1715,6 +1716,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_acc[5];
     const uint32_t nc = R.n_chunks[p];
+    if (R.small_done && nc != 0 && nc <= 64) return;      // pair_reduce_small_kernel took it
     if (nc == 0) {      // only reached when the launch visits every pair (no live list): the empty record of pair_empty_kernel
         if (threadIdx.x == 0) {
             psk_hit h{};
@@ -1856,6 +1858,82 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
         R.hits[p] = h;
     }
 }
+// Pairs whose chunk table has at most 64 rows (short contigs: 1-3 chunks) - ONE WAVE per pair, a lane per chunk, shuffles instead
+// of LDS and workgroup barriers; four independent pairs per workgroup. Same arithmetic and summation order as pair_reduce_pair
+// (values in chunk order for the mean, ascending for median / trimmed mean).
+__global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, uint32_t n_pairs) {
+    __shared__ double s_sorted[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = R.live ? *R.n_live : n_pairs;
+    for (uint32_t k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
+        const uint32_t p = R.live ? R.live[k] : k;
+        const uint32_t nc = R.n_chunks[p];
+        if (nc == 0 || nc > 64) continue;                 // empty records / larger tables: the other kernels
+        const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
+        ChunkOut c{};
+        if ((uint32_t)lane < nc) c = co[lane];
+        const bool valid = (uint32_t)lane < nc && c.n_intervals != 0;
+        unsigned long long t_cq = c.cov_q, t_a = c.anchors, t_s = valid ? c.seeds : 0, t_i = c.n_intervals;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t_cq += __shfl_xor(t_cq, o); t_a += __shfl_xor(t_a, o); t_s += __shfl_xor(t_s, o); t_i += __shfl_xor(t_i, o); }
+        const unsigned long long vm = __ballot(valid);
+        const uint32_t m = (uint32_t)__popcll(vm);
+        double v = 0.0;
+        if (valid) {
+            double ratio = (double)c.anchors / (double)(c.seeds > 1 ? c.seeds - 1 : 1);   // end seeds are anchors by construction
+            if (ratio > 1.0) ratio = 1.0;
+            v = pow(ratio, 1.0 / (double)R.k);
+        }
+        // compact the values in chunk order (position = number of valid lanes below)
+        const uint32_t pos = (uint32_t)__popcll(vm & ((1ull << lane) - 1));
+        double* sv = s_sorted[wave];
+        lds_wave_sync();
+        if (valid) sv[pos] = v;
+        lds_wave_sync();
+        // mean and sample standard deviation of all values
+        double sum_all = 0;
+        for (uint32_t j = 0; j < m; j++) sum_all += sv[j];                 // chunk order, like the serial sum of the big path
+        const double mean_all = m ? sum_all / (double)m : 0.0;
+        double dev = valid ? (v - mean_all) * (v - mean_all) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dev += __shfl_xor(dev, o);
+        const double std_all = m > 1 ? sqrt(dev / (double)(m - 1)) : 0.0;
+        double ani = mean_all;
+        if ((R.median || R.robust) && m) {
+            // ascending order: rank = values below + equal values at lower positions
+            uint32_t rank = 0;
+            const double mine = (uint32_t)lane < m ? sv[lane] : 0.0;
+            for (uint32_t j = 0; j < m; j++) { const double o = sv[j]; rank += (o < mine) || (o == mine && j < (uint32_t)lane); }
+            lds_wave_sync();
+            if ((uint32_t)lane < m) sv[rank] = mine;
+            lds_wave_sync();
+            if (R.median) ani = sv[m / 2];
+            else {
+                uint32_t lo = 0, hi = m;
+                if (m - 2 * (m / 10) > 0) { lo = m / 10; hi = m - m / 10; }
+                double sum = 0; for (uint32_t j = lo; j < hi; j++) sum += sv[j];
+                ani = sum / (double)(hi - lo);
+            }
+        }
+        if (lane == 0) {
+            psk_hit h{};
+            h.ani = -1.0f;
+            h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+            h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
+            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
+            if (m > 0) {
+                double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
+                double afr = (double)t_cq / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;   // one covered-bases count serves both
+                h.af_query = (float)afq; h.af_ref = (float)afr;
+                if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
+                h.ani_raw = h.ani; h.ani_std = (float)std_all;
+            }
+            R.hits[p] = h;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R, uint32_t n_pairs) {      // one workgroup per LIVE pair, fixed grid over the list
     const uint32_t n = R.live ? *R.n_live : n_pairs;        // small launches skip the list: every pair is visited
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
@@ -2135,6 +2213,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     ctx->t_begin(K_PAIR_REDUCE);
     R.live = use_live ? L.live : nullptr; R.n_live = L.misc + 9;
     if (use_live) hipLaunchKernelGGL(pair_empty_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, R, n_pairs);
+    // many pairs with short chunk tables (contigs): one wave per pair first; the workgroup-per-pair kernel then only sees the long tables
+    const char* rs_env = getenv("PSK_REDUCE_SMALL");
+    const bool no_small = rs_env && rs_env[0] == '0';
+    R.small_done = use_live && !no_small && n_rows / n_pairs < 16;
+    if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
     ctx->t_end();
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given

@@ -252,3 +252,42 @@ def test_query_edge_cases(psk):
     other = psk.Database(compression=60)
     with pytest.raises(ValueError, match="different parameters"):
         db.query_sketches([other.sketch_only("x", g)], learned_ani=False)
+
+
+@pytest.mark.parametrize("kw", [{}, {"median": True}, {"robust": True}, {"faster_small": True}])
+def test_many_small_pairs_against_oracle(psk, oracle, kw, monkeypatch):
+    """A batch of > 4 096 small pairs (short contigs, most of them rescued against every reference, lib.rs:538-541) takes the
+    paths a handful of pairs never sees: the list of live pairs, the wave-per-pair reduction of short chunk tables, the
+    pair-major join. Every hit against the oracle; and the same batch with those paths switched off."""
+    rng = np.random.default_rng(91)
+    anc = [random_genome(rng, 90_000) for _ in range(4)]
+    refs = [(f"r{f}_{j}", mutate(rng, anc[f], 0.004 * j)) for f in range(4) for j in range(15)]          # 60 references
+    contigs = []
+    for i in range(84):
+        a = anc[i % 4]
+        st = int(rng.integers(0, len(a) - 9000))
+        L = int(rng.integers(1500, 3500)) if i % 3 else int(rng.integers(5000, 9000))                    # two thirds below 20 markers
+        contigs.append((f"c{i}", mutate(rng, a[st:st + L], rng.uniform(0, 0.04))))
+    db = psk.Database(compression=30, marker_compression=200)
+    db.sketch_many(refs)
+    got = db.query_many(contigs, learned_ani=False, **kw)
+    orefs = [(n, oracle.Sketch([g], c=30, marker_c=200)) for n, g in refs]
+    n_pairs_chained = 0
+    step = 1 if not kw else 4                      # the oracle side is the slow one: every contig for the default flags, a quarter otherwise
+    for (name, seq), hits in list(zip(contigs, got))[::step]:
+        want = oracle.query(orefs, oracle.Sketch([seq], c=30, marker_c=200), median=kw.get("median", False), robust=kw.get("robust", False),
+                            faster_small=kw.get("faster_small", False))
+        assert [h.reference_name for h in hits] == [n for n, _ in want], name
+        for h, (_, w) in zip(hits, want):
+            for f in ("n_anchors", "n_chunks", "n_intervals", "covered_query", "sum_chain_anchors", "sum_chunk_seeds"):
+                assert h._raw[f] == getattr(w, f), (name, h.reference_name, f)
+            assert abs(h.identity - w.ani) < 1e-6 and abs(h._raw["ani_std"] - w.ani_std) < 1e-6
+        n_pairs_chained += len(hits)
+    assert n_pairs_chained > 500 // step
+    if not kw:
+        ref = [[(h.reference_name, h.identity, h._raw["n_anchors"]) for h in hs] for hs in got]
+        for var, val in (("PSK_REDUCE_SMALL", "0"), ("PSK_JOIN_PAIRS", "0"), ("PSK_JOIN_PAIRS", "1")):
+            monkeypatch.setenv(var, val)
+            alt = db.query_many(contigs, learned_ani=False)
+            monkeypatch.delenv(var)
+            assert [[(h.reference_name, h.identity, h._raw["n_anchors"]) for h in hs] for hs in alt] == ref, var
