@@ -172,6 +172,14 @@ class Engine:
             offsets = (C.c_uint64 * (n + 1))()
             capi.check(lib.psk_query_many(db, out, n, C.byref(opts), C.byref(hits_p), offsets))
             nh = int(offsets[n])
+            if nh:      # algorithmic work of the chain stage, for the per-kernel roofline figures: anchors and (pair, query seed) items of the hits
+                rec = np.frombuffer((capi.Hit * nh).from_address(C.addressof(hits_p.contents)), dtype=np.dtype(capi.Hit))
+                per_q = np.diff(np.frombuffer(offsets, dtype=np.uint64).astype(np.int64))
+                seeds = np.zeros(n, np.int64)
+                ns = C.c_uint64()
+                for i in range(n):
+                    capi.check(lib.psk_sketch_info(out[i], None, C.byref(ns), None, None, None)); seeds[i] = ns.value
+                self.last_chain_work = {"anchors": int(rec["n_anchors"].sum()), "items": int((per_q * seeds).sum()), "pairs": nh}
             if hits_p:
                 lib.psk_free(hits_p)
         finally:
@@ -446,6 +454,19 @@ def main():
                        "bases_sketched_per_s": bases * world * args.steps / dt,
                        "reported_hits_per_step": int(n_hits)},
         }
+        if args.workload == "allvsall" and getattr(eng, "last_chain_work", None):
+            # per-kernel roofline of the chain stage: ALGORITHMIC bytes (SURVEY.md §8d B_ch terms) / HIP-event kernel time
+            w = eng.last_chain_work
+            kr = {}
+            for name, key, nbytes, what in (("anchor_join", "anchor", 16.0 * w["items"], "8 B query k-mer + order read and 8 B record written per (pair, query seed)"),
+                                            ("chain_lane", "chain_chunk", 16.0 * w["anchors"], "16 B per anchor read")):
+                t = kernel_ms[key] * 1e-3
+                if t > 0:
+                    kr[name] = {"achieved_GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": nbytes,
+                                "ms_per_step": kernel_ms[key], "bytes": what}
+            line["extras"]["chain_kernel_roofline"] = {"work_per_step": w, "kernels": kr,
+                                                       "note": "neither kernel is HBM-bound: chain_lane is VALU-issue bound, the join is bound by dependent-load latency and issue "
+                                                               "(profiles/r2/r2j_pmc_allvsall1000.md, r2e_pmc_join_kernels_sq.txt)"}
         if args.workload == "metagenome":
             line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
             if world == 1 and args.api_queries > 0:

@@ -10,8 +10,8 @@ def load(f):
         d[k] = d.get(k, 0) + float(p[2])
     return d
 F = load(sys.argv[1]); W = load(sys.argv[2]); steps = 2
-items = 3.70e9   # (pair, query seed) items per step: 99 980 chained pairs x ~37 k seeds
-anch = 3.10e9    # anchors per step
+items = 3.94e9   # (pair, query seed) items per step: 99 980 chained pairs x ~39 k seeds (bench line, extras.chain_kernel_roofline)
+anch = 1.97e9    # anchors per step (same source)
 alg = {
  'anchor_join4_kernel': (8*items, 8*items, 'q_key + q_perm (8 B/item; re-used by the ~100 pairs of a query) / 8 B/item records'),
  'rocprim scan (main)': (8*items, 4*items, '8 B/item records / 4 B/item offsets'),
@@ -36,5 +36,5 @@ print(f'\nSum over these kernels: {tf:.0f}-{2*tf:.0f} GB read + {tw:.0f} GB writ
 print('about a quarter of the HBM roof. None of its kernels is bandwidth-bound: `chain_lane` is VALU-issue bound (DESIGN.md section 4), the join kernels are bound by the')
 print('latency of their chains of dependent loads at ~7 resident waves per SIMD (`profiles/r2/r2e_pmc_join_kernels_sq.txt`: 79 % of wave residency waiting, 5 % waiting to issue,')
 print('4.7e9 L2 requests per step of which 3.9e9 are the per-lane 8-byte record stores). No kernel re-reads its inputs from HBM: measured traffic is')
-print('within 1.0-1.4x of the algorithmic bytes (below it where a query\'s arrays are shared by its ~100 pairs) except `chain_lane`, whose per-lane 16-byte loads of four')
-print('arrays touch more lines than they use (1.3-2.6x).')
+print('within 1.0-1.7x of the algorithmic bytes (below it where a query\'s arrays are shared by its ~100 pairs) except `chain_lane`, whose per-lane 16-byte loads of three')
+print('arrays touch more lines than they use (2.2-4.4x: the one place where traffic well above the algorithmic bytes remains; the kernel is VALU-bound, so it does not show in its time).')
