@@ -488,8 +488,7 @@ __global__ __launch_bounds__(256) void anchor_join_kernel(const PairDesc* __rest
 __global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                                  uint32_t n_pairs, uint32_t n_items,
                                                                  const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
-                                                                 uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
-                                                                 uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                                 uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
                                                                  const uint32_t* __restrict__ blk_pair) {
     const uint32_t lb = xcd_block_id();
     uint32_t i = lb * blockDim.x + threadIdx.x;
@@ -504,8 +503,7 @@ __global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc*
     if ((uint64_t)dst + c > cap) { atomicOr(err, 2u); return; }   // beyond the optimistic capacity: the host reruns the batch with the true total
     const uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
     if (c == 1) {
-        a_qp[dst] = qp; a_qc[dst] = qm >> 1; a_rp[dst] = it.x;
-        a_rm[dst] = (it.y & 0xFFFFFEu) | ((it.y ^ qm) & 1u);   // ref contig << 1 | reverse_match
+        anc[dst] = make_uint4(qp, it.x, (it.y & 0xFFFFFEu) | ((it.y ^ qm) & 1u), qm >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig): one 16-byte store
         return;
     }
     uint32_t l, c2;     // a repeat: find its run in the reference index again (rare)
@@ -513,9 +511,7 @@ __global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc*
     for (uint32_t j = 0; j < c; j++) {
         const uint64_t pm = P.r_pms[l + j];
         const uint32_t rmeta = (uint32_t)pm;
-        a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
-        a_rp[dst + j] = (uint32_t)(pm >> 32);
-        a_rm[dst + j] = (rmeta & ~1u) | ((rmeta ^ qm) & 1u);
+        anc[dst + j] = make_uint4(qp, (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm) & 1u), qm >> 1);
     }
 }
 
@@ -667,8 +663,7 @@ __global__ __launch_bounds__(256) void anchor_join_pairs_kernel(const PairDesc* 
 __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                                   uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
                                                                   const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
-                                                                  uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
-                                                                  uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                                  uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
                                                                   const uint32_t* __restrict__ blk_pair) {
     const uint32_t lb = xcd_block_id();
     uint32_t i[JT], p[JT], c[JT], dst[JT], qp[JT], qm[JT], hint[JT];
@@ -700,8 +695,7 @@ __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc
         if (!act[t]) continue;
         if (c[t] == 1) {
             const uint32_t d = dst[t];
-            a_qp[d] = qp[t]; a_qc[d] = qm[t] >> 1; a_rp[d] = rec[t].x;
-            a_rm[d] = (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u);   // ref contig << 1 | reverse_match
+            anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
         } else {      // a repeat: find its run in the reference index again (rare)
             const PairDesc& P = pairs[p[t]];
             uint32_t l, c2;
@@ -709,9 +703,7 @@ __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc
             for (uint32_t j = 0; j < c[t]; j++) {
                 const uint64_t pm = P.r_pms[l + j];
                 const uint32_t rmeta = (uint32_t)pm;
-                a_qp[dst[t] + j] = qp[t]; a_qc[dst[t] + j] = qm[t] >> 1;
-                a_rp[dst[t] + j] = (uint32_t)(pm >> 32);
-                a_rm[dst[t] + j] = (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u);
+                anc[dst[t] + j] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
             }
         }
     }
@@ -721,8 +713,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
                                                           uint32_t n_pairs, uint32_t n_items,
                                                           const uint2* __restrict__ lbcnt,
                                                           const uint32_t* __restrict__ aoff,
-                                                          uint32_t* __restrict__ a_qp, uint32_t* __restrict__ a_qc,
-                                                          uint32_t* __restrict__ a_rp, uint32_t* __restrict__ a_rm, uint32_t cap, uint32_t* __restrict__ err,
+                                                          uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
                                                           const uint32_t* __restrict__ blk_pair) {
     const uint32_t lb = xcd_block_id();
     uint32_t i = lb * blockDim.x + threadIdx.x;
@@ -739,9 +730,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
     for (uint32_t j = 0; j < c; j++) {
         uint64_t pm = P.r_pms[l + j];        // (pos, meta) of the ref seed, stored in index order
         uint32_t rmeta = (uint32_t)pm;
-        a_qp[dst + j] = qp; a_qc[dst + j] = qm >> 1;
-        a_rp[dst + j] = (uint32_t)(pm >> 32);
-        a_rm[dst + j] = (rmeta & ~1u) | ((rmeta ^ qm) & 1u);   // ref contig << 1 | reverse_match
+        anc[dst + j] = make_uint4(qp, (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm) & 1u), qm >> 1);   // ref contig << 1 | reverse_match
     }
 }
 
@@ -767,7 +756,7 @@ __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restr
 // a window of anchor keys in LDS with coalesced loads and finds each boundary with 64-wide compares + ballot
 // (a chunk is ~190 anchors at c = 125: three rounds).
 constexpr int HEAD_WIN = 2048;
-__global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
+__global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restrict__ pstart, const uint4* __restrict__ anc,
                                                          const uint32_t* __restrict__ cbase, uint32_t n_pairs, uint2* __restrict__ chunks,
                                                          uint32_t* __restrict__ n_chunks, uint32_t* __restrict__ err) {
     __shared__ unsigned long long s_key[HEAD_WIN];
@@ -782,7 +771,7 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
     auto load_window = [&](uint32_t from) {
         lds_wave_sync();
         w0 = from; wn = pend - w0 < (uint32_t)HEAD_WIN ? pend - w0 : (uint32_t)HEAD_WIN;
-        for (uint32_t i = lane; i < wn; i += 64) s_key[i] = ((unsigned long long)a_qc[w0 + i] << 32) | a_qp[w0 + i];
+        for (uint32_t i = lane; i < wn; i += 64) { const uint4 a = anc[w0 + i]; s_key[i] = ((unsigned long long)a.w << 32) | a.x; }
         lds_wave_sync();
     };
     if (h < pend) load_window(h);
@@ -806,16 +795,16 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
 }
 
 // nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
-__global__ __launch_bounds__(256) void anchor_next_kernel(const uint32_t* __restrict__ a_qp, const uint32_t* __restrict__ a_qc,
+__global__ __launch_bounds__(256) void anchor_next_kernel(const uint4* __restrict__ anc,
                                                           const uint32_t* __restrict__ pstart, uint32_t n_pairs,
                                                           uint32_t* __restrict__ nxt) {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= pstart[n_pairs]) return;      // the grid covers the capacity, the device knows the total
     const uint32_t p = find_le(pstart, n_pairs, a);
     uint32_t pend = pstart[p + 1];
-    uint64_t key = ((uint64_t)a_qc[a] << 32) + (uint64_t)a_qp[a] + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
+    uint64_t key = ((uint64_t)anc[a].w << 32) + (uint64_t)anc[a].x + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
     uint32_t l = a + 1, h = pend;
-    while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)a_qc[mid] << 32) | a_qp[mid]; if (k2 <= key) l = mid + 1; else h = mid; }
+    while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)anc[mid].w << 32) | anc[mid].x; if (k2 <= key) l = mid + 1; else h = mid; }
     nxt[a] = l;
 }
 
@@ -857,7 +846,7 @@ __global__ __launch_bounds__(64) void chunk_hops_kernel(const uint32_t* __restri
 struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, right; uint64_t cov_q; };
 
 struct ChainArgs {
-    const uint32_t *a_qp, *a_qc, *a_rp, *a_rm;
+    const uint4* anc;      // anchors, array of (q pos, r pos, ref contig << 1 | reverse_match, q contig): a lane's chunk is one contiguous run of 16-byte records
     const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs, n_rows;
     const uint32_t* row_pair;   // pair of every row of the chunk table
     const PairDesc* pairs;
@@ -892,12 +881,12 @@ __device__ uint32_t seeds_between(const PairDesc& P, uint32_t qc, uint32_t lo, u
 __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t e) {
     for (uint32_t x = s; x < e; x++) {
         int32_t bs = ANCHOR_SCORE2; uint32_t bp = x;
-        uint32_t qx = A.a_qp[x], rx = A.a_rp[x], mx = A.a_rm[x];
+        uint32_t qx = A.anc[x].x, rx = A.anc[x].y, mx = A.anc[x].z;
         for (uint32_t y = x; y-- > s && x - y <= (uint32_t)A.band;) {
-            if (A.a_rm[y] != mx) continue;
-            int64_t dq = (int64_t)qx - (int64_t)A.a_qp[y];
+            if (A.anc[y].z != mx) continue;
+            int64_t dq = (int64_t)qx - (int64_t)A.anc[y].x;
             if (dq > BP_CHAIN_BAND) break;
-            int64_t dr = (mx & 1) ? (int64_t)A.a_rp[y] - (int64_t)rx : (int64_t)rx - (int64_t)A.a_rp[y];
+            int64_t dr = (mx & 1) ? (int64_t)A.anc[y].y - (int64_t)rx : (int64_t)rx - (int64_t)A.anc[y].y;
             if (dq <= 0 || dr <= 0) continue;
             int64_t gap = dq > dr ? dq - dr : dr - dq;
             if (gap > MAX_GAP_LENGTH) continue;
@@ -915,10 +904,10 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
         if (A.sc_root[x] != x) continue;
         uint32_t b = A.sc_best[x];
         if (A.sc_depth[b] < MIN_ANCHORS || A.sc_f[b] < MIN_SCORE2) continue;
-        uint32_t ra = A.a_rp[x], rb = A.a_rp[b];
-        A.c_score[s + nc] = A.sc_f[b]; A.c_q0[s + nc] = A.a_qp[x]; A.c_q1[s + nc] = A.a_qp[b];
+        uint32_t ra = A.anc[x].y, rb = A.anc[b].y;
+        A.c_score[s + nc] = A.sc_f[b]; A.c_q0[s + nc] = A.anc[x].x; A.c_q1[s + nc] = A.anc[b].x;
         A.c_r0[s + nc] = ra < rb ? ra : rb; A.c_r1[s + nc] = ra < rb ? rb : ra; A.c_n[s + nc] = A.sc_depth[b];
-        A.c_rc[s + nc] = A.a_rm[x] >> 1;
+        A.c_rc[s + nc] = A.anc[x].z >> 1;
         nc++;
     }
     return nc;
@@ -990,13 +979,9 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     const int band = A.band;
     for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
         const uint32_t x0 = s_al + t0;
-        uint4 q4 = make_uint4(0, 0, 0, 0), r4 = q4, m4 = q4;
-        if (t0 < len) {
-            q4 = *reinterpret_cast<const uint4*>(A.a_qp + x0);
-            r4 = *reinterpret_cast<const uint4*>(A.a_rp + x0);
-            m4 = *reinterpret_cast<const uint4*>(A.a_rm + x0);
-        }
-        const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+        uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
+        if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
+        const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
         LaneAnchor nw[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1052,10 +1037,10 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
                 for (int j = 0; j < LANE_TREES; j++)
                     if (sroot[j] != 0xFFFFFFFFu && (c == 0 || sroot[j] > last) && sroot[j] < pick) { pick = sroot[j]; k = bk[j]; q1 = bq[j]; rb = br[j]; }
                 last = pick;
-                const uint32_t xr = s + pick, ra = A.a_rp[xr], o = s + nc;
-                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.a_qp[xr]; A.c_q1[o] = q1;
+                const uint32_t xr = s + pick, ra = A.anc[xr].y, o = s + nc;
+                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.anc[xr].x; A.c_q1[o] = q1;
                 A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
-                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.a_rm[xr] >> 1;
+                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.anc[xr].z >> 1;
                 nc++;
             }
             ChunkOut o{};
@@ -1118,13 +1103,9 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
     const int band = A.band;
     for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
         const uint32_t x0 = s_al + t0;
-        uint4 q4 = make_uint4(0, 0, 0, 0), r4 = q4, m4 = q4;
-        if (t0 < len) {
-            q4 = *reinterpret_cast<const uint4*>(A.a_qp + x0);
-            r4 = *reinterpret_cast<const uint4*>(A.a_rp + x0);
-            m4 = *reinterpret_cast<const uint4*>(A.a_rm + x0);
-        }
-        const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+        uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
+        if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
+        const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t x = x0 + u, t = t0 + u;
@@ -1184,10 +1165,10 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
                 for (int i = 0; i < LANE_TREES; i++)
                     if (sroot[i] != 0xFFFFFFFFu && (c == 0 || sroot[i] > last) && sroot[i] < pick) { pick = sroot[i]; k = bk[i]; q1 = bq[i]; rb = br[i]; }
                 last = pick;
-                const uint32_t xr = s + pick, ra = A.a_rp[xr], o = s + nc;
-                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.a_qp[xr]; A.c_q1[o] = q1;
+                const uint32_t xr = s + pick, ra = A.anc[xr].y, o = s + nc;
+                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.anc[xr].x; A.c_q1[o] = q1;
                 A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
-                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.a_rm[xr] >> 1;
+                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.anc[xr].z >> 1;
                 nc++;
             }
             ChunkOut o{};
@@ -1222,7 +1203,8 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
         for (uint32_t base = s; base < e && fast; base += 64) {
             const uint32_t idx = base + lane;
             const bool have = idx < e;
-            const uint32_t my_qp = have ? A.a_qp[idx] : 0, my_rp = have ? A.a_rp[idx] : 0, my_rm = have ? A.a_rm[idx] : 0;
+            const uint4 my_a = have ? A.anc[idx] : make_uint4(0, 0, 0, 0);
+            const uint32_t my_qp = my_a.x, my_rp = my_a.y, my_rm = my_a.z;
             const uint32_t cnt = e - base < 64 ? e - base : 64;
             for (uint32_t j = 0; j < cnt; j++) {
                 const uint32_t x = base + j;
@@ -1288,10 +1270,10 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
             if (C > 64) { fast = false; break; }
             if (qual) {
                 uint32_t xr = s + s_rootx_w[r], xb = s + lx;
-                uint32_t ra = A.a_rp[xr], rb = A.a_rp[xb];
-                s_cand_w[0][ci] = f; s_cand_w[1][ci] = A.a_qp[xr]; s_cand_w[2][ci] = A.a_qp[xb];
+                uint32_t ra = A.anc[xr].y, rb = A.anc[xb].y;
+                s_cand_w[0][ci] = f; s_cand_w[1][ci] = A.anc[xr].x; s_cand_w[2][ci] = A.anc[xb].x;
                 s_cand_w[3][ci] = ra < rb ? ra : rb; s_cand_w[4][ci] = ra < rb ? rb : ra; s_cand_w[5][ci] = dep;
-                s_cand_w[6][ci] = A.a_rm[xr] >> 1;
+                s_cand_w[6][ci] = A.anc[xr].z >> 1;
             }
         }
     }
@@ -1683,7 +1665,7 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
     if (row >= A.n_rows) return;
     if (row - A.cbase[pair] >= A.n_chunks[pair]) return;
     ChunkOut* o = &A.out[row];
-    if (o->n_intervals) o->seeds = seeds_between(A.pairs[pair], A.a_qc[A.chunks[row].x], o->left, o->right);
+    if (o->n_intervals) o->seeds = seeds_between(A.pairs[pair], A.anc[A.chunks[row].x].w, o->left, o->right);
 }
 
 // ------------------------------------------------------------------ per-pair ANI / AF
@@ -2126,9 +2108,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
     PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 8 + 1) + 64));   // select_big_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
-    uint32_t *a_qp = D, *a_qc = D + na, *a_rp = D + 2 * na, *a_rm = D + 3 * na, *a_nxt = D + 4 * na;
+    uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
+    uint32_t* a_nxt = D + 4 * na;
     ChainArgs A{};
-    A.a_qp = a_qp; A.a_qc = a_qc; A.a_rp = a_rp; A.a_rm = a_rm;
+    A.anc = anc;
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
     A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
     A.c_state = a_nxt;   // spare per-anchor array
@@ -2138,16 +2121,16 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
-    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
-    else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
-    else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, a_qp, a_qc, a_rp, a_rm, (uint32_t)cap, L.misc, L.blk_pair);
+    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
-        hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, a_qp, a_qc, L.pstart, n_pairs, a_nxt);
+        hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else
-        hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_qp, a_qc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
+        hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
