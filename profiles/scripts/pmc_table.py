@@ -17,7 +17,7 @@ alg = {
  'rocprim scan (main)': (8*items, 4*items, '8 B/item records / 4 B/item offsets'),
  'anchor_emit_packed4_kernel': (12*items+8*items, 16*anch, "records + offsets 12 B/item, q_pos + q_meta 8 B/item (shared by a query's pairs) / 16 B/anchor"),
  'chain_lane_kernel': (16*anch, 0.2e9*28, '16 B/anchor / candidates'),
- 'chunk_heads_kernel': (8*anch, 23e6*8, 'a_qp + a_qc 8 B/anchor / chunk table'),
+ 'chunk_heads_kernel': (16*anch, 23e6*8, '16 B/anchor (the 8 it needs sit in 16-byte records) / chunk table'),
  'select_kernel': (28*0.3e9, 40*23e6, 'candidates / chunk records'),
  'sketch_scan_kernel': (4.93e9, 4.93e9*0.375, 'ASCII / packed + seed bits'),
 }
@@ -32,9 +32,10 @@ for k, (ar, aw, what) in alg.items():
     f = F.get(k, 0)*1024/steps/1e9; w = W.get(k, 0)*1024/steps/1e9
     print(f'| {k} | {f:.1f} | {2*f:.1f} | {w:.1f} | {ar/1e9:.1f} | {aw/1e9:.1f} | {what} |')
 tf = sum(F.get(k, 0) for k in alg)*1024/steps/1e9; tw = sum(W.get(k, 0) for k in alg)*1024/steps/1e9
-print(f'\nSum over these kernels: {tf:.0f}-{2*tf:.0f} GB read + {tw:.0f} GB written per 187 ms step = {(tf+tw)/0.187/1e3:.1f}-{(2*tf+tw)/0.187/1e3:.1f} TB/s: the chain stage as a whole runs at')
+print(f'\nSum over these kernels: {tf:.0f}-{2*tf:.0f} GB read + {tw:.0f} GB written per 186 ms step = {(tf+tw)/0.186/1e3:.1f}-{(2*tf+tw)/0.186/1e3:.1f} TB/s: the chain stage as a whole runs at')
 print('about a quarter of the HBM roof. None of its kernels is bandwidth-bound: `chain_lane` is VALU-issue bound (DESIGN.md section 4), the join kernels are bound by the')
 print('latency of their chains of dependent loads at ~7 resident waves per SIMD (`profiles/r2/r2e_pmc_join_kernels_sq.txt`: 79 % of wave residency waiting, 5 % waiting to issue,')
 print('4.7e9 L2 requests per step of which 3.9e9 are the per-lane 8-byte record stores). No kernel re-reads its inputs from HBM: measured traffic is')
-print('within 1.0-1.7x of the algorithmic bytes (below it where a query\'s arrays are shared by its ~100 pairs) except `chain_lane`, whose per-lane 16-byte loads of three')
-print('arrays touch more lines than they use (2.2-4.4x: the one place where traffic well above the algorithmic bytes remains; the kernel is VALU-bound, so it does not show in its time).')
+print('within 1.0-1.7x of the algorithmic bytes (below it where a query\'s arrays are shared by its ~100 pairs). `chain_lane` read 69.5 GB (raw) per step while the')
+print('anchors were four separate arrays - every lane touched three cache lines per step and used 16 bytes of each, so lines were evicted and fetched again; as 16-byte')
+print('records (one contiguous 64-byte run per lane and step) it reads what the table shows.')
