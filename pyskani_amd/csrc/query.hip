@@ -315,6 +315,7 @@ struct PairDesc {
     const uint32_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
     const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
     const uint32_t* q_kmer;                                                   // their k-mers, same order
+    uint32_t q_nc, pad_;                                                      // kept contigs of the query
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
     const uint32_t* q_contig_start;
     uint64_t q_total_len, r_total_len;
@@ -840,6 +841,57 @@ __global__ __launch_bounds__(64) void chunk_hops_kernel(const uint32_t* __restri
         h = s_h; n = s_n;
     }
     if (lane == 0) n_chunks[p] = n < max_chunks ? n : max_chunks;
+}
+
+// Gb-scale pairs: one wave chasing 150 000 heads of a 3 Gb pair is 80 ms of pure latency. A chunk never spans two contigs, so
+// the first anchor of every contig is a head whatever came before: HOP_SLICES waves per pair each walk the contigs of their
+// slice, once to count their chunks (the rows of the table must stay dense and in order) and once more to write them.
+constexpr int HOP_SLICES = 32;
+__device__ __forceinline__ uint32_t first_anchor_of_contig(const uint4* __restrict__ anc, uint32_t a, uint32_t b, uint32_t c) {
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if (anc[mid].w < c) a = mid + 1; else b = mid; }
+    return a;
+}
+// pass 0: count; pass 1: write. slice_cnt[p * HOP_SLICES + w] holds the slice's chunk count between the passes.
+__global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint4* __restrict__ anc,
+                                                                const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ cbase, uint32_t n_pairs,
+                                                                uint32_t* __restrict__ slice_cnt, int pass, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+                                                                uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_win[HOP_WIN];
+    __shared__ uint32_t s_h, s_n;
+    const uint32_t p = blockIdx.x, w = blockIdx.y;
+    const int lane = threadIdx.x;
+    const uint32_t a = pstart[p], b = pstart[p + 1];
+    const uint32_t nc = pairs[p].q_nc;
+    const uint32_t c_lo = (uint32_t)((uint64_t)nc * w / HOP_SLICES), c_hi = (uint32_t)((uint64_t)nc * (w + 1) / HOP_SLICES);
+    const bool dead = b - a < MIN_ANCHORS;
+    if (pass == 0 && (dead || c_lo == c_hi)) { if (lane == 0) slice_cnt[p * HOP_SLICES + w] = 0; return; }
+    if (pass == 1 && dead) { if (lane == 0 && w == 0) n_chunks[p] = 0; return; }
+    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
+    uint32_t off = 0, total = 0;
+    if (pass == 1) {
+        for (int j = 0; j < HOP_SLICES; j++) { const uint32_t c = slice_cnt[p * HOP_SLICES + j]; if ((uint32_t)j < w) off += c; total += c; }
+        if (lane == 0 && w == 0) { n_chunks[p] = total < max_chunks ? total : max_chunks; if (total > max_chunks) atomicOr(err, 1u); }
+        if (c_lo == c_hi) return;
+    }
+    uint32_t h = first_anchor_of_contig(anc, a, b, c_lo);
+    const uint32_t hend = c_hi >= nc ? b : first_anchor_of_contig(anc, a, b, c_hi);
+    uint32_t n = 0;
+    while (h < hend) {
+        const uint32_t w0 = h, wn = hend - w0 < (uint32_t)HOP_WIN ? hend - w0 : (uint32_t)HOP_WIN;
+        for (uint32_t i = lane; i < wn; i += 64) s_win[i] = nxt[w0 + i];
+        lds_wave_sync();
+        if (lane == 0) {
+            while (h < hend && h - w0 < wn) {
+                const uint32_t e = s_win[h - w0];
+                if (pass == 1 && off + n < max_chunks) chunks[(size_t)row0 + off + n] = make_uint2(h, e);
+                n++; h = e;
+            }
+            s_h = h; s_n = n;
+        }
+        lds_wave_sync();
+        h = s_h; n = s_n;
+    }
+    if (pass == 0 && lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
 }
 
 // ------------------------------------------------------------------ chaining
@@ -1955,7 +2007,7 @@ static SketchDesc make_desc(const psk_sketch* s) {
 __device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
     PairDesc P;
     P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
-    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer;
+    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer; P.q_nc = Q.n_contigs; P.pad_ = 0;
     P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
     P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
     return P;
@@ -2128,6 +2180,12 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
         hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
+        if (n_items / n_pairs > (1u << 20) && !getenv("PSK_HOPS_UNSLICED")) {      // Gb-scale pairs: HOP_SLICES waves per pair, count then write
+            PSK_TRY(ctx->q_g.reserve(4 * (size_t)n_pairs * HOP_SLICES + 256));
+            uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
+            for (int pass = 0; pass < 2; pass++)
+                hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, pass, L.chunks, L.nch, L.misc);
+        } else
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
