@@ -106,6 +106,13 @@ class Engine:
         self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
         return out
 
+    def sketch_device_contigs(self, d_ptr, c_offs, c_lens, gfc):
+        n, nc = len(gfc) - 1, len(c_offs)
+        c_off = (C.c_uint64 * nc)(*c_offs); c_len = (C.c_uint64 * nc)(*c_lens); g = (C.c_uint32 * (n + 1))(*gfc)
+        out = (C.c_void_p * n)()
+        self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, g, n, 1, out))
+        return out
+
     def make_db(self, names, handles, n):
         db = C.c_void_p()
         self.capi.check(self.lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
@@ -280,6 +287,35 @@ def api_rates(psk, genomes, query):
     return out
 
 
+def make_big_genomes(torch, device, n_genomes, n_contigs, contig_len, fam_size, seed):
+    """BASELINE configs[4] shape: genomes of n_contigs x contig_len bases (24 x 125 Mb = 3 Gb), families of fam_size members that
+    carry independent substitutions (rates cycled from DIVERGENCE[:4]) on a shared ancestor. Built contig by contig on the GPU
+    (never more than one ancestor contig live). Returns the ASCII buffer, per-contig offsets / lengths and genome_first_contig."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    stride = (contig_len + 15 + 16) & ~15
+    buf = torch.zeros(n_genomes * n_contigs * stride + 64, dtype=torch.uint8, device=device)
+    offs = [(gi * n_contigs + c) * stride for gi in range(n_genomes) for c in range(n_contigs)]
+    lens = [contig_len] * (n_genomes * n_contigs)
+    n_fam = (n_genomes + fam_size - 1) // fam_size
+    for f in range(n_fam):
+        for c in range(n_contigs):
+            a = torch.randint(0, 4, (contig_len,), generator=g, device=device, dtype=torch.uint8)
+            for j in range(fam_size):
+                gi = f * fam_size + j
+                if gi >= n_genomes:
+                    break
+                d = DIVERGENCE[:4][j % 4]
+                mut = torch.rand(a.shape, generator=g, device=device) < d
+                shift = torch.randint(1, 4, a.shape, generator=g, device=device, dtype=torch.uint8)
+                o = offs[gi * n_contigs + c]
+                buf[o:o + contig_len] = lut[torch.where(mut, (a + shift) & 3, a).long()]
+                del mut, shift
+            del a
+    gfc = [gi * n_contigs for gi in range(n_genomes + 1)]
+    return buf, offs, lens, gfc
+
+
 def make_contigs(torch, device, buf, offs, lens, n_refs, n_contigs, seed):
     """BASELINE configs[3] / SURVEY.md §8(d) config 4: query contigs = substrings of random references, length
     log-uniform in [2 kb, 50 kb], extra divergence U[0, 5 %]. Built on the GPU; 16-byte aligned offsets."""
@@ -309,9 +345,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--refs", type=int, default=None, help="references per GPU (search / allvsall default 1000 = BASELINE configs[1]; metagenome default 5000)")
-    ap.add_argument("--workload", choices=["search", "allvsall", "metagenome"], default="search",
+    ap.add_argument("--workload", choices=["search", "allvsall", "metagenome", "mammalian"], default="search",
                     help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes; metagenome = configs[3] shape (extras, not the headline)")
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
+    ap.add_argument("--contig-mb", type=int, default=125, help="mammalian: contig length in Mb (24 contigs per genome; 125 = 3 Gb genomes)")
     ap.add_argument("--api-queries", type=int, default=2000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
@@ -343,9 +380,14 @@ def main():
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    n_refs = args.refs if args.refs is not None else (5000 if args.workload == "metagenome" else N_REFS)
+    n_refs = args.refs if args.refs is not None else (5000 if args.workload == "metagenome" else (8 if args.workload == "mammalian" else N_REFS))
     n_families = N_FAMILIES if args.workload == "search" else max(1, n_refs // 100)     # families of 100 for configs 3-4
-    buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=n_families)
+    big = None
+    if args.workload == "mammalian":      # BASELINE configs[4] shape at reduced count: n_refs genomes of 24 contigs, families of 4, all-vs-all
+        big = make_big_genomes(torch, device, n_refs, 24, args.contig_mb * 1_000_000, 4, seed=5 + rank)
+        buf, offs, lens = big[0], big[1], big[2]
+    else:
+        buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=n_families)
     torch.cuda.synchronize()
 
     from pyskani_amd.parallel import all_gather_hits
@@ -366,6 +408,13 @@ def main():
     def step():
         if args.workload == "allvsall":
             return eng.step_all_vs_all(buf.data_ptr(), offs, lens, names)
+        if args.workload == "mammalian":     # sketch every genome, load the database, every genome against all of them
+            handles = eng.sketch_device_contigs(buf.data_ptr(), big[1], big[2], big[3])
+            db = eng.make_db(names, handles, n_refs)
+            try:
+                return eng.query_many(db, handles, n_refs)
+            finally:
+                eng.lib.psk_db_destroy(db)
         if args.workload == "metagenome":   # sketch every contig, query them all against the resident database
             qh = eng.sketch_device(meta_state["cbuf"].data_ptr(), meta_state["coffs"], meta_state["clens"])
             try:
@@ -408,6 +457,11 @@ def main():
             pairs_per_step, sketched = n_refs * n_refs, n_refs
             bases = float(sum(lens[:n_refs]))
             wl = f"all-vs-all {n_refs} x {n_refs} synthetic ~5 Mb genomes per GPU ({n_families} families x {n_refs // n_families}), c=125 marker_c=1000 k=15"
+        elif args.workload == "mammalian":
+            pairs_per_step, sketched = n_refs * n_refs, n_refs
+            bases = float(sum(lens))
+            wl = (f"mammalian scale (BASELINE configs[4] shape at reduced count): all-vs-all of {n_refs} synthetic genomes of 24 x {args.contig_mb} Mb contigs "
+                  f"({24 * args.contig_mb / 1000:.1f} Gb each; families of 4, substitution rates {DIVERGENCE[:4]}), c=125 marker_c=1000 k=15")
         elif args.workload == "metagenome":
             pairs_per_step, sketched = args.queries * n_refs, args.queries
             bases = float(sum(meta_state["clens"]))
@@ -425,7 +479,7 @@ def main():
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = valu = None
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_sketch_scan.json")
-        if os.path.exists(pmc) and args.workload != "metagenome":
+        if os.path.exists(pmc) and args.workload not in ("metagenome", "mammalian"):
             # OFFLINE counters (rocprofv3 --pmc in separate passes, profiles/r1_pmc_traffic.md), scaled by this launch's bases:
             # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) and VALU wave-instructions (SQ_INSTS_VALU = 26.8 per 64 bases, 61 % of them
             # four-cycle and 39 % two-cycle by profiles/micro/valu_rates.hip = 3.2 cycles on average)

@@ -1577,22 +1577,52 @@ struct BigArgs {
 };
 constexpr int BIG_T = 1024;
 
+// Bitonic sort of P (a power of two >= 1024) keys in global memory by one workgroup. Compare-exchange distances below BIG_TILE stay
+// inside an aligned tile of BIG_TILE keys, so those passes run on a tile staged in LDS (one global round trip per tile and stage
+// instead of one per pass: 29 instead of 171 sweeps over the array for 2^18 keys); only the longer distances sweep global memory.
+constexpr uint32_t BIG_TILE = 4096;
 __device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, bool descending) {
-    for (uint32_t kk = 2; kk <= P; kk <<= 1)
-        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t t = threadIdx.x; t < P; t += BIG_T) {
-                uint32_t ixj = t ^ jj;
-                if (ixj > t) {
-                    unsigned long long a = key[t], b = key[ixj];
-                    bool up = ((t & kk) == 0) != descending;      // ascending run?
-                    if ((a > b) == up) {
-                        key[t] = b; key[ixj] = a;
-                        if (pay) { uint32_t pa = pay[t]; pay[t] = pay[ixj]; pay[ixj] = pa; }
+    __shared__ unsigned long long t_key[BIG_TILE];
+    __shared__ uint32_t t_pay[BIG_TILE];
+    const uint32_t tile = P < BIG_TILE ? P : BIG_TILE;
+    // kk_lo..kk_hi stages restricted to distances < tile, on LDS
+    auto tile_passes = [&](uint32_t kk_first, uint32_t kk_last) {
+        for (uint32_t b = 0; b < P; b += tile) {
+            for (uint32_t t = threadIdx.x; t < tile; t += BIG_T) { t_key[t] = key[b + t]; if (pay) t_pay[t] = pay[b + t]; }
+            __syncthreads();
+            for (uint32_t kk = kk_first; kk <= kk_last; kk <<= 1)
+                for (uint32_t jj = (kk >> 1) < tile ? (kk >> 1) : (tile >> 1); jj > 0; jj >>= 1) {
+                    for (uint32_t c = threadIdx.x; c < (tile >> 1); c += BIG_T) {
+                        const uint32_t t = ((c & ~(jj - 1)) << 1) | (c & (jj - 1)), u = t | jj;
+                        const unsigned long long a = t_key[t], v = t_key[u];
+                        const bool up = (((b + t) & kk) == 0) != descending;
+                        if ((a > v) == up) {
+                            t_key[t] = v; t_key[u] = a;
+                            if (pay) { const uint32_t pa = t_pay[t]; t_pay[t] = t_pay[u]; t_pay[u] = pa; }
+                        }
                     }
+                    __syncthreads();
+                }
+            for (uint32_t t = threadIdx.x; t < tile; t += BIG_T) { key[b + t] = t_key[t]; if (pay) pay[b + t] = t_pay[t]; }
+            __syncthreads();
+        }
+    };
+    tile_passes(2, tile);                                   // every tile sorted (direction by its position)
+    for (uint32_t kk = tile << 1; kk <= P; kk <<= 1) {
+        for (uint32_t jj = kk >> 1; jj >= tile; jj >>= 1) {
+            for (uint32_t c = threadIdx.x; c < (P >> 1); c += BIG_T) {
+                const uint32_t t = ((c & ~(jj - 1)) << 1) | (c & (jj - 1)), u = t | jj;
+                const unsigned long long a = key[t], v = key[u];
+                const bool up = ((t & kk) == 0) != descending;
+                if ((a > v) == up) {
+                    key[t] = v; key[u] = a;
+                    if (pay) { const uint32_t pa = pay[t]; pay[t] = pay[u]; pay[u] = pa; }
                 }
             }
             __syncthreads();
         }
+        tile_passes(kk, kk);
+    }
 }
 
 __device__ void select_big_pair(const BigArgs& B, const uint32_t p) {
