@@ -1564,30 +1564,53 @@ __global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
     }
 }
 
-// ---- pairs with more than CMAX candidate chains (genomes beyond ~10 Mb): the same algorithm on global
-// scratch, one 1024-thread workgroup per pair. Scratch is indexed from the pair's first anchor: a pair with n
-// anchors has at most n/3 candidates, and the padded sort length stays below n.
+// ---- pairs with more than CMAX candidate chains (genomes beyond ~10 Mb): the same algorithm on global scratch, by a GROUP of
+// G workgroups of 1024 threads per pair (G = 1 for up to BIG_SOLO candidates; for Gb-scale pairs the cooperative kernel below
+// gives every pair 8..128 workgroups that meet at a counter barrier between phases). Scratch is indexed from the pair's first
+// anchor: a pair with n anchors has at most n/3 candidates, and the padded sort length stays below n.
 struct BigArgs {
     SelArgs S; const uint32_t* pstart;
     unsigned long long* key;   // sort keys
     uint32_t *slot, *crow;     // candidate j -> global candidate slot, chunk row (generation order)
     uint32_t *idx, *pm, *pm2;  // payload of the reference-order sort; running max of r1 (double buffer)
-    uint32_t *ord, *clist, *kept;
+    uint32_t *ord, *clist;
     uint8_t* conf;
+    uint32_t *huge_list, *huge_count;   // pairs with more than BIG_SOLO candidates, listed by the solo kernel for the cooperative one
+    uint32_t *ctr, *parts;              // per group: barrier counter; 2 x BIG_GMAX partial sums of the two ordered compactions
+    uint32_t solo;                      // BIG_SOLO ($PSK_BIG_SOLO in tests)
 };
 constexpr int BIG_T = 1024;
+constexpr uint32_t BIG_TILE = 4096;       // keys of one LDS-staged sort tile
+constexpr uint32_t BIG_SOLO = 32768;      // up to here one workgroup per pair: a barrier between workgroups costs more than it divides
+constexpr uint32_t BIG_GMAX = 128;        // workgroups of the cooperative launch (co-resident: one per CU, at most two launches per CU pair of lanes)
+constexpr uint32_t BIG_GROUPS = 16;       // pairs in flight in the cooperative launch
 
-// Bitonic sort of P (a power of two >= 1024) keys in global memory by one workgroup. Compare-exchange distances below BIG_TILE stay
+struct BigGrp { uint32_t G, gr, epoch; uint32_t* ctr; uint32_t* part_a; uint32_t* part_b; };
+
+// all G workgroups of the group arrive; global writes made before are visible to every member after (the recipe of a grid-wide
+// sync: workgroup barrier, agent-scope release by one thread, counter, agent-scope acquire, workgroup barrier)
+__device__ __forceinline__ void grp_sync(BigGrp& g) {
+    __syncthreads();
+    if (g.G > 1) {
+        g.epoch++;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(g.ctr, 1u);
+            const uint32_t target = g.epoch * g.G;
+            while (__hip_atomic_load(g.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
+
+// Bitonic sort of P (a power of two >= 1024) keys in global memory by the group. Compare-exchange distances below BIG_TILE stay
 // inside an aligned tile of BIG_TILE keys, so those passes run on a tile staged in LDS (one global round trip per tile and stage
-// instead of one per pass: 29 instead of 171 sweeps over the array for 2^18 keys); only the longer distances sweep global memory.
-constexpr uint32_t BIG_TILE = 4096;
-__device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, bool descending) {
-    __shared__ unsigned long long t_key[BIG_TILE];
-    __shared__ uint32_t t_pay[BIG_TILE];
+// instead of one per pass: 36 instead of 190 sweeps over the array for 2^19 keys); only the longer distances sweep global memory.
+__device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, bool descending, BigGrp& g, unsigned long long* t_key, uint32_t* t_pay) {
     const uint32_t tile = P < BIG_TILE ? P : BIG_TILE;
-    // kk_lo..kk_hi stages restricted to distances < tile, on LDS
     auto tile_passes = [&](uint32_t kk_first, uint32_t kk_last) {
-        for (uint32_t b = 0; b < P; b += tile) {
+        for (uint32_t b = g.gr * tile; b < P; b += g.G * tile) {
             for (uint32_t t = threadIdx.x; t < tile; t += BIG_T) { t_key[t] = key[b + t]; if (pay) t_pay[t] = pay[b + t]; }
             __syncthreads();
             for (uint32_t kk = kk_first; kk <= kk_last; kk <<= 1)
@@ -1606,11 +1629,12 @@ __device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, 
             for (uint32_t t = threadIdx.x; t < tile; t += BIG_T) { key[b + t] = t_key[t]; if (pay) pay[b + t] = t_pay[t]; }
             __syncthreads();
         }
+        grp_sync(g);
     };
     tile_passes(2, tile);                                   // every tile sorted (direction by its position)
     for (uint32_t kk = tile << 1; kk <= P; kk <<= 1) {
         for (uint32_t jj = kk >> 1; jj >= tile; jj >>= 1) {
-            for (uint32_t c = threadIdx.x; c < (P >> 1); c += BIG_T) {
+            for (uint32_t c = g.gr * BIG_T + threadIdx.x; c < (P >> 1); c += g.G * BIG_T) {
                 const uint32_t t = ((c & ~(jj - 1)) << 1) | (c & (jj - 1)), u = t | jj;
                 const unsigned long long a = key[t], v = key[u];
                 const bool up = ((t & kk) == 0) != descending;
@@ -1619,71 +1643,113 @@ __device__ void big_bitonic(unsigned long long* key, uint32_t* pay, uint32_t P, 
                     if (pay) { const uint32_t pa = pay[t]; pay[t] = pay[u]; pay[u] = pa; }
                 }
             }
-            __syncthreads();
+            grp_sync(g);
         }
         tile_passes(kk, kk);
     }
 }
 
-__device__ void select_big_pair(const BigArgs& B, const uint32_t p) {
-    __shared__ uint32_t s_scan[BIG_T];
-    __shared__ uint32_t s_carry, s_nk, s_flag;
+// inclusive scan of one value per thread over the workgroup (s_scan: BIG_T words)
+__device__ __forceinline__ uint32_t big_block_scan(uint32_t v, uint32_t* s_scan) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up(v, o); if (lane >= (uint32_t)o) v += x; }
+    __syncthreads();
+    if (lane == 63) s_scan[w] = v;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t x = lane < BIG_T / 64 ? s_scan[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < BIG_T / 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+        if (lane < BIG_T / 64) s_scan[lane] = x;
+    }
+    __syncthreads();
+    return v + (w ? s_scan[w - 1] : 0);
+}
+
+// number of candidate chains of a pair (sum of its rows' counts), by one workgroup
+__device__ uint32_t big_count_candidates(const SelArgs& S, uint32_t p, uint32_t* s_scan) {
+    const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
+    uint32_t c = 0;
+    for (uint32_t r = threadIdx.x; r < nrows; r += BIG_T) c += S.out[row0 + r].n_cand;
+    const uint32_t incl = big_block_scan(c, s_scan);
+    __syncthreads();
+    if (threadIdx.x == BIG_T - 1) s_scan[BIG_T / 64] = incl;
+    __syncthreads();
+    const uint32_t tot = s_scan[BIG_T / 64];
+    __syncthreads();
+    return tot;
+}
+
+__device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, unsigned char* s_raw, uint32_t* s_scan) {
+    __shared__ uint32_t s_carry;
     const SelArgs& S = B.S;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, G = g.G, gr = g.gr;
+    const uint32_t gt = gr * BIG_T + tid, GT = G * BIG_T;          // this thread in the group, threads of the group
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
     const uint32_t base = B.pstart[p];
-    __syncthreads();
-    // ---- candidates in generation order: block scan over the rows' candidate counts ----
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t r0 = 0; r0 < nrows; r0 += BIG_T) {
-        const uint32_t r = r0 + tid;
-        const uint32_t cnt = r < nrows ? S.out[row0 + r].n_cand : 0;
-        s_scan[tid] = cnt;
-        __syncthreads();
-        for (uint32_t o = 1; o < BIG_T; o <<= 1) { uint32_t v = tid >= o ? s_scan[tid - o] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-        const uint32_t off = s_carry + s_scan[tid] - cnt;
-        if (cnt) { const uint32_t sl = S.chunks[row0 + r].x; for (uint32_t i = 0; i < cnt; i++) { B.slot[base + off + i] = sl + i; B.crow[base + off + i] = r; } }
-        __syncthreads();
-        if (tid == BIG_T - 1) s_carry += s_scan[tid];
-        __syncthreads();
-    }
-    const uint32_t C = s_carry;
     unsigned long long* key = B.key + base; uint32_t* slot = B.slot + base; uint32_t* crow = B.crow + base;
     uint32_t* idx = B.idx + base; uint32_t* pm = B.pm + base; uint32_t* pm2 = B.pm2 + base;
-    uint32_t* ord = B.ord + base; uint32_t* clist = B.clist + base; uint32_t* kept = B.kept + base; uint8_t* conf = B.conf + base;
-    uint32_t P = 1024; while (P < C) P <<= 1;
-    // ---- priority order ----
-    for (uint32_t j = tid; j < P; j += BIG_T) key[j] = j < C ? (((unsigned long long)(uint32_t)S.c_score[slot[j]] << 32) | (0xFFFFFFFFu - j)) : 0ull;
+    uint32_t* ord = B.ord + base; uint32_t* clist = B.clist + base; uint8_t* conf = B.conf + base;
+    unsigned long long* t_key = (unsigned long long*)s_raw; uint32_t* t_pay = (uint32_t*)(s_raw + 8 * BIG_TILE);
     __syncthreads();
-    big_bitonic(key, nullptr, P, true);
-    for (uint32_t t = tid; t < C; t += BIG_T) ord[t] = 0xFFFFFFFFu - (uint32_t)key[t];
+    // ---- candidates in generation order: every workgroup takes a span of rows; spans are stitched by the partial sums ----
+    const uint32_t rspan = (((nrows + G - 1) / G) + BIG_T - 1) / BIG_T * BIG_T;
+    const uint32_t ra = gr * rspan < nrows ? gr * rspan : nrows, rb = ra + rspan < nrows ? ra + rspan : nrows;
+    {
+        uint32_t c = 0;
+        for (uint32_t r = ra + tid; r < rb; r += BIG_T) c += S.out[row0 + r].n_cand;
+        const uint32_t incl = big_block_scan(c, s_scan);
+        if (tid == BIG_T - 1) g.part_a[gr] = incl;
+    }
+    grp_sync(g);
+    uint32_t C = 0, pre = 0;
+    for (uint32_t w = 0; w < G; w++) { const uint32_t v = g.part_a[w]; if (w < gr) pre += v; C += v; }
+    if (tid == 0) s_carry = pre;
+    __syncthreads();
+    for (uint32_t r0 = ra; r0 < rb; r0 += BIG_T) {
+        const uint32_t r = r0 + tid;
+        const uint32_t cnt = r < rb ? S.out[row0 + r].n_cand : 0;
+        const uint32_t incl = big_block_scan(cnt, s_scan);
+        const uint32_t off = s_carry + incl - cnt;
+        if (cnt) { const uint32_t sl = S.chunks[row0 + r].x; for (uint32_t i = 0; i < cnt; i++) { slot[off + i] = sl + i; crow[off + i] = r; } }
+        __syncthreads();
+        if (tid == BIG_T - 1) s_carry += incl;
+        __syncthreads();
+    }
+    uint32_t P = 1024; while (P < C) P <<= 1;
+    grp_sync(g);
+    // ---- priority order ----
+    for (uint32_t j = gt; j < P; j += GT) key[j] = j < C ? (((unsigned long long)(uint32_t)S.c_score[slot[j]] << 32) | (0xFFFFFFFFu - j)) : 0ull;
     // ---- conflicts: chunk mates on the query ----
-    for (uint32_t j = tid; j < C; j += BIG_T) {
+    for (uint32_t j = gt; j < C; j += GT) {
         const uint32_t row = crow[j], q0 = S.c_q0[slot[j]], q1 = S.c_q1[slot[j]];
         bool cf = false;
         for (uint32_t v = j; v-- > 0 && crow[v] == row;) if (!(q1 < S.c_q0[slot[v]] || q0 > S.c_q1[slot[v]])) cf = true;
         for (uint32_t v = j + 1; v < C && crow[v] == row; v++) if (!(q1 < S.c_q0[slot[v]] || q0 > S.c_q1[slot[v]])) cf = true;
         conf[j] = cf;
     }
-    __syncthreads();
+    grp_sync(g);
+    big_bitonic(key, nullptr, P, true, g, t_key, t_pay);
+    for (uint32_t t = gt; t < C; t += GT) ord[t] = 0xFFFFFFFFu - (uint32_t)key[t];
+    grp_sync(g);
     // ---- conflicts on the reference: order by (ref contig, r0), running max of r1 by doubling ----
-    for (uint32_t j = tid; j < P; j += BIG_T) { key[j] = j < C ? (((unsigned long long)S.c_rc[slot[j]] << 32) | S.c_r0[slot[j]]) : ~0ull; idx[j] = j; }
-    __syncthreads();
-    big_bitonic(key, idx, P, false);
-    for (uint32_t u = tid; u < C; u += BIG_T) pm[u] = S.c_r1[slot[idx[u]]];
-    __syncthreads();
+    for (uint32_t j = gt; j < P; j += GT) { key[j] = j < C ? (((unsigned long long)S.c_rc[slot[j]] << 32) | S.c_r0[slot[j]]) : ~0ull; idx[j] = j; }
+    grp_sync(g);
+    big_bitonic(key, idx, P, false, g, t_key, t_pay);
+    for (uint32_t u = gt; u < C; u += GT) pm[u] = S.c_r1[slot[idx[u]]];
+    grp_sync(g);
     uint32_t* src = pm; uint32_t* dst = pm2;
     for (uint32_t o = 1; o < C; o <<= 1) {
-        for (uint32_t u = tid; u < C; u += BIG_T) {
+        for (uint32_t u = gt; u < C; u += GT) {
             uint32_t v = src[u];
             if (u >= o && (uint32_t)(key[u - o] >> 32) == (uint32_t)(key[u] >> 32)) { uint32_t w = src[u - o]; v = w > v ? w : v; }
             dst[u] = v;
         }
-        __syncthreads();
+        grp_sync(g);
         uint32_t* t2 = src; src = dst; dst = t2;
     }
-    for (uint32_t u = tid; u < C; u += BIG_T) {
+    for (uint32_t u = gt; u < C; u += GT) {
         const uint32_t j = idx[u];
         const uint32_t rc = (uint32_t)(key[u] >> 32), r0 = (uint32_t)key[u], r1 = S.c_r1[slot[j]];
         bool cf = false;
@@ -1691,51 +1757,116 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p) {
         if (u + 1 < C && (uint32_t)(key[u + 1] >> 32) == rc && (uint32_t)key[u + 1] <= r1) cf = true;
         if (cf) conf[j] = 1;
     }
+    grp_sync(g);
+    // ---- unconflicted chains are kept; conflicted ones listed in priority order (spans of ranks, stitched as above) ----
+    const uint32_t tspan = (((C + G - 1) / G) + BIG_T - 1) / BIG_T * BIG_T;
+    const uint32_t ta = gr * tspan < C ? gr * tspan : C, tb = ta + tspan < C ? ta + tspan : C;
+    {
+        uint32_t c = 0;
+        for (uint32_t t = ta + tid; t < tb; t += BIG_T) {
+            const uint32_t j = ord[t];
+            if (conf[j]) c++;
+            else { const uint32_t sl = slot[j]; sel_commit(S, row0 + crow[j], S.c_q0[sl], S.c_q1[sl], S.c_n[sl]); }
+        }
+        const uint32_t incl = big_block_scan(c, s_scan);
+        if (tid == BIG_T - 1) g.part_b[gr] = incl;
+    }
+    grp_sync(g);
+    uint32_t ncf = 0; pre = 0;
+    for (uint32_t w = 0; w < G; w++) { const uint32_t v = g.part_b[w]; if (w < gr) pre += v; ncf += v; }
+    if (tid == 0) s_carry = pre;
     __syncthreads();
-    // ---- unconflicted chains are kept; conflicted ones listed in priority order ----
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < C; t0 += BIG_T) {
+    for (uint32_t t0 = ta; t0 < tb; t0 += BIG_T) {
         const uint32_t t = t0 + tid;
-        const uint32_t j = t < C ? ord[t] : 0;
-        const uint32_t cf = (t < C && conf[j]) ? 1u : 0u;
-        if (t < C && !cf) { const uint32_t sl = slot[j]; sel_commit(S, row0 + crow[j], S.c_q0[sl], S.c_q1[sl], S.c_n[sl]); }
-        s_scan[tid] = cf;
+        const uint32_t j = t < tb ? ord[t] : 0;
+        const uint32_t cf = (t < tb && conf[j]) ? 1u : 0u;
+        const uint32_t incl = big_block_scan(cf, s_scan);
+        if (cf) clist[s_carry + incl - 1] = j;
         __syncthreads();
-        for (uint32_t o = 1; o < BIG_T; o <<= 1) { uint32_t v = tid >= o ? s_scan[tid - o] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-        if (cf) clist[s_carry + s_scan[tid] - 1] = j;
-        __syncthreads();
-        if (tid == BIG_T - 1) s_carry += s_scan[tid];
+        if (tid == BIG_T - 1) s_carry += incl;
         __syncthreads();
     }
-    const uint32_t ncf = s_carry;
-    if (tid == 0) s_nk = 0;
-    __syncthreads();
-    for (uint32_t t = 0; t < ncf; t++) {
-        const uint32_t j = clist[t], sl = slot[j];
-        const uint32_t q0 = S.c_q0[sl], q1 = S.c_q1[sl], r0 = S.c_r0[sl], r1 = S.c_r1[sl], rc = S.c_rc[sl], row = crow[j];
-        const uint32_t nk = s_nk;
-        if (tid == 0) s_flag = 0;
+    grp_sync(g);
+    if (gr != 0) return;
+    // ---- greedy over the conflicted chains in priority order, by the group's first workgroup: candidates staged 1024 at a time
+    // in LDS, kept chains in LDS (the first KL) and in compact global arrays (pm, pm2, idx, ord and the key array are free now) ----
+    constexpr uint32_t KL = 512;
+    uint32_t* L = (uint32_t*)s_raw;
+    uint32_t *g_q0 = L, *g_q1 = L + BIG_T, *g_r0 = L + 2 * BIG_T, *g_r1 = L + 3 * BIG_T, *g_rc = L + 4 * BIG_T, *g_row = L + 5 * BIG_T, *g_n = L + 6 * BIG_T;
+    uint32_t* K = L + 7 * BIG_T;
+    uint32_t *l_q0 = K, *l_q1 = K + KL, *l_r0 = K + 2 * KL, *l_r1 = K + 3 * KL, *l_rc = K + 4 * KL, *l_row = K + 5 * KL;
+    uint32_t *k_q0 = pm, *k_q1 = pm2, *k_r0 = idx, *k_r1 = ord, *k_rc = (uint32_t*)key, *k_row = (uint32_t*)key + C;
+    uint32_t nk = 0;
+    for (uint32_t t0 = 0; t0 < ncf; t0 += BIG_T) {
+        const uint32_t nb = ncf - t0 < (uint32_t)BIG_T ? ncf - t0 : (uint32_t)BIG_T;
         __syncthreads();
-        bool ov = false;
-        for (uint32_t v = tid; v < nk; v += BIG_T) {
-            const uint32_t j2 = kept[v], s2 = slot[j2];
-            if (crow[j2] == row && !(q1 < S.c_q0[s2] || q0 > S.c_q1[s2])) ov = true;
-            else if (S.c_rc[s2] == rc && !(r1 < S.c_r0[s2] || r0 > S.c_r1[s2])) ov = true;
+        if (tid < nb) {
+            const uint32_t j = clist[t0 + tid], sl = slot[j];
+            g_q0[tid] = S.c_q0[sl]; g_q1[tid] = S.c_q1[sl]; g_r0[tid] = S.c_r0[sl]; g_r1[tid] = S.c_r1[sl]; g_rc[tid] = S.c_rc[sl];
+            g_row[tid] = crow[j]; g_n[tid] = S.c_n[sl];
         }
-        if (ov) s_flag = 1;
         __syncthreads();
-        if (tid == 0 && !s_flag) { kept[nk] = j; s_nk = nk + 1; sel_commit(S, row0 + row, q0, q1, S.c_n[sl]); }
-        __syncthreads();
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t q0 = g_q0[i], q1 = g_q1[i], r0 = g_r0[i], r1 = g_r1[i], rc = g_rc[i], row = g_row[i];
+            int ov = 0;
+            for (uint32_t v = tid; v < nk; v += BIG_T) {
+                uint32_t a0, a1, b0, b1, bc, brow;
+                if (v < KL) { a0 = l_q0[v]; a1 = l_q1[v]; b0 = l_r0[v]; b1 = l_r1[v]; bc = l_rc[v]; brow = l_row[v]; }
+                else { a0 = k_q0[v]; a1 = k_q1[v]; b0 = k_r0[v]; b1 = k_r1[v]; bc = k_rc[v]; brow = k_row[v]; }
+                if (brow == row && !(q1 < a0 || q0 > a1)) ov = 1;
+                else if (bc == rc && !(r1 < b0 || r0 > b1)) ov = 1;
+            }
+            if (!__syncthreads_or(ov)) {
+                if (tid == 0) {
+                    if (nk < KL) { l_q0[nk] = q0; l_q1[nk] = q1; l_r0[nk] = r0; l_r1[nk] = r1; l_rc[nk] = rc; l_row[nk] = row; }
+                    else { k_q0[nk] = q0; k_q1[nk] = q1; k_r0[nk] = r0; k_r1[nk] = r1; k_rc[nk] = rc; k_row[nk] = row; }
+                    sel_commit(S, row0 + row, q0, q1, g_n[i]);
+                }
+                nk++;
+                __syncthreads();
+            }
+        }
     }
     if (tid == 0) atomicAdd(&S.stats[3], 1u);
 }
-// the few pairs select_kernel listed (more than CMAX candidates): a small fixed grid walks the list
+
+// the pairs select_kernel listed (more than CMAX candidates): a small fixed grid walks the list, one workgroup per pair; pairs
+// with more than BIG_SOLO candidates are passed on to the cooperative kernel
 __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[12 * BIG_TILE];
+    __shared__ uint32_t s_scan[BIG_T / 64 + 1];
     if (B.S.force_serial) return;
     const uint32_t n = *B.S.big_count;
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        select_big_pair(B, B.S.big_list[k]);
+        const uint32_t p = B.S.big_list[k];
+        if (big_count_candidates(B.S, p, s_scan) > B.solo) { if (threadIdx.x == 0) B.huge_list[atomicAdd(B.huge_count, 1u)] = p; continue; }
+        BigGrp g{1, 0, 0, nullptr, B.parts, B.parts + BIG_GMAX};
+        g.part_a = B.parts + (size_t)(BIG_GROUPS + blockIdx.x) * 2 * BIG_GMAX; g.part_b = g.part_a + BIG_GMAX;
+        select_big_pair(B, p, g, s_raw, s_scan);
+        __syncthreads();
+    }
+}
+
+// Gb-scale pairs: the launch's workgroups (all co-resident: at most BIG_GMAX, one per CU) split into min(16, pairs) groups, each
+// group takes every groups-th listed pair. Workgroups of a group sit on as few XCDs as possible (workgroup b runs on XCD b % 8).
+__global__ __launch_bounds__(BIG_T) void select_huge_kernel(BigArgs B) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[12 * BIG_TILE];
+    __shared__ uint32_t s_scan[BIG_T / 64 + 1];
+    const uint32_t n = *B.huge_count;
+    if (n == 0) return;
+    const uint32_t NB = gridDim.x;                  // a power of two, >= 8 (or 1)
+    uint32_t groups = 1; while (groups < n && groups < BIG_GROUPS && groups < NB) groups <<= 1;
+    const uint32_t G = NB / groups;
+    uint32_t gid, gr;
+    if (NB < 8) { gid = blockIdx.x / G; gr = blockIdx.x % G; }
+    else {
+        const uint32_t xcd = blockIdx.x & 7, sl = blockIdx.x >> 3, per_xcd = NB >> 3;
+        if (groups >= 8) { const uint32_t gpx = groups >> 3; gid = xcd * gpx + sl / G; gr = sl % G; }
+        else { gid = xcd % groups; gr = (xcd / groups) * per_xcd + sl; }
+    }
+    BigGrp g{G, gr, 0, B.ctr + gid, B.parts + (size_t)gid * 2 * BIG_GMAX, B.parts + (size_t)gid * 2 * BIG_GMAX + BIG_GMAX};
+    for (uint32_t k = gid; k < n; k += groups) {
+        select_big_pair(B, B.huge_list[k], g, s_raw, s_scan);
         __syncthreads();
     }
 }
@@ -2110,7 +2241,7 @@ struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const {
 struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
-    uint32_t *blk_pair, *row_pair, *live, *big_list;
+    uint32_t *blk_pair, *row_pair, *live, *big_list, *huge_list;
     uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum (the 64-bit total sits at bsum[gi_sum])
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -2120,17 +2251,17 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
-           o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 64), o_bsum = al256(o_ovf + 4 * n_rows),
+           o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 256), o_bsum = al256(o_ovf + 4 * n_rows),
            o_qr = al256(o_bsum + 8 * (gi_sum + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
            o_rp = al256(o_bp + 4 * (gi + 1)), o_live = al256(o_rp + 4 * (n_rows + 1)), o_big = al256(o_live + 4 * (n_pairs + 1)),
-           o_end = o_big + 4 * (n_pairs + 1);
+           o_huge = al256(o_big + 4 * (n_pairs + 1)), o_end = o_huge + 4 * (n_pairs + 1);
     PSK_TRY(ctx->q_b.reserve(o_end));
     char* B = (char*)ctx->q_b.p;
     L->pairs = (PairDesc*)(B + o_pairs); L->sbase = (uint32_t*)(B + o_sbase); L->cbase = (uint32_t*)(B + o_cbase); L->pstart = (uint32_t*)(B + o_pstart);
     L->lbcnt = (uint2*)(B + o_lb); L->aoff = (uint32_t*)(B + o_aoff); L->nch = (uint32_t*)(B + o_nch); L->chunks = (uint2*)(B + o_chunks);
     L->cout = (ChunkOut*)(B + o_cout); L->hits = (psk_hit*)(B + o_hits); L->hits_sel = (psk_hit*)(B + o_sel); L->misc = (uint32_t*)(B + o_misc);
     L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
-    L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp); L->live = (uint32_t*)(B + o_live); L->big_list = (uint32_t*)(B + o_big);
+    L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp); L->live = (uint32_t*)(B + o_live); L->big_list = (uint32_t*)(B + o_big); L->huge_list = (uint32_t*)(B + o_huge);
     L->gi = (uint32_t)gi; L->gi_sum = (uint32_t)gi_sum;
     return PSK_OK;
 }
@@ -2142,7 +2273,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                             const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
-    PSK_HIP(hipMemsetAsync(L.misc, 0, 64, st));
+    PSK_HIP(hipMemsetAsync(L.misc, 0, 256, st));     // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[32..47] its group barriers
     PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
     const uint32_t gi = L.gi;
     hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair);
@@ -2188,7 +2319,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
-    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 8 + 1) + 64));   // select_big_kernel scratch
+    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
     uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
     uint32_t* a_nxt = D + 4 * na;
@@ -2266,9 +2397,22 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             BA.S = SA; BA.pstart = L.pstart;
             char* E = (char*)ctx->q_e.p;
             BA.key = (unsigned long long*)E; uint32_t* U = (uint32_t*)(E + 8 * na);
-            BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na; BA.kept = U + 7 * na;
-            BA.conf = (uint8_t*)(U + 8 * na);
+            BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na;
+            BA.conf = (uint8_t*)(U + 7 * na);
+            BA.parts = (uint32_t*)(E + (((size_t)na * (8 + 4 * 7 + 1) + 255) & ~(size_t)255));
+            BA.huge_list = L.huge_list; BA.huge_count = L.misc + 11; BA.ctr = L.misc + 32;
+            static const uint32_t solo = getenv("PSK_BIG_SOLO") ? (uint32_t)std::max(atoi(getenv("PSK_BIG_SOLO")), CMAX) : BIG_SOLO;
+            BA.solo = solo;
             hipLaunchKernelGGL(select_big_kernel, dim3(std::min<uint32_t>(n_pairs, 64u)), dim3(BIG_T), 0, st, BA);
+            // the cooperative launch only where a pair can have more than BIG_SOLO candidates (a candidate needs 3 anchors; there are
+            // at most as many anchors as the capacity). Its workgroups spin at barriers, so all of them must be resident at once: every
+            // lane of the context may run one, a CU holds two.
+            if (na / 3 > solo) {
+                uint32_t nb = BIG_GMAX;
+                while (nb > 1 && (size_t)nb * ctx->dev->max_lanes > 512) nb >>= 1;
+                if (nb < 8) nb = 1;
+                hipLaunchKernelGGL(select_huge_kernel, dim3(nb), dim3(BIG_T), 0, st, BA);
+            }
         }
     }
     ctx->t_end();

@@ -63,3 +63,40 @@ def test_mammalian_scale_pair_matches_oracle(oracle):
     assert abs(hits[0].identity - 0.99) < 0.002 and hits[0].query_fraction > 0.9
     if mb >= 1000:
         assert hits[0]._raw["n_chunks"] > 4096 and len(gs) > (1 << 18)      # beyond the LDS paths of select / pair_reduce / index_block
+
+
+def test_group_selection_matches_solo_and_serial():
+    """Pairs with more than 1 024 candidate chains: the one-workgroup selection, the cooperative several-workgroups-per-pair
+    selection (forced down to small pairs by PSK_BIG_SOLO; by default it takes pairs with more than 32 768 candidates) and the
+    lane-serial transliteration of the oracle (PSK_CHAIN_SERIAL) must give the same integers. 60 Mb genomes with an inserted
+    repeat family so that a few hundred chains conflict on the reference."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import pyskani_amd as psk\n"
+        "rng = np.random.default_rng(11)\n"
+        "L = 60_000_000\n"
+        "a = rng.integers(0, 4, L, dtype=np.uint8)\n"
+        "rep = rng.integers(0, 4, 30_000, dtype=np.uint8)\n"
+        "for s in rng.integers(0, L - 30_000, 60): a[s:s + 30_000] = rep\n"
+        "b = a.copy(); m = rng.random(L) < 0.01; b[m] = (b[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3\n"
+        "lut = np.frombuffer(b'ACGT', np.uint8)\n"
+        "cut = [0, 9_000_000, 25_000_000, 41_000_000, L]\n"
+        "ref = [lut[a[cut[i]:cut[i + 1]]].tobytes() for i in range(4)]\n"
+        "qry = [lut[b[cut[i]:cut[i + 1]]].tobytes() for i in (2, 0, 3, 1)]\n"
+        "db = psk.Database(); db.sketch('ref', *ref)\n"
+        "for kw in ({}, {'median': True}):\n"
+        "    h = db.query('qry', *qry, learned_ani=False, **kw)[0]\n"
+        "    print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
+    ) % (root,)
+    outs = {}
+    for name, extra in (("solo", {}), ("group", {"PSK_BIG_SOLO": "1024"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
+        env = dict(os.environ)
+        for k in ("PSK_BIG_SOLO", "PSK_CHAIN_SERIAL"):
+            env.pop(k, None)
+        env.update(extra)
+        outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().strip()
+    assert len(set(outs.values())) == 1, outs
+    assert int(outs["solo"].split()[1]) > 1024
