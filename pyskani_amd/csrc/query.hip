@@ -1925,16 +1925,30 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
     if (threadIdx.x == 0) { s_n = 0; for (int i = 0; i < 5; i++) s_acc[i] = 0; }
     __syncthreads();
-    // integer totals (order-free)
-    unsigned long long t_cq = 0, t_cr = 0, t_a = 0, t_s = 0, t_i = 0;
-    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { t_cq += co[i].cov_q; t_cr += co[i].cov_q; t_a += co[i].anchors; t_s += co[i].n_intervals ? co[i].seeds : 0; t_i += co[i].n_intervals; }
+    // integer totals (order-free) and the number of chunks that kept a chain
+    unsigned long long t_cq = 0, t_cr = 0, t_a = 0, t_s = 0, t_i = 0; uint32_t t_m = 0;
+    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { const uint32_t ni = co[i].n_intervals; t_cq += co[i].cov_q; t_cr += co[i].cov_q; t_a += co[i].anchors; t_s += ni ? co[i].seeds : 0; t_i += ni; t_m += ni != 0; }
     atomicAdd(&s_acc[0], t_cq); atomicAdd(&s_acc[1], t_cr); atomicAdd(&s_acc[2], t_a); atomicAdd(&s_acc[3], t_s); atomicAdd(&s_acc[4], t_i);
-    // chunk ANI values, compacted in chunk order (serial prefix by thread 0 keeps the oracle's summation order)
+    atomicAdd(&s_n, t_m);
+    __syncthreads();
+    // their rows compacted in chunk order (the oracle's summation order), 256 rows per step: ballot ranks inside a wave, the four
+    // wave totals through LDS. Not needed beyond RED_CAP values (those pairs never index s_idx).
     __shared__ uint32_t s_idx[RED_CAP];
-    if (threadIdx.x == 0) {
-        uint32_t m = 0;
-        for (uint32_t i = 0; i < nc; i++) if (co[i].n_intervals) { if (m < RED_CAP) s_idx[m] = i; m++; }
-        s_n = m;
+    __shared__ uint32_t s_wt[2][4];
+    if (s_n <= RED_CAP) {
+        uint32_t run = 0;
+        const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (uint32_t i0 = 0, it = 0; i0 < nc; i0 += 256, it++) {
+            const uint32_t i = i0 + threadIdx.x;
+            const bool f = i < nc && co[i].n_intervals != 0;
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) s_wt[it & 1][w] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+            for (uint32_t x = 0; x < 4; x++) { const uint32_t c = s_wt[it & 1][x]; if (x < w) before += c; tot += c; }
+            if (f) s_idx[run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = i;
+            run += tot;
+        }
     }
     __syncthreads();
     const uint32_t m = s_n;
