@@ -22,6 +22,7 @@ Other workloads (not the headline; `--workload`):
   allvsall    BASELINE configs[2] shape on one GPU: every genome against all (families of 100)
   metagenome  BASELINE configs[3] shape: short contigs (2-50 kb) against a resident database of 5 Mb references,
               c=30 marker_c=200
+  mammalian   BASELINE configs[4] shape at reduced count: all-vs-all of --refs genomes of 24 x --contig-mb Mb contigs
 """
 import argparse
 import ctypes as C
@@ -478,18 +479,19 @@ def main():
         avg_s = (scan_ms / max(1, scan_n)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = valu = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_sketch_scan.json")
+        pmc = os.path.join(ROOT, "profiles", "r2", "r2n_pmc_sketch_scan.json")
         if os.path.exists(pmc) and args.workload not in ("metagenome", "mammalian"):
-            # OFFLINE counters (rocprofv3 --pmc in separate passes, profiles/r1_pmc_traffic.md), scaled by this launch's bases:
+            # OFFLINE counters (rocprofv3 --pmc in separate passes, profiles/r2/r2n_pmc_sketch_scan.json), scaled by this launch's bases:
             # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) and VALU wave-instructions (SQ_INSTS_VALU = 26.8 per 64 bases, 61 % of them
             # four-cycle and 39 % two-cycle by profiles/micro/valu_rates.hip = 3.2 cycles on average)
-            traffic = json.load(open(pmc))["traffic_bytes_per_base"] * bases * args.steps / max(1, scan_n)
-            insts = 2.069e9 / 4926656976.0 * bases * args.steps / max(1, scan_n)
+            pm = json.load(open(pmc))
+            traffic = pm["traffic_bytes_per_base"] * bases * args.steps / max(1, scan_n)
+            insts = pm["valu_wave_instructions_per_launch"] / pm["bases_per_launch"] * bases * args.steps / max(1, scan_n)
             simd_cycles_peak = avg_s * 2.4e9 * 1024          # 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock
             valu = {"valu_issue_frac": insts * 3.2 / simd_cycles_peak if avg_s > 0 else None,
                     "valu_issue_frac_at_1p93GHz": insts * 3.2 / (avg_s * 1.93e9 * 1024) if avg_s > 0 else None,
                     "valu_wave_instructions_per_launch": insts,
-                    "source": "SQ_INSTS_VALU measured offline (profiles/r1_pmc_traffic.md), cycle classes from profiles/micro/valu_rates.hip; "
+                    "source": "SQ_INSTS_VALU measured offline (profiles/r2/r2n_pmc_sketch_scan.json), cycle classes from profiles/micro/valu_rates.hip; "
                               "launch duration measured live; 1.93 GHz = GRBM_GUI_ACTIVE clock of the profiled launch"}
         line = {
             "metric": "genome-pairs/sec (sketch+ANI)", "value": value, "unit": "genome-pairs/s",
@@ -497,7 +499,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl, "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc pass (profiles/r1_pmc_traffic.md), scaled by bases" if traffic else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc pass (profiles/r2/r2n_pmc_sketch_scan.json), scaled by bases" if traffic else None,
                          "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "priced against HBM as the contract asks; the kernel's real roof is integer VALU issue (one 64-bit mix per base: "
