@@ -2710,7 +2710,14 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         SketchDesc* d_qd = (SketchDesc*)ctx->q_h.p;
         PSK_HIP(hipMemcpyAsync(d_qd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
         // ---- batches: consecutive (query, rank range) entries under the per-launch limits
-        uint64_t max_items = 1ull << 27, max_pairs = 1ull << 20, max_rows = 1ull << 26;
+        // 2^29 query seeds per batch (about 25 GB of scratch for 5 Mb genomes; the per-pair latency chains of chunk_heads / select /
+        // pair_reduce and the batch's synchronisation are spread over four times the pairs of 2^27: all-vs-all 185 -> 169 ms);
+        // 2^27 when a query is Gb-scale (~6 anchors per seed from chance 15-mer matches: 2^27 seeds already carry 14 GB of anchors).
+        // A batch whose scratch cannot be allocated is planned again at a quarter of the size.
+        static const int items_env = getenv("PSK_BATCH_ITEMS_LOG2") ? std::min(31, std::max(16, atoi(getenv("PSK_BATCH_ITEMS_LOG2")))) : 0;
+        int items_log2 = items_env ? items_env : 29;
+        if (!items_env) for (uint32_t i = 0; i < m; i++) if (h_qd[i].n > (1u << 20)) { items_log2 = 27; break; }
+        uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << 20, max_rows = 1ull << 26;
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
         while (qi < m) {
@@ -2740,7 +2747,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 // nothing to chain (queries without seeds): no hits
             } else {
                 ChainBufs L;
-                PSK_TRY(chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L));
+                psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
+                if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
+                PSK_TRY(lrc);
                 PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL(pair_build_rows_kernel, dim3((uint32_t)bqs.size()), dim3(256), 0, st, L.bq, d_pass, n, d_qd, (const SketchDesc*)db->d_refdesc.p,
                                    L.pairs, L.sbase, L.cbase, L.pair_qr, n_pairs, (uint32_t)items, (uint32_t)rows);
@@ -2750,7 +2759,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
                 bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
-                    PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide));
+                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide);
+                    if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); too_big = true; break; }
+                    PSK_TRY(rrc);
                     const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
                     if (!host_filter) {
                         size_t tmp3 = 0;
