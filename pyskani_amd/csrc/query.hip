@@ -525,7 +525,8 @@ constexpr int JT = 4;
 __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                            uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
                                                            uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
-                                                           uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair) {
+                                                           uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair,
+                                                           uint32_t* __restrict__ pair_cnt) {
     __shared__ uint32_t s_key[JT][4][JOIN_WIN];
     const uint32_t lb = xcd_block_id();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -610,16 +611,51 @@ __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __res
             item_out[dst[t]] = make_uint2(x, y);      // one 8-byte scattered store per item
         }
     }
-    {   // 64-bit anchor total of the workgroup (the host compares it with the 32-bit offsets the scan produces)
+    {   // 64-bit anchor total of the workgroup (the host compares it with the 32-bit offsets the scan produces), and - for
+        // anchor_emit_pairs_kernel, which starts every pair at the prefix of these - the anchors per PAIR: one atomic per workgroup
+        // when all its items belong to one pair (39 of 40 workgroups of a 5 Mb pair), one per matching item otherwise
         __shared__ unsigned long long s_ws[4];
+        __shared__ uint32_t s_wp[4];
         unsigned long long c64 = 0;
 #pragma unroll
         for (int t = 0; t < JT; t++) c64 += cnt[t];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
-        if (lane == 0) s_ws[wave] = c64;
+        uint32_t wp = 0xFFFFFFFFu;      // the wave's pair; 0xFFFFFFFE: more than one; 0xFFFFFFFF: no item
+        if (pair_cnt) {
+#pragma unroll
+            for (int t = 0; t < JT; t++) {
+                const unsigned long long vm = __ballot(valid[t]);
+                if (!vm) continue;
+                const uint32_t p0 = __shfl(p[t], __ffsll((long long)vm) - 1);
+                const bool uni = __all(!valid[t] || p[t] == p0);
+                if (!uni || (wp != 0xFFFFFFFFu && wp != p0)) wp = 0xFFFFFFFEu; else if (wp == 0xFFFFFFFFu) wp = p0;
+            }
+        }
+        if (lane == 0) { s_ws[wave] = c64; s_wp[wave] = wp; }
         __syncthreads();
         if (threadIdx.x == 0) block_sum[lb] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+        if (pair_cnt) {
+            uint32_t bp = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const uint32_t x = s_wp[w]; if (x == 0xFFFFFFFFu) continue; if (bp == 0xFFFFFFFFu) bp = x; else if (bp != x) bp = 0xFFFFFFFEu; }
+            if (bp < 0xFFFFFFFEu) { if (threadIdx.x == 0) { const unsigned long long tot = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3]; if (tot) atomicAdd(&pair_cnt[bp], (uint32_t)tot); } }
+            else if (bp == 0xFFFFFFFEu) {      // a workgroup across a pair boundary: one atomic per (wave, tile, pair), not per item (same-address atomics serialise)
+#pragma unroll
+                for (int t = 0; t < JT; t++) {
+                    unsigned long long todo = __ballot(valid[t] && cnt[t]);
+                    while (todo) {
+                        const uint32_t p0 = __shfl(p[t], __ffsll((long long)todo) - 1);
+                        const bool mine = valid[t] && cnt[t] && p[t] == p0;
+                        uint32_t v = mine ? cnt[t] : 0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                        if (lane == 0) atomicAdd(&pair_cnt[p0], v);
+                        todo &= ~__ballot(mine);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -735,11 +771,91 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
     }
 }
 
+// Emit for batches of many mid-sized pairs (all-vs-all): the join already counted every pair's anchors (pair_cnt), their prefix
+// is where each pair's anchors start, so ONE WORKGROUP PER PAIR walks the pair's packed records in item order, 1 024 at a time,
+// with a running offset - no per-item offsets array, no scan over the items: the records are read once (DeviceScan read them,
+// wrote 4 B/item of offsets, and the emit kernel read both again). The next 1 024 records are in flight while the current ones
+// are written out. Same anchors at the same positions as the scan + emit path.
+struct Widen { __host__ __device__ unsigned long long operator()(const uint32_t& v) const { return v; } };
+__global__ __launch_bounds__(256) void anchor_emit_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs,
+                                                                const uint2* __restrict__ item, const unsigned long long* __restrict__ poff,
+                                                                uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_wt[2][JT][4];
+    const uint32_t p = blockIdx.x;
+    const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
+    if (s0 == s1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const PairDesc& P = pairs[p];
+    const uint32_t* __restrict__ q_pos = P.q_pos; const uint32_t* __restrict__ q_meta = P.q_meta;
+    unsigned long long run = poff[p];
+    uint2 nxt[JT];
+#pragma unroll
+    for (int t = 0; t < JT; t++) { const uint32_t i = s0 + t * 256u + threadIdx.x; nxt[t] = i < s1 ? item[i] : make_uint2(0, 0); }
+    for (uint32_t c0 = s0, it = 0; c0 < s1; c0 += JT * 256u, it++) {
+        uint2 rec[JT];
+        uint32_t c[JT], incl[JT], qp[JT], qm[JT];
+#pragma unroll
+        for (int t = 0; t < JT; t++) { rec[t] = nxt[t]; c[t] = rec[t].y >> 24; }
+        // the query side of every matching item (does not wait for the offsets), THEN the next records: the wait for the former
+        // leaves the latter in flight (vector-memory loads complete in order)
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            qp[t] = 0; qm[t] = 0;
+            if (c[t]) { const uint32_t j0 = c0 - s0 + t * 256u + threadIdx.x; qp[t] = q_pos[j0]; qm[t] = q_meta[j0]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < JT; t++) { const uint32_t i = c0 + (JT + t) * 256u + threadIdx.x; nxt[t] = (i >= c0 && i < s1) ? item[i] : make_uint2(0, 0); }      // (a second round in flight was measured: one wave per SIMD fewer, slower)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            uint32_t v = c[t];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(v, o); if (lane >= o) v += x; }
+            incl[t] = v;
+            if (lane == 63) s_wt[it & 1][t][wave] = v;
+        }
+        __syncthreads();
+        uint32_t agg = 0;
+        unsigned long long dst[JT];
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            const uint4 w4 = *(const uint4*)s_wt[it & 1][t];
+            dst[t] = run + agg + (wave > 0 ? w4.x : 0) + (wave > 1 ? w4.y : 0) + (wave > 2 ? w4.z : 0) + (incl[t] - c[t]);
+            agg += w4.x + w4.y + w4.z + w4.w;
+        }
+        run += agg;
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            if (!c[t]) continue;
+            if (dst[t] + c[t] > cap) { atomicOr(err, 2u); continue; }   // beyond the optimistic capacity: the host reruns the batch
+            const uint32_t d = (uint32_t)dst[t];
+            if (c[t] == 1) {
+                anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
+            } else {      // a repeat: find its run in the reference index again (rare)
+                uint32_t l, c2;
+                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[c0 - s0 + t * 256u + threadIdx.x], l, c2);
+                for (uint32_t j = 0; j < c[t]; j++) {
+                    const uint64_t pm = P.r_pms[l + j];
+                    const uint32_t rmeta = (uint32_t)pm;
+                    anc[d + j] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
+                }
+            }
+        }
+    }
+}
+
+// pstart from the 64-bit prefix of the pairs' anchor counts (clamped into the optimistically sized anchor arrays)
+__global__ __launch_bounds__(256) void pair_start64_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= n_pairs) { const unsigned long long a = poff[p]; pstart[p] = a < cap ? (uint32_t)a : cap; }
+}
+
 // pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
 __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap,
                                                          const unsigned long long* __restrict__ bsum, uint32_t n_sum, unsigned long long* __restrict__ total64) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = a < cap ? a : cap; }   // inside the (optimistically sized) anchor arrays whatever the counts were
+    if (aoff && p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = a < cap ? a : cap; }   // inside the (optimistically sized) anchor arrays whatever the counts were
     if (n_sum && blockIdx.x == 0) {   // small launches: the 64-bit anchor total here instead of a device-wide reduction (two launches fewer)
         __shared__ unsigned long long s_t[4];
         unsigned long long t = 0;
@@ -2314,7 +2430,14 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         n_sum = nb;
     }
     else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
-    else if (!wide) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair); n_sum = gi4; }
+    // many mid-sized pairs (all-vs-all): the join counts every pair's anchors, one workgroup per pair then emits with a running offset
+    // (anchor_emit_pairs_kernel) instead of a scan over all items; PSK_EMIT_PAIRS=1 / 0 force / forbid it (tests, A/B)
+    const char* ep_env = getenv("PSK_EMIT_PAIRS");
+    const bool emit_pairs = !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
+                            (ep_env ? ep_env[0] == '1' : (n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17)));
+    uint32_t* pair_cnt = L.live;      // free until the live list is built
+    if (emit_pairs) PSK_HIP(hipMemsetAsync(pair_cnt, 0, 4 * ((size_t)n_pairs + 1), st));
+    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr); n_sum = gi4; }
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
@@ -2324,12 +2447,22 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     size_t tmp3 = 0;
     PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
-    if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
+    unsigned long long* poff = (unsigned long long*)L.aoff;      // emit_pairs: 64-bit prefix of the pairs' counts (the per-item offsets array is not used then)
+    hipcub::TransformInputIterator<unsigned long long, Widen, const uint32_t*> pc_it(pair_cnt, Widen());
+    if (emit_pairs) {
+        size_t tmp4 = 0;
+        PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
+        PSK_TRY(ctx->q_c.reserve(std::max(tmp4, std::max(tmp, std::max(tmp2, tmp3)))));
+        PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
+        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap);
+    }
+    else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
     if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + L.gi_sum, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
-    hipLaunchKernelGGL(pair_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
-                       L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
+    if (!emit_pairs || small_sum)
+        hipLaunchKernelGGL(pair_start_kernel, dim3(emit_pairs ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, emit_pairs ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
+                           L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
@@ -2350,6 +2483,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
     if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc);
     else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
