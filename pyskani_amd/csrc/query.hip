@@ -777,17 +777,31 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
 // wrote 4 B/item of offsets, and the emit kernel read both again). The next 1 024 records are in flight while the current ones
 // are written out. Same anchors at the same positions as the scan + emit path.
 struct Widen { __host__ __device__ unsigned long long operator()(const uint32_t& v) const { return v; } };
-__global__ __launch_bounds__(256) void anchor_emit_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs,
+// ... and because the workgroup sees the pair's items in (contig, position) order anyway, it also builds the pair's CHUNK TABLE
+// (chunk_heads_kernel's rows: a chunk runs from its head anchor to the first anchor more than FRAGMENT_LENGTH further on the
+// query): every thread leaves its items' keys and in-wave offsets in LDS, and after the round's barrier wave 0 steps from head to
+// head through the 1 024 keys with 64-wide compares while the other waves write their anchors out - the separate pass over all
+// anchors (16 B each) that chunk_heads_kernel makes is gone.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void anchor_emit_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs,
                                                                 const uint2* __restrict__ item, const unsigned long long* __restrict__ poff,
-                                                                uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err) {
+                                                                uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
+                                                                const uint32_t* __restrict__ cbase, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wt[2][JT][4];
+    __shared__ unsigned long long s_key[2][JT * 256];     // (q contig << 32 | q pos) + 1 of the items with a match, 0 otherwise
+    __shared__ uint32_t s_pre[2][JT * 256];               // anchors of the item's wave and sub-tile before it
     const uint32_t p = blockIdx.x;
     const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
-    if (s0 == s1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long run0 = poff[p], total = poff[p + 1] - run0;
+    const bool heads = chunks != nullptr && total >= MIN_ANCHORS;     // fewer: no chain can form, no chunk table, every later kernel skips the pair
+    if (chunks != nullptr && !heads && threadIdx.x == 0) n_chunks[p] = 0;
+    if (s0 == s1) return;
     const PairDesc& P = pairs[p];
     const uint32_t* __restrict__ q_pos = P.q_pos; const uint32_t* __restrict__ q_meta = P.q_meta;
-    unsigned long long run = poff[p];
+    unsigned long long run = run0;
+    // chunk walk (wave 0; uniform over its lanes): current head anchor, its key + FRAGMENT_LENGTH, rows written
+    const uint32_t row0 = heads ? cbase[p] : 0, max_chunks = heads ? cbase[p + 1] - row0 : 0;
+    unsigned long long lim1 = 0; uint32_t h = 0, n_rows = 0; bool have = false;
     uint2 nxt[JT];
 #pragma unroll
     for (int t = 0; t < JT; t++) { const uint32_t i = s0 + t * 256u + threadIdx.x; nxt[t] = i < s1 ? item[i] : make_uint2(0, 0); }
@@ -815,6 +829,13 @@ __global__ __launch_bounds__(256) void anchor_emit_pairs_kernel(const PairDesc* 
             incl[t] = v;
             if (lane == 63) s_wt[it & 1][t][wave] = v;
         }
+        if (heads) {
+#pragma unroll
+            for (int t = 0; t < JT; t++) {
+                s_key[it & 1][t * 256 + threadIdx.x] = c[t] ? ((((unsigned long long)(qm[t] >> 1)) << 32) | qp[t]) + 1ull : 0ull;
+                s_pre[it & 1][t * 256 + threadIdx.x] = incl[t] - c[t];
+            }
+        }
         __syncthreads();
         uint32_t agg = 0;
         unsigned long long dst[JT];
@@ -824,7 +845,6 @@ __global__ __launch_bounds__(256) void anchor_emit_pairs_kernel(const PairDesc* 
             dst[t] = run + agg + (wave > 0 ? w4.x : 0) + (wave > 1 ? w4.y : 0) + (wave > 2 ? w4.z : 0) + (incl[t] - c[t]);
             agg += w4.x + w4.y + w4.z + w4.w;
         }
-        run += agg;
 #pragma unroll
         for (int t = 0; t < JT; t++) {
             if (!c[t]) continue;
@@ -841,6 +861,37 @@ __global__ __launch_bounds__(256) void anchor_emit_pairs_kernel(const PairDesc* 
                     anc[d + j] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
                 }
             }
+        }
+        if (heads && wave == 0) {      // heads among this round's items: the first item with a match and a key beyond the current head's reach, again and again
+            const unsigned long long* sk = s_key[it & 1];
+            uint32_t sp = 0;
+            while (sp < (uint32_t)(JT * 256)) {
+                const uint32_t idx = sp + lane;
+                const unsigned long long k1 = idx < (uint32_t)(JT * 256) ? sk[idx] : 0ull;
+                const unsigned long long bal = __ballot(k1 > lim1);      // lim1 = 0 before the pair's first anchor: any match starts the first chunk
+                if (!bal) { sp += 64; continue; }
+                const uint32_t j = sp + (uint32_t)__ffsll((long long)bal) - 1;
+                const uint32_t t = j >> 8, w = (j >> 6) & 3;
+                unsigned long long b = run + s_pre[it & 1][j];
+                for (uint32_t tt = 0; tt < t; tt++) b += s_wt[it & 1][tt][0] + s_wt[it & 1][tt][1] + s_wt[it & 1][tt][2] + s_wt[it & 1][tt][3];
+                for (uint32_t ww = 0; ww < w; ww++) b += s_wt[it & 1][t][ww];
+                const uint32_t bc = b < cap ? (uint32_t)b : cap;
+                if (have) {
+                    if (lane == 0) { if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, bc); else atomicOr(err, 1u); }
+                    n_rows++;
+                }
+                have = true; h = bc; lim1 = sk[j] + FRAGMENT_LENGTH;
+                sp = j + 1;
+            }
+        }
+        run += agg;
+    }
+    if (heads && wave == 0 && have) {
+        const unsigned long long e = run0 + total;
+        const uint32_t pend = e < cap ? (uint32_t)e : cap;
+        if (lane == 0) {
+            if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, pend); else atomicOr(err, 1u);
+            n_chunks[p] = n_rows + 1 < max_chunks ? n_rows + 1 : max_chunks;
         }
     }
 }
@@ -2481,13 +2532,18 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
+    // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
+    const char* hops_env = getenv("PSK_CHUNK_HOPS");
+    const bool use_hops = hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20));
+    static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
+    const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
-    else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc);
+    else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
+                                            L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
     else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    const char* hops_env = getenv("PSK_CHUNK_HOPS");
-    if (hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20))) {
+    if (use_hops) {
         hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
         if (n_items / n_pairs > (1u << 20) && !getenv("PSK_HOPS_UNSLICED")) {      // Gb-scale pairs: HOP_SLICES waves per pair, count then write
             PSK_TRY(ctx->q_g.reserve(4 * (size_t)n_pairs * HOP_SLICES + 256));
@@ -2496,7 +2552,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                 hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, pass, L.chunks, L.nch, L.misc);
         } else
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
-    } else
+    } else if (!emit_heads)
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)

@@ -52,7 +52,8 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
     if seed % 4 == 1:
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another
     if seed % 4 == 2:
-        monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another
+        monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
+        monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
     for _ in range(4):
         k, c, mc, ref, qry = _case(rng)
         kw = {"median": True} if rng.random() < 0.2 else ({"robust": True} if rng.random() < 0.2 else {})

@@ -254,7 +254,8 @@ def test_alternative_device_paths_agree(ecoli):
     (PSK_INDEX_RADIX=1) against the one-workgroup-per-sketch builder, and the wide (lower bound, count) join format
     (PSK_JOIN=wide), the one-wave-per-pair reference-major join (PSK_JOIN_PAIRS=1) and the one-tile-per-workgroup join
     (PSK_JOIN_T=1) against the default four-tile packed merge join, and the one-workgroup-per-pair emit from the join's pair
-    totals (PSK_EMIT_PAIRS=1; the default for batches of >= 1 024 mid-sized pairs) against scan + emit over all items."""
+    totals (PSK_EMIT_PAIRS=1; the default for batches of >= 1 024 mid-sized pairs; with PSK_CHUNK_HOPS=0 it also builds the chunk
+    table) against scan + emit over all items."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from conftest import load_fasta_first_record as L\n"
@@ -264,7 +265,7 @@ def test_alternative_device_paths_agree(ecoli):
         "print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     outs = {}
-    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"}), ("wide_join", {"PSK_JOIN": "wide"}), ("pair_join", {"PSK_JOIN_PAIRS": "1"}), ("tile_join", {"PSK_JOIN_T": "1"}), ("emit_per_pair", {"PSK_EMIT_PAIRS": "1"})):
+    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"}), ("wide_join", {"PSK_JOIN": "wide"}), ("pair_join", {"PSK_JOIN_PAIRS": "1"}), ("tile_join", {"PSK_JOIN_T": "1"}), ("emit_per_pair", {"PSK_EMIT_PAIRS": "1"}), ("emit_per_pair_with_chunk_table", {"PSK_EMIT_PAIRS": "1", "PSK_CHUNK_HOPS": "0"})):
         env = dict(os.environ)
         for k in ("PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX", "PSK_JOIN", "PSK_JOIN_PAIRS", "PSK_JOIN_T", "PSK_EMIT_PAIRS"):
             env.pop(k, None)
