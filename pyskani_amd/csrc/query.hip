@@ -361,6 +361,17 @@ __device__ __forceinline__ uint32_t xcd_block_id() {
     return xcd * q + (xcd < r ? xcd : r) + (b >> 3);
 }
 
+// The same with the XCDs taking turns every `g` logical workgroups (g ~ the workgroups of a few pairs): neighbouring pairs - one
+// query against neighbouring references of its family - are joined at the same time on the eight XCDs, so what the device as a
+// whole has in flight is ONE family's reference indices (64 MB for 100 x 5 Mb: they stay in the 256 MB memory-side cache) rather
+// than the eight families that eight contiguous eighths of a large batch span. The last nb % (8 g) workgroups keep their number.
+__device__ __forceinline__ uint32_t xcd_group_block_id(uint32_t g) {
+    const uint32_t nb = gridDim.x, b = blockIdx.x, full = nb / (8u * g) * (8u * g);
+    if (b >= full) return b;
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    return ((k / g) * 8u + xcd) * g + (k % g);
+}
+
 // range of index entries of `key` equal to km: bucket table (the k-mer's top bits give ~4 entries), short scan, galloping
 // upper bound for repeats
 __device__ __forceinline__ void lookup_lane(const uint32_t* __restrict__ key, uint32_t rn, const uint32_t* __restrict__ bucket, uint32_t bshift,
@@ -526,9 +537,9 @@ __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __res
                                                            uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
                                                            uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
                                                            uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair,
-                                                           uint32_t* __restrict__ pair_cnt) {
+                                                           uint32_t* __restrict__ pair_cnt, uint32_t xcd_group) {
     __shared__ uint32_t s_key[JT][4][JOIN_WIN];
-    const uint32_t lb = xcd_block_id();
+    const uint32_t lb = xcd_group ? xcd_group_block_id(xcd_group) : xcd_block_id();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t it[JT], p[JT], km[JT], dst[JT], lo[JT], cnt[JT], w_lo[JT], wn[JT];
     bool valid[JT], coop[JT], done[JT];
@@ -2488,7 +2499,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                             (ep_env ? ep_env[0] == '1' : (n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17)));
     uint32_t* pair_cnt = L.live;      // free until the live list is built
     if (emit_pairs) PSK_HIP(hipMemsetAsync(pair_cnt, 0, 4 * ((size_t)n_pairs + 1), st));
-    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr); n_sum = gi4; }
+    // workgroups of one pair per XCD turn (0 = contiguous eighths of the grid; PSK_XCD_GROUP overrides): see xcd_group_block_id
+    static const int xg_env = getenv("PSK_XCD_GROUP") ? atoi(getenv("PSK_XCD_GROUP")) : -1;
+    const uint32_t xcd_group = xg_env >= 0 ? (uint32_t)xg_env : (n_pairs >= 64 ? (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, 4 * (n_items / n_pairs) / (JT * 256))) : 0u);      // four pairs per turn (measured: 1 pair 38.5, 2: 37.4, 4 and more: 36.8 ms of join per 10^5 pairs; contiguous eighths: 44.0)
+    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
