@@ -1594,10 +1594,13 @@ __device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
     }
 }
 
-// (A 512-candidate instantiation with half the LDS - six waves per CU instead of three - was measured and is no faster:
-// the kernel's time is each wave's own chain of LDS round trips, not occupancy.)
-constexpr int CM = CMAX;
-__device__ void select_pair(const SelArgs& S, const uint32_t p) {
+// Two instantiations: CSMALL candidates (25 KB of LDS: six waves per CU) for the bulk - a 5 Mb pair has ~300 candidate chains -,
+// which passes the pairs that do not fit to the CMAX one (51 KB: three waves per CU), which passes on to select_big_kernel. With
+// ~13 000 pairs per launch the kernel's time is residency (12.8 -> 9.4 ms per 10^5 pairs); with 3 000 it was each wave's own
+// chain of LDS round trips and the smaller instantiation gained nothing.
+constexpr int CSMALL = 512;
+template <int CM>
+__device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __restrict__ over_list, uint32_t* __restrict__ over_count, const bool first_tier) {
     __shared__ int32_t l_sc[CM];
     __shared__ uint32_t l_q0[CM], l_q1[CM], l_r0[CM], l_r1[CM], l_rc[CM], l_row[CM], l_n[CM];
     __shared__ unsigned long long l_key[CM];     // priority keys, then (ref contig, r0) keys
@@ -1629,11 +1632,11 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p) {
         C += tot;
     }
     if (C == 0) return;
-    if (S.force_serial) {   // cross-check path: O(C^2) by one lane (run by the CMAX instantiation only)
-        if (CM == CMAX && lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
+    if (S.force_serial) {   // cross-check path: O(C^2) by one lane (run by the first tier only)
+        if (first_tier && lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
         return;
     }
-    if (C > (uint32_t)CM) { if (lane == 0) S.big_list[atomicAdd(S.big_count, 1u)] = p; return; }   // select_big_kernel takes the pairs that do not fit in LDS (rare: an append per such pair)
+    if (C > (uint32_t)CM) { if (lane == 0) over_list[atomicAdd(over_count, 1u)] = p; return; }   // the next tier takes the pairs that do not fit in this one's LDS (an append per such pair)
     uint32_t P = 64; while (P < C) P <<= 1;
     // ---- priority order: (score desc, generation order asc) ----
     for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
@@ -1734,10 +1737,18 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p) {
 // one wave per LIVE pair (pairs without a chunk table - every rescued short contig against an unrelated reference - never reach
 // the selection): a fixed grid walks the device-side list, so a batch of 10^6 pairs of which 10^5 are live does not schedule
 // 10^6 workgroups of 51 KB of LDS each to find that out
-__global__ __launch_bounds__(64) void select_kernel(SelArgs S) {
+__global__ __launch_bounds__(64) void select_kernel(SelArgs S, uint32_t* __restrict__ mid_list, uint32_t* __restrict__ mid_count) {
     const uint32_t n = S.live ? *S.n_live : S.n_pairs;      // small launches skip the list: every pair is visited
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        select_pair(S, S.live ? S.live[k] : k);
+        select_pair<CSMALL>(S, S.live ? S.live[k] : k, mid_list, mid_count, true);
+        lds_wave_sync();
+    }
+}
+// second tier: the pairs with more than CSMALL candidates
+__global__ __launch_bounds__(64) void select_mid_kernel(SelArgs S, const uint32_t* __restrict__ mid_list, const uint32_t* __restrict__ mid_count) {
+    const uint32_t n = *mid_count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        select_pair<CMAX>(S, mid_list[k], S.big_list, S.big_count, false);
         lds_wave_sync();
     }
 }
@@ -2608,7 +2619,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tl, ids, L.live, L.misc + 9, (int)n_pairs, IsLivePair{L.nch}, st));
     }
     ctx->t_begin(K_SELECT);
-    hipLaunchKernelGGL(select_kernel, dim3(std::min<uint32_t>(n_pairs, 16384u)), dim3(64), 0, st, SA);
+    // (the list of the second tier lives in huge_list: select_big_kernel only writes that after select_mid_kernel has read it)
+    hipLaunchKernelGGL(select_kernel, dim3(std::min<uint32_t>(n_pairs, 16384u)), dim3(64), 0, st, SA, L.huge_list, L.misc + 14);
+    hipLaunchKernelGGL(select_mid_kernel, dim3(std::min<uint32_t>(n_pairs, 768u)), dim3(64), 0, st, SA, (const uint32_t*)L.huge_list, (const uint32_t*)(L.misc + 14));
     {   // pairs whose candidates do not fit the LDS kernel (large genomes); workgroups of small pairs exit at once
         if (!force_serial) {
             BigArgs BA{};
