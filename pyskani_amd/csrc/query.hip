@@ -2804,6 +2804,97 @@ psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
 // table and the ani > 0.1 filter all stay on the device; the host sees, per round, the per-query pass counts and the
 // per-reference flags (ONE synchronisation: it sizes the batches and indexes the references about to be chained), and per
 // batch of up to 2^20 pairs the surviving hits (ONE synchronisation).
+// ------------------------------------------------------------------ seed prefilter of rescued queries
+// A contig with fewer than SMALL_MARKER_COUNT markers passes the marker screen against EVERY reference (lib.rs:617-630), but a pair
+// with fewer than MIN_ANCHORS shared seeds cannot form a chain and never produces a hit. For a batch of such contigs the exact
+// anchor count of every (contig, reference) pair is cheap the other way round: the contigs' seed k-mers (a few hundred thousand
+// entries) are cut into k-mer slices that fit an LDS hash table, and every reference's k-mer-sorted index - whose entries of one
+// slice are contiguous - streams past the table of its slice. Pairs below MIN_ANCHORS are then taken out of the pass matrix, so
+// that the join, which probes a 1.3 MB reference index once per (pair, query seed), only sees the pairs that can chain (metagenome
+// with rescue: 10.7 M pairs -> ~1 M; the join was 92 of 231 ms). Counts are exact: one per (query seed, reference seed) of equal k-mer.
+constexpr uint32_t PF_SLOTS = 8192;           // LDS hash slots per slice (48 KB: 4-byte k-mer + 2-byte query each; three workgroups per CU)
+constexpr uint32_t PF_MAX_FILL = 4096;
+constexpr int PF_T = 512;
+constexpr uint32_t PF_EMPTY = 0xFFFFFFFFu;    // no k-mer of k <= 15 (30 bits)
+
+__global__ __launch_bounds__(256) void pref_gather_kernel(const SketchDesc* __restrict__ qd, const uint32_t* __restrict__ rq, const uint32_t* __restrict__ eoff,
+                                                          const uint32_t* __restrict__ qn, uint32_t n_resc, uint32_t* __restrict__ e_key, uint32_t* __restrict__ e_qid) {
+    const uint32_t j = blockIdx.x;
+    if (j >= n_resc) return;
+    const uint32_t* __restrict__ km = qd[rq[j]].kmer;
+    const uint32_t o = eoff[j], nn = qn[j];
+    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) { e_key[o + i] = km[i]; e_qid[o + i] = j; }
+}
+
+// workgroup (slice, reference chunk): table of the slice in LDS, then the slice's stretch of every reference of the chunk
+__global__ __launch_bounds__(PF_T) void pref_count_kernel(const uint32_t* __restrict__ e_key, const uint32_t* __restrict__ e_qid, uint32_t n_entries,
+                                                         uint32_t slice_shift, const SketchDesc* __restrict__ rd, uint32_t n_refs, uint32_t refs_per_chunk,
+                                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t t_key[PF_SLOTS];
+    __shared__ uint16_t t_qid[PF_SLOTS];
+    __shared__ uint32_t s_lo, s_hi;
+    const uint32_t slice = blockIdx.x, chunk = blockIdx.y;
+    const uint32_t k_lo = slice << slice_shift;
+    const uint64_t k_hi64 = ((uint64_t)(slice + 1)) << slice_shift;      // exclusive
+    for (uint32_t i = threadIdx.x; i < PF_SLOTS; i += blockDim.x) t_key[i] = PF_EMPTY;
+    if (threadIdx.x == 0) {      // the slice's entries in the k-mer-sorted table
+        uint32_t a = 0, b = n_entries;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (e_key[mid] < k_lo) a = mid + 1; else b = mid; }
+        s_lo = a; b = n_entries;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if ((uint64_t)e_key[mid] < k_hi64) a = mid + 1; else b = mid; }
+        s_hi = a;
+    }
+    __syncthreads();
+    const uint32_t lo = s_lo, hi = s_hi;
+    if (hi == lo) return;
+    if (hi - lo > PF_MAX_FILL) { if (threadIdx.x == 0) atomicOr(overflow, 1u); return; }      // skewed k-mers: the caller leaves the pass matrix as it is
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t km = e_key[i];
+        uint32_t slot = (km * 2654435761u) >> 19;      // 13 bits
+        while (atomicCAS(&t_key[slot], PF_EMPTY, km) != PF_EMPTY) slot = (slot + 1) & (PF_SLOTS - 1);
+        t_qid[slot] = (uint16_t)e_qid[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = chunk * refs_per_chunk, r1 = r0 + refs_per_chunk < n_refs ? r0 + refs_per_chunk : n_refs;
+    for (uint32_t r = r0 + wave; r < r1; r += PF_T / 64) {      // a wave per reference
+        const SketchDesc& R = rd[r];
+        const uint32_t rn = R.n;
+        const uint32_t* __restrict__ key = R.key;
+        if (rn == 0 || key == nullptr) continue;
+        uint32_t first, last;
+        if (slice_shift >= R.bshift) {      // slice boundaries are bucket boundaries: two reads of the bucket table
+            const uint32_t sh = slice_shift - R.bshift;
+            first = R.bucket[slice << sh]; last = R.bucket[(slice + 1) << sh];
+        } else {
+            uint32_t a = 0, b = rn;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (key[mid] < k_lo) a = mid + 1; else b = mid; }
+            first = a; b = rn;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if ((uint64_t)key[mid] < k_hi64) a = mid + 1; else b = mid; }
+            last = a;
+        }
+        for (uint32_t i = first + lane; i < last; i += 64) {
+            const uint32_t km = key[i];
+            uint32_t slot = (km * 2654435761u) >> 19;
+            for (;;) {
+                const uint32_t k2 = t_key[slot];
+                if (k2 == PF_EMPTY) break;
+                if (k2 == km) atomicAdd(&cnt[(size_t)t_qid[slot] * n_refs + r], 1u);
+                slot = (slot + 1) & (PF_SLOTS - 1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pref_apply_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ rq, uint32_t n_resc, uint32_t n_refs,
+                                                         const uint32_t* __restrict__ overflow, uint8_t* __restrict__ pass) {
+    if (*overflow) return;
+    const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (size_t)n_resc * n_refs) return;
+    const uint32_t j = (uint32_t)(cell / n_refs), r = (uint32_t)(cell % n_refs);
+    if (cnt[cell] < MIN_ANCHORS) pass[(size_t)rq[j] * n_refs + r] = 0;
+}
+
 static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
     uint64_t indexed = 0;
@@ -2872,6 +2963,67 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         ScreenStaging keep;
         PSK_TRY(screen_many_device(ctx, db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
         if (db->has_dups) hipLaunchKernelGGL(pass_canon_kernel, dim3(m), dim3(256), 0, st, d_pass, n, (const uint32_t*)db->d_canon.p);
+        // ---- rescued short queries: exact anchor counts against every reference, pairs that cannot chain leave the pass matrix
+        PoolScratch pf_buf;      // lives until the round's synchronisations are through, like the host arrays the copies read
+        std::vector<uint32_t> rq, eoff, qn;
+        {
+            const char* pf_env = getenv("PSK_PREFILTER");      // "0": never; "1": whatever the number of pairs (tests)
+            const bool pf_off = pf_env && pf_env[0] == '0', pf_force = pf_env && pf_env[0] == '1';
+            uint64_t E = 0;
+            if (!o->faster_small && !pf_off && db->params.k <= 15)
+                for (uint32_t i = 0; i < m; i++) {
+                    const psk_sketch* q = queries[b + i];
+                    if (q->has_seeds && q->store && q->n_seeds && q->n_seeds <= 4096 && q->n_markers < SMALL_MARKER_COUNT &&
+                        q->params.k == db->params.k && q->params.c == db->params.c && rq.size() < 65535) {
+                        rq.push_back(i); eoff.push_back((uint32_t)E); qn.push_back((uint32_t)q->n_seeds); E += q->n_seeds;
+                    }
+                }
+            bool refs_ok = !rq.empty() && ((uint64_t)rq.size() * n >= (pf_force ? 1ull : (1ull << 20))) && (uint64_t)rq.size() * n * 4 <= (1ull << 31);
+            if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
+            if (refs_ok) {
+                bool all_idx = !db->desc_dirty && db->desc_n == n;
+                uint64_t indexed = 0;
+                for (const psk_sketch* rs : db->refs) { indexed += rs->idx != nullptr; if (!rs->idx && rs->n_seeds && rs->store) all_idx = false; }
+                if (!all_idx || indexed != db->desc_indexed)
+                    PSK_TRY(exclusive([&]() -> psk_status {
+                        std::vector<const psk_sketch*> all_refs(db->refs.begin(), db->refs.end());
+                        PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
+                        return refresh_ref_descs(ctx, db);
+                    }));
+                const uint32_t nr = (uint32_t)rq.size();
+                // slices: a power of two with ~2 048 entries each (the table takes 4 096)
+                uint32_t slices = 1; while ((uint64_t)slices * 2048 < E && slices < (1u << 16)) slices <<= 1;
+                const uint32_t kbits = 2u * (uint32_t)db->params.k;
+                uint32_t lg = 0; while ((1u << lg) < slices) lg++;
+                if (lg > kbits) { lg = kbits; slices = 1u << lg; }
+                const uint32_t slice_shift = kbits - lg;
+                h_qd.resize(m);
+                for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
+                size_t ts = 0;
+                PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)E, 0, (int)kbits, st));
+                const size_t o_rq = 0, o_eoff = al256(4 * (size_t)nr), o_qn = al256(o_eoff + 4 * (size_t)nr), o_qd = al256(o_qn + 4 * (size_t)nr),
+                             o_k0 = al256(o_qd + sizeof(SketchDesc) * (size_t)m), o_v0 = al256(o_k0 + 4 * E), o_k1 = al256(o_v0 + 4 * E), o_v1 = al256(o_k1 + 4 * E),
+                             o_cnt = al256(o_v1 + 4 * E), o_ovf = al256(o_cnt + 4 * (size_t)nr * n), o_tmp = al256(o_ovf + 4), o_endp = o_tmp + ts + 256;
+                PSK_TRY(pf_buf.reserve(ctx->dev, o_endp));
+                char* Bp = (char*)pf_buf.p;
+                uint32_t *d_rq = (uint32_t*)(Bp + o_rq), *d_eoff = (uint32_t*)(Bp + o_eoff), *d_qn = (uint32_t*)(Bp + o_qn);
+                SketchDesc* d_pqd = (SketchDesc*)(Bp + o_qd);
+                uint32_t *k0 = (uint32_t*)(Bp + o_k0), *v0 = (uint32_t*)(Bp + o_v0), *k1 = (uint32_t*)(Bp + o_k1), *v1 = (uint32_t*)(Bp + o_v1);
+                uint32_t *d_pcnt = (uint32_t*)(Bp + o_cnt), *d_ovf = (uint32_t*)(Bp + o_ovf);
+                PSK_HIP(hipMemcpyAsync(d_rq, rq.data(), 4 * (size_t)nr, hipMemcpyHostToDevice, st));
+                PSK_HIP(hipMemcpyAsync(d_eoff, eoff.data(), 4 * (size_t)nr, hipMemcpyHostToDevice, st));
+                PSK_HIP(hipMemcpyAsync(d_qn, qn.data(), 4 * (size_t)nr, hipMemcpyHostToDevice, st));
+                PSK_HIP(hipMemcpyAsync(d_pqd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
+                PSK_HIP(hipMemsetAsync(d_pcnt, 0, 4 * (size_t)nr * n + 256 + 4, st));      // counts and (behind them) the overflow flag
+                hipLaunchKernelGGL(pref_gather_kernel, dim3(nr), dim3(256), 0, st, d_pqd, d_rq, d_eoff, d_qn, nr, k0, v0);
+                PSK_HIP(hipcub::DeviceRadixSort::SortPairs(Bp + o_tmp, ts, (const uint32_t*)k0, k1, (const uint32_t*)v0, v1, (int)E, 0, (int)kbits, st));
+                const uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(n, 4096 / slices));      // ~4 096 workgroups in all
+                const uint32_t rpc = (n + chunks - 1) / chunks;
+                hipLaunchKernelGGL(pref_count_kernel, dim3(slices, (n + rpc - 1) / rpc), dim3(PF_T), 0, st, (const uint32_t*)k1, (const uint32_t*)v1, (uint32_t)E, slice_shift,
+                                   (const SketchDesc*)db->d_refdesc.p, n, rpc, d_pcnt, d_ovf);
+                hipLaunchKernelGGL(pref_apply_kernel, dim3((uint32_t)(((size_t)nr * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pcnt, (const uint32_t*)d_rq, nr, n, (const uint32_t*)d_ovf, d_pass);
+            }
+        }
         void* hpin;
         if ((size_t)m * n <= 65536) {     // a handful of queries: the pass rows themselves cross (<= 64 kB), counted on the host (two launches fewer)
             PSK_TRY(ctx->pinned((size_t)m * n + 64, &hpin));

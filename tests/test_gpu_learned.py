@@ -258,7 +258,8 @@ def test_query_edge_cases(psk):
 def test_many_small_pairs_against_oracle(psk, oracle, kw, monkeypatch):
     """A batch of > 4 096 small pairs (short contigs, most of them rescued against every reference, lib.rs:538-541) takes the
     paths a handful of pairs never sees: the list of live pairs, the wave-per-pair reduction of short chunk tables, the
-    pair-major join. Every hit against the oracle; and the same batch with those paths switched off."""
+    pair-major join. Every hit against the oracle; and the same batch with those paths switched off, and with the seed
+    prefilter of rescued contigs (default from 2^20 pairs on) forced on."""
     rng = np.random.default_rng(91)
     anc = [random_genome(rng, 90_000) for _ in range(4)]
     refs = [(f"r{f}_{j}", mutate(rng, anc[f], 0.004 * j)) for f in range(4) for j in range(15)]          # 60 references
@@ -286,7 +287,7 @@ def test_many_small_pairs_against_oracle(psk, oracle, kw, monkeypatch):
     assert n_pairs_chained > 500 // step
     if not kw:
         ref = [[(h.reference_name, h.identity, h._raw["n_anchors"]) for h in hs] for hs in got]
-        for var, val in (("PSK_REDUCE_SMALL", "0"), ("PSK_JOIN_PAIRS", "0"), ("PSK_JOIN_PAIRS", "1")):
+        for var, val in (("PSK_REDUCE_SMALL", "0"), ("PSK_JOIN_PAIRS", "0"), ("PSK_JOIN_PAIRS", "1"), ("PSK_PREFILTER", "1")):
             monkeypatch.setenv(var, val)
             alt = db.query_many(contigs, learned_ani=False)
             monkeypatch.delenv(var)

@@ -320,7 +320,7 @@ def test_chain_other_sketch_parameters(psk, oracle, k, c, mc):
     assert abs(got[0].identity - want[0][1].ani) < 1e-6
 
 
-def test_metagenome_mode_short_contigs(psk, oracle):
+def test_metagenome_mode_short_contigs(psk, oracle, monkeypatch):
     """BASELINE configs[3] in miniature: c=30 / marker_c=200, short contigs as separate queries, both
     faster_small settings; every hit list must equal the oracle's."""
     rng = np.random.default_rng(31)
@@ -335,7 +335,9 @@ def test_metagenome_mode_short_contigs(psk, oracle):
         L = int(np.exp(rng.uniform(np.log(2000), np.log(50000))))
         a = anc[i % 2]; st = int(rng.integers(0, len(a) - L))
         contigs.append((f"ctg{i}", mutate(rng, a[st:st + L], rng.uniform(0, 0.05))))
-    for fs in (False, True):
+    for fs, prefilter in ((False, None), (True, None), (False, "1")):      # "1": seed prefilter of the rescued contigs forced on (default from 2^20 pairs)
+        if prefilter:
+            monkeypatch.setenv("PSK_PREFILTER", prefilter)
         got_all = db.query_many(contigs, learned_ani=False, faster_small=fs)
         for (name, seq), got in zip(contigs, got_all):
             want = {n: r for n, r in oracle.query(osk, oracle.Sketch([seq], c=30, marker_c=200), faster_small=fs)}
