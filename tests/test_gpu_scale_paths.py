@@ -1,0 +1,76 @@
+"""GPU: the paths that only large batches take - one-workgroup-per-pair emit with the chunk table (>= 1 024 mid-sized pairs),
+XCD turns in the join, two-tier selection, 2^29-seed batches, the seed prefilter of rescued contigs (>= 2^20 pairs) - against
+the same batch with each of them switched off. Every hit (reference, all chaining integers, ANI, AF) must be identical.
+(The small-batch paths are held to the oracle in test_gpu_parity / test_gpu_fuzz; these runs are held to those paths.)"""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COMMON = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import pyskani_amd as psk
+lut = np.frombuffer(b"ACGT", np.uint8)
+rng = np.random.default_rng(77)
+def mutate(a, d):
+    b = a.copy(); m = rng.random(len(a)) < d; b[m] = (b[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3; return b
+def digest(hit_lists):
+    h = hashlib.sha256(); n = 0
+    for hs in hit_lists:
+        for x in hs:
+            r = x._raw
+            h.update(repr((x.reference_name, int(r["n_anchors"]), int(r["n_chunks"]), int(r["n_intervals"]), int(r["covered_query"]), int(r["covered_ref"]),
+                           int(r["sum_chain_anchors"]), int(r["sum_chunk_seeds"]), float(r["ani"]), float(r["af_query"]), float(r["af_ref"]), float(r["ani_std"]))).encode())
+            n += 1
+    return n, h.hexdigest()
+""" % (ROOT,)
+
+ALL_VS_ALL = COMMON + r"""
+anc = [rng.integers(0, 4, 600_000, dtype=np.uint8) for _ in range(8)]
+genomes = [(f"g{f}_{j}", lut[mutate(anc[f], 0.002 * j)].tobytes()) for f in range(8) for j in range(40)]      # 320 genomes, families of 40
+db = psk.Database()
+db.sketch_many(genomes)
+print(*digest(db.query_many(genomes, learned_ani=False)))
+"""
+
+RESCUE = COMMON + r"""
+anc = [rng.integers(0, 4, 400_000, dtype=np.uint8) for _ in range(10)]
+refs = [(f"r{f}_{j}", lut[mutate(anc[f], 0.003 * j)].tobytes()) for f in range(10) for j in range(30)]        # 300 references
+contigs = []
+for i in range(4800):
+    a = anc[i % 10]; L = int(rng.integers(1200, 3500)) if i % 4 else int(rng.integers(6000, 12000)); st = int(rng.integers(0, len(a) - L))
+    contigs.append((f"c{i}", lut[mutate(a[st:st + L], rng.uniform(0, 0.04))].tobytes()))
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many(refs)
+print(*digest(db.query_many(contigs, learned_ani=False)))
+"""
+
+
+def _run(code, extra):
+    env = dict(os.environ)
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS"):
+        env.pop(k, None)
+    env.update(extra)
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
+    return int(out[0]), out[1]
+
+
+def test_all_vs_all_batch_paths_agree():
+    base = _run(ALL_VS_ALL, {})
+    assert base[0] >= 320 * 40                      # every genome finds its family: >= 1 024 chained pairs in one batch
+    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0"}, {"PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_CHUNK_HOPS": "1"}):
+        assert _run(ALL_VS_ALL, extra) == base, extra
+
+
+def test_rescue_prefilter_agrees_at_scale():
+    base = _run(RESCUE, {})                         # 3 600 rescued contigs x 300 references: 2^20 pairs and more, the prefilter's default range
+    assert base[0] > 4800 * 20
+    for extra in ({"PSK_PREFILTER": "0"}, {"PSK_PREFILTER": "1"}, {"PSK_PREFILTER": "1", "PSK_JOIN_PAIRS": "0"}):
+        assert _run(RESCUE, extra) == base, extra
