@@ -686,22 +686,65 @@ __global__ __launch_bounds__(256) void anchor_join_pairs_kernel(const PairDesc* 
         const uint32_t p = order[w];
         const PairDesc P = pairs[p];
         const uint32_t base = sbase[p];
-        for (uint32_t i0 = 0; i0 < P.q_n; i0 += 64) {
-            const uint32_t iq = i0 + lane;
-            if (iq < P.q_n) {
-                const uint32_t km = P.q_key[iq];
-                uint32_t lo, cnt;
-                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km, lo, cnt);
-                uint32_t x = 0, y = 0;
-                if (cnt) {
-                    const uint64_t pm = P.r_pms[lo];
-                    const uint32_t rmeta = (uint32_t)pm;
-                    x = (uint32_t)(pm >> 32);
-                    if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
-                    else y = rmeta | (cnt << 24);
+        // Four query seeds per lane go through every stage TOGETHER (k-mer, bucket bounds, a lower-bound search that all four
+        // step through in lockstep, the entry found and its successor, the reference position): a stage is one round trip to
+        // L2 for four independent loads instead of one - the kernel's time is that chain of round trips (at c = 30 a 5 Mb
+        // reference has ~10 entries per bucket: the linear scan of lookup_lane was five of them).
+        constexpr int U = 4;
+        for (uint32_t i0 = 0; i0 < P.q_n; i0 += 64 * U) {
+            uint32_t iq[U], km[U], lo[U], hi[U], k0[U], k1[U], cnt[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { iq[u] = i0 + u * 64 + lane; ok[u] = iq[u] < P.q_n && P.r_n != 0; km[u] = ok[u] ? P.q_key[iq[u]] : 0; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                lo[u] = 0; hi[u] = 0;
+                if (ok[u]) { const uint32_t bk = km[u] >> P.r_bshift; lo[u] = P.r_bucket[bk]; hi[u] = P.r_bucket[bk + 1]; }
+            }
+            for (;;) {      // lower bound of km in [lo, hi): one probe per seed and step
+                bool any = false;
+                uint32_t mid[U], kv[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { mid[u] = (lo[u] + hi[u]) >> 1; any = any || lo[u] < hi[u]; }
+                if (!__any(any)) break;
+#pragma unroll
+                for (int u = 0; u < U; u++) kv[u] = lo[u] < hi[u] ? P.r_key[mid[u]] : 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) if (lo[u] < hi[u]) { if (kv[u] < km[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {      // equal k-mers share a bucket, but the run may be the last thing in the index
+                k0[u] = (ok[u] && lo[u] < P.r_n) ? P.r_key[lo[u]] : 0xFFFFFFFFu;
+                k1[u] = (ok[u] && lo[u] + 1 < P.r_n) ? P.r_key[lo[u] + 1] : 0xFFFFFFFFu;
+            }
+            uint64_t pm[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                cnt[u] = 0;
+                if (ok[u] && k0[u] == km[u]) {
+                    cnt[u] = 1;
+                    if (k1[u] == km[u]) {      // a repeat (rare): gallop for the end of the run
+                        uint32_t step = 2;
+                        while (lo[u] + step < P.r_n && P.r_key[lo[u] + step] == km[u]) step <<= 1;
+                        uint32_t a2 = lo[u] + (step >> 1), b2 = lo[u] + step < P.r_n ? lo[u] + step : P.r_n;
+                        while (a2 + 1 < b2) { const uint32_t m2 = (a2 + b2) >> 1; if (P.r_key[m2] == km[u]) a2 = m2; else b2 = m2; }
+                        cnt[u] = b2 - lo[u];
+                    }
                 }
-                item_out[base + P.q_perm[iq]] = make_uint2(x, y);
-                total += cnt;
+                pm[u] = cnt[u] ? P.r_pms[lo[u]] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (iq[u] >= P.q_n) continue;
+                uint32_t x = 0, y = 0;
+                if (cnt[u]) {
+                    const uint32_t rmeta = (uint32_t)pm[u];
+                    x = (uint32_t)(pm[u] >> 32);
+                    if (cnt[u] >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
+                    else y = rmeta | (cnt[u] << 24);
+                }
+                item_out[base + P.q_perm[iq[u]]] = make_uint2(x, y);
+                total += cnt[u];
             }
         }
     }
