@@ -340,11 +340,9 @@ psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_ref
     return chain_impl(lg.lane, refs, n_refs, q, o, out);
 }
 
-static psk_status hits_out(const std::vector<psk_hit>& all, psk_hit** hits) {
-    psk_hit* outp = (psk_hit*)malloc(sizeof(psk_hit) * (all.size() ? all.size() : 1));
-    if (!outp) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
-    if (!all.empty()) memcpy(outp, all.data(), sizeof(psk_hit) * all.size());
-    *hits = outp;
+static psk_status hits_out(HitList& all, psk_hit** hits) {
+    if (!all.p) { all.p = (psk_hit*)malloc(sizeof(psk_hit)); if (!all.p) { psk_set_error("out of host memory"); return PSK_ENOMEM; } }      // no hit: still a pointer psk_free takes
+    *hits = all.release();      // the list's own malloc'd array: no copy
     return PSK_OK;
 }
 
@@ -352,11 +350,12 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
     if (!db || !q || !o || !hits || !n_hits) { psk_set_error("query: NULL argument"); return PSK_EINVAL; }
     *hits = nullptr; *n_hits = 0;
     PSK_LANE(lg, db->ctx);
-    std::vector<psk_hit> all;
+    HitList all;
     uint64_t offs[2];
     PSK_TRY(query_many_impl(lg.lane, db, &q, 1, o, all, offs));
+    const uint64_t nh = all.n;
     PSK_TRY(hits_out(all, hits));
-    *n_hits = all.size();
+    *n_hits = nh;
     return PSK_OK;
 }
 
@@ -368,7 +367,7 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     *hits = nullptr;
     offsets[0] = 0;
     PSK_LANE(lg, db->ctx);
-    std::vector<psk_hit> all;
+    HitList all;
     PSK_TRY(query_many_impl(lg.lane, db, queries, n_queries, o, all, offsets));
     return hits_out(all, hits);
 }

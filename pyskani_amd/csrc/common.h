@@ -429,8 +429,27 @@ psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double sc
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out);
+// growing array of hits in malloc'd memory: what the query entry points hand to the caller (psk_free) without another copy
+struct HitList {
+    psk_hit* p = nullptr; size_t n = 0, cap = 0;
+    HitList() = default;
+    HitList(const HitList&) = delete; HitList& operator=(const HitList&) = delete;
+    ~HitList() { free(p); }
+    bool append(const psk_hit* src, size_t k) {
+        if (n + k > cap) {
+            size_t want = std::max<size_t>(n + k, cap + cap / 2 + 64);
+            psk_hit* q = (psk_hit*)realloc(p, sizeof(psk_hit) * want);
+            if (!q) return false;
+            p = q; cap = want;
+        }
+        if (k) memcpy(p + n, src, sizeof(psk_hit) * k);
+        n += k;
+        return true;
+    }
+    psk_hit* release() { psk_hit* q = p; p = nullptr; n = cap = 0; return q; }
+};
 // Database.query for n_queries sketches (lib.rs:569-659): hits of query i are all[offsets[i] .. offsets[i+1]), ref insertion order
 psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
-                           std::vector<psk_hit>& all, uint64_t* offsets);
+                           HitList& all, uint64_t* offsets);
 psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);

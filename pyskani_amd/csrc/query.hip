@@ -2953,7 +2953,7 @@ static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
 }
 
 psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
-                           std::vector<psk_hit>& all, uint64_t* offsets) {
+                           HitList& all, uint64_t* offsets) {
     hipStream_t st = ctx->stream;
     offsets[0] = 0;
     if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
@@ -3132,6 +3132,22 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << 20, max_rows = 1ull << 26;
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
+        // The hits of a batch are appended to the result (and counted per query) while the NEXT batch runs on the GPU: two halves of one
+        // pinned staging buffer, sized once for the round so that it never moves while a half is still unread.
+        const size_t half_pairs = (size_t)std::min<uint64_t>(round_pairs, max_pairs);
+        const size_t half_bytes = al256(sizeof(psk_hit) * half_pairs + 512);
+        void* hpin2 = nullptr;
+        PSK_TRY(ctx->pinned(2 * half_bytes, &hpin2));
+        int parity = 0;
+        const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
+        auto consume = [&]() -> psk_status {
+            if (!pend_n) return PSK_OK;
+            const size_t old = all.n;
+            if (!all.append(pend_hits, pend_n)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+            for (uint32_t i = 0; i < pend_n; i++) { psk_hit& h = all.p[old + i]; q_hits[h.reserved]++; h.reserved = 0; }      // pair_reduce left the round-local query index in `reserved`
+            pend_n = 0;
+            return PSK_OK;
+        };
         while (qi < m) {
             if (rank >= h_cnt[qi]) { qi++; rank = 0; continue; }
             // plan one batch from (qi, rank)
@@ -3166,7 +3182,8 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 hipLaunchKernelGGL(pair_build_rows_kernel, dim3((uint32_t)bqs.size()), dim3(256), 0, st, L.bq, d_pass, n, d_qd, (const SketchDesc*)db->d_refdesc.p,
                                    L.pairs, L.sbase, L.cbase, L.pair_qr, n_pairs, (uint32_t)items, (uint32_t)rows);
                 const uint32_t spec = std::min<uint32_t>(n_pairs, 1u << 16);      // hits copied back speculatively with the count
-                PSK_TRY(ctx->pinned(sizeof(psk_hit) * (size_t)n_pairs + 512, &hpin));
+                if (sizeof(psk_hit) * (size_t)n_pairs + 512 > half_bytes) { psk_set_error("internal: batch larger than its staging half"); return PSK_EHIP; }
+                hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
                 bool too_big = false, wide = join_wide_default();
@@ -3183,6 +3200,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
                     PSK_HIP(hipMemcpyAsync(h_sel, host_filter ? L.hits : L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
+                    PSK_TRY(consume());                     // the previous batch's hits, while this one runs
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     bool retry;
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
@@ -3203,14 +3221,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_HIP(hipStreamSynchronize(st));
                 }
             }
-            // hits arrive in (query, ref) order; pair_reduce left the round-local query index in `reserved`
-            for (uint32_t i = 0; i < n_sel; i++) {
-                q_hits[h_sel[i].reserved]++;
-                all.push_back(h_sel[i]);
-                all.back().reserved = 0;
-            }
+            // hits arrive in (query, ref) order; they join the result during the next batch (or after the last one)
+            if (n_sel) { pend_hits = h_sel; pend_n = n_sel; parity ^= 1; }
             qi = pq; rank = pr;
         }
+        PSK_TRY(consume());
         for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i] + q_hits[i];
     }
     return PSK_OK;
