@@ -102,7 +102,11 @@ class Engine:
 
     def sketch_device(self, d_ptr, offs, lens):
         n = len(offs)
-        c_off = (C.c_uint64 * n)(*offs); c_len = (C.c_uint64 * n)(*lens); gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
+        key = (id(offs), n)       # ctypes views of a constant layout are built once (they describe the resident input)
+        if getattr(self, "_sd_key", None) != key:
+            self._sd_key = key
+            self._sd = ((C.c_uint64 * n)(*offs), (C.c_uint64 * n)(*lens), (C.c_uint32 * (n + 1))(*range(n + 1)))
+        c_off, c_len, gfc = self._sd
         out = (C.c_void_p * n)()
         self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
         return out

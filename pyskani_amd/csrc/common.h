@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <algorithm>
 #include <memory>
 #include <mutex>
@@ -435,13 +436,25 @@ struct HitList {
     HitList() = default;
     HitList(const HitList&) = delete; HitList& operator=(const HitList&) = delete;
     ~HitList() { free(p); }
+    // room for `want` hits in all. Large arrays are 2 MB-aligned and advised as huge pages: a fresh 80 MB result is 20 000 first-touch
+    // page faults otherwise (~10 ms of the caller's time after the last kernel); pages that are never touched cost nothing
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        const size_t bytes = sizeof(psk_hit) * want;
+        psk_hit* q;
+        if (bytes >= ((size_t)8 << 20)) {
+            const size_t al = (size_t)2 << 20, rounded = (bytes + al - 1) / al * al;
+            q = (psk_hit*)aligned_alloc(al, rounded);
+            if (q) (void)madvise(q, rounded, MADV_HUGEPAGE);
+        } else q = (psk_hit*)malloc(bytes);
+        if (!q) return false;
+        if (n) memcpy(q, p, sizeof(psk_hit) * n);
+        free(p);
+        p = q; cap = want;
+        return true;
+    }
     bool append(const psk_hit* src, size_t k) {
-        if (n + k > cap) {
-            size_t want = std::max<size_t>(n + k, cap + cap / 2 + 64);
-            psk_hit* q = (psk_hit*)realloc(p, sizeof(psk_hit) * want);
-            if (!q) return false;
-            p = q; cap = want;
-        }
+        if (n + k > cap && !reserve(std::max<size_t>(n + k, cap + cap / 2 + 64))) return false;
         if (k) memcpy(p + n, src, sizeof(psk_hit) * k);
         n += k;
         return true;

@@ -3138,6 +3138,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         const size_t half_bytes = al256(sizeof(psk_hit) * half_pairs + 512);
         void* hpin2 = nullptr;
         PSK_TRY(ctx->pinned(2 * half_bytes, &hpin2));
+        if (round_pairs > 4096 && !all.reserve(all.n + (size_t)std::min<uint64_t>(round_pairs, 1ull << 26))) { psk_set_error("out of host memory"); return PSK_ENOMEM; }   // one allocation for the round's hits (untouched pages are free)
         int parity = 0;
         const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
         auto consume = [&]() -> psk_status {
