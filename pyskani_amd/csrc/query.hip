@@ -2138,11 +2138,16 @@ __global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t 
     R.hits[p] = h;
 }
 
+// Two instantiations, like the selection: CAP = RED_SMALL for the bulk (12 KB of LDS instead of 49: residency: 4.1 -> 3.4 ms per 10^5
+// pairs of 5 Mb genomes), CAP = RED_CAP for the pairs with more chunk rows than that (and, beyond RED_CAP values, the global sort).
+constexpr int RED_SMALL = 1024;
+template <int CAP>
 __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
-    __shared__ double s_v[RED_CAP];
+    __shared__ double s_v[CAP];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_acc[5];
     const uint32_t nc = R.n_chunks[p];
+    if (CAP == RED_SMALL ? nc > (uint32_t)RED_SMALL : nc <= (uint32_t)RED_SMALL) return;      // the other instantiation's pair
     if (R.small_done && nc != 0 && nc <= 64) return;      // pair_reduce_small_kernel took it
     if (nc == 0) {      // only reached when the launch visits every pair (no live list): the empty record of pair_empty_kernel
         if (threadIdx.x == 0) {
@@ -2165,9 +2170,9 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     __syncthreads();
     // their rows compacted in chunk order (the oracle's summation order), 256 rows per step: ballot ranks inside a wave, the four
     // wave totals through LDS. Not needed beyond RED_CAP values (those pairs never index s_idx).
-    __shared__ uint32_t s_idx[RED_CAP];
+    __shared__ uint32_t s_idx[CAP];
     __shared__ uint32_t s_wt[2][4];
-    if (s_n <= RED_CAP) {
+    if (s_n <= (uint32_t)CAP) {
         uint32_t run = 0;
         const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         for (uint32_t i0 = 0, it = 0; i0 < nc; i0 += 256, it++) {
@@ -2186,7 +2191,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     const uint32_t m = s_n;
     psk_hit h{};
     h.ani = -1.0f;
-    const bool overflow = m > RED_CAP;
+    const bool overflow = m > (uint32_t)CAP;
     double mean_serial = 0;   // only thread 0 uses it
     if (!overflow) {
         for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) {
@@ -2378,7 +2383,14 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
 __global__ __launch_bounds__(256) void pair_reduce_kernel(ReduceArgs R, uint32_t n_pairs) {      // one workgroup per LIVE pair, fixed grid over the list
     const uint32_t n = R.live ? *R.n_live : n_pairs;        // small launches skip the list: every pair is visited
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        pair_reduce_pair(R, R.live ? R.live[k] : k);
+        pair_reduce_pair<RED_SMALL>(R, R.live ? R.live[k] : k);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void pair_reduce_large_kernel(ReduceArgs R, uint32_t n_pairs) {      // the pairs with more than RED_SMALL chunk rows
+    const uint32_t n = R.live ? *R.n_live : n_pairs;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        pair_reduce_pair<RED_CAP>(R, R.live ? R.live[k] : k);
         __syncthreads();
     }
 }
@@ -2708,6 +2720,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     R.small_done = use_live && !no_small && n_rows / n_pairs < 16;
     if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
+    if (n_rows > (size_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
     const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
