@@ -1673,6 +1673,7 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
             }
         }
         C += tot;
+        if (C > (uint32_t)CM && !S.force_serial) break;      // does not fit this tier whatever follows (a Gb-scale pair has 150 000 rows to count otherwise)
     }
     if (C == 0) return;
     if (S.force_serial) {   // cross-check path: O(C^2) by one lane (run by the first tier only)
