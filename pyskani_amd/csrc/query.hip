@@ -826,23 +826,25 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(const PairDesc* __rest
 }
 
 // Emit for batches of many mid-sized pairs (all-vs-all): the join already counted every pair's anchors (pair_cnt), their prefix
-// is where each pair's anchors start, so ONE WORKGROUP PER PAIR walks the pair's packed records in item order, 1 024 at a time,
+// is where each pair's anchors start, so ONE WAVE PER PAIR (EP_W) walks the pair's packed records in item order, JT x 64 at a time,
 // with a running offset - no per-item offsets array, no scan over the items: the records are read once (DeviceScan read them,
-// wrote 4 B/item of offsets, and the emit kernel read both again). The next 1 024 records are in flight while the current ones
+// wrote 4 B/item of offsets, and the emit kernel read both again). The next round's records are in flight while the current ones
 // are written out. Same anchors at the same positions as the scan + emit path.
 struct Widen { __host__ __device__ unsigned long long operator()(const uint32_t& v) const { return v; } };
 // ... and because the workgroup sees the pair's items in (contig, position) order anyway, it also builds the pair's CHUNK TABLE
 // (chunk_heads_kernel's rows: a chunk runs from its head anchor to the first anchor more than FRAGMENT_LENGTH further on the
-// query): every thread leaves its items' keys and in-wave offsets in LDS, and after the round's barrier wave 0 steps from head to
-// head through the 1 024 keys with 64-wide compares while the other waves write their anchors out - the separate pass over all
-// anchors (16 B each) that chunk_heads_kernel makes is gone.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void anchor_emit_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs,
+// query): every lane leaves its items' keys and in-wave offsets in LDS, and once the round's anchors are written wave 0 steps from
+// head to head through the round's keys with 64-wide compares - the separate pass over all anchors (16 B each) that
+// chunk_heads_kernel makes is gone.
+constexpr int EP_W = 1;                 // waves per workgroup (EP_T threads, JT x EP_T items per round). Measured per 10^5 pairs of the all-vs-all step: 8 waves 160 ms, 4: 139.6, 2: 136.6, 1: 134.5 - the fewer waves wait at the round's barrier for wave 0's walk from head to head, the better
+constexpr int EP_T = 64 * EP_W;
+__global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) void anchor_emit_pairs_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs,
                                                                 const uint2* __restrict__ item, const unsigned long long* __restrict__ poff,
                                                                 uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
                                                                 const uint32_t* __restrict__ cbase, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_wt[2][JT][4];
-    __shared__ unsigned long long s_key[2][JT * 256];     // (q contig << 32 | q pos) + 1 of the items with a match, 0 otherwise
-    __shared__ uint32_t s_pre[2][JT * 256];               // anchors of the item's wave and sub-tile before it
+    __shared__ __attribute__((aligned(16))) uint32_t s_wt[2][JT][EP_W];
+    __shared__ unsigned long long s_key[2][JT * EP_T];     // (q contig << 32 | q pos) + 1 of the items with a match, 0 otherwise
+    __shared__ uint32_t s_pre[2][JT * EP_T];               // anchors of the item's wave and sub-tile before it
     const uint32_t p = blockIdx.x;
     const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -858,8 +860,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     unsigned long long lim1 = 0; uint32_t h = 0, n_rows = 0; bool have = false;
     uint2 nxt[JT];
 #pragma unroll
-    for (int t = 0; t < JT; t++) { const uint32_t i = s0 + t * 256u + threadIdx.x; nxt[t] = i < s1 ? item[i] : make_uint2(0, 0); }
-    for (uint32_t c0 = s0, it = 0; c0 < s1; c0 += JT * 256u, it++) {
+    for (int t = 0; t < JT; t++) { const uint32_t i = s0 + t * (uint32_t)EP_T + threadIdx.x; nxt[t] = i < s1 ? item[i] : make_uint2(0, 0); }
+    for (uint32_t c0 = s0, it = 0; c0 < s1; c0 += JT * (uint32_t)EP_T, it++) {
         uint2 rec[JT];
         uint32_t c[JT], incl[JT], qp[JT], qm[JT];
 #pragma unroll
@@ -869,11 +871,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 #pragma unroll
         for (int t = 0; t < JT; t++) {
             qp[t] = 0; qm[t] = 0;
-            if (c[t]) { const uint32_t j0 = c0 - s0 + t * 256u + threadIdx.x; qp[t] = q_pos[j0]; qm[t] = q_meta[j0]; }
+            if (c[t]) { const uint32_t j0 = c0 - s0 + t * (uint32_t)EP_T + threadIdx.x; qp[t] = q_pos[j0]; qm[t] = q_meta[j0]; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < JT; t++) { const uint32_t i = c0 + (JT + t) * 256u + threadIdx.x; nxt[t] = (i >= c0 && i < s1) ? item[i] : make_uint2(0, 0); }      // (a second round in flight was measured: one wave per SIMD fewer, slower)
+        for (int t = 0; t < JT; t++) { const uint32_t i = c0 + (JT + t) * (uint32_t)EP_T + threadIdx.x; nxt[t] = (i >= c0 && i < s1) ? item[i] : make_uint2(0, 0); }      // (a second round in flight was measured: one wave per SIMD fewer, slower)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < JT; t++) {
@@ -886,18 +888,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (heads) {
 #pragma unroll
             for (int t = 0; t < JT; t++) {
-                s_key[it & 1][t * 256 + threadIdx.x] = c[t] ? ((((unsigned long long)(qm[t] >> 1)) << 32) | qp[t]) + 1ull : 0ull;
-                s_pre[it & 1][t * 256 + threadIdx.x] = incl[t] - c[t];
+                s_key[it & 1][t * EP_T + threadIdx.x] = c[t] ? ((((unsigned long long)(qm[t] >> 1)) << 32) | qp[t]) + 1ull : 0ull;
+                s_pre[it & 1][t * EP_T + threadIdx.x] = incl[t] - c[t];
             }
         }
-        __syncthreads();
+        if (EP_W == 1) lds_wave_sync(); else __syncthreads();
         uint32_t agg = 0;
         unsigned long long dst[JT];
 #pragma unroll
         for (int t = 0; t < JT; t++) {
-            const uint4 w4 = *(const uint4*)s_wt[it & 1][t];
-            dst[t] = run + agg + (wave > 0 ? w4.x : 0) + (wave > 1 ? w4.y : 0) + (wave > 2 ? w4.z : 0) + (incl[t] - c[t]);
-            agg += w4.x + w4.y + w4.z + w4.w;
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < EP_W; w++) { const uint32_t x = s_wt[it & 1][t][w]; before += w < wave ? x : 0; tot += x; }
+            dst[t] = run + agg + before + (incl[t] - c[t]);
+            agg += tot;
         }
 #pragma unroll
         for (int t = 0; t < JT; t++) {
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
             } else {      // a repeat: find its run in the reference index again (rare)
                 uint32_t l, c2;
-                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[c0 - s0 + t * 256u + threadIdx.x], l, c2);
+                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[c0 - s0 + t * (uint32_t)EP_T + threadIdx.x], l, c2);
                 for (uint32_t j = 0; j < c[t]; j++) {
                     const uint64_t pm = P.r_pms[l + j];
                     const uint32_t rmeta = (uint32_t)pm;
@@ -919,15 +923,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (heads && wave == 0) {      // heads among this round's items: the first item with a match and a key beyond the current head's reach, again and again
             const unsigned long long* sk = s_key[it & 1];
             uint32_t sp = 0;
-            while (sp < (uint32_t)(JT * 256)) {
+            while (sp < (uint32_t)(JT * EP_T)) {
                 const uint32_t idx = sp + lane;
-                const unsigned long long k1 = idx < (uint32_t)(JT * 256) ? sk[idx] : 0ull;
+                const unsigned long long k1 = idx < (uint32_t)(JT * EP_T) ? sk[idx] : 0ull;
                 const unsigned long long bal = __ballot(k1 > lim1);      // lim1 = 0 before the pair's first anchor: any match starts the first chunk
                 if (!bal) { sp += 64; continue; }
                 const uint32_t j = sp + (uint32_t)__ffsll((long long)bal) - 1;
-                const uint32_t t = j >> 8, w = (j >> 6) & 3;
+                const uint32_t t = j / (uint32_t)EP_T, w = (j >> 6) & (uint32_t)(EP_W - 1);
                 unsigned long long b = run + s_pre[it & 1][j];
-                for (uint32_t tt = 0; tt < t; tt++) b += s_wt[it & 1][tt][0] + s_wt[it & 1][tt][1] + s_wt[it & 1][tt][2] + s_wt[it & 1][tt][3];
+                for (uint32_t tt = 0; tt < t; tt++) for (uint32_t ww = 0; ww < (uint32_t)EP_W; ww++) b += s_wt[it & 1][tt][ww];
                 for (uint32_t ww = 0; ww < w; ww++) b += s_wt[it & 1][t][ww];
                 const uint32_t bc = b < cap ? (uint32_t)b : cap;
                 if (have) {
@@ -2620,7 +2624,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
-    else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
+    else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
     else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
