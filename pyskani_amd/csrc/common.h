@@ -90,8 +90,9 @@ struct psk_ctx {
     std::condition_variable lanes_cv;
     std::vector<Lane*> lanes;
     std::vector<char> busy;
-    int max_lanes = 4;
+    int max_lanes = 8;             // per-contig queries from host threads: 1.6 k/s from one thread, 3.6 k from four, 5.0 k from eight, no more from sixteen (profiles/scripts/lanes_scaling.py)
     std::mutex index_mu;           // k-mer index builds mutate sketches: one at a time
+    std::mutex huge_mu;            // select_huge_kernel's workgroups spin at barriers and must all be resident: one such launch in flight per device
     // device block pool: sketch stores are recycled instead of hipMalloc/hipFree'd per batch
     struct PoolBlock { void* p; size_t bytes; };
     std::vector<PoolBlock> pool;
@@ -124,6 +125,9 @@ struct Lane {
     psk_ctx* dev = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool holds_huge = false;       // between the launch of select_huge_kernel and the synchronisation that follows it
+    void huge_acquire() { if (!holds_huge) { dev->huge_mu.lock(); holds_huge = true; } }
+    void huge_release() { if (holds_huge) { (void)hipStreamSynchronize(stream); dev->huge_mu.unlock(); holds_huge = false; } }
     std::vector<TimerRec> pending;
     void t_begin(int id, hipStream_t st = nullptr) {
         if (!dev->timing) return;
@@ -225,7 +229,7 @@ struct LaneGuard {
         lk.unlock();
         (void)hipSetDevice(c->device);
     }
-    ~LaneGuard() { if (idx >= 0) { { std::lock_guard<std::mutex> lk(c->lanes_mu); c->busy[idx] = 0; } c->lanes_cv.notify_one(); } }
+    ~LaneGuard() { if (idx >= 0) { lane->huge_release(); { std::lock_guard<std::mutex> lk(c->lanes_mu); c->busy[idx] = 0; } c->lanes_cv.notify_one(); } }
     LaneGuard(const LaneGuard&) = delete;
     LaneGuard& operator=(const LaneGuard&) = delete;
 };

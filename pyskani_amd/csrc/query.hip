@@ -2696,12 +2696,17 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             BA.solo = solo;
             hipLaunchKernelGGL(select_big_kernel, dim3(std::min<uint32_t>(n_pairs, 64u)), dim3(BIG_T), 0, st, BA);
             // the cooperative launch only where a pair can have more than BIG_SOLO candidates (a candidate needs 3 anchors; there are
-            // at most as many anchors as the capacity). Its workgroups spin at barriers, so all of them must be resident at once: every
-            // lane of the context may run one, a CU holds two.
+            // at most as many anchors as the capacity). Its workgroups spin at barriers, so all of them must be resident at once, and a
+            // CU holds two of them: 512 in all. A batch of Gb-scale pairs takes the device's one full-size launch (BIG_GMAX workgroups,
+            // under huge_mu until the batch's synchronisation); any other batch - where such a pair is an exception - a share of the rest
+            // that stays safe if every lane launched at once.
             if (na / 3 > solo) {
                 uint32_t nb = BIG_GMAX;
-                while (nb > 1 && (size_t)nb * ctx->dev->max_lanes > 512) nb >>= 1;
-                if (nb < 8) nb = 1;
+                if (n_items / n_pairs > (1u << 20)) ctx->huge_acquire();
+                else {
+                    while (nb > 1 && (size_t)nb * ctx->dev->max_lanes > 512 - BIG_GMAX) nb >>= 1;
+                    if (nb < 8) nb = 1;
+                }
                 hipLaunchKernelGGL(select_huge_kernel, dim3(nb), dim3(BIG_T), 0, st, BA);
             }
         }
@@ -2798,6 +2803,7 @@ static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, c
         PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
         PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a launch sequence (also keeps the host staging above alive)
+        ctx->huge_release();
         bool retry;
         PSK_TRY(chain_check(*T, n_pairs, &cap, &wide, &retry));
         if (!retry) break;
@@ -3208,7 +3214,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
                     psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide);
-                    if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); too_big = true; break; }
+                    if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
                     const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
                     if (!host_filter) {
@@ -3221,6 +3227,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_HIP(hipMemcpyAsync(h_sel, host_filter ? L.hits : L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
                     PSK_TRY(consume());                     // the previous batch's hits, while this one runs
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
+                    ctx->huge_release();
                     bool retry;
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
