@@ -546,14 +546,22 @@ def main():
                 t0 = time.perf_counter()
                 nh = sum(len(pdb.query(f"c{i}", c, learned_ani=False, faster_small=args.faster_small)) for i, c in enumerate(contigs))
                 t_q = time.perf_counter() - t0
+                # ... and the same calls from eight host threads (the reference's query() releases the GIL: threads are its route to
+                # concurrency; here every thread's call runs on its own lane of the context)
+                import threading
+                def _work(lo, hi):
+                    for i in range(lo, hi):
+                        pdb.query(f"c{i}", contigs[i], learned_ani=False, faster_small=args.faster_small)
+                th = [threading.Thread(target=_work, args=(k * nq // 8, (k + 1) * nq // 8)) for k in range(8)]
+                t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; t_q8 = time.perf_counter() - t0
                 many = pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
                 assert sum(len(h) for h in many) == nh
                 t0 = time.perf_counter()
                 pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
                 t_many = time.perf_counter() - t0
-                line["extras"].update(api_queries_per_s=nq / t_q, api_query_ms=t_q / nq * 1e3, api_query_many_per_s=nq / t_many,
+                line["extras"].update(api_queries_per_s=nq / t_q, api_query_ms=t_q / nq * 1e3, api_queries_per_s_8_threads=nq / t_q8, api_query_many_per_s=nq / t_many,
                                       api_db_load_s=t_load, api_hits=nh,
-                                      api_note=f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig, and one Database.query_many() for all of them")
+                                      api_note=f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig (from one host thread, and from eight), and one Database.query_many() for all of them")
         if world == 1 and args.workload == "search" and (args.cpu_sample > 0 or not args.no_api):
             host = buf.cpu().numpy()
             fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
