@@ -270,6 +270,35 @@ def cpu_baseline_allvsall(fetch, n_refs, n_queries, threads):
             "note": "the repo's own C restatement (the Rust reference cannot be built here); flat arrays where skani uses hash maps: a conservative floor for the speed-up"}
 
 
+def cpu_baseline_metagenome(fetch_ref, n_cpu_refs, contigs, threads, faster_small):
+    """CPU oracle on a bounded sample of the metagenome workload: a database of the first n_cpu_refs references (sketched with all
+    cores, untimed like the GPU side's resident database), then every sampled contig as its own query (sketch + screen of every
+    reference + chaining of the shortlist): one core for the first few, all cores (one contig per thread) for all of them."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        sk = list(ex.map(lambda i: O.Sketch([fetch_ref(i)], c=30, marker_c=200), range(n_cpu_refs)))
+    t_db = time.perf_counter() - t0
+
+    def one(c):
+        return O.query_count(sk, O.Sketch([c], c=30, marker_c=200), faster_small=faster_small)
+    n1 = min(16, len(contigs))
+    t0 = time.perf_counter()
+    h1 = [one(c) for c in contigs[:n1]]
+    t_one = (time.perf_counter() - t0) / n1
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        hall = list(ex.map(one, contigs))
+    t_all = time.perf_counter() - t0
+    return {"value": 1.0 / t_one, "unit": "queries/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{len(contigs)} of the contigs, each its own query against a database of the first {n_cpu_refs} references only (a tenth of the GPU run's 5 000: "
+                      f"the CPU figure is flattered by it); {sum(hall)} hits; one core: {t_one * 1e3:.1f} ms per query ({n1} timed); database sketched in {t_db:.1f} s on {threads} threads (not counted)",
+            "all_cores": {"value": len(contigs) / t_all, "cores": threads, "seconds": t_all},
+            "note": "the repo's own C restatement (the Rust reference cannot be built here)"}
+
+
 def api_rates(psk, genomes, query):
     """The drop-in path a pyskani user calls, from ASCII in HOST memory (SURVEY.md §8d 'Metric'):
     (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query."""
@@ -529,6 +558,13 @@ def main():
                                                                "(profiles/r2/r2q_pmc_allvsall1000.md, r2e_pmc_join_kernels_sq.txt)"}
         if args.workload == "metagenome":
             line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
+            if world == 1 and args.cpu_sample > 0:
+                n_cpu_refs = min(n_refs, 500)
+                href = buf[:offs[n_cpu_refs]].cpu().numpy()
+                chost0 = meta_state["cbuf"].cpu().numpy()
+                sample = [chost0[meta_state["coffs"][i]:meta_state["coffs"][i] + meta_state["clens"][i]].tobytes() for i in range(min(512, args.queries))]
+                line["cpu_baseline"] = cpu_baseline_metagenome(lambda i: href[offs[i]:offs[i] + lens[i]].tobytes(), n_cpu_refs, sample, os.cpu_count() or 1, args.faster_small)
+                del href, chost0
             if world == 1 and args.api_queries > 0:
                 # the same contigs ONE AT A TIME through the pyskani-shaped API, from host bytes: Database.query(name, contig)
                 import pyskani_amd as psk

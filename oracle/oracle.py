@@ -17,7 +17,7 @@ class _Sketch(C.Structure):
     _fields_ = [("c", C.c_int), ("marker_c", C.c_int), ("k", C.c_int), ("n_contigs", C.c_uint32),
                 ("contig_len", C.POINTER(C.c_uint32)), ("total_len", C.c_uint64),
                 ("n_seeds", C.c_uint64), ("seeds", C.c_void_p),
-                ("n_markers", C.c_uint64), ("markers", C.POINTER(C.c_uint64))]
+                ("n_markers", C.c_uint64), ("markers", C.POINTER(C.c_uint64)), ("kindex", C.c_void_p)]
 
 
 class Node(C.Structure):

@@ -46,6 +46,8 @@ static int cmp_u64(const void* a, const void* b) {
 }
 
 /* fmh_seeds (lib.rs:165-171) applied by the _sketch driver (lib.rs:140-185). */
+static void build_kindex(orc_sketch* s);
+
 orc_sketch* orc_sketch_new(const uint8_t* const* contigs, const uint64_t* lens, uint32_t n,
                            int c, int marker_c, int k, int want_seeds) {
     init_tab();
@@ -98,12 +100,13 @@ orc_sketch* orc_sketch_new(const uint8_t* const* contigs, const uint64_t* lens, 
     for (uint64_t i = 0; i < s->n_markers; i++)
         if (i == 0 || s->markers[i] != s->markers[i - 1]) s->markers[w++] = s->markers[i];
     s->n_markers = w;
+    build_kindex(s);
     return s;
 }
 
 void orc_sketch_free(orc_sketch* s) {
     if (!s) return;
-    free(s->contig_len); free(s->seeds); free(s->markers); free(s);
+    free(s->contig_len); free(s->seeds); free(s->markers); free(s->kindex); free(s);
 }
 
 /* check_markers_quickly (lib.rs:623-628): containment of the smaller marker set. */
@@ -133,6 +136,16 @@ static int cmp_kseed(const void* a, const void* b) {
     if (x->contig != y->contig) return x->contig < y->contig ? -1 : 1;
     if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
     return 0;
+}
+
+/* the reference-side index of chaining: built once per sketch (skani inserts every seed into the sketch's k-mer map while seeding) */
+static void build_kindex(orc_sketch* s) {
+    s->kindex = NULL;
+    if (s->n_seeds == 0) return;
+    kseed_t* rs = malloc(sizeof(kseed_t) * s->n_seeds);
+    for (uint64_t i = 0; i < s->n_seeds; i++) { rs[i].kmer = s->seeds[i].kmer; rs[i].pos = s->seeds[i].pos; rs[i].contig = s->seeds[i].contig; rs[i].canon = s->seeds[i].canon; }
+    qsort(rs, s->n_seeds, sizeof(kseed_t), cmp_kseed);
+    s->kindex = rs;
 }
 
 typedef struct { int32_t score; uint32_t q0, q1, r0, r1, rc, nanch, order, chunk; } cand_t;
@@ -207,9 +220,7 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
     uint64_t nq = query->n_seeds, nr = ref->n_seeds;
     if (nq == 0 || nr == 0) return 0;
     /* reference index: seeds ordered by (kmer, contig, pos) = a stable sort by k-mer of the (contig,pos)-ordered seeds — the sorted stand-in for the k-mer map */
-    kseed_t* rs = malloc(sizeof(kseed_t) * nr);
-    for (uint64_t i = 0; i < nr; i++) { rs[i].kmer = ref->seeds[i].kmer; rs[i].pos = ref->seeds[i].pos; rs[i].contig = ref->seeds[i].contig; rs[i].canon = ref->seeds[i].canon; }
-    qsort(rs, nr, sizeof(kseed_t), cmp_kseed);
+    const kseed_t* rs = (const kseed_t*)ref->kindex;      /* built with the sketch (build_kindex) */
     /* anchors: every (query seed, ref seed) pair with equal k-mer; walking query seeds in (contig,pos)
      * order and ref matches in (contig,pos) order yields them sorted by (qc,qp,rc,rp) */
     uint64_t cap = nq + 1024, na = 0;
@@ -225,7 +236,6 @@ int orc_chain(const orc_sketch* ref, const orc_sketch* query, const orc_query_op
             na++;
         }
     }
-    free(rs);
     out->n_anchors = na;
     if (na == 0) { free(A); return 0; }
     /* per-contig start offsets of the query seeds */

@@ -51,6 +51,8 @@ typedef struct {
     orc_seed* seeds;
     uint64_t n_markers;        /* sorted, unique canonical 21-mers */
     uint64_t* markers;
+    void* kindex;              /* the seeds once more, ordered by (k-mer, contig, pos): the sorted stand-in for the k-mer -> positions map a
+                                * skani Sketch carries (built with the sketch, as skani fills its map while seeding; NULL without seeds) */
 } orc_sketch;
 
 /* Learned-ANI regression model (skani::regression::get_model, lib.rs:614): gradient-boosted regression trees with
