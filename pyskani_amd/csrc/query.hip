@@ -546,20 +546,35 @@ __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __res
     uint32_t hint[JT];
 #pragma unroll
     for (int t = 0; t < JT; t++) { const uint32_t tile = lb * JT + t; hint[t] = blk_pair[tile < n_tiles ? tile : n_tiles - 1]; }
+    // The tile's pair is almost always the pair of its first item: its descriptor and item range are fetched on that assumption
+    // together with the next pair's start that confirms it - one round trip instead of two in the kernel's chain of dependent loads
+    // (join 37.0 -> 35.4 ms per 10^5 pairs; fetching the reference-side fields the same way as well gains nothing more)
+    uint32_t nxs[JT], bs[JT];
+    const uint32_t* qk[JT]; const uint32_t* qpm[JT];
 #pragma unroll
     for (int t = 0; t < JT; t++) {
         it[t] = (lb * JT + t) * 256u + threadIdx.x;
         valid[t] = it[t] < n_items;
-        p[t] = pair_from_hint(sbase, n_pairs, valid[t] ? it[t] : n_items - 1, hint[t]);
+        p[t] = hint[t];
+        nxs[t] = p[t] + 1 < n_pairs ? sbase[p[t] + 1] : 0xFFFFFFFFu;
+        bs[t] = sbase[p[t]];
+        qk[t] = pairs[p[t]].q_key; qpm[t] = pairs[p[t]].q_perm;
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        const uint32_t x = valid[t] ? it[t] : n_items - 1;
+        if (nxs[t] <= x) {      // a tile across a pair boundary (or pairs without items in between): the walk
+            p[t] = pair_from_hint(sbase, n_pairs, x, p[t]);
+            bs[t] = sbase[p[t]]; qk[t] = pairs[p[t]].q_key; qpm[t] = pairs[p[t]].q_perm;
+        }
     }
 #pragma unroll
     for (int t = 0; t < JT; t++) {
         km[t] = 0; dst[t] = 0; lo[t] = 0; cnt[t] = 0; coop[t] = false; done[t] = false; w_lo[t] = 0; wn[t] = 0;
         if (valid[t]) {
-            const PairDesc& P = pairs[p[t]];
-            const uint32_t iq = it[t] - sbase[p[t]];
-            km[t] = P.q_key[iq];
-            dst[t] = sbase[p[t]] + P.q_perm[iq];     // results are stored in (contig,pos) order
+            const uint32_t iq = it[t] - bs[t];
+            km[t] = qk[t][iq];
+            dst[t] = bs[t] + qpm[t][iq];     // results are stored in (contig,pos) order
         }
     }
     // bucket reads of every tile whose wave joins one pair
