@@ -1472,23 +1472,36 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
     }
 }
 
+// maximum over the wave, uniform result: four DPP steps leave every row of 16 lanes with its maximum, four lane reads finish it
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;      // quad_perm [1,0,3,2]
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;               // quad_perm [2,3,0,1]
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true); v = o > v ? o : v;              // row_ror:4
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true); v = o > v ? o : v;              // row_ror:8
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 // The wave-per-chunk chaining of ONE row of the chunk table (one wavefront): DP over an LDS ring, per-tree bests,
 // candidate emission. Shared arrays are the calling wave's slices.
+// (the kernel's throughput follows the waves a CU holds, and those follow this struct: the candidate staging shares the ring's
+// space - the ring is dead once the DP is through - and the roots' indices ride in the unused top bits of the per-tree best keys)
 struct ChainWaveLds {
-    hipcub::WarpReduce<uint32_t, 64>::TempStorage wr;
-    uint32_t ring[6][RING];            // qp, rp, rm, f, root id, depth
-    unsigned long long best[RMAX];     // f<<28 | (16383-local idx)<<14 | depth
-    uint32_t rootx[RMAX];              // local index of each tree's root anchor
-    uint32_t cand[7][64];              // score, q0, q1, r0, r1, nanch, ref contig
+    union {
+        uint32_t ring[6][RING];        // qp, rp, rm, f, root id, depth
+        uint32_t cand[7][64];          // score, q0, q1, r0, r1, nanch, ref contig (after the DP)
+    };
+    unsigned long long best[RMAX];     // root's local index << 49 | f<<28 | (16383-local idx)<<14 | depth
 };
+static_assert(sizeof(uint32_t) * 7 * 64 <= sizeof(uint32_t) * 6 * RING, "candidate staging fits the ring");
 
 __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds& L, int lane) {
-    typedef hipcub::WarpReduce<uint32_t, 64> WR;
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
     ChunkOut* op = &A.out[slot];
     uint32_t (*ring)[RING] = L.ring;
-    unsigned long long* s_best_w = L.best; uint32_t* s_rootx_w = L.rootx; uint32_t (*s_cand_w)[64] = L.cand;
+    unsigned long long* s_best_w = L.best; uint32_t (*s_cand_w)[64] = L.cand;
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
     if (fast) {
@@ -1523,8 +1536,7 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
                         }
                     }
                 }
-                uint32_t best = WR(L.wr).Reduce(key, hipcub::Max());
-                best = __builtin_amdgcn_readfirstlane(best);
+                uint32_t best = wave_max_u32(key);
                 int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
                 if (best) {
                     f = (int32_t)(best >> 7);
@@ -1533,13 +1545,14 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
                 } else {
                     rid = R++; dep = 1;
                     if (rid >= RMAX) { fast = false; break; }
-                    if (lane == 0) { s_rootx_w[rid] = avail; s_best_w[rid] = 0; }
+                    if (lane == 0) s_best_w[rid] = (unsigned long long)avail << 49;      // the root's index; any real key of the tree compares above it
                 }
                 if (lane == 0) {
                     const uint32_t sl = x & (RING - 1);
                     ring[0][sl] = qx; ring[1][sl] = rx; ring[2][sl] = mx; ring[3][sl] = (uint32_t)f; ring[4][sl] = rid; ring[5][sl] = dep;
-                    unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - avail) << 14) | dep;
-                    if (k64 > s_best_w[rid]) s_best_w[rid] = k64;
+                    const unsigned long long old = s_best_w[rid];
+                    const unsigned long long k64 = (old & ~((1ull << 49) - 1)) | ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - avail) << 14) | dep;
+                    if (k64 > old) s_best_w[rid] = k64;
                 }
                 lds_wave_sync();
             }
@@ -1550,9 +1563,10 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
         // candidates: one per chain tree whose best anchor passes the thresholds, in root order
         for (uint32_t r0 = 0; r0 < R && fast; r0 += 64) {
             const uint32_t r = r0 + lane;
-            bool qual = false; uint32_t f = 0, lx = 0, dep = 0;
+            bool qual = false; uint32_t f = 0, lx = 0, dep = 0, rootx = 0;
             if (r < R) {
                 unsigned long long bk = s_best_w[r];
+                rootx = (uint32_t)(bk >> 49); bk &= (1ull << 49) - 1;
                 f = (uint32_t)(bk >> 28); lx = 16383u - (uint32_t)((bk >> 14) & 16383u); dep = (uint32_t)(bk & 16383u);
                 qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE2;
             }
@@ -1561,7 +1575,7 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
             C += __popcll(bal);
             if (C > 64) { fast = false; break; }
             if (qual) {
-                uint32_t xr = s + s_rootx_w[r], xb = s + lx;
+                uint32_t xr = s + rootx, xb = s + lx;
                 uint32_t ra = A.anc[xr].y, rb = A.anc[xb].y;
                 s_cand_w[0][ci] = f; s_cand_w[1][ci] = A.anc[xr].x; s_cand_w[2][ci] = A.anc[xb].x;
                 s_cand_w[3][ci] = ra < rb ? ra : rb; s_cand_w[4][ci] = ra < rb ? rb : ra; s_cand_w[5][ci] = dep;
