@@ -1237,7 +1237,8 @@ __device__ __forceinline__ uint32_t lane_eval(uint32_t qx, uint32_t ux, uint32_t
     return ((((uint32_t)scp << 7) + (((uint32_t)ANCHOR_SCORE2 << 7) | (127u - (uint32_t)d)))) & ok;
 }
 
-__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A, uint32_t rows_per_wave) {
+template <int W>      // window depth: the band rounded up to a multiple of four (20 at c = 125; 24 covers c >= 105)
+__device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32_t rows_per_wave) {
     __shared__ uint32_t s_rd[LANE_WAVES][32][64];     // tree id << 14 | depth of the last 32 anchors, per lane
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
@@ -1254,17 +1255,17 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
     }
     const uint32_t s_al = s & ~3u;
     const uint32_t len = mine ? e - s_al : 0;          // steps this lane takes part in (the first s - s_al are idle)
-    LaneAnchor P[LANE_N];
+    LaneAnchor P[W];
 #pragma unroll
-    for (int i = 0; i < LANE_N; i++) { P[i].q = 0; P[i].u = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
+    for (int i = 0; i < W; i++) { P[i].q = 0; P[i].u = 0; P[i].m = 0xFFFFFFFFu; P[i].f = 0; }
     // Chain trees that can yield a candidate, at most LANE_TREES per chunk, keyed by the local index of their ROOT
     // anchor. A tree gets a slot when its first anchor with score >= MIN_SCORE2 appears (such an anchor has depth >= 3,
     // and lower-scoring anchors can never be the tree's best once one exists); the many single-anchor trees of
     // spurious matches never take one. Slot: best anchor key f<<28 | (16383 - local index)<<14 | depth, its (q, r).
     unsigned long long bk[LANE_TREES];
-    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
+    uint32_t sroot[LANE_TREES];      // (the best anchor's q and r are read back from the anchor array at the end: its index is in the key)
 #pragma unroll
-    for (int j = 0; j < LANE_TREES; j++) { bk[j] = 0; sroot[j] = 0xFFFFFFFFu; bq[j] = br[j] = 0; }
+    for (int j = 0; j < LANE_TREES; j++) { bk[j] = 0; sroot[j] = 0xFFFFFFFFu; }
     uint32_t S = 0;
     bool ovf = false;
     uint32_t (*rd)[64] = s_rd[wave];      // root index << 14 | depth of the last 32 anchors
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
             const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
             uint32_t best = 0;
 #pragma unroll
-            for (int d = 1; d <= LANE_N; d++) {
+            for (int d = 1; d <= W; d++) {
                 if (d <= band) {
                     const uint32_t k = d <= u ? lane_eval(qx, ux, mx, nw[u - d], d) : lane_eval(qx, ux, mx, P[d - 1 - u], d);
                     best = k > best ? k : best;
@@ -1304,19 +1305,19 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
                 for (int j = 0; j < LANE_TREES; j++) {
                     const bool hit = sroot[j] == ridx;
                     found = found || hit;
-                    if (hit && k64 > bk[j]) { bk[j] = k64; bq[j] = qx; br[j] = rx; }
+                    if (hit && k64 > bk[j]) bk[j] = k64;
                 }
                 if (!found) {
                     if (S >= (uint32_t)LANE_TREES) ovf = true;
 #pragma unroll
-                    for (int j = 0; j < LANE_TREES; j++) if (S == (uint32_t)j) { sroot[j] = ridx; bk[j] = k64; bq[j] = qx; br[j] = rx; }
+                    for (int j = 0; j < LANE_TREES; j++) if (S == (uint32_t)j) { sroot[j] = ridx; bk[j] = k64; }
                     S++;
                 }
             }
         }
         // shift the register window by four anchors
 #pragma unroll
-        for (int i = LANE_N - 1; i >= 4; i--) P[i] = P[i - 4];
+        for (int i = W - 1; i >= 4; i--) P[i] = P[i - 4];
         P[0] = nw[3]; P[1] = nw[2]; P[2] = nw[1]; P[3] = nw[0];
     }
     if ((uint32_t)lane < rows_per_wave && slot < A.n_rows && real) {
@@ -1324,11 +1325,13 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
             // candidates in ROOT order (slots were taken in order of first qualifying anchor): pick the smallest root left
             uint32_t nc = 0, last = 0;
             for (uint32_t c = 0; c < S; c++) {
-                uint32_t pick = 0xFFFFFFFFu; unsigned long long k = 0; uint32_t q1 = 0, rb = 0;
+                uint32_t pick = 0xFFFFFFFFu; unsigned long long k = 0;
 #pragma unroll
                 for (int j = 0; j < LANE_TREES; j++)
-                    if (sroot[j] != 0xFFFFFFFFu && (c == 0 || sroot[j] > last) && sroot[j] < pick) { pick = sroot[j]; k = bk[j]; q1 = bq[j]; rb = br[j]; }
+                    if (sroot[j] != 0xFFFFFFFFu && (c == 0 || sroot[j] > last) && sroot[j] < pick) { pick = sroot[j]; k = bk[j]; }
                 last = pick;
+                const uint32_t xb = s + (16383u - (uint32_t)((k >> 14) & 16383u));      // the tree's best anchor
+                const uint32_t q1 = A.anc[xb].x, rb = A.anc[xb].y;
                 const uint32_t xr = s + pick, ra = A.anc[xr].y, o = s + nc;
                 A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.anc[xr].x; A.c_q1[o] = q1;
                 A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
@@ -1343,6 +1346,11 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A
         }
     }
 }
+
+// W = 20 fits three waves per SIMD (168 registers; the 24-deep window needs 192 and runs two): the kernel is VALU-issue bound and
+// a third wave fills issue slots that two leave empty
+__global__ __launch_bounds__(64 * LANE_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8))) void chain_lane20_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<20>(A, rows_per_wave); }
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<LANE_N>(A, rows_per_wave); }
 
 // ---- four lanes per chunk, for launches too small to fill the chip with one lane per chunk -----------------
 // (the headline search: 100 pairs = 22 k chunks). Lane j of a quad owns the anchors whose index is j mod 4: ownership
@@ -2684,7 +2692,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                 const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
                 hipLaunchKernelGGL(chain_quad_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
             } else
-            hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+            if (A.band <= 20) hipLaunchKernelGGL(chain_lane20_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+            else hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
             // the few chunks it passes on (more than LANE_TREES trees, >= 16 384 anchors): wave kernel over the list
             const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
             hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);
