@@ -555,7 +555,7 @@ def main():
                                 "ms_per_step": kernel_ms[key], "bytes": what}
             line["extras"]["chain_kernel_roofline"] = {"work_per_step": w, "kernels": kr,
                                                        "note": "neither kernel is HBM-bound: chain_lane is VALU-issue bound, the join is bound by dependent-load latency and issue "
-                                                               "(profiles/r2/r2q_pmc_allvsall1000.md, r2e_pmc_join_kernels_sq.txt)"}
+                                                               "(profiles/r2/r2s_pmc_allvsall1000.md, r2e_pmc_join_kernels_sq.txt)"}
         if args.workload == "metagenome":
             line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
             if world == 1 and args.cpu_sample > 0:
