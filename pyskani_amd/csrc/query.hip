@@ -1685,13 +1685,12 @@ __device__ void select_serial(const SelArgs& S, uint32_t row0, uint32_t nrows) {
 constexpr int CSMALL = 512;
 template <int CM>
 __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __restrict__ over_list, uint32_t* __restrict__ over_count, const bool first_tier) {
-    __shared__ int32_t l_sc[CM];
     __shared__ uint32_t l_q0[CM], l_q1[CM], l_r0[CM], l_r1[CM], l_rc[CM], l_row[CM], l_n[CM];
     __shared__ unsigned long long l_key[CM];     // priority keys, then (ref contig, r0) keys
-    __shared__ uint32_t l_pm[CM];                // running max of r1 in reference order
+    __shared__ uint32_t l_pm[CM];                // running max of r1 in reference order; afterwards (first half) the kept list of the greedy
     __shared__ uint16_t l_ord[CM];               // candidate index by priority rank
     __shared__ uint16_t l_idx[CM];               // payload of the reference-order sort, then the conflicted list
-    __shared__ uint16_t l_kept[CM];
+    uint16_t* const l_kept = (uint16_t*)l_pm;    // (the running maxima are dead once the conflicts are known)
     __shared__ uint8_t l_conf[CM];
     const int lane = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
@@ -1708,7 +1707,8 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
         if (!S.force_serial && C + tot <= (uint32_t)CM && cnt) {
             uint32_t s = S.chunks[row0 + r].x;
             for (uint32_t i = 0; i < cnt; i++) {
-                l_sc[off + i] = S.c_score[s + i]; l_q0[off + i] = S.c_q0[s + i]; l_q1[off + i] = S.c_q1[s + i];
+                l_key[off + i] = ((unsigned long long)(uint32_t)S.c_score[s + i] << 32) | (0xFFFFFFFFu - (off + i));      // priority key: (score desc, generation order asc)
+                l_q0[off + i] = S.c_q0[s + i]; l_q1[off + i] = S.c_q1[s + i];
                 l_r0[off + i] = S.c_r0[s + i]; l_r1[off + i] = S.c_r1[s + i]; l_rc[off + i] = S.c_rc[s + i];
                 l_row[off + i] = r; l_n[off + i] = S.c_n[s + i];
             }
@@ -1724,7 +1724,7 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
     if (C > (uint32_t)CM) { if (lane == 0) over_list[atomicAdd(over_count, 1u)] = p; return; }   // the next tier takes the pairs that do not fit in this one's LDS (an append per such pair)
     uint32_t P = 64; while (P < C) P <<= 1;
     // ---- priority order: (score desc, generation order asc) ----
-    for (uint32_t i = lane; i < P; i += 64) l_key[i] = i < C ? (((unsigned long long)(uint32_t)l_sc[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
+    for (uint32_t i = C + lane; i < P; i += 64) l_key[i] = 0ull;      // padding (the keys of the candidates were written as they were gathered)
     lds_wave_sync();
     for (uint32_t kk = 2; kk <= P; kk <<= 1)
         for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
