@@ -783,63 +783,68 @@ __global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restr
 constexpr int IDXB_THREADS = 1024;
 constexpr int IDXB_MAX_LB = 14;                       // 16 384 buckets = 64 kB of LDS counters
 constexpr uint32_t IDXB_MAX_SEEDS = 1u << 18;
+constexpr int IDXT_MAX_LB = 10;                       // tiny sketches: 1 024 buckets = 4 kB of LDS counters, 256 threads
+constexpr uint32_t IDXT_MAX_SEEDS = 1u << 12;
 
-__global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg* __restrict__ segs, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
+// T threads, 2^LB LDS counters: (1 024, 14) for genomes, (256, 10) for sketches of up to IDXT_MAX_SEEDS seeds (contigs): a workgroup of the
+// former takes half a CU whatever the sketch's size - 10 000 contigs indexed in 3.8 ms - the latter fits sixteen to a CU
+template <int T, int LB>
+__global__ __launch_bounds__(T) void index_block_kernel(const IdxSeg* __restrict__ segs, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
                                                                     uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket, uint32_t* __restrict__ km32) {
     // `slices` workgroups share one sketch: workgroup (seg, sl) owns buckets [B0, B1) = the sl-th part of the bucket
     // space and the index positions its k-mers sort to. Every workgroup streams ALL of the sketch's k-mers (coalesced,
     // cheap) but histograms, scatters, orders and writes only its own part, so the scattered traffic of a sketch
     // is spread over `slices` CUs; the number of k-mers below B0 gives its base position without any grid sync.
-    __shared__ uint32_t s_cnt[1 << IDXB_MAX_LB];
-    __shared__ uint32_t s_part[IDXB_THREADS / 64 + 1];
+    __shared__ uint32_t s_cnt[1 << LB];
+    __shared__ uint32_t s_part[T / 64 + 1];
     const IdxSeg sg = segs[blockIdx.x / slices];
     const uint32_t sl = blockIdx.x % slices;
     const uint32_t tid = threadIdx.x, n = sg.n, nb = sg.nb, sh = sg.bshift;
     const uint32_t B0 = (uint32_t)((uint64_t)nb * sl / slices), B1 = (uint32_t)((uint64_t)nb * (sl + 1) / slices), nbl = B1 - B0;
     uint64_t* __restrict__ K = key + sg.out_off;
-    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) s_cnt[b] = 0;
+    for (uint32_t b = tid; b < nbl; b += T) s_cnt[b] = 0;
     __syncthreads();
     // eight independent loads per thread per round trip, then the dependent LDS atomics
     uint32_t below = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 8 * IDXB_THREADS) {
+    for (uint32_t i0 = 0; i0 < n; i0 += 8 * T) {
         uint32_t km[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * IDXB_THREADS; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
+        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * T; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
 #pragma unroll
-        for (int r = 0; r < 8; r++) if (i0 + tid + r * IDXB_THREADS < n) {
+        for (int r = 0; r < 8; r++) if (i0 + tid + r * T < n) {
             const uint32_t b = km[r] >> sh;
             if (b < B0) below++; else if (b < B1) atomicAdd(&s_cnt[b - B0], 1u);
         }
     }
     uint32_t base;
-    block_exclusive_scan<IDXB_THREADS>(below, s_part, &base);        // base = k-mers that sort before this part
+    block_exclusive_scan<T>(below, s_part, &base);        // base = k-mers that sort before this part
     __syncthreads();
     // exclusive scan of the bucket counts: a run of `per` buckets per thread, then one workgroup scan of the run totals
-    const uint32_t per = (nbl + IDXB_THREADS - 1) / IDXB_THREADS, b0 = tid * per;
+    const uint32_t per = (nbl + T - 1) / T, b0 = tid * per;
     uint32_t sum = 0;
     for (uint32_t j = 0; j < per; j++) if (b0 + j < nbl) sum += s_cnt[b0 + j];
     uint32_t mine_total;
-    uint32_t run = base + block_exclusive_scan<IDXB_THREADS>(sum, s_part, &mine_total);
+    uint32_t run = base + block_exclusive_scan<T>(sum, s_part, &mine_total);
     for (uint32_t j = 0; j < per; j++) if (b0 + j < nbl) { const uint32_t c = s_cnt[b0 + j]; s_cnt[b0 + j] = run; run += c; }
     __syncthreads();
-    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) bucket[sg.boff + B0 + b] = s_cnt[b];
+    for (uint32_t b = tid; b < nbl; b += T) bucket[sg.boff + B0 + b] = s_cnt[b];
     if (tid == 0 && sl == slices - 1) bucket[sg.boff + nb] = n;
     __syncthreads();
     // scatter (k-mer, seed index) to the bucket's range; the counters become the bucket ENDS
-    for (uint32_t i0 = 0; i0 < n; i0 += 8 * IDXB_THREADS) {
+    for (uint32_t i0 = 0; i0 < n; i0 += 8 * T) {
         uint32_t km[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * IDXB_THREADS; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
+        for (int r = 0; r < 8; r++) { const uint32_t i = i0 + tid + r * T; km[r] = i < n ? sg.kmer[i] : 0xFFFFFFFFu; }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t i = i0 + tid + r * IDXB_THREADS, b = km[r] >> sh;
+            const uint32_t i = i0 + tid + r * T, b = km[r] >> sh;
             if (i < n && b >= B0 && b < B1) K[atomicAdd(&s_cnt[b - B0], 1u)] = ((uint64_t)km[r] << 32) | i;
         }
     }
     __threadfence_block();
     __syncthreads();
     // order every bucket by (k-mer, seed index): equal k-mers keep their (contig, pos) order, like a stable sort
-    for (uint32_t b = tid; b < nbl; b += IDXB_THREADS) {
+    for (uint32_t b = tid; b < nbl; b += T) {
         const uint32_t lo = b ? s_cnt[b - 1] : base, hi = s_cnt[b], m = hi - lo;
         if (m < 2) continue;
         uint64_t* a = K + lo;
@@ -887,15 +892,15 @@ __global__ __launch_bounds__(IDXB_THREADS) void index_block_kernel(const IdxSeg*
     __threadfence_block();
     __syncthreads();
     const uint32_t pend = base + mine_total;
-    for (uint32_t p0 = base; p0 < pend; p0 += 8 * IDXB_THREADS) {
+    for (uint32_t p0 = base; p0 < pend; p0 += 8 * T) {
         uint64_t v[8], pm[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * IDXB_THREADS; v[r] = p < pend ? K[p] : 0; }
+        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * T; v[r] = p < pend ? K[p] : 0; }
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * IDXB_THREADS; pm[r] = p < pend ? sg.pm[(uint32_t)v[r]] : 0; }
+        for (int r = 0; r < 8; r++) { const uint32_t p = p0 + tid + r * T; pm[r] = p < pend ? sg.pm[(uint32_t)v[r]] : 0; }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t p = p0 + tid + r * IDXB_THREADS;
+            const uint32_t p = p0 + tid + r * T;
             if (p < pend) { K[p] = ((uint64_t)(blockIdx.x / slices) << 32) | (uint32_t)(v[r] >> 32); km32[sg.out_off + p] = (uint32_t)(v[r] >> 32); perm[sg.out_off + p] = (uint32_t)v[r]; pms[sg.out_off + p] = pm[r]; }
         }
     }
@@ -912,12 +917,14 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
     // small sketches first (one workgroup each), large ones after (device radix sort); PSK_INDEX_RADIX=1 forces the latter
     const bool force_radix = getenv("PSK_INDEX_RADIX") != nullptr;
     auto is_small = [&](const psk_sketch* s) { return !force_radix && s->n_seeds <= IDXB_MAX_SEEDS; };
+    auto is_tiny = [&](const psk_sketch* s) { return !force_radix && s->n_seeds <= IDXT_MAX_SEEDS; };
     std::stable_partition(todo.begin(), todo.end(), is_small);
+    std::stable_partition(todo.begin(), todo.end(), is_tiny);      // tiny ones first, then the other one-workgroup ones, then the radix-sorted ones
     size_t i0 = 0;
     while (i0 < todo.size()) {
-        const bool small = is_small(todo[i0]);
+        const bool small = is_small(todo[i0]), tiny = is_tiny(todo[i0]);
         size_t i1 = i0; uint64_t T = 0;
-        while (i1 < todo.size() && is_small(todo[i1]) == small && i1 - i0 < 65535 && (i1 == i0 || T + todo[i1]->n_seeds <= GROUP)) { T += todo[i1]->n_seeds; i1++; }
+        while (i1 < todo.size() && is_small(todo[i1]) == small && is_tiny(todo[i1]) == tiny && i1 - i0 < 65535 && (i1 == i0 || T + todo[i1]->n_seeds <= GROUP)) { T += todo[i1]->n_seeds; i1++; }
         const uint32_t m = (uint32_t)(i1 - i0);
         std::vector<IdxSeg> segs(m);
         uint32_t off = 0, maxn = 0;
@@ -926,7 +933,7 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             const psk_sketch* s = todo[i0 + j];
             // ~4 entries per bucket; k-mers of hash-selected seeds are spread evenly over the 2k-bit space
             int kbits = 2 * s->params.k, lb = 4;
-            while (lb < (small ? IDXB_MAX_LB : 22) && (1ull << (lb + 2)) < s->n_seeds) lb++;
+            while (lb < (tiny ? IDXT_MAX_LB : small ? IDXB_MAX_LB : 22) && (1ull << (lb + 2)) < s->n_seeds) lb++;
             if (lb > kbits) lb = kbits;
             segs[j] = IdxSeg{s->store->seed_kmer + s->seed_off, s->store->seed_pm + s->seed_off, (uint32_t)s->n_seeds, off, (uint32_t)(kbits - lb), 1u << lb, (uint32_t)boff};
             off += (uint32_t)s->n_seeds; maxn = std::max(maxn, (uint32_t)s->n_seeds);
@@ -948,7 +955,8 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             // kernel's time is its chain of dependent round trips, not one CU's scattered traffic. PSK_INDEX_SLICES overrides.
             uint32_t slices = 1;
             if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
-            hipLaunchKernelGGL(index_block_kernel, dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
+            if (tiny) hipLaunchKernelGGL((index_block_kernel<256, IDXT_MAX_LB>), dim3(m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, 1u, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
+            else hipLaunchKernelGGL((index_block_kernel<IDXB_THREADS, IDXB_MAX_LB>), dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
             ctx->t_end();
             PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {
