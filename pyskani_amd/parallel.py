@@ -34,33 +34,52 @@ def weighted_shard_cuts(weights, world):
     return cuts + [n]
 
 
+_HIT_CAP = {}      # rows the gathered buffer held last time, per process group: the next call sends that many (+ the header row)
+
+
 def all_gather_hits(idx, vals, dist, device="cpu", group=None):
     """All-gather ragged per-shard hit lists.
 
     idx:  int64 [n_local, 2] = (global query index, global ref index) — integers travel as integers (exact for any
           database size); vals: float32 [n_local, 3] = (ani, af_query, af_ref).
-    Returns (idx, vals) concatenated over ranks in rank order, identical on every rank. Three collectives:
-    an all-gather of the counts, then one each of the two lists padded to the largest count.
+    Returns (idx, vals) concatenated over ranks in rank order, identical on every rank.
+
+    ONE collective in the steady state: every rank sends a fixed number of int64 rows — row 0 carries its true count, the
+    others (query, ref, the three floats bit-cast into two int64) — sized by the largest count seen so far. If a count does
+    not fit (every rank sees every header, so all agree), the capacity grows and the gather is repeated once; the first
+    call therefore exchanges the counts alone and then the lists.
     """
     import torch
     world = dist.get_world_size(group)
     idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1, 2)
     vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1, HIT_VALS)
     assert len(idx) == len(vals)
-    cnt = torch.tensor([idx.shape[0]], dtype=torch.int64, device=device)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    counts = [int(c.item()) for c in cnts]
-    m = max(max(counts), 1)
-    out = []
-    for local, dtype, cols in ((idx, torch.int64, 2), (vals, torch.float32, HIT_VALS)):
-        mine = torch.zeros((m, cols), dtype=dtype, device=device)
-        if local.shape[0]:
-            mine[:local.shape[0]] = torch.from_numpy(local).to(device)
+    n = idx.shape[0]
+    rows = np.zeros((n, 4), dtype=np.int64)
+    rows[:, :2] = idx
+    v4 = np.zeros((n, 4), dtype=np.float32)
+    v4[:, :HIT_VALS] = vals
+    rows[:, 2:] = v4.view(np.int64)
+    key = id(group) if group is not None else 0
+    cap = _HIT_CAP.get(key, 0)
+    while True:
+        mine = torch.zeros((cap + 1, 4), dtype=torch.int64, device=device)
+        mine[0, 0] = n
+        k = min(n, cap)
+        if k:
+            mine[1:1 + k] = torch.from_numpy(rows[:k]).to(device)
         parts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
-        out.append(np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0))
-    return out[0], out[1]
+        host = [p.cpu().numpy() for p in parts]
+        counts = [int(h[0, 0]) for h in host]
+        if max(counts) <= cap:
+            break
+        cap = max(counts)      # the same on every rank: they all saw the same headers
+    _HIT_CAP[key] = cap
+    got = np.concatenate([h[1:1 + c] for h, c in zip(host, counts)], axis=0) if sum(counts) else np.zeros((0, 4), np.int64)
+    out_idx = np.ascontiguousarray(got[:, :2])
+    out_vals = np.ascontiguousarray(got[:, 2:]).view(np.float32).reshape(-1, 4)[:, :HIT_VALS].copy()
+    return out_idx, out_vals
 
 
 def all_gather_sketches(sketches, ctx, dist, device, group=None):
