@@ -24,7 +24,7 @@
  * Inputs are borrowed for the duration of the call only. Outputs returned through `**`
  * are library-allocated and released with the matching psk_*_free / psk_free.
  * Threading: every call runs on one of the context's execution lanes (own HIP stream, scratch and pinned
- * staging; at most $PSK_LANES = 4 at a time, further callers wait), so psk_query / psk_screen / psk_chain /
+ * staging; at most $PSK_LANES = 8 at a time, further callers wait), so psk_query / psk_screen / psk_chain /
  * psk_sketch_host from different host threads overlap on the device, as `&self` + the released GIL allow in
  * lib.rs:551,569. A database is held shared by queries and exclusively by psk_db_add (`&mut self`, lib.rs:479)
  * and by whatever (re)builds its device tables.
@@ -45,7 +45,8 @@ typedef enum {
     PSK_EHIP = 3,     /* HIP runtime error / no device             -> RuntimeError        */
     PSK_ENOMODEL = 4, /* learned-ANI requested, no model loaded    -> RuntimeError        */
     PSK_EKEY = 5,     /* unknown reference name                    -> KeyError            */
-    PSK_ELIMIT = 6    /* input exceeds a documented limit          -> OverflowError       */
+    PSK_ELIMIT = 6,   /* input exceeds a documented limit          -> OverflowError       */
+    PSK_ERCCL = 7     /* RCCL missing or a collective failed       -> RuntimeError        */
 } psk_status;
 
 typedef struct psk_ctx psk_ctx;       /* one GPU: device id, stream, scratch arenas         */
@@ -98,8 +99,11 @@ void psk_ctx_destroy(psk_ctx* ctx);
 psk_status psk_ctx_synchronize(psk_ctx* ctx);
 /* Measurement: bracket the named kernels' launches with HIP events on the ctx stream.
  * kernel in {"sketch_scan","sketch_emit","sketch_sort","screen","anchor","chain_chunk",
- * "select","pair_reduce"}; "reset" clears the accumulators. psk_ctx_timing synchronises the stream. */
+ * "select","pair_reduce","anchor_emit"}; "reset" clears the accumulators. psk_ctx_timing synchronises the stream. */
 psk_status psk_ctx_set_timing(psk_ctx* ctx, int on);
+/* Shader clock the device holds under an integer-VALU load: a fixed ~1 ms micro-kernel (v_alignbit_b32 chains, 4 cycles per
+ * wave64 instruction on gfx950) timed with HIP events; *mhz = cycles / duration, *ms = the duration (may be NULL). */
+psk_status psk_ctx_clock_probe(psk_ctx* ctx, double* mhz, double* ms);
 psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
 psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
@@ -192,6 +196,32 @@ psk_status psk_model_predict(const psk_model* m, const float* rows, uint32_t n_r
 psk_status psk_sketch_pack_size(const psk_sketch* s, uint64_t* bytes);
 psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity);
 psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out);
+/* n sketches (of one context) -> n records at d_dst + offsets[i] (16-byte aligned, inside `capacity` bytes): one header upload,
+ * one copy launch and one synchronisation for the whole batch */
+psk_status psk_sketch_pack_many(const psk_sketch* const* sketches, uint32_t n, void* d_dst, const uint64_t* offsets, uint64_t capacity);
+
+/* ---- multi-GPU exchange. One process per GPU; a psk_comm is this rank's end of an RCCL communicator bound to its
+ * context ("one ani_ctx owns its devices and its RCCL communicator", §8b threading row). The path shards by reference
+ * (lib.rs:617-657: every (query, ref) pair is independent), so the only collectives are the all-gather of the per-shard hit lists and,
+ * for an all-vs-all, the all-gather of the shards' sketches as the query side. librccl.so is loaded at run time: without it every
+ * call below returns PSK_ERCCL and the library is otherwise complete (replicas only).
+ * Bootstrap: rank 0 calls psk_comm_unique_id, the host program hands the PSK_COMM_ID_BYTES bytes to every rank over any channel
+ * it has (MPI, a file, torch.distributed), every rank calls psk_comm_create (collective: returns when all ranks have joined). */
+typedef struct psk_comm psk_comm;
+#define PSK_COMM_ID_BYTES 128
+psk_status psk_comm_unique_id(void* id);
+psk_status psk_comm_create(psk_ctx* ctx, int rank, int world, const void* id, psk_comm** out);
+void psk_comm_destroy(psk_comm* comm);
+/* rank, world, bytes this rank has sent through the communicator and the number of collectives (any may be NULL) */
+psk_status psk_comm_info(const psk_comm* comm, int* rank, int* world, uint64_t* bytes_sent, uint64_t* collectives);
+/* All-gather of ragged per-shard hit lists (host arrays). Records travel as they are: the caller has put the GLOBAL reference
+ * index in ref_index and the global query index in `reserved`. *all (psk_free) = every rank's list in rank order, identical on
+ * every rank; counts (world entries, may be NULL) = the ranks' list lengths. */
+psk_status psk_gather_hits(psk_comm* comm, const psk_hit* local, uint64_t n_local, psk_hit** all, uint64_t* n_all, uint64_t* counts);
+/* All-gather of device-resident sketches as packed records, HBM -> xGMI -> HBM (no host hop): every rank contributes n sketches
+ * and receives everybody's as sketches on ITS GPU. *all (psk_free; each entry psk_sketch_free) = the ranks' sketches in rank
+ * order; counts[r] (world entries) = how many came from rank r. */
+psk_status psk_gather_sketches(psk_comm* comm, const psk_sketch* const* mine, uint32_t n, psk_sketch*** all, uint32_t* counts);
 
 psk_status psk_db_create(psk_ctx* ctx, const psk_params* p, psk_db** out);
 void psk_db_destroy(psk_db* db);

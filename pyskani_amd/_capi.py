@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSK_LIB_PATH") or os.path.join(_HERE, "libpyskani_amd.so")   # override: A/B builds only
 
-PSK_OK, PSK_EINVAL, PSK_ENOMEM, PSK_EHIP, PSK_ENOMODEL, PSK_EKEY, PSK_ELIMIT = range(7)
+PSK_OK, PSK_EINVAL, PSK_ENOMEM, PSK_EHIP, PSK_ENOMODEL, PSK_EKEY, PSK_ELIMIT, PSK_ERCCL = range(8)
+COMM_ID_BYTES = 128
 
 
 class Params(C.Structure):
@@ -51,7 +52,8 @@ SYMBOLS = [
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
-    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack",
+    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe",
+    "psk_comm_unique_id", "psk_comm_create", "psk_comm_destroy", "psk_comm_info", "psk_gather_hits", "psk_gather_sketches",
     "psk_model_create", "psk_model_load_json", "psk_model_load_file", "psk_model_free", "psk_model_info", "psk_model_predict",
 ]
 
@@ -108,6 +110,15 @@ def load():
     lib.psk_sketch_pack_size.argtypes = [vp, C.POINTER(u64)]
     lib.psk_sketch_pack.argtypes = [vp, vp, u64]
     lib.psk_sketch_unpack.argtypes = [vp, vp, C.POINTER(u64), u32, C.POINTER(vp)]
+    lib.psk_sketch_pack_many.argtypes = [C.POINTER(vp), u32, vp, C.POINTER(u64), u64]
+    lib.psk_ctx_clock_probe.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.psk_comm_unique_id.argtypes = [vp]
+    lib.psk_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.psk_comm_destroy.argtypes = [vp]
+    lib.psk_comm_destroy.restype = None
+    lib.psk_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(u64), C.POINTER(u64)]
+    lib.psk_gather_hits.argtypes = [vp, vp, u64, C.POINTER(C.POINTER(Hit)), C.POINTER(u64), C.POINTER(u64)]
+    lib.psk_gather_sketches.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(C.POINTER(vp)), C.POINTER(u32)]
     lib.psk_model_create.argtypes = [vp, C.POINTER(TreeNode), u64, C.POINTER(u32), u32, C.c_float, C.c_float, C.POINTER(C.c_int32), u32, C.POINTER(vp)]
     lib.psk_model_load_json.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
     lib.psk_model_load_file.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
@@ -120,7 +131,7 @@ def load():
 
 
 _EXC = {PSK_EINVAL: ValueError, PSK_ENOMEM: MemoryError, PSK_EHIP: RuntimeError,
-        PSK_ENOMODEL: RuntimeError, PSK_EKEY: KeyError, PSK_ELIMIT: OverflowError}
+        PSK_ENOMODEL: RuntimeError, PSK_EKEY: KeyError, PSK_ELIMIT: OverflowError, PSK_ERCCL: RuntimeError}
 
 
 def check(status):

@@ -108,6 +108,57 @@ psk_status psk_ctx_timing(psk_ctx* c, const char* kernel, double* total_ms, uint
     return PSK_EINVAL;
 }
 
+// ---- shader-clock probe: a fixed integer-VALU load (8 independent chains of v_alignbit_b32 per lane, 8 waves per SIMD), ~1 ms.
+// v_alignbit_b32 issues at 16 lanes per SIMD and cycle on gfx950 (profiles/micro/valu_rates.hip: 4 cycles per wave64
+// instruction), so clock = wave-instructions per SIMD x 4 / duration. bench.py runs it before a timed loop: sketch_scan is bound by
+// VALU issue, so its time follows the clock the box holds, and the record lets box-to-box spread be told from a regression.
+}  // extern "C"
+namespace {
+constexpr int CLK_CHAINS = 8, CLK_UNROLL = 32, CLK_ITERS = 256, CLK_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void clock_probe_kernel(uint32_t* __restrict__ out, int iters, uint32_t c) {
+    uint32_t a[CLK_CHAINS];
+#pragma unroll
+    for (int j = 0; j < CLK_CHAINS; j++) a[j] = threadIdx.x * 7u + j + blockIdx.x;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < CLK_UNROLL; u++) {
+#pragma unroll
+            for (int j = 0; j < CLK_CHAINS; j++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[j]) : "v"(c));
+        }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < CLK_CHAINS; j++) s += a[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}
+extern "C" {
+psk_status psk_ctx_clock_probe(psk_ctx* c, double* mhz, double* ms_out) {
+    if (!c || !mhz) { psk_set_error("clock_probe: NULL argument"); return PSK_EINVAL; }
+    PSK_LANE(lg, c);
+    Lane* lane = lg.lane;
+    PSK_TRY(lane->s_misc.reserve(4 * (size_t)CLK_BLOCKS * 256));
+    int cus = 0;
+    PSK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    hipEvent_t a, b;
+    PSK_HIP(hipEventCreate(&a)); PSK_HIP(hipEventCreate(&b));
+    float best = 0;
+    for (int rep = 0; rep < 4; rep++) {      // the first launch is a warm-up (clock ramp); the shortest of the rest counts
+        PSK_HIP(hipEventRecord(a, lane->stream));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(CLK_BLOCKS), dim3(256), 0, lane->stream, (uint32_t*)lane->s_misc.p, CLK_ITERS, 0x9E3779B9u);
+        PSK_HIP(hipEventRecord(b, lane->stream));
+        PSK_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        PSK_HIP(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0 && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    const double wave_inst = (double)CLK_BLOCKS * 4 * CLK_CHAINS * CLK_UNROLL * CLK_ITERS;
+    *mhz = best > 0 ? wave_inst * 4.0 / ((double)cus * 4.0) / (best * 1e-3) / 1e6 : 0.0;
+    if (ms_out) *ms_out = best;
+    return PSK_OK;
+}
+
 psk_status psk_device_alloc(psk_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) { psk_set_error("device_alloc: NULL argument"); return PSK_EINVAL; }
     PSK_HIP(hipSetDevice(c->device));
@@ -374,145 +425,6 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
 
 }  // extern "C"
 
-// ------------------------------------------------------------------ device-side sketch records (multi-GPU exchange)
-// A packed sketch is one self-contained byte range of HBM: what ShardedDatabase.all_vs_all all-gathers over xGMI
-//  without the D2H -> bytes -> H2D hop of psk_sketch_export / psk_sketch_import.
-//   [PackHeader 64 B][contig_len u32 x nc][contig_seed_start u32 x (nc+1)] pad16
-//   [seed_kmer u32 x ns] pad16 [seed_pos u32 x ns] pad16 [seed_meta u32 x ns] pad16 [markers u64 x nm] pad16
-namespace {
-struct PackHeader { uint32_t magic, version; int32_t c, marker_c, k; uint32_t has_seeds, n_contigs, reserved; uint64_t n_seeds, n_markers, total_len, bytes; };
-static_assert(sizeof(PackHeader) == 64, "PackHeader is 64 bytes");
-constexpr uint32_t PACK_MAGIC = 0x4B53504Bu;   // "KPSK"
-inline uint64_t al16(uint64_t x) { return (x + 15) & ~15ull; }
-struct PackLayout { uint64_t o_len, o_cs, o_kmer, o_pos, o_meta, o_mark, end; };
-inline PackLayout pack_layout(uint64_t nc, uint64_t ns, uint64_t nm) {
-    PackLayout L;
-    L.o_len = sizeof(PackHeader); L.o_cs = L.o_len + 4 * nc; L.o_kmer = al16(L.o_cs + 4 * (nc + 1));
-    L.o_pos = al16(L.o_kmer + 4 * ns); L.o_meta = al16(L.o_pos + 4 * ns); L.o_mark = al16(L.o_meta + 4 * ns); L.end = al16(L.o_mark + 8 * nm);
-    return L;
-}
-__global__ void build_pm_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ meta, uint64_t* __restrict__ pm, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) pm[i] = ((uint64_t)pos[i] << 32) | meta[i];
-}
-}  // namespace
-
-extern "C" {
-
-psk_status psk_sketch_pack_size(const psk_sketch* s, uint64_t* bytes) {
-    if (!s || !bytes) { psk_set_error("pack_size: NULL argument"); return PSK_EINVAL; }
-    *bytes = pack_layout(s->contig_len.size(), s->n_seeds, s->n_markers).end;
-    return PSK_OK;
-}
-
-psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity) {
-    if (!s || !d_dst) { psk_set_error("pack: NULL argument"); return PSK_EINVAL; }
-    if (((uintptr_t)d_dst & 15) != 0) { psk_set_error("pack: destination must be 16-byte aligned"); return PSK_EINVAL; }
-    psk_ctx* ctx = s->ctx;
-    const uint64_t nc = s->contig_len.size(), ns = s->n_seeds, nm = s->n_markers;
-    const PackLayout L = pack_layout(nc, ns, nm);
-    if (capacity < L.end) { psk_set_error("pack: destination holds %llu bytes, the record needs %llu", (unsigned long long)capacity, (unsigned long long)L.end); return PSK_EINVAL; }
-    PSK_LANE(lg, ctx);
-    Lane* lane = lg.lane;
-    void* hp;
-    PSK_TRY(lane->pinned(L.o_kmer, &hp));
-    memset(hp, 0, L.o_kmer);
-    PackHeader* H = (PackHeader*)hp;
-    H->magic = PACK_MAGIC; H->version = 1; H->c = s->params.c; H->marker_c = s->params.marker_c; H->k = s->params.k;
-    H->has_seeds = s->has_seeds; H->n_contigs = (uint32_t)nc; H->n_seeds = ns; H->n_markers = nm; H->total_len = s->total_len; H->bytes = L.end;
-    uint32_t* hl = (uint32_t*)((char*)hp + L.o_len);
-    for (uint64_t i = 0; i < nc; i++) hl[i] = s->contig_len[i];
-    uint32_t* hc = (uint32_t*)((char*)hp + L.o_cs);
-    for (uint64_t i = 0; i <= nc; i++) hc[i] = i < s->contig_seed_start.size() ? s->contig_seed_start[i] : (uint32_t)ns;
-    char* d = (char*)d_dst;
-    hipStream_t st = lane->stream;
-    PSK_HIP(hipMemcpyAsync(d, hp, L.o_kmer, hipMemcpyHostToDevice, st));
-    if (ns) {
-        PSK_HIP(hipMemcpyAsync(d + L.o_kmer, s->store->seed_kmer + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
-        PSK_HIP(hipMemcpyAsync(d + L.o_pos, s->store->seed_pos + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
-        PSK_HIP(hipMemcpyAsync(d + L.o_meta, s->store->seed_meta + s->seed_off, 4 * ns, hipMemcpyDeviceToDevice, st));
-    }
-    if (nm) PSK_HIP(hipMemcpyAsync(d + L.o_mark, s->store->markers + s->marker_off, 8 * nm, hipMemcpyDeviceToDevice, st));
-    PSK_HIP(hipStreamSynchronize(st));      // the pinned staging block is reused by the next call
-    return PSK_OK;
-}
-
-/* n records at d_src + offsets[i] -> n device-resident sketches sharing one store. Two host syncs per call. */
-psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out) {
-    if (!ctx || (n && (!d_src || !offsets || !out))) { psk_set_error("unpack: NULL argument"); return PSK_EINVAL; }
-    for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
-    if (!n) return PSK_OK;
-    PSK_LANE(lg, ctx);
-    hipStream_t st = lg.lane->stream;
-    const char* src = (const char*)d_src;
-    std::vector<PackHeader> H(n);
-    for (uint32_t i = 0; i < n; i++) {
-        if (offsets[i] & 15) { psk_set_error("unpack: record %u is not 16-byte aligned", i); return PSK_EINVAL; }
-        PSK_HIP(hipMemcpyAsync(&H[i], src + offsets[i], sizeof(PackHeader), hipMemcpyDeviceToHost, st));
-    }
-    PSK_HIP(hipStreamSynchronize(st));
-    uint64_t tot_c = 0, tot_s = 0, tot_m = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const PackHeader& h = H[i];
-        if (h.magic != PACK_MAGIC || h.version != 1 || h.k < 1 || h.k > 16 || h.c < 1 || h.marker_c < 1 ||
-            h.bytes != pack_layout(h.n_contigs, h.n_seeds, h.n_markers).end) { psk_set_error("unpack: record %u is not a packed sketch", i); return PSK_EINVAL; }
-        tot_c += h.n_contigs; tot_s += h.n_seeds; tot_m += h.n_markers;
-    }
-    if (tot_s >= 0x7FFFFFF0ull || tot_m >= 0x7FFFFFF0ull) { psk_set_error("unpack: batch too large for one store; split it"); return PSK_ELIMIT; }
-    std::vector<uint32_t> meta(2 * tot_c + n);      // per record: contig_len[nc], contig_seed_start[nc+1]
-    {
-        uint64_t w = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            const uint64_t nb = 4 * (2 * (uint64_t)H[i].n_contigs + 1);
-            PSK_HIP(hipMemcpyAsync(meta.data() + w, src + offsets[i] + sizeof(PackHeader), nb, hipMemcpyDeviceToHost, st));
-            w += 2 * (uint64_t)H[i].n_contigs + 1;
-        }
-    }
-    auto store = std::make_shared<SketchStore>();
-    store->ctx = ctx;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t ns = (size_t)tot_s;
-    const size_t b_kmer = 0, b_pos = al(b_kmer + 4 * ns), b_meta = al(b_pos + 4 * ns), b_pm = al(b_meta + 4 * ns), b_cs = al(b_pm + 8 * ns), b_end = al(b_cs + 4 * (size_t)(tot_c + n));
-    PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
-    char* sb = (char*)store->base;
-    store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
-    store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cs);
-    PSK_TRY(ctx->pool_alloc(8 * ((size_t)tot_m + 1), &store->mbase, &store->mbytes));
-    store->markers = (uint64_t*)store->mbase;
-    PSK_HIP(hipStreamSynchronize(st));              // meta[] is on the host
-    std::vector<uint32_t> cstart(tot_c + n);
-    std::vector<std::unique_ptr<psk_sketch>> sk(n);
-    uint64_t so = 0, mo = 0, co = 0, w = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const PackHeader& h = H[i];
-        const PackLayout L = pack_layout(h.n_contigs, h.n_seeds, h.n_markers);
-        sk[i].reset(new psk_sketch());
-        psk_sketch* s = sk[i].get();
-        s->ctx = ctx; s->params = psk_params{h.c, h.marker_c, h.k}; s->has_seeds = h.has_seeds != 0; s->total_len = h.total_len;
-        s->store = store; s->seed_off = so; s->n_seeds = h.n_seeds; s->marker_off = mo; s->n_markers = h.n_markers; s->contig_off = co;
-        s->contig_len.assign(meta.begin() + w, meta.begin() + w + h.n_contigs);
-        s->contig_seed_start.assign(meta.begin() + w + h.n_contigs, meta.begin() + w + 2 * (uint64_t)h.n_contigs + 1);
-        for (uint64_t c = 0; c <= h.n_contigs; c++) {
-            if (s->contig_seed_start[c] > h.n_seeds || (c && s->contig_seed_start[c] < s->contig_seed_start[c - 1])) { psk_set_error("unpack: record %u has a corrupt contig table", i); return PSK_EINVAL; }
-            cstart[co + c] = (uint32_t)(so + s->contig_seed_start[c]);
-        }
-        const char* r = src + offsets[i];
-        if (h.n_seeds) {
-            PSK_HIP(hipMemcpyAsync(store->seed_kmer + so, r + L.o_kmer, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
-            PSK_HIP(hipMemcpyAsync(store->seed_pos + so, r + L.o_pos, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
-            PSK_HIP(hipMemcpyAsync(store->seed_meta + so, r + L.o_meta, 4 * h.n_seeds, hipMemcpyDeviceToDevice, st));
-        }
-        if (h.n_markers) PSK_HIP(hipMemcpyAsync(store->markers + mo, r + L.o_mark, 8 * h.n_markers, hipMemcpyDeviceToDevice, st));
-        so += h.n_seeds; mo += h.n_markers; co += (uint64_t)h.n_contigs + 1; w += 2 * (uint64_t)h.n_contigs + 1;
-    }
-    PSK_HIP(hipMemcpyAsync(store->contig_seed_start, cstart.data(), 4 * cstart.size(), hipMemcpyHostToDevice, st));
-    if (ns) hipLaunchKernelGGL(build_pm_kernel, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, st, store->seed_pos, store->seed_meta, store->seed_pm, (uint64_t)ns);
-    PSK_HIP(hipStreamSynchronize(st));
-    for (uint32_t i = 0; i < n; i++) out[i] = sk[i].release();
-    return PSK_OK;
-}
-
-}  // extern "C"
 
 // ------------------------------------------------------------------ host-ASCII ingest pipeline
 // psk_sketch_many_host: many genomes whose contigs sit in ordinary (pageable) host memory. The boundary of the reference
@@ -598,16 +510,31 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
         std::lock_guard<std::mutex> g(g_ingest_mu);
         IngestRes*& slot = g_ingest[ctx];
         if (!slot) {
-            slot = new IngestRes();
-            PSK_HIP(hipStreamCreateWithFlags(&slot->copy, hipStreamNonBlocking));
-            for (int i = 0; i < INGEST_SLOTS; i++) {
-                PSK_HIP(hipHostMalloc(&slot->pinned[i], INGEST_SLOT, hipHostMallocDefault));
-                PSK_HIP(hipEventCreateWithFlags(&slot->slot_free[i], hipEventDisableTiming));
+            // built aside and published only once every resource exists: a failure half-way (4 x 32 MB of pinned memory, events, the
+            // stream) leaves no half-initialised entry for the next call to trip over
+            IngestRes* fresh = new IngestRes();
+            auto init = [&]() -> psk_status {
+                PSK_HIP(hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking));
+                for (int i = 0; i < INGEST_SLOTS; i++) {
+                    PSK_HIP(hipHostMalloc(&fresh->pinned[i], INGEST_SLOT, hipHostMallocDefault));
+                    PSK_HIP(hipEventCreateWithFlags(&fresh->slot_free[i], hipEventDisableTiming));
+                }
+                for (int i = 0; i < 2; i++) PSK_HIP(hipEventCreateWithFlags(&fresh->ready[i], hipEventDisableTiming));
+                return PSK_OK;
+            };
+            const psk_status irc = init();
+            if (irc != PSK_OK) {
+                for (int i = 0; i < INGEST_SLOTS; i++) { if (fresh->pinned[i]) (void)hipHostFree(fresh->pinned[i]); if (fresh->slot_free[i]) (void)hipEventDestroy(fresh->slot_free[i]); }
+                for (int i = 0; i < 2; i++) if (fresh->ready[i]) (void)hipEventDestroy(fresh->ready[i]);
+                if (fresh->copy) (void)hipStreamDestroy(fresh->copy);
+                delete fresh;
+                g_ingest.erase(ctx);
+                return irc;
             }
-            for (int i = 0; i < 2; i++) PSK_HIP(hipEventCreateWithFlags(&slot->ready[i], hipEventDisableTiming));
             const char* env = getenv("PSK_INGEST_THREADS");
             int nt = env ? atoi(env) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
-            slot->pool.reset(new ParallelFor(std::max(0, nt - 1)));
+            fresh->pool.reset(new ParallelFor(std::max(0, nt - 1)));
+            slot = fresh;
         }
         R = slot;
     }

@@ -71,8 +71,8 @@ struct Scratch {
 };
 
 // kernels whose launches can be bracketed by HIP events on the ctx stream (psk_ctx_timing)
-enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANCHOR, K_CHAIN_CHUNK, K_SELECT, K_PAIR_REDUCE, K_COUNT };
-static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce"};
+enum KernelId { K_SKETCH_SCAN = 0, K_SKETCH_EMIT, K_SKETCH_SORT, K_SCREEN, K_ANCHOR, K_CHAIN_CHUNK, K_SELECT, K_PAIR_REDUCE, K_ANCHOR_EMIT, K_COUNT };
+static const char* const KERNEL_NAMES[K_COUNT] = {"sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce", "anchor_emit"};
 struct TimerRec { int id; hipEvent_t a, b; };
 
 // One GPU (the public psk_ctx handle): the HBM block pool and the execution lanes. A LANE is what a call runs on: its own HIP
@@ -241,6 +241,12 @@ struct PoolScratch {
     psk_ctx* dev = nullptr;
     void* p = nullptr;
     size_t cap = 0;
+    PoolScratch() = default;
+    PoolScratch(const PoolScratch&) = delete;
+    PoolScratch& operator=(const PoolScratch&) = delete;
+    PoolScratch(PoolScratch&& o) noexcept : dev(o.dev), p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    PoolScratch& operator=(PoolScratch&& o) noexcept { if (this != &o) { release(); dev = o.dev; p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~PoolScratch() { release(); }      // a local (the prefilter's scratch of one round) goes back to the pool on every exit path
     psk_status reserve(psk_ctx* d, size_t bytes) {
         if (bytes <= cap) return PSK_OK;
         release();

@@ -2659,6 +2659,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool use_hops = hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20));
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
+    ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
     if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
@@ -2676,6 +2677,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else if (!emit_heads)
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
+    ctx->t_end();
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
@@ -2739,12 +2741,32 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             // under huge_mu until the batch's synchronisation); any other batch - where such a pair is an exception - a share of the rest
             // that stays safe if every lane launched at once.
             if (na / 3 > solo) {
-                uint32_t nb = BIG_GMAX;
-                if (n_items / n_pairs > (1u << 20)) ctx->huge_acquire();
-                else {
-                    while (nb > 1 && (size_t)nb * ctx->dev->max_lanes > 512 - BIG_GMAX) nb >>= 1;
-                    if (nb < 8) nb = 1;
+                // co-resident slots of this kernel on THIS device (occupancy query, once): a partition with fewer CUs, a CU mask or
+                // a different LDS budget changes it, and a workgroup that cannot become resident would be waited on forever
+                static std::mutex slots_mu;
+                static std::unordered_map<int, uint32_t> slots_of;
+                uint32_t slots;
+                {
+                    std::lock_guard<std::mutex> lk(slots_mu);
+                    auto it = slots_of.find(ctx->device);
+                    if (it == slots_of.end()) {
+                        int per_cu = 0, cus = 0;
+                        PSK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_huge_kernel, BIG_T, 0));
+                        PSK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+                        if (const char* e = getenv("PSK_HUGE_SLOTS")) { per_cu = 1; cus = std::max(0, atoi(e)); }      // tests: pretend a smaller device
+                        it = slots_of.emplace(ctx->device, (uint32_t)std::max(0, per_cu) * (uint32_t)std::max(0, cus)).first;
+                    }
+                    slots = it->second;
                 }
+                uint32_t nb = BIG_GMAX;
+                if (n_items / n_pairs > (1u << 20)) {      // the device's one full-size launch: the largest power of two that is resident at once
+                    ctx->huge_acquire();
+                    while (nb > 1 && nb > slots) nb >>= 1;
+                } else {                                     // a share of what the full-size launch leaves, safe if every lane launched at once
+                    const uint32_t rest = slots > BIG_GMAX ? slots - BIG_GMAX : 0;
+                    while (nb > 1 && (size_t)nb * ctx->dev->max_lanes > rest) nb >>= 1;
+                }
+                if (nb < 8) nb = 1;      // one workgroup per pair: no barrier between workgroups, nothing to wait for
                 hipLaunchKernelGGL(select_huge_kernel, dim3(nb), dim3(BIG_T), 0, st, BA);
             }
         }

@@ -105,7 +105,8 @@ def all_gather_sketches(sketches, ctx, dist, device, group=None):
     all_sizes = [t.cpu().numpy()[:c] for t, c in zip(all_sizes, counts)]
     offs = [np.concatenate([[0], np.cumsum(sz)]).astype(np.int64) for sz in all_sizes]     # record sizes are multiples of 16
     width = max(int(max(o[-1] for o in offs)), 16)
-    buf = torch.zeros(width, dtype=torch.uint8, device=device)
+    buf = torch.empty(width, dtype=torch.uint8, device=device)      # pad bytes are never read; a fill kernel on torch's stream
+    torch.cuda.current_stream(device).synchronize()                   # would race the library's own (non-blocking) stream
     rank = dist.get_rank(group)
     for s, o, sz in zip(sketches, offs[rank][:-1], sizes):
         s.pack_into(buf.data_ptr() + int(o), int(sz))

@@ -10,6 +10,8 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct PskSketch { _p: [u8; 0] }
 #[repr(C)] pub struct PskDb { _p: [u8; 0] }
 #[repr(C)] pub struct PskModel { _p: [u8; 0] }
+#[repr(C)] pub struct PskComm { _p: [u8; 0] }
+pub const PSK_COMM_ID_BYTES: usize = 128;
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct PskParams { pub c: i32, pub marker_c: i32, pub k: i32 }
@@ -47,6 +49,7 @@ extern "C" {
     pub fn psk_ctx_synchronize(ctx: *mut PskCtx) -> c_int;
     pub fn psk_ctx_set_timing(ctx: *mut PskCtx, on: c_int) -> c_int;
     pub fn psk_ctx_timing(ctx: *mut PskCtx, kernel: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn psk_ctx_clock_probe(ctx: *mut PskCtx, mhz: *mut f64, ms: *mut f64) -> c_int;
     pub fn psk_device_alloc(ctx: *mut PskCtx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
     pub fn psk_device_free(ctx: *mut PskCtx, dptr: *mut c_void) -> c_int;
     pub fn psk_memcpy_h2d(ctx: *mut PskCtx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
@@ -74,6 +77,14 @@ extern "C" {
     pub fn psk_sketch_pack(s: *const PskSketch, d_dst: *mut c_void, capacity: u64) -> c_int;
     pub fn psk_sketch_unpack(ctx: *mut PskCtx, d_src: *const c_void, offsets: *const u64, n: u32,
                              out: *mut *mut PskSketch) -> c_int;
+    pub fn psk_sketch_pack_many(sketches: *const *const PskSketch, n: u32, d_dst: *mut c_void, offsets: *const u64, capacity: u64) -> c_int;
+    // multi-GPU exchange over RCCL (one process per GPU; the id travels over whatever channel the host program has)
+    pub fn psk_comm_unique_id(id: *mut c_void) -> c_int;
+    pub fn psk_comm_create(ctx: *mut PskCtx, rank: c_int, world: c_int, id: *const c_void, out: *mut *mut PskComm) -> c_int;
+    pub fn psk_comm_destroy(comm: *mut PskComm);
+    pub fn psk_comm_info(comm: *const PskComm, rank: *mut c_int, world: *mut c_int, bytes_sent: *mut u64, collectives: *mut u64) -> c_int;
+    pub fn psk_gather_hits(comm: *mut PskComm, local: *const PskHit, n_local: u64, all: *mut *mut PskHit, n_all: *mut u64, counts: *mut u64) -> c_int;
+    pub fn psk_gather_sketches(comm: *mut PskComm, mine: *const *const PskSketch, n: u32, all: *mut *mut *mut PskSketch, counts: *mut u32) -> c_int;
     // learned-ANI regression: regression::get_model (lib.rs:614)
     pub fn psk_model_create(ctx: *mut PskCtx, nodes: *const PskTreeNode, n_nodes: u64, tree_first_node: *const u32,
                             n_trees: u32, bias: f32, shrinkage: f32, features: *const i32, n_features: u32,
@@ -114,6 +125,6 @@ pub fn check(status: c_int) -> pyo3::PyResult<()> {
         2 => PyMemoryError::new_err(msg),     // PSK_ENOMEM
         5 => PyKeyError::new_err(msg),        // PSK_EKEY     (lib.rs:97,110)
         6 => PyOverflowError::new_err(msg),   // PSK_ELIMIT
-        _ => PyRuntimeError::new_err(msg),    // PSK_EHIP, PSK_ENOMODEL
+        _ => PyRuntimeError::new_err(msg),    // PSK_EHIP, PSK_ENOMODEL, PSK_ERCCL
     })
 }

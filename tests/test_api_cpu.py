@@ -18,14 +18,35 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.psk_version()
 
 
-def test_rust_binding_and_integration_doc_list_every_symbol():
-    """the FFI block must mirror the header, not a subset of it."""
+def test_rust_binding_lists_every_symbol_and_handover_files_use_them():
+    """the FFI block mirrors the header, not a subset of it; the lib.rs patch and the model hand-over exist as source."""
     header = open(os.path.join(ROOT, "include", "pyskani_amd.h")).read()
     declared = set(re.findall(r"\b(psk_[a-z0-9_]+)\s*\(", header))
-    for rel in ("rust/ffi.rs", "INTEGRATION.md"):
-        text = open(os.path.join(ROOT, rel)).read()
-        bound = set(re.findall(r"pub fn (psk_[a-z0-9_]+)\s*\(", text))
-        assert bound == declared, (rel, bound ^ declared)
+    text = open(os.path.join(ROOT, "rust", "ffi.rs")).read()
+    bound = set(re.findall(r"pub fn (psk_[a-z0-9_]+)\s*\(", text))
+    assert bound == declared, bound ^ declared
+    patch = open(os.path.join(ROOT, "rust", "lib_patch.rs")).read()
+    for sym in ("psk_ctx_create", "psk_db_create", "psk_sketch_host", "psk_db_add", "psk_query", "psk_db_name", "psk_free", "psk_sketch_free"):
+        assert f"ffi::{sym}(" in patch, sym
+    model = open(os.path.join(ROOT, "rust", "model.rs")).read()
+    assert "fn to_psk_model(g: &gbdt::gradient_boost::GBDT)" in model and "ffi::psk_model_create(" in model and "ffi::psk_model_load_json(" in model
+    used = set(re.findall(r"ffi::(psk_[a-z0-9_]+)\(", patch + model))
+    assert used <= declared, used - declared
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for rel in ("rust/ffi.rs", "rust/lib_patch.rs", "rust/model.rs", "tools/dump_pyskani_goldens.py"):
+        assert rel in doc and os.path.exists(os.path.join(ROOT, rel)), rel
+
+
+def test_comm_entry_points_fail_cleanly_without_a_device():
+    """The multi-GPU entry points validate their arguments before touching RCCL or a GPU."""
+    import ctypes as C
+    from pyskani_amd import _capi
+    lib = _capi.load()
+    out = C.c_void_p()
+    assert lib.psk_comm_create(None, 0, 1, None, C.byref(out)) == _capi.PSK_EINVAL
+    assert lib.psk_comm_unique_id(None) == _capi.PSK_EINVAL
+    assert lib.psk_gather_hits(None, None, 0, None, None, None) == _capi.PSK_EINVAL
+    lib.psk_comm_destroy(None)
 
 
 def test_no_gpu_fails_loudly():

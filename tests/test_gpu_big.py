@@ -1,5 +1,6 @@
 """GPU: BASELINE configs[4] at reduced count — mammalian-scale genomes (24 contigs; 2 genomes instead of 50) sketched and
-chained pairwise, every integer of the chain against the oracle. Default size 300 Mb per genome (a few seconds);
+chained pairwise, every integer of the chain against the oracle. Default size 1 Gb per genome
+(> 2^18 seeds, > 4 096 chunks, the group selection: ~1-2 min, mostly the CPU oracle; PSK_BIG_MB=300 for a quick pass);
 PSK_BIG_MB=3000 runs the real 3 Gb shape (24 x 125 Mb contigs, ~24 M seeds per genome; minutes, mostly the CPU oracle)."""
 import os
 import time
@@ -35,7 +36,7 @@ def big_pair(total_mb, n_contigs=24, divergence=0.01, seed=5):
 
 def test_mammalian_scale_pair_matches_oracle(oracle):
     import pyskani_amd as psk
-    mb = int(os.environ.get("PSK_BIG_MB", "300"))
+    mb = int(os.environ.get("PSK_BIG_MB", "1000"))
     ref, qry = big_pair(mb)
     t0 = time.time()
     db = psk.Database()

@@ -202,6 +202,7 @@ def test_pack_unpack_device_records(psk, oracle):
     assert all(sz % 16 == 0 and sz >= 64 for sz in sizes)
     offs = np.concatenate([[0], np.cumsum(sizes)])
     buf = torch.zeros(int(offs[-1]), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library packs on its own: order them
     for s, o, sz in zip(sketches, offs, sizes):
         s.pack_into(buf.data_ptr() + int(o), sz)
     with pytest.raises(ValueError):
