@@ -1,31 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — genome-pairs/sec (sketch + ANI) of the MI355X-native pyskani hot path.
 
-One "step" = one pass of the whole hot path over one batch of synthetic genomes that are already
-resident in HBM as ASCII: sketch every reference and the query (FracMinHash seeds, marker sets,
-k-mer index), load them into a fresh database, run Database.query (marker screen -> seed-index
-lookup -> chaining -> ANI/AF) and bring the hit list back to the host. Nothing is cached between
-steps. At N=1 the workload is BASELINE.json configs[1]: 1 query vs 1 000 synthetic ~5 Mb refs,
-c=125, marker_c=1000, k=15. For N>1 the references are sharded: every rank holds its own 1 000
-references (weak scaling), the query is replicated, and the per-shard hit lists are all-gathered
-with RCCL (torch.distributed backend "nccl").
+One "step" = one pass of the whole hot path over one batch of synthetic genomes that are already resident in HBM as ASCII:
+sketch every genome (FracMinHash seeds, marker sets, k-mer index), load them into a fresh database, run the query (marker
+screen -> seed-index lookup -> chaining -> ANI/AF) and bring the hit list back to the host. Nothing is cached between steps.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — dominant kernel (sketch_scan) timed with HIP events on the library's stream
-  cpu_baseline — the CPU oracle (oracle/, a port) on a bounded sample of the same workload: one core (what a
-                 pyskani call uses, lib.rs:493,569) and all host cores (one query / reference per thread)
-  extras       — at N=1: the same workload through the pyskani-shaped API from HOST memory
-                 (api_pairs_per_s: 1 000 x Database.sketch(bytes) + Database.query(bytes);
-                  host_ascii_pairs_per_s: Database.sketch_many + query, the pipelined ingest)
+The ONE JSON line (rank 0) is the headline workload, BASELINE.json configs[1]: 1 query vs 1 000 synthetic ~5 Mb refs, c=125,
+marker_c=1000, k=15 (`--workload search`, the default). At N=1 the default run then also measures the other configurations
+`north_star` names, each as an entry of `extras.workloads` with its own ms/step, hits, dominant-kernel `roofline` and a bounded
+`cpu_baseline`:
+  allvsall_10k      BASELINE configs[2] on ONE GPU: 10 000 x 10 000 genomes (100 families of 100), 10^8 pairs, ~10^6 chained
+  metagenome_100k   BASELINE configs[3]: 100 000 contigs (2-50 kb) vs a resident database of 5 000 x ~5 Mb refs, c=30 marker_c=200,
+                    with the rescue of short contigs on (default) and off (`faster_small`)
+  mammalian_8x3Gb   BASELINE configs[4] shape at reduced count: all-vs-all of 8 genomes of 24 x 125 Mb contigs; two of the chained
+                    pairs are checked against the CPU oracle outside the timed region
+(`--no-workloads` skips them; `--workload X` runs X alone as the line.)
 
-Other workloads (not the headline; `--workload`):
-  allvsall    BASELINE configs[2] shape on one GPU: every genome against all (families of 100)
-  metagenome  BASELINE configs[3] shape: short contigs (2-50 kb) against a resident database of 5 Mb references,
-              c=30 marker_c=200
-  mammalian   BASELINE configs[4] shape at reduced count: all-vs-all of --refs genomes of 24 x --contig-mb Mb contigs
+Every line / entry carries
+  roofline      the workload's dominant kernel among those with a stated algorithmic byte count, timed with HIP events
+                on the library's stream: achieved = algorithmic bytes / kernel time, against the 8 TB/s HBM peak; `traffic` = HBM bytes
+                from an offline rocprofv3 --pmc pass scaled by the run's units when profiles/ holds one for that kernel, else null
+  cpu_baseline  the CPU oracle (oracle/, a port — the Rust reference cannot be built here) on a bounded sample: one core (what a
+                pyskani call uses, lib.rs:493,569) and all host cores
+  clock         shader clock under an integer-VALU load, probed before the timed loop (sketch_scan is bound by VALU issue: its
+                time follows the clock the box holds)
+
+N>1 (one process per GPU, launched by torch.distributed.run): `search` shards the references (1 000 per GPU: weak scaling), the
+query is replicated and the per-shard hit lists are all-gathered; `--workload allvsall` shards a FIXED job of --refs genomes over
+the ranks (strong scaling): every rank sketches its share, the shards' sketches are all-gathered as packed device records in
+batches (the query side), queried against the local shard, and the hit records are all-gathered. `--comm torch` moves both
+through torch.distributed (backend nccl = RCCL), `--comm capi` through the library's own RCCL communicator (psk_comm_*).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -36,10 +44,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_REFS = 1000            # per GPU
+N_REFS = 1000            # per GPU (search)
 N_FAMILIES = 10
 DIVERGENCE = (0.0005, 0.002, 0.005, 0.01, 0.02, 0.04, 0.07, 0.10)   # SURVEY.md §8(d) family model
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+KERNELS = ("sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "anchor_emit", "chain_chunk", "select", "pair_reduce")
+PORT_NOTE = ("the repo's own C restatement (the Rust reference cannot be built here); it keeps seeds in flat arrays where skani inserts "
+             "into hash maps, so it is if anything faster than the Rust path: a conservative floor for the speed-up")
 
 
 def cpu_model():
@@ -52,273 +63,44 @@ def cpu_model():
     return "unknown"
 
 
-def make_genomes(torch, device, seed_shared, seed_members, n_refs, n_families):
-    """Family model of SURVEY.md §8(d): ancestors of iid ACGT, L ~ U[4.5, 5.5] Mb (shared by all
-    ranks); members carry independent substitutions at the cycled rates above (rank-specific);
-    the last genome is the query (family 0, d = 0.02, shared). Built on the GPU; returns one uint8
-    ASCII tensor plus per-genome (offset, length), every offset 16-byte aligned."""
-    gs = torch.Generator(device=device)
-    gs.manual_seed(seed_shared)
-    gm = torch.Generator(device=device)
-    gm.manual_seed(seed_members)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+# ------------------------------------------------------------------ synthetic data (built on the GPU)
+def family_layout(seed_shared, n_genomes, n_families):
+    """Family model of SURVEY.md §8(d): ancestors of iid ACGT, L ~ U[4.5, 5.5] Mb; genome i belongs to family i // (n / families).
+    Returns (ancestor lengths, family of every genome)."""
     rng = np.random.default_rng(seed_shared)
     lens = [int(rng.integers(4_500_000, 5_500_001)) for _ in range(n_families)]
-    per_fam = max(1, n_refs // n_families)
-    n_genomes = n_refs + 1
+    per_fam = max(1, n_genomes // n_families)
+    return lens, [min(i // per_fam, n_families - 1) for i in range(n_genomes)]
+
+
+def make_genomes(torch, device, seed_shared, seed_members, ids, fam_of, anc_lens, query_family=None):
+    """Members `ids` (GLOBAL genome indices) of the family model: each carries independent substitutions at the cycled rates on its
+    family's ancestor, drawn from a generator seeded by (seed_members, global index) — so a rank that builds only its shard gets
+    the same genomes as a rank that builds them all. With `query_family` set, one more genome follows: the query (d = 0.02).
+    Returns one uint8 ASCII tensor plus per-genome (offset, length), every offset 16-byte aligned."""
+    gs = torch.Generator(device=device)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    fams = sorted({fam_of[i] for i in ids} | ({query_family} if query_family is not None else set()))
+    anc = {}
+    for f in fams:      # every rank draws the ancestors it needs from the shared seed
+        gs.manual_seed(seed_shared * 1_000_003 + f)
+        anc[f] = torch.randint(0, 4, (anc_lens[f],), generator=gs, device=device, dtype=torch.uint8)
+    todo = [(i, fam_of[i], DIVERGENCE[i % len(DIVERGENCE)]) for i in ids]
+    if query_family is not None:
+        todo.append((-1, query_family, 0.02))
     offs, glen, total = [], [], 0
-    fam_of = [min(i // per_fam, n_families - 1) for i in range(n_refs)] + [0]
-    for i in range(n_genomes):
-        offs.append(total)
-        glen.append(lens[fam_of[i]])
-        total += (lens[fam_of[i]] + 15 + 16) & ~15
+    for _, f, _ in todo:
+        offs.append(total); glen.append(anc_lens[f]); total += (anc_lens[f] + 15 + 16) & ~15
     buf = torch.zeros(total + 64, dtype=torch.uint8, device=device)
-    anc = [torch.randint(0, 4, (L,), generator=gs, device=device, dtype=torch.uint8) for L in lens]
-    for i in range(n_genomes):
-        a = anc[fam_of[i]]
-        g = gs if i == n_refs else gm
-        d = 0.02 if i == n_refs else DIVERGENCE[i % len(DIVERGENCE)]
-        mut = torch.rand(a.shape, generator=g, device=device) < d
-        shift = torch.randint(1, 4, a.shape, generator=g, device=device, dtype=torch.uint8)
-        codes = torch.where(mut, (a + shift) & 3, a)
-        buf[offs[i]:offs[i] + glen[i]] = lut[codes.long()]
-        del mut, shift, codes
+    gm = torch.Generator(device=device)
+    for j, (i, f, d) in enumerate(todo):
+        a = anc[f]
+        gm.manual_seed((seed_members if i >= 0 else seed_shared) * 1_000_003 + (i if i >= 0 else 999_983))
+        mut = torch.rand(a.shape, generator=gm, device=device) < d
+        shift = torch.randint(1, 4, a.shape, generator=gm, device=device, dtype=torch.uint8)
+        buf[offs[j]:offs[j] + glen[j]] = lut[torch.where(mut, (a + shift) & 3, a).long()]
+        del mut, shift
     return buf, offs, glen
-
-
-class Engine:
-    """Thin driver over the C-ABI for device-resident genomes."""
-
-    def __init__(self, device):
-        from pyskani_amd import _capi
-        self.capi = _capi
-        self.lib = _capi.load()
-        self.ctx = C.c_void_p()
-        _capi.check(self.lib.psk_ctx_create(device, C.byref(self.ctx)))
-        self.params = _capi.Params(125, 1000, 15)
-
-    def set_params(self, c, marker_c, k=15):
-        self.params = self.capi.Params(c, marker_c, k)
-
-    def sketch_device(self, d_ptr, offs, lens):
-        n = len(offs)
-        key = (id(offs), n)       # ctypes views of a constant layout are built once (they describe the resident input)
-        if getattr(self, "_sd_key", None) != key:
-            self._sd_key = key
-            self._sd = ((C.c_uint64 * n)(*offs), (C.c_uint64 * n)(*lens), (C.c_uint32 * (n + 1))(*range(n + 1)))
-        c_off, c_len, gfc = self._sd
-        out = (C.c_void_p * n)()
-        self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
-        return out
-
-    def sketch_device_contigs(self, d_ptr, c_offs, c_lens, gfc):
-        n, nc = len(gfc) - 1, len(c_offs)
-        c_off = (C.c_uint64 * nc)(*c_offs); c_len = (C.c_uint64 * nc)(*c_lens); g = (C.c_uint32 * (n + 1))(*gfc)
-        out = (C.c_void_p * n)()
-        self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, g, n, 1, out))
-        return out
-
-    def make_db(self, names, handles, n):
-        db = C.c_void_p()
-        self.capi.check(self.lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
-        self.capi.check(self.lib.psk_db_add_batch(db, names, handles, n))
-        return db
-
-    def query_many(self, db, handles, n, faster_small=False):
-        opts = self.capi.QueryOpts(0, 0, 0, int(faster_small), 0.0, 0.0, None)
-        hits_p = C.POINTER(self.capi.Hit)()
-        offsets = (C.c_uint64 * (n + 1))()
-        self.capi.check(self.lib.psk_query_many(db, handles, n, C.byref(opts), C.byref(hits_p), offsets))
-        nh = int(offsets[n])
-        if hits_p:
-            self.lib.psk_free(hits_p)
-        return nh
-
-    def _layout(self, offs, lens, n):
-        """ctypes views of the (constant) genome layout, built once: they describe the resident input"""
-        key = (id(offs), n)
-        if getattr(self, "_layout_key", None) != key:
-            self._layout_key = key
-            self._c_off = (C.c_uint64 * n)(*offs[:n]); self._c_len = (C.c_uint64 * n)(*lens[:n])
-            self._gfc = (C.c_uint32 * (n + 1))(*range(n + 1))
-        return self._c_off, self._c_len, self._gfc
-
-    def step(self, d_ptr, offs, lens, names):
-        lib, capi = self.lib, self.capi
-        n = len(offs)
-        c_off, c_len, gfc = self._layout(offs, lens, n)
-        out = (C.c_void_p * n)()
-        capi.check(lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
-        db = C.c_void_p()
-        capi.check(lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
-        try:
-            capi.check(lib.psk_db_add_batch(db, names, out, n - 1))
-            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
-            hits_p = C.POINTER(capi.Hit)()
-            nh = C.c_uint64(0)
-            capi.check(lib.psk_query(db, out[n - 1], C.byref(opts), C.byref(hits_p), C.byref(nh)))
-            hits = np.zeros((nh.value, 4), dtype=np.float32)
-            if nh.value:   # one structured view of the returned psk_hit array instead of a ctypes loop
-                rec = np.frombuffer((capi.Hit * nh.value).from_address(C.addressof(hits_p.contents)), dtype=np.dtype(capi.Hit))
-                hits[:, 0] = rec["ref_index"]; hits[:, 1] = rec["ani"]; hits[:, 2] = rec["af_query"]; hits[:, 3] = rec["af_ref"]
-            if hits_p:
-                lib.psk_free(hits_p)
-        finally:
-            lib.psk_sketch_free(out[n - 1])
-            lib.psk_db_destroy(db)
-        return hits
-
-    def step_all_vs_all(self, d_ptr, offs, lens, names):
-        """BASELINE configs[2] shape on one GPU: every genome against a database of all of them."""
-        lib, capi = self.lib, self.capi
-        n = len(offs) - 1                      # the trailing query genome is not used here
-        c_off, c_len, gfc = self._layout(offs, lens, n)
-        out = (C.c_void_p * n)()
-        capi.check(lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
-        db = C.c_void_p()
-        capi.check(lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
-        try:
-            capi.check(lib.psk_db_add_batch(db, names, out, n))
-            opts = capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
-            hits_p = C.POINTER(capi.Hit)()
-            offsets = (C.c_uint64 * (n + 1))()
-            capi.check(lib.psk_query_many(db, out, n, C.byref(opts), C.byref(hits_p), offsets))
-            nh = int(offsets[n])
-            if nh:      # algorithmic work of the chain stage, for the per-kernel roofline figures: anchors and (pair, query seed) items of the hits
-                rec = np.frombuffer((capi.Hit * nh).from_address(C.addressof(hits_p.contents)), dtype=np.dtype(capi.Hit))
-                per_q = np.diff(np.frombuffer(offsets, dtype=np.uint64).astype(np.int64))
-                seeds = np.zeros(n, np.int64)
-                ns = C.c_uint64()
-                for i in range(n):
-                    capi.check(lib.psk_sketch_info(out[i], None, C.byref(ns), None, None, None)); seeds[i] = ns.value
-                self.last_chain_work = {"anchors": int(rec["n_anchors"].sum()), "items": int((per_q * seeds).sum()), "pairs": nh}
-            if hits_p:
-                lib.psk_free(hits_p)
-        finally:
-            lib.psk_db_destroy(db)
-        return nh
-
-    def timing(self, kernel):
-        ms, n = C.c_double(0), C.c_uint64(0)
-        self.capi.check(self.lib.psk_ctx_timing(self.ctx, kernel.encode(), C.byref(ms), C.byref(n)))
-        return ms.value, n.value
-
-
-def cpu_baseline(fetch, n_sample, threads):
-    """The CPU oracle (a port of the restated skani path) on 1 query vs the first n_sample references of this rank's
-    shard. `fetch(i)` returns genome i's bytes (i = -1: the query); only oracle time is counted, not the D2H copies
-    that feed it. Two figures: ONE core (a pyskani call is single-threaded, lib.rs:493,569) and ALL host cores with one
-    reference per thread (what a user gets from the GIL release) — ctypes drops the GIL, so plain threads scale."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    O.build()
-    genomes = [fetch(i) for i in range(n_sample)]
-    gq = fetch(-1)
-    t0 = time.perf_counter()
-    q = O.Sketch([gq])
-    refs = [(str(i), O.Sketch([g])) for i, g in enumerate(genomes)]
-    hits = O.query(refs, q)
-    secs1 = time.perf_counter() - t0
-    del refs
-
-    def one(i):
-        r = O.Sketch([genomes[i]])
-        return O.query_count([r], q)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        nh = sum(ex.map(one, range(n_sample)))
-    secs_all = time.perf_counter() - t0
-    assert nh == len(hits)
-    return n_sample / secs1, secs1, len(hits), n_sample / secs_all, secs_all
-
-
-def cpu_baseline_allvsall(fetch, n_refs, n_queries, threads):
-    """CPU oracle on a SUB-SAMPLE of the all-vs-all workload (sub-sample configs 3-5 and extrapolate
-    linearly in pairs): every reference is sketched once (all cores), then n_queries of them are queried against all
-    n_refs (screen every reference, chain the shortlist). One-core figure from the first few queries alone."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    O.build()
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        sk = list(ex.map(lambda i: O.Sketch([fetch(i)]), range(n_refs)))
-    t_sketch_all = time.perf_counter() - t0
-    step = max(1, n_refs // n_queries)
-    qs = list(range(0, n_refs, step))[:n_queries]
-
-    def one(qi):      # screen every reference + chain the shortlist, one C call (the interpreter lock is released inside)
-        return O.query_count(sk, sk[qi])
-    n1 = min(4, len(qs))
-    t0 = time.perf_counter()
-    h1 = [one(q) for q in qs[:n1]]
-    t_one = (time.perf_counter() - t0) / n1                     # seconds per query on one core
-    t0 = time.perf_counter()
-    g = fetch(0); O.Sketch([g]); t_sk1 = time.perf_counter() - t0  # seconds per sketch on one core
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        hall = list(ex.map(one, qs))
-    t_q_all = time.perf_counter() - t0
-    # extrapolation to the full n_refs x n_refs job
-    secs_1core = n_refs * t_sk1 + n_refs * t_one
-    secs_all = t_sketch_all + t_q_all * (n_refs / len(qs))
-    pairs = float(n_refs) * n_refs
-    return {"value": pairs / secs_1core, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
-            "sample": f"{len(qs)} of {n_refs} queries against all {n_refs} references ({sum(hall)} chained hits), every reference sketched once; "
-                      f"extrapolated linearly in queries to {n_refs} x {n_refs}; one core: {t_sk1 * 1e3:.1f} ms per sketch, {t_one:.2f} s per query ({n1} queries timed)",
-            "all_cores": {"value": pairs / secs_all, "cores": threads, "seconds_extrapolated": secs_all,
-                          "measured": {"sketch_all_refs_s": t_sketch_all, "queries_s": t_q_all, "queries": len(qs)}},
-            "note": "the repo's own C restatement (the Rust reference cannot be built here); flat arrays where skani uses hash maps: a conservative floor for the speed-up"}
-
-
-def cpu_baseline_metagenome(fetch_ref, n_cpu_refs, contigs, threads, faster_small):
-    """CPU oracle on a bounded sample of the metagenome workload: a database of the first n_cpu_refs references (sketched with all
-    cores, untimed like the GPU side's resident database), then every sampled contig as its own query (sketch + screen of every
-    reference + chaining of the shortlist): one core for the first few, all cores (one contig per thread) for all of them."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    O.build()
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        sk = list(ex.map(lambda i: O.Sketch([fetch_ref(i)], c=30, marker_c=200), range(n_cpu_refs)))
-    t_db = time.perf_counter() - t0
-
-    def one(c):
-        return O.query_count(sk, O.Sketch([c], c=30, marker_c=200), faster_small=faster_small)
-    n1 = min(16, len(contigs))
-    t0 = time.perf_counter()
-    h1 = [one(c) for c in contigs[:n1]]
-    t_one = (time.perf_counter() - t0) / n1
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        hall = list(ex.map(one, contigs))
-    t_all = time.perf_counter() - t0
-    return {"value": 1.0 / t_one, "unit": "queries/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
-            "sample": f"{len(contigs)} of the contigs, each its own query against a database of the first {n_cpu_refs} references only (a tenth of the GPU run's 5 000: "
-                      f"the CPU figure is flattered by it); {sum(hall)} hits; one core: {t_one * 1e3:.1f} ms per query ({n1} timed); database sketched in {t_db:.1f} s on {threads} threads (not counted)",
-            "all_cores": {"value": len(contigs) / t_all, "cores": threads, "seconds": t_all},
-            "note": "the repo's own C restatement (the Rust reference cannot be built here)"}
-
-
-def api_rates(psk, genomes, query):
-    """The drop-in path a pyskani user calls, from ASCII in HOST memory (SURVEY.md §8d 'Metric'):
-    (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query."""
-    out = {}
-    n = len(genomes)
-    for label, bulk in (("api", False), ("host_ascii", True), ("api", False), ("host_ascii", True)):   # second pass = warm
-        db = psk.Database()
-        t0 = time.perf_counter()
-        if bulk:
-            db.sketch_many([(f"r{i}", g) for i, g in enumerate(genomes)])
-        else:
-            for i, g in enumerate(genomes):
-                db.sketch(f"r{i}", g)
-        t1 = time.perf_counter()
-        hits = db.query("q", query, learned_ani=False)
-        t2 = time.perf_counter()
-        out[label] = {"pairs_per_s": n / (t2 - t0), "sketch_s": t1 - t0, "query_ms": (t2 - t1) * 1e3, "hits": len(hits),
-                      "host_GBps": sum(len(g) for g in genomes) / (t1 - t0) / 1e9}
-        del db
-    return out
 
 
 def make_big_genomes(torch, device, n_genomes, n_contigs, contig_len, fam_size, seed):
@@ -373,21 +155,688 @@ def make_contigs(torch, device, buf, offs, lens, n_refs, n_contigs, seed):
     return out, coffs, [int(x) for x in clen]
 
 
+# ------------------------------------------------------------------ the library, through its C-ABI
+class Engine:
+    """Thin driver over the C-ABI for device-resident genomes."""
+
+    def __init__(self, device, c=125, marker_c=1000, k=15):
+        from pyskani_amd import _capi
+        self.capi = _capi
+        self.lib = _capi.load()
+        self.ctx = C.c_void_p()
+        _capi.check(self.lib.psk_ctx_create(device, C.byref(self.ctx)))
+        self.params = _capi.Params(c, marker_c, k)
+        self.hit_dtype = np.dtype(_capi.Hit)
+
+    def close(self):
+        if self.ctx:
+            self.lib.psk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        self.capi.check(self.lib.psk_ctx_synchronize(self.ctx))
+
+    def clock_probe(self):
+        mhz, ms = C.c_double(), C.c_double()
+        self.capi.check(self.lib.psk_ctx_clock_probe(self.ctx, C.byref(mhz), C.byref(ms)))
+        return {"shader_clock_mhz": mhz.value, "probe_ms": ms.value,
+                "how": "fixed integer-VALU micro-kernel (v_alignbit_b32 chains, 4 cycles per wave64 instruction, 8 waves per SIMD) timed with HIP events just before the timed loop"}
+
+    def sketch_device(self, d_ptr, offs, lens, gfc=None):
+        n = len(gfc) - 1 if gfc is not None else len(offs)
+        nc = len(offs)
+        c_off = (C.c_uint64 * nc)(*offs); c_len = (C.c_uint64 * nc)(*lens)
+        g = (C.c_uint32 * (n + 1))(*(gfc if gfc is not None else range(n + 1)))
+        return self.sketch_device_c(d_ptr, c_off, c_len, g, n)
+
+    def layout(self, offs, lens, gfc=None):
+        """ctypes views of a constant genome layout, built once: they describe the resident input"""
+        n = len(gfc) - 1 if gfc is not None else len(offs)
+        nc = len(offs)
+        return ((C.c_uint64 * nc)(*offs), (C.c_uint64 * nc)(*lens), (C.c_uint32 * (n + 1))(*(gfc if gfc is not None else range(n + 1))), n)
+
+    def sketch_device_c(self, d_ptr, c_off, c_len, gfc, n):
+        out = (C.c_void_p * n)()
+        self.capi.check(self.lib.psk_sketch_batch_device(self.ctx, C.byref(self.params), C.c_void_p(d_ptr), c_off, c_len, gfc, n, 1, out))
+        return out
+
+    def make_db(self, names, handles, n):
+        db = C.c_void_p()
+        self.capi.check(self.lib.psk_db_create(self.ctx, C.byref(self.params), C.byref(db)))
+        self.capi.check(self.lib.psk_db_add_batch(db, names, handles, n))
+        return db
+
+    def query_many(self, db, handles, n, faster_small=False, keep=False):
+        """psk_query_many -> number of hits (keep=True: the psk_hit records and the per-query offsets as numpy arrays)"""
+        opts = self.capi.QueryOpts(0, 0, 0, int(faster_small), 0.0, 0.0, None)
+        hits_p = C.POINTER(self.capi.Hit)()
+        offsets = (C.c_uint64 * (n + 1))()
+        self.capi.check(self.lib.psk_query_many(db, handles, n, C.byref(opts), C.byref(hits_p), offsets))
+        nh = int(offsets[n])
+        recs = None
+        if keep:
+            recs = (np.frombuffer((self.capi.Hit * nh).from_address(C.addressof(hits_p.contents)), dtype=self.hit_dtype).copy() if nh else np.zeros(0, self.hit_dtype),
+                    np.frombuffer(offsets, dtype=np.uint64).astype(np.int64))
+        if hits_p:
+            self.lib.psk_free(hits_p)
+        return (nh, recs) if keep else nh
+
+    def query_one(self, db, handle):
+        opts = self.capi.QueryOpts(0, 0, 0, 0, 0.0, 0.0, None)
+        hits_p = C.POINTER(self.capi.Hit)()
+        nh = C.c_uint64(0)
+        self.capi.check(self.lib.psk_query(db, handle, C.byref(opts), C.byref(hits_p), C.byref(nh)))
+        recs = np.frombuffer((self.capi.Hit * nh.value).from_address(C.addressof(hits_p.contents)), dtype=self.hit_dtype).copy() if nh.value else np.zeros(0, self.hit_dtype)
+        if hits_p:
+            self.lib.psk_free(hits_p)
+        return recs
+
+    def timing(self, kernel):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self.capi.check(self.lib.psk_ctx_timing(self.ctx, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def work(self, reset=False):
+        p, i, a = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.capi.check(self.lib.psk_ctx_work(self.ctx, C.byref(p), C.byref(i), C.byref(a), int(reset)))
+        return {"chained_pairs": p.value, "items": i.value, "anchors": a.value}
+
+
+def timed_loop(eng, step, steps, warmup, fence):
+    """W untimed warm-up steps, the clock probe, then EXACTLY K timed steps bracketed by fence() on both sides. Returns seconds,
+    the last step's result, per-kernel HIP-event ms per step + launch counts, chain-stage work per step, and the clock record."""
+    res = None
+    for _ in range(warmup):
+        res = step()
+    clock = eng.clock_probe()
+    eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 1))
+    eng.timing("reset")
+    eng.work(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern = {k: eng.timing(k) for k in KERNELS}
+    eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
+    work = {k: v / max(1, steps) for k, v in eng.work(reset=True).items()}
+    return dt, res, kern, work, clock
+
+
+def load_pmc():
+    """offline counter passes (rocprofv3 --pmc, separate runs; profiles/scripts/pmc_summary.py writes the JSON): HBM bytes per unit
+    of every profiled kernel, {timer name: {"bytes_per_unit": x, "unit": "base" | "item" | "anchor", "source": ...}}"""
+    out = {}
+    for rel in ("profiles/r2/r2n_pmc_sketch_scan.json", "profiles/r3/pmc_kernels.json"):
+        p = os.path.join(ROOT, rel)
+        if not os.path.exists(p):
+            continue
+        d = json.load(open(p))
+        if "traffic_bytes_per_base" in d:      # round-2 format: sketch_scan only
+            out["sketch_scan"] = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": rel, "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
+        else:
+            for k, v in d.items():
+                out[k] = dict(v, source=rel)
+    return out
+
+
+def kernel_rooflines(kern, steps, units, pmc):
+    """Per-kernel roofline table of one workload. `units` = per STEP {bases, c, marker_c, items, anchors}. ALGORITHMIC bytes (DESIGN.md §4,
+    SURVEY.md §8d B_sk / B_ch terms):
+       sketch_scan   L (ASCII read) + L/4 (2-bit packed write)                                    per base
+       sketch_emit   L/8 (seed mask) + L/4 (packed read) + 20 L/c (seed records) + 8 L/marker_c   per base
+       anchor        8 B (query k-mer + its position order) read + 8 B record written             per (pair, query seed) item
+       anchor_emit   8 B record read per item + 16 B anchor written per anchor
+       chain_chunk   16 B per anchor read (the DP; its candidates are a few bytes per chunk)
+    Kernels without a stated byte count (screen, select, pair_reduce, the sorts) are reported as time only."""
+    bases, items, anchors = units["bases"], units.get("items", 0.0), units.get("anchors", 0.0)
+    alg = {"sketch_scan": (1.25 * bases, "L + L/4 per base"),
+           "sketch_emit": ((0.125 + 0.25 + 20.0 / units["c"] + 8.0 / units["marker_c"]) * bases, "L/8 + L/4 + 20 L/c + 8 L/marker_c per base"),
+           "anchor": (16.0 * items, "16 B per (pair, query seed) item"),
+           "anchor_emit": (8.0 * items + 16.0 * anchors, "8 B per item + 16 B per anchor"),
+           "chain_chunk": (16.0 * anchors, "16 B per anchor")}
+    unit_of = {"sketch_scan": ("base", bases), "sketch_emit": ("base", bases), "anchor": ("item", items), "anchor_emit": ("item", items), "chain_chunk": ("anchor", anchors)}
+    table = {}
+    for k in KERNELS:
+        ms_total, launches = kern[k]
+        ms_step = ms_total / max(1, steps)
+        row = {"ms_per_step": ms_step, "launches_per_step": launches / max(1, steps)}
+        if k in alg and alg[k][0] > 0 and ms_step > 0:
+            b = alg[k][0]
+            row.update(algorithmic_bytes_per_step=b, bytes=alg[k][1], achieved_GBps=b / (ms_step * 1e-3) / 1e9, frac_of_hbm_peak=b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            pm = pmc.get(k)
+            if pm and pm.get("unit") == unit_of[k][0]:
+                row["traffic_bytes_per_step"] = pm["bytes_per_unit"] * unit_of[k][1]
+                row["traffic_source"] = f"offline rocprofv3 --pmc pass ({pm['source']}), scaled by {unit_of[k][0]}s"
+        table[k] = row
+    return table
+
+
+def roofline_of(table, steps, prefer=None):
+    """The `roofline` object of a line: the dominant kernel among those with an algorithmic byte count (or `prefer`)."""
+    cands = [k for k, r in table.items() if "algorithmic_bytes_per_step" in r]
+    if not cands:
+        return None
+    k = prefer if prefer in cands else max(cands, key=lambda x: table[x]["ms_per_step"])
+    r = table[k]
+    launches = max(1.0, r["launches_per_step"])
+    top = max(table, key=lambda x: table[x]["ms_per_step"])
+    out = {"kernel": k, "bound": "hbm", "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_of_hbm_peak"],
+           "traffic": r.get("traffic_bytes_per_step", None) and r["traffic_bytes_per_step"] / launches,
+           "traffic_source": r.get("traffic_source"),
+           "avg_launch_ms": r["ms_per_step"] / launches, "launches": int(round(launches * steps)),
+           "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_step"] / launches, "bytes": r["bytes"]}
+    if top != k:
+        out["note"] = f"largest timed bracket of the step is '{top}' ({table[top]['ms_per_step']:.2f} ms), which has no stated HBM byte count (sort / LDS-latency work); '{k}' is the largest kernel that has one"
+    return out
+
+
+# ------------------------------------------------------------------ CPU baselines (the oracle: test infrastructure, used here as the checker's clock)
+def cpu_baseline_search(fetch, n_sample, threads):
+    """The CPU oracle on 1 query vs the first n_sample references. `fetch(i)` returns genome i's bytes (i = -1: the query); only
+    oracle time is counted. ONE core (a pyskani call is single-threaded, lib.rs:493,569) and ALL host cores with one reference per
+    thread (what a user gets from the GIL release) — ctypes drops the GIL, so plain threads scale."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    genomes = [fetch(i) for i in range(n_sample)]
+    gq = fetch(-1)
+    t0 = time.perf_counter()
+    q = O.Sketch([gq])
+    refs = [(str(i), O.Sketch([g])) for i, g in enumerate(genomes)]
+    hits = O.query(refs, q)
+    secs1 = time.perf_counter() - t0
+    del refs
+
+    def one(i):
+        r = O.Sketch([genomes[i]])
+        return O.query_count([r], q)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        nh = sum(ex.map(one, range(n_sample)))
+    secs_all = time.perf_counter() - t0
+    assert nh == len(hits)
+    return {"value": n_sample / secs1, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+            "sample": f"1 query vs the first {n_sample} refs of the same workload (sketch {n_sample + 1} genomes + {n_sample} screens + {len(hits)} chained hits), {secs1:.1f} s of oracle time",
+            "all_cores": {"value": n_sample / secs_all, "cores": threads, "seconds": secs_all,
+                          "how": "same sample, one reference (sketch + screen + chain) per thread over every hardware thread of the host"},
+            "note": PORT_NOTE}
+
+
+def cpu_baseline_allvsall(fetch, n_refs, n_queries, threads):
+    """CPU oracle on a SUB-SAMPLE of the all-vs-all workload (sub-sample configs 3-5 and extrapolate linearly in
+    pairs): every reference is sketched once (all cores), then n_queries of them are queried against all n_refs (screen every
+    reference, chain the shortlist). One-core figure from the first few queries alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        sk = list(ex.map(lambda i: O.Sketch([fetch(i)]), range(n_refs)))
+    t_sketch_all = time.perf_counter() - t0
+    step = max(1, n_refs // n_queries)
+    qs = list(range(0, n_refs, step))[:n_queries]
+
+    def one(qi):      # screen every reference + chain the shortlist, one C call (the interpreter lock is released inside)
+        return O.query_count(sk, sk[qi])
+    n1 = min(4, len(qs))
+    t0 = time.perf_counter()
+    [one(q) for q in qs[:n1]]
+    t_one = (time.perf_counter() - t0) / n1                     # seconds per query on one core
+    t0 = time.perf_counter()
+    O.Sketch([fetch(0)]); t_sk1 = time.perf_counter() - t0       # seconds per sketch on one core
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        hall = list(ex.map(one, qs))
+    t_q_all = time.perf_counter() - t0
+    secs_1core = n_refs * t_sk1 + n_refs * t_one                # extrapolation to the full n_refs x n_refs job
+    secs_all = t_sketch_all + t_q_all * (n_refs / len(qs))
+    pairs = float(n_refs) * n_refs
+    return {"value": pairs / secs_1core, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{len(qs)} of {n_refs} queries against all {n_refs} references ({sum(hall)} chained hits), every reference sketched once; "
+                      f"extrapolated linearly in queries to {n_refs} x {n_refs}; one core: {t_sk1 * 1e3:.1f} ms per sketch, {t_one:.2f} s per query ({n1} queries timed)",
+            "all_cores": {"value": pairs / secs_all, "cores": threads, "seconds_extrapolated": secs_all,
+                          "measured": {"sketch_all_refs_s": t_sketch_all, "queries_s": t_q_all, "queries": len(qs)}},
+            "note": PORT_NOTE}
+
+
+def cpu_baseline_metagenome(fetch_ref, n_cpu_refs, n_refs, contigs, threads, faster_small):
+    """CPU oracle on a bounded sample of the metagenome workload: a database of the first n_cpu_refs references (sketched with all
+    cores, untimed like the GPU side's resident database), then every sampled contig as its own query (sketch + screen of every
+    reference + chaining of the shortlist): one core for the first few, all cores (one contig per thread) for all of them."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        sk = list(ex.map(lambda i: O.Sketch([fetch_ref(i)], c=30, marker_c=200), range(n_cpu_refs)))
+    t_db = time.perf_counter() - t0
+
+    def one(c):
+        return O.query_count(sk, O.Sketch([c], c=30, marker_c=200), faster_small=faster_small)
+    n1 = min(16, len(contigs))
+    t0 = time.perf_counter()
+    [one(c) for c in contigs[:n1]]
+    t_one = (time.perf_counter() - t0) / n1
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        hall = list(ex.map(one, contigs))
+    t_all = time.perf_counter() - t0
+    return {"value": 1.0 / t_one, "unit": "queries/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{len(contigs)} of the contigs, each its own query against a database of the first {n_cpu_refs} of the {n_refs} references "
+                      f"(the CPU figure is flattered by the smaller database); {sum(hall)} hits; one core: {t_one * 1e3:.1f} ms per query ({n1} timed); "
+                      f"database sketched in {t_db:.1f} s on {threads} threads (not counted)",
+            "all_cores": {"value": len(contigs) / t_all, "cores": threads, "seconds": t_all},
+            "note": PORT_NOTE}
+
+
+def api_rates(psk, genomes, query):
+    """The drop-in path a pyskani user calls, from ASCII in HOST memory (SURVEY.md §8d 'Metric'):
+    (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query."""
+    out = {}
+    n = len(genomes)
+    for label, bulk in (("api", False), ("host_ascii", True), ("api", False), ("host_ascii", True)):   # second pass = warm
+        db = psk.Database()
+        t0 = time.perf_counter()
+        if bulk:
+            db.sketch_many([(f"r{i}", g) for i, g in enumerate(genomes)])
+        else:
+            for i, g in enumerate(genomes):
+                db.sketch(f"r{i}", g)
+        t1 = time.perf_counter()
+        hits = db.query("q", query, learned_ani=False)
+        t2 = time.perf_counter()
+        out[label] = {"pairs_per_s": n / (t2 - t0), "sketch_s": t1 - t0, "query_ms": (t2 - t1) * 1e3, "hits": len(hits),
+                      "host_GBps": sum(len(g) for g in genomes) / (t1 - t0) / 1e9}
+        del db
+    return out
+
+
+# ------------------------------------------------------------------ workloads
+class Job:
+    """what every workload runner needs: torch, the device, the distributed state, the arguments"""
+
+    def __init__(self, torch, device, local_rank, rank, world, dist, coll_device, args):
+        self.torch, self.device, self.local_rank, self.rank, self.world, self.dist, self.coll_device, self.args = torch, device, local_rank, rank, world, dist, coll_device, args
+        self.pmc = load_pmc()
+
+    def fence(self, eng):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        eng.sync()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], device=self.coll_device, dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+
+def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
+    """BASELINE configs[1]: 1 query vs n_refs references per GPU (weak scaling for N>1: every rank holds its own n_refs)."""
+    torch, rank, world = job.torch, job.rank, job.world
+    anc_lens, fam_of = family_layout(2, n_refs, N_FAMILIES)
+    buf, offs, lens = make_genomes(torch, job.device, 2, 1000 * rank + 3, list(range(n_refs)), fam_of, anc_lens, query_family=0)
+    torch.cuda.synchronize()
+    eng = Engine(job.local_rank)
+    names = (C.c_char_p * n_refs)(*[f"r{rank}_{i}".encode() for i in range(n_refs)])
+    c_off, c_len, gfc, n = eng.layout(offs, lens)
+    comm = None
+    if world > 1:
+        from pyskani_amd import parallel
+        if job.args.comm == "capi":
+            from pyskani_amd.database import Context
+            shim = Context.__new__(Context); shim._lib, shim._h = eng.lib, eng.ctx
+            comm = parallel.CapiComm(shim, job.dist)
+        else:
+            comm = parallel.TorchComm(job.dist, None, job.coll_device)
+
+    def step():
+        out = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, n)
+        db = eng.make_db(names, out, n - 1)
+        try:
+            recs = eng.query_one(db, out[n - 1])
+        finally:
+            eng.lib.psk_sketch_free(out[n - 1])
+            eng.lib.psk_db_destroy(db)
+        if comm is not None:   # exchange step: all-gather of the per-shard hit records (RCCL over xGMI), global reference indices
+            recs["ref_index"] += rank * n_refs
+            recs, _ = comm.gather_hit_records(recs)
+        return len(recs)
+
+    dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+    dt = job.max_over_ranks(dt)
+    line = None
+    if rank == 0:
+        bases = float(sum(lens))
+        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+        roof = roofline_of(table, steps, prefer="sketch_scan")
+        pm = job.pmc.get("sketch_scan")
+        if pm and "valu_per_base" in pm and roof:
+            # VALU issue: SQ_INSTS_VALU per base measured offline (26.8 wave-instructions per 64 bases, 61 % four-cycle and 39 % two-cycle by
+            # profiles/micro/valu_rates.hip = 3.2 cycles on average), launch duration measured live, clock probed live
+            insts = pm["valu_per_base"] * bases / max(1.0, table["sketch_scan"]["launches_per_step"])
+            avg_s = roof["avg_launch_ms"] * 1e-3
+            roof["valu"] = {"valu_issue_frac_at_probed_clock": insts * 3.2 / (avg_s * clock["shader_clock_mhz"] * 1e6 * 1024) if avg_s > 0 and clock["shader_clock_mhz"] > 0 else None,
+                            "valu_issue_frac_at_2p4GHz": insts * 3.2 / (avg_s * 2.4e9 * 1024) if avg_s > 0 else None,
+                            "valu_wave_instructions_per_launch": insts,
+                            "source": f"SQ_INSTS_VALU measured offline ({pm['source']}), cycle classes from profiles/micro/valu_rates.hip; launch duration and clock measured live"}
+            roof["note"] = ("priced against HBM as the contract asks; the kernel's real roof is integer VALU issue (one 64-bit mix per base: "
+                            "15 four-cycle + 7 two-cycle wave instructions per base, DESIGN.md section 4): see valu")
+        line = {
+            "metric": "genome-pairs/sec (sketch+ANI)", "value": n_refs * world * steps / dt, "unit": "genome-pairs/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
+                       "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)" + (f", hit lists all-gathered ({job.args.comm})" if world > 1 else "")},
+            "roofline": roof, "clock": clock,
+            "kernel_ms_per_step": {k: table[k]["ms_per_step"] for k in KERNELS},
+            "extras": {"genomes_sketched_per_s": (n_refs + 1) * world * steps / dt, "bases_sketched_per_s": bases * world * steps / dt,
+                       "reported_hits_per_step": int(n_hits), "chain_work_per_step": work},
+        }
+        if world == 1 and (cpu_sample > 0 or with_api):
+            host = buf.cpu().numpy()
+            fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
+            if with_api:
+                import pyskani_amd as psk
+                r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
+                line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"],
+                                      api_detail=r["api"], host_ascii_detail=r["host_ascii"],
+                                      api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
+                                               "api = n x sketch() + query(); host_ascii = sketch_many() (pinned, double-buffered H2D pipeline) + query()")
+            if cpu_sample > 0:
+                line["cpu_baseline"] = cpu_baseline_search(fetch, min(cpu_sample, n_refs), os.cpu_count() or 1)
+            del host
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
+    del buf
+    eng.close()
+    torch.cuda.empty_cache()
+    return line
+
+
+def records_digest(recs):
+    """order-independent-free digest of a sorted hit-record array: (query, ref, the three floats' bits, the chain integers)"""
+    h = hashlib.sha256()
+    for f in ("reserved", "ref_index", "ani", "af_query", "af_ref", "n_anchors", "n_chunks", "covered_query", "sum_chain_anchors", "sum_chunk_seeds"):
+        h.update(np.ascontiguousarray(recs[f]).tobytes())
+    return h.hexdigest()[:16]
+
+
+def run_allvsall(job, steps, warmup, n_total, cpu_queries):
+    """BASELINE configs[2] shape: every genome against a database of all of them (families of 100). N=1: one psk_query_many. N>1: the
+    FIXED job of n_total genomes is sharded over the ranks (strong scaling) and run through parallel.ShardedDatabase.all_vs_all_records."""
+    torch, rank, world, args = job.torch, job.rank, job.world, job.args
+    n_families = max(1, n_total // 100)
+    anc_lens, fam_of = family_layout(3, n_total, n_families)
+    from pyskani_amd.parallel import shard_bounds
+    lo, hi = shard_bounds(n_total, rank, world)
+    n_local = hi - lo
+    buf, offs, lens = make_genomes(torch, job.device, 3, 31, list(range(lo, hi)), fam_of, anc_lens)
+    torch.cuda.synchronize()
+    all_names = [f"g{i}" for i in range(n_total)]
+    bases_local = float(sum(lens))
+    line = None
+    if world == 1:
+        eng = Engine(job.local_rank)
+        names = (C.c_char_p * n_total)(*[s.encode() for s in all_names])
+        c_off, c_len, gfc, n = eng.layout(offs, lens)
+        last = {}
+
+        def step():
+            out = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, n)
+            db = eng.make_db(names, out, n)
+            try:
+                nh, (recs, qoffs) = eng.query_many(db, out, n, keep=True)
+                last["recs"], last["offs"] = recs, qoffs
+                return nh
+            finally:
+                eng.lib.psk_db_destroy(db)
+        dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+        recs = last["recs"]
+        recs["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(last["offs"]))
+        digest = records_digest(recs)
+        table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc)
+        line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
+                "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}), c=125 marker_c=1000 k=15",
+                "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
+                "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
+        if cpu_queries > 0:
+            host = buf.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline_allvsall(lambda i: host[offs[i]:offs[i] + lens[i]].tobytes(), n_total, min(cpu_queries, n_total), os.cpu_count() or 1)
+            del host
+        eng.close()
+    else:
+        import pyskani_amd as psk
+        from pyskani_amd.parallel import ShardedDatabase
+        # the timed step builds a fresh local Database every time (nothing cached): sketch the shard, load it, exchange + query
+        from pyskani_amd import parallel
+        from pyskani_amd.database import default_context
+        ctx = default_context(job.local_rank)
+        comm = parallel.CapiComm(ctx, job.dist) if args.comm == "capi" else parallel.TorchComm(job.dist, None, job.coll_device)      # made once, reused by every step
+        state = {}
+
+        def step():
+            sent0 = comm.bytes_sent
+            db = psk.Database(device=job.local_rank)
+            db.sketch_many_device(all_names[lo:hi], buf.data_ptr(), offs, lens)
+            sdb = ShardedDatabase(job.dist, local=db, device=job.device, comm=comm)
+            sdb.adopt_local(all_names)
+            recs = sdb.all_vs_all_records(batch=args.exchange_batch, learned_ani=False)
+            state["stats"], state["bytes_sent"], state["recs"] = dict(sdb.stats), comm.bytes_sent - sent0, recs
+            return len(recs)
+        eng = Engine.__new__(Engine)      # the timers / counters of the Database's own context
+        from pyskani_amd import _capi
+        eng.capi, eng.lib, eng.ctx, eng.hit_dtype = _capi, ctx._lib, ctx._h, np.dtype(_capi.Hit)
+        dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+        dt = job.max_over_ranks(dt)
+        if rank == 0:
+            st = state["stats"]
+            other = st["total_s"] - st["psk_s"] - st["collective_s"]
+            table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc)
+            line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
+                    "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15; "
+                                f"query side = all-gather of the shards' packed sketch records, {args.exchange_batch} genomes per rank and round; hit records all-gathered once ({args.comm})",
+                    "hits": int(n_hits), "hits_digest": records_digest(state["recs"]), "scaling": "strong",
+                    "exchange": {"bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
+                                 "python_s_last_step": other, "all_vs_all_s_last_step": st["total_s"],
+                                 "outside_psk_and_collectives_frac": other / st["total_s"] if st["total_s"] > 0 else None,
+                                 "note": "rank 0's split of the last step's ShardedDatabase.all_vs_all_records call (sketching the shard and loading the database come before it)"},
+                    "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "chain_work_per_step_rank0": work}
+        if hasattr(comm, "close"):
+            comm.close()
+    del buf
+    torch.cuda.empty_cache()
+    return line
+
+
+def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs, api_queries):
+    """BASELINE configs[3]: n_queries contigs against a RESIDENT database of n_refs references, c=30 marker_c=200. One entry per
+    `faster_small` setting in `settings`; the database and the contigs are built once."""
+    torch, args = job.torch, job.args
+    n_families = max(1, n_refs // 100)
+    anc_lens, fam_of = family_layout(4, n_refs, n_families)
+    buf, offs, lens = make_genomes(torch, job.device, 4, 41 + 1000 * job.rank, list(range(n_refs)), fam_of, anc_lens)
+    torch.cuda.synchronize()
+    eng = Engine(job.local_rank, 30, 200)
+    names = (C.c_char_p * n_refs)(*[f"r{i}".encode() for i in range(n_refs)])
+    t0 = time.perf_counter()
+    handles = eng.sketch_device(buf.data_ptr(), offs, lens)
+    db = eng.make_db(names, handles, n_refs)
+    eng.sync()
+    db_build_s = time.perf_counter() - t0
+    cbuf, coffs, clens = make_contigs(torch, job.device, buf, offs, lens, n_refs, n_queries, seed=4 + job.rank)
+    torch.cuda.synchronize()
+    c_off, c_len, gfc, nq = eng.layout(coffs, clens)
+    bases = float(sum(clens))
+    out = {}
+    for faster_small in settings:
+        def step():   # sketch every contig, query them all against the resident database
+            qh = eng.sketch_device_c(cbuf.data_ptr(), c_off, c_len, gfc, nq)
+            try:
+                return eng.query_many(db, qh, nq, faster_small)
+            finally:
+                for h in qh:
+                    eng.lib.psk_sketch_free(h)
+        dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+        dt = job.max_over_ranks(dt)
+        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 30, "marker_c": 200, **work}, job.pmc)
+        entry = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": n_queries * job.world * steps / dt, "unit": "queries/s",
+                 "pairs_per_s": float(n_queries) * n_refs * job.world * steps / dt,
+                 "workload": f"metagenome: {n_queries} contigs (2-50 kb, log-uniform, 0-5 % divergence) vs a resident database of {n_refs} synthetic ~5 Mb refs ({n_families} families), "
+                             f"c=30 marker_c=200 k=15, faster_small={faster_small}; a step = sketch every contig + psk_query_many + hits to host",
+                 "hits": int(n_hits), "chain_work_per_step": work, "db_build_s": db_build_s,
+                 "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock}
+        if job.world == 1 and cpu_contigs > 0 and job.rank == 0:
+            n_cpu_refs = min(n_refs, 500)
+            href = buf[:offs[n_cpu_refs - 1] + lens[n_cpu_refs - 1]].cpu().numpy()
+            k = min(cpu_contigs, n_queries)
+            chost0 = cbuf[:coffs[k - 1] + clens[k - 1]].cpu().numpy()
+            sample = [chost0[coffs[i]:coffs[i] + clens[i]].tobytes() for i in range(k)]
+            entry["cpu_baseline"] = cpu_baseline_metagenome(lambda i: href[offs[i]:offs[i] + lens[i]].tobytes(), n_cpu_refs, n_refs, sample, os.cpu_count() or 1, faster_small)
+            del href, chost0
+        out["faster_small" if faster_small else "rescue"] = entry
+    if job.world == 1 and api_queries > 0 and job.rank == 0:
+        out["api"] = metagenome_api(job, buf, offs, lens, n_refs, cbuf, coffs, clens, min(api_queries, n_queries), settings[0])
+    eng.lib.psk_db_destroy(db)
+    del buf, cbuf
+    eng.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def metagenome_api(job, buf, offs, lens, n_refs, cbuf, coffs, clens, nq, faster_small):
+    """the same contigs ONE AT A TIME through the pyskani-shaped API, from host bytes: Database.query(name, contig) — the call SURVEY.md
+    §8d config 4 specifies — from one host thread and from eight (the reference's query() releases the GIL: threads are its route to
+    concurrency; here every thread's call runs on its own lane of the context), and one Database.query_many for all of them"""
+    import threading
+    import pyskani_amd as psk
+    host = buf.cpu().numpy()
+    pdb = psk.Database(compression=30, marker_compression=200, device=job.local_rank)
+    t0 = time.perf_counter()
+    pdb.sketch_many([(f"r{i}", host[offs[i]:offs[i] + lens[i]].tobytes()) for i in range(n_refs)])
+    t_load = time.perf_counter() - t0
+    del host
+    chost = cbuf[:coffs[nq - 1] + clens[nq - 1]].cpu().numpy()
+    contigs = [chost[coffs[i]:coffs[i] + clens[i]].tobytes() for i in range(nq)]
+    for c in contigs[:20]:
+        pdb.query("w", c, learned_ani=False, faster_small=faster_small)
+    t0 = time.perf_counter()
+    nh = sum(len(pdb.query(f"c{i}", c, learned_ani=False, faster_small=faster_small)) for i, c in enumerate(contigs))
+    t_q = time.perf_counter() - t0
+
+    def _work(lo, hi):
+        for i in range(lo, hi):
+            pdb.query(f"c{i}", contigs[i], learned_ani=False, faster_small=faster_small)
+    th = [threading.Thread(target=_work, args=(k * nq // 8, (k + 1) * nq // 8)) for k in range(8)]
+    t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; t_q8 = time.perf_counter() - t0
+    many = pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=faster_small)
+    assert sum(len(h) for h in many) == nh
+    t0 = time.perf_counter()
+    pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=faster_small)
+    t_many = time.perf_counter() - t0
+    del pdb
+    return {"queries": nq, "api_queries_per_s": nq / t_q, "api_query_ms": t_q / nq * 1e3, "api_queries_per_s_8_threads": nq / t_q8, "api_query_many_per_s": nq / t_many,
+            "api_db_load_s": t_load, "api_hits": nh, "faster_small": faster_small,
+            "note": f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig (from one host thread, and from eight), and one Database.query_many() for all of them"}
+
+
+def run_mammalian(job, steps, warmup, n_genomes, contig_mb, verify_pairs):
+    """BASELINE configs[4] shape at reduced count: all-vs-all of n_genomes genomes of 24 x contig_mb Mb contigs (families of 4). Outside
+    the timed region, `verify_pairs` of the chained pairs are recomputed by the CPU oracle and every integer of the chain is compared;
+    the oracle's time for them is the CPU baseline."""
+    torch = job.torch
+    buf, offs, lens, gfc = make_big_genomes(torch, job.device, n_genomes, 24, contig_mb * 1_000_000, 4, seed=5 + job.rank)
+    torch.cuda.synchronize()
+    eng = Engine(job.local_rank)
+    names = (C.c_char_p * n_genomes)(*[f"m{i}".encode() for i in range(n_genomes)])
+    c_off, c_len, c_gfc, n = eng.layout(offs, lens, gfc)
+    last = {}
+
+    def step():     # sketch every genome, load the database, every genome against all of them
+        handles = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, c_gfc, n)
+        db = eng.make_db(names, handles, n)
+        try:
+            nh, (recs, qoffs) = eng.query_many(db, handles, n, keep=True)
+            last["recs"], last["offs"] = recs, qoffs
+            return nh
+        finally:
+            eng.lib.psk_db_destroy(db)
+    dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+    dt = job.max_over_ranks(dt)
+    bases = float(sum(lens))
+    table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+    entry = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_genomes) * n_genomes * job.world * steps / dt, "unit": "genome-pairs/s",
+             "workload": f"mammalian scale (BASELINE configs[4] shape at reduced count): all-vs-all of {n_genomes} synthetic genomes of 24 x {contig_mb} Mb contigs "
+                         f"({24 * contig_mb / 1000:.1f} Gb each; families of 4, substitution rates {DIVERGENCE[:4]}), c=125 marker_c=1000 k=15",
+             "hits": int(n_hits), "chain_work_per_step": work, "bases_sketched_per_s": bases * job.world * steps / dt,
+             "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock}
+    if job.rank == 0 and verify_pairs > 0 and n_hits:
+        entry["oracle_check"], entry["cpu_baseline"] = mammalian_verify(buf, offs, lens, gfc, last["recs"], last["offs"], n_genomes, verify_pairs, int(n_hits))
+    del buf
+    eng.close()
+    torch.cuda.empty_cache()
+    return entry
+
+
+def mammalian_verify(buf, offs, lens, gfc, recs, qoffs, n_genomes, verify_pairs, n_hits):
+    """Two genomes of one family -> host -> oracle sketches -> oracle.chain for the ordered pairs between them; the hits of the last
+    timed step must carry the same integers. Returns (check record, cpu_baseline extrapolated from the oracle's times)."""
+    from oracle import oracle as O
+    O.build()
+    qa, qb = 0, 1                       # two members of family 0
+    t0 = time.perf_counter()
+    contigs = {g: [buf[offs[c]:offs[c] + lens[c]].cpu().numpy().tobytes() for c in range(gfc[g], gfc[g + 1])] for g in (qa, qb)}
+    t_copy = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sk = {g: O.Sketch(contigs[g]) for g in (qa, qb)}
+    t_sketch = (time.perf_counter() - t0) / 2
+    del contigs
+    fields = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+    checked, t_chain = [], 0.0
+    for q, r in ((qa, qb), (qb, qa))[:verify_pairs]:
+        t0 = time.perf_counter()
+        want = O.chain(sk[r], sk[q])
+        t_chain += time.perf_counter() - t0
+        mine = recs[qoffs[q]:qoffs[q + 1]]
+        hit = mine[mine["ref_index"] == r]
+        assert len(hit) == 1, f"pair ({q}, {r}) is missing from the GPU hits"
+        for f in fields:
+            assert int(hit[0][f]) == int(getattr(want, f)), (q, r, f, int(hit[0][f]), int(getattr(want, f)))
+        assert abs(float(hit[0]["ani"]) - want.ani) < 1e-6 and abs(float(hit[0]["af_query"]) - want.af_query) < 1e-6
+        checked.append({"query": q, "ref": r, "ani": float(hit[0]["ani"]), "n_anchors": int(hit[0]["n_anchors"]), "n_chunks": int(hit[0]["n_chunks"])})
+    t_chain /= max(1, len(checked))
+    secs = n_genomes * t_sketch + n_hits * t_chain      # screens are negligible at this scale
+    check = {"pairs": checked, "fields": list(fields) + ["ani (1e-6)", "af_query (1e-6)"], "result": "bit-exact integers", "d2h_copy_s": t_copy}
+    cpu = {"value": float(n_genomes) * n_genomes / secs, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+           "sample": f"2 of the {n_genomes} genomes sketched ({t_sketch:.1f} s each) and {len(checked)} of the {n_hits} chained pairs ({t_chain:.1f} s each) by the oracle on one core; "
+                     f"extrapolated to {n_genomes} sketches + {n_hits} chains = {secs:.0f} s",
+           "note": PORT_NOTE}
+    return check, cpu
+
+
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--refs", type=int, default=None, help="references per GPU (search / allvsall default 1000 = BASELINE configs[1]; metagenome default 5000)")
+    ap.add_argument("--refs", type=int, default=None, help="search: references per GPU (default 1000 = BASELINE configs[1]); allvsall: TOTAL genomes of the job (default 1000); metagenome: database size (default 5000); mammalian: genomes (default 8)")
     ap.add_argument("--workload", choices=["search", "allvsall", "metagenome", "mammalian"], default="search",
-                    help="search = BASELINE configs[1] (the headline); allvsall = configs[2] shape on this GPU's genomes; metagenome = configs[3] shape (extras, not the headline)")
+                    help="search = BASELINE configs[1] (the headline, with the other configurations under extras.workloads at N=1); the others run alone as the line")
+    ap.add_argument("--no-workloads", action="store_true", help="search at N=1: skip extras.workloads (all-vs-all 10k, metagenome 100k, mammalian 8 x 3 Gb)")
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
     ap.add_argument("--contig-mb", type=int, default=125, help="mammalian: contig length in Mb (24 contigs per genome; 125 = 3 Gb genomes)")
     ap.add_argument("--api-queries", type=int, default=2000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
+    ap.add_argument("--comm", choices=["torch", "capi"], default="torch", help="N>1: who moves the exchange steps — torch.distributed, or the library's own RCCL communicator (psk_comm_*)")
+    ap.add_argument("--exchange-batch", type=int, default=256, help="allvsall N>1: genomes per rank and round of the sketch all-gather")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
-    ap.add_argument("--cpu-sample", type=int, default=1000, help="references in the CPU-baseline sample (0 = skip); 1000 = the whole workload, ~10-20 s")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="CPU-baseline sample size (0 = skip): search: references (1000 = the whole workload, ~10-20 s); allvsall: queries (capped at 128); metagenome: contigs (capped at 512)")
     ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
     args = ap.parse_args()
 
@@ -413,218 +862,49 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    job = Job(torch, device, local_rank, rank, world, dist, coll_device, args)
+    cpu_n = args.cpu_sample if world == 1 else 0
 
-    n_refs = args.refs if args.refs is not None else (5000 if args.workload == "metagenome" else (8 if args.workload == "mammalian" else N_REFS))
-    n_families = N_FAMILIES if args.workload == "search" else max(1, n_refs // 100)     # families of 100 for configs 3-4
-    big = None
-    if args.workload == "mammalian":      # BASELINE configs[4] shape at reduced count: n_refs genomes of 24 contigs, families of 4, all-vs-all
-        big = make_big_genomes(torch, device, n_refs, 24, args.contig_mb * 1_000_000, 4, seed=5 + rank)
-        buf, offs, lens = big[0], big[1], big[2]
+    def as_line(entry, workload, extra_cfg=None):
+        """a non-headline workload run alone: its entry re-shaped into the contract's line"""
+        pairs_value = entry.get("pairs_per_s", entry["value"]) if entry["unit"] != "genome-pairs/s" else entry["value"]
+        line = {"metric": "genome-pairs/sec (sketch+ANI)", "value": pairs_value, "unit": "genome-pairs/s", "n_gpus": world, "steps": entry["steps"], "warmup": entry["warmup"],
+                "ms_per_step": entry["ms_per_step"], "higher_is_better": True, "scaling": entry.get("scaling", "weak"), "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": dict({"workload": entry["workload"], "hits": entry["hits"]}, **(extra_cfg or {})),
+                "roofline": entry["roofline"], "clock": entry["clock"], "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in entry["kernel_roofline"].items()},
+                "extras": {k: v for k, v in entry.items() if k not in ("roofline", "clock", "cpu_baseline", "workload", "ms_per_step", "steps", "warmup", "value", "unit", "hits")}}
+        if "cpu_baseline" in entry:
+            line["cpu_baseline"] = entry["cpu_baseline"]
+        return line
+
+    line = None
+    if args.workload == "search":
+        line = run_search(job, args.steps, args.warmup, args.refs or N_REFS, cpu_n, with_api=(world == 1 and not args.no_api))
+        if world == 1 and not args.no_workloads:
+            t0 = time.perf_counter()
+            wl = {}
+            wl["allvsall_10k"] = run_allvsall(job, 2, 1, 10000, min(cpu_n, 128))
+            meta = run_metagenome(job, 2, 1, 5000, 100000, (False, True), min(cpu_n, 512), 2000)
+            wl["metagenome_100k"], wl["metagenome_100k_faster_small"], wl["metagenome_api"] = meta["rescue"], meta["faster_small"], meta.get("api")
+            wl["mammalian_8x3Gb"] = run_mammalian(job, 2, 1, 8, 125, 2 if cpu_n > 0 else 0)
+            line["extras"]["workloads"] = wl
+            line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
+    elif args.workload == "allvsall":
+        e = run_allvsall(job, args.steps, args.warmup, args.refs or 1000, min(cpu_n, 128))
+        line = as_line(e, "allvsall") if e else None
+    elif args.workload == "metagenome":
+        m = run_metagenome(job, args.steps, args.warmup, args.refs or 5000, args.queries, (args.faster_small,), min(cpu_n, 512), args.api_queries)
+        if rank == 0:
+            e = m["faster_small" if args.faster_small else "rescue"]
+            line = as_line(e, "metagenome")
+            line["extras"]["queries_per_s"] = e["value"]
+            if m.get("api"):
+                line["extras"]["api"] = m["api"]
     else:
-        buf, offs, lens = make_genomes(torch, device, seed_shared=2, seed_members=1000 * rank + 3, n_refs=n_refs, n_families=n_families)
-    torch.cuda.synchronize()
-
-    from pyskani_amd.parallel import all_gather_hits
-    eng = Engine(local_rank)
-    names = (C.c_char_p * n_refs)(*[f"r{rank}_{i}".encode() for i in range(n_refs)])
-    meta_state = {}
-    if args.workload == "metagenome":
-        eng.set_params(30, 200)
-        t0 = time.perf_counter()
-        handles = eng.sketch_device(buf.data_ptr(), offs[:n_refs], lens[:n_refs])
-        meta_state["db"] = eng.make_db(names, handles, n_refs)
-        eng.capi.check(eng.lib.psk_ctx_synchronize(eng.ctx))
-        meta_state["db_build_s"] = time.perf_counter() - t0
-        cbuf, coffs, clens = make_contigs(torch, device, buf, offs, lens, n_refs, args.queries, seed=4 + rank)
-        torch.cuda.synchronize()
-        meta_state.update(cbuf=cbuf, coffs=coffs, clens=clens)
-
-    def step():
-        if args.workload == "allvsall":
-            return eng.step_all_vs_all(buf.data_ptr(), offs, lens, names)
-        if args.workload == "mammalian":     # sketch every genome, load the database, every genome against all of them
-            handles = eng.sketch_device_contigs(buf.data_ptr(), big[1], big[2], big[3])
-            db = eng.make_db(names, handles, n_refs)
-            try:
-                return eng.query_many(db, handles, n_refs)
-            finally:
-                eng.lib.psk_db_destroy(db)
-        if args.workload == "metagenome":   # sketch every contig, query them all against the resident database
-            qh = eng.sketch_device(meta_state["cbuf"].data_ptr(), meta_state["coffs"], meta_state["clens"])
-            try:
-                return eng.query_many(meta_state["db"], qh, len(meta_state["coffs"]), args.faster_small)
-            finally:
-                for h in qh:
-                    eng.lib.psk_sketch_free(h)
-        hits = eng.step(buf.data_ptr(), offs, lens, names)
-        if world > 1:   # exchange step: all-gather of per-shard hit lists (RCCL over xGMI)
-            idx = np.stack([np.zeros(len(hits), np.int64), hits[:, 0].astype(np.int64) + rank * n_refs], axis=1)   # (query, GLOBAL ref index)
-            return all_gather_hits(idx, hits[:, 1:4], dist, device=coll_device)[0].shape[0]
-        return hits.shape[0]
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.capi.check(eng.lib.psk_ctx_synchronize(eng.ctx))
-
-    for _ in range(args.warmup):
-        n_hits = step()
-    eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 1))
-    eng.timing("reset")
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_hits = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    scan_ms, scan_n = eng.timing("sketch_scan")
-    kernel_ms = {k: eng.timing(k)[0] / max(1, args.steps) for k in ("sketch_scan", "sketch_emit", "sketch_sort", "screen", "anchor", "chain_chunk", "select", "pair_reduce")}
-    eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
-
-    if rank == 0:
-        if args.workload == "allvsall":
-            pairs_per_step, sketched = n_refs * n_refs, n_refs
-            bases = float(sum(lens[:n_refs]))
-            wl = f"all-vs-all {n_refs} x {n_refs} synthetic ~5 Mb genomes per GPU ({n_families} families x {n_refs // n_families}), c=125 marker_c=1000 k=15"
-        elif args.workload == "mammalian":
-            pairs_per_step, sketched = n_refs * n_refs, n_refs
-            bases = float(sum(lens))
-            wl = (f"mammalian scale (BASELINE configs[4] shape at reduced count): all-vs-all of {n_refs} synthetic genomes of 24 x {args.contig_mb} Mb contigs "
-                  f"({24 * args.contig_mb / 1000:.1f} Gb each; families of 4, substitution rates {DIVERGENCE[:4]}), c=125 marker_c=1000 k=15")
-        elif args.workload == "metagenome":
-            pairs_per_step, sketched = args.queries * n_refs, args.queries
-            bases = float(sum(meta_state["clens"]))
-            wl = (f"metagenome: {args.queries} contigs (2-50 kb, log-uniform, 0-5 % divergence) vs a resident database of {n_refs} synthetic ~5 Mb refs "
-                  f"({n_families} families), c=30 marker_c=200 k=15, faster_small={args.faster_small}")
-        else:
-            pairs_per_step, sketched = n_refs, n_refs + 1
-            bases = float(sum(lens))
-            wl = f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15"
-        value = pairs_per_step * world * args.steps / dt
-        # sketch_scan: ALGORITHMIC bytes per launch = sum over the launch's genomes of
-        # L (ASCII read) + L/4 (2-bit packed write)   [SURVEY.md §8(d) B_sk, first two terms; DESIGN.md §4]
-        alg_bytes = bases * 1.25 * args.steps / max(1, scan_n)   # per launch (a step may split into sub-batches)
-        avg_s = (scan_ms / max(1, scan_n)) * 1e-3
-        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = valu = None
-        pmc = os.path.join(ROOT, "profiles", "r2", "r2n_pmc_sketch_scan.json")
-        if os.path.exists(pmc) and args.workload not in ("metagenome", "mammalian"):
-            # OFFLINE counters (rocprofv3 --pmc in separate passes, profiles/r2/r2n_pmc_sketch_scan.json), scaled by this launch's bases:
-            # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) and VALU wave-instructions (SQ_INSTS_VALU = 26.8 per 64 bases, 61 % of them
-            # four-cycle and 39 % two-cycle by profiles/micro/valu_rates.hip = 3.2 cycles on average)
-            pm = json.load(open(pmc))
-            traffic = pm["traffic_bytes_per_base"] * bases * args.steps / max(1, scan_n)
-            insts = pm["valu_wave_instructions_per_launch"] / pm["bases_per_launch"] * bases * args.steps / max(1, scan_n)
-            simd_cycles_peak = avg_s * 2.4e9 * 1024          # 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock
-            valu = {"valu_issue_frac": insts * 3.2 / simd_cycles_peak if avg_s > 0 else None,
-                    "valu_issue_frac_at_1p93GHz": insts * 3.2 / (avg_s * 1.93e9 * 1024) if avg_s > 0 else None,
-                    "valu_wave_instructions_per_launch": insts,
-                    "source": "SQ_INSTS_VALU measured offline (profiles/r2/r2n_pmc_sketch_scan.json), cycle classes from profiles/micro/valu_rates.hip; "
-                              "launch duration measured live; 1.93 GHz = GRBM_GUI_ACTIVE clock of the profiled launch"}
-        line = {
-            "metric": "genome-pairs/sec (sketch+ANI)", "value": value, "unit": "genome-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl, "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)"},
-            "roofline": {"kernel": "sketch_scan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc pass (profiles/r2/r2n_pmc_sketch_scan.json), scaled by bases" if traffic else None,
-                         "avg_launch_ms": avg_s * 1e3, "launches": int(scan_n),
-                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
-                         "note": "priced against HBM as the contract asks; the kernel's real roof is integer VALU issue (one 64-bit mix per base: "
-                                 "15 four-cycle + 7 two-cycle wave instructions per base, DESIGN.md section 4): see valu.valu_issue_frac"},
-            "kernel_ms_per_step": kernel_ms,
-            # SURVEY.md §8(d) side figures, whole job
-            "extras": {"genomes_sketched_per_s": sketched * world * args.steps / dt,
-                       "bases_sketched_per_s": bases * world * args.steps / dt,
-                       "reported_hits_per_step": int(n_hits)},
-        }
-        if args.workload == "allvsall" and getattr(eng, "last_chain_work", None):
-            # per-kernel roofline of the chain stage: ALGORITHMIC bytes (SURVEY.md §8d B_ch terms) / HIP-event kernel time
-            w = eng.last_chain_work
-            kr = {}
-            for name, key, nbytes, what in (("anchor_join", "anchor", 16.0 * w["items"], "8 B query k-mer + order read and 8 B record written per (pair, query seed)"),
-                                            ("chain_lane", "chain_chunk", 16.0 * w["anchors"], "16 B per anchor read")):
-                t = kernel_ms[key] * 1e-3
-                if t > 0:
-                    kr[name] = {"achieved_GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": nbytes,
-                                "ms_per_step": kernel_ms[key], "bytes": what}
-            line["extras"]["chain_kernel_roofline"] = {"work_per_step": w, "kernels": kr,
-                                                       "note": "neither kernel is HBM-bound: chain_lane is VALU-issue bound, the join is bound by dependent-load latency and issue "
-                                                               "(profiles/r2/r2s_pmc_allvsall1000.md, r2e_pmc_join_kernels_sq.txt)"}
-        if args.workload == "metagenome":
-            line["extras"].update(queries_per_s=args.queries * world * args.steps / dt, db_build_s=meta_state["db_build_s"])
-            if world == 1 and args.cpu_sample > 0:
-                n_cpu_refs = min(n_refs, 500)
-                href = buf[:offs[n_cpu_refs]].cpu().numpy()
-                chost0 = meta_state["cbuf"].cpu().numpy()
-                sample = [chost0[meta_state["coffs"][i]:meta_state["coffs"][i] + meta_state["clens"][i]].tobytes() for i in range(min(512, args.queries))]
-                line["cpu_baseline"] = cpu_baseline_metagenome(lambda i: href[offs[i]:offs[i] + lens[i]].tobytes(), n_cpu_refs, sample, os.cpu_count() or 1, args.faster_small)
-                del href, chost0
-            if world == 1 and args.api_queries > 0:
-                # the same contigs ONE AT A TIME through the pyskani-shaped API, from host bytes: Database.query(name, contig)
-                import pyskani_amd as psk
-                host = buf.cpu().numpy()
-                pdb = psk.Database(compression=30, marker_compression=200)
-                t0 = time.perf_counter()
-                pdb.sketch_many([(f"r{i}", host[offs[i]:offs[i] + lens[i]].tobytes()) for i in range(n_refs)])
-                t_load = time.perf_counter() - t0
-                del host
-                chost = meta_state["cbuf"].cpu().numpy()
-                nq = min(args.api_queries, args.queries)
-                contigs = [chost[meta_state["coffs"][i]:meta_state["coffs"][i] + meta_state["clens"][i]].tobytes() for i in range(nq)]
-                for c in contigs[:20]:
-                    pdb.query("w", c, learned_ani=False, faster_small=args.faster_small)
-                t0 = time.perf_counter()
-                nh = sum(len(pdb.query(f"c{i}", c, learned_ani=False, faster_small=args.faster_small)) for i, c in enumerate(contigs))
-                t_q = time.perf_counter() - t0
-                # ... and the same calls from eight host threads (the reference's query() releases the GIL: threads are its route to
-                # concurrency; here every thread's call runs on its own lane of the context)
-                import threading
-                def _work(lo, hi):
-                    for i in range(lo, hi):
-                        pdb.query(f"c{i}", contigs[i], learned_ani=False, faster_small=args.faster_small)
-                th = [threading.Thread(target=_work, args=(k * nq // 8, (k + 1) * nq // 8)) for k in range(8)]
-                t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; t_q8 = time.perf_counter() - t0
-                many = pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
-                assert sum(len(h) for h in many) == nh
-                t0 = time.perf_counter()
-                pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=args.faster_small)
-                t_many = time.perf_counter() - t0
-                line["extras"].update(api_queries_per_s=nq / t_q, api_query_ms=t_q / nq * 1e3, api_queries_per_s_8_threads=nq / t_q8, api_query_many_per_s=nq / t_many,
-                                      api_db_load_s=t_load, api_hits=nh,
-                                      api_note=f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig (from one host thread, and from eight), and one Database.query_many() for all of them")
-        if world == 1 and args.workload == "search" and (args.cpu_sample > 0 or not args.no_api):
-            host = buf.cpu().numpy()
-            fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
-            if not args.no_api:
-                import pyskani_amd as psk
-                r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
-                line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"],
-                                      api_detail=r["api"], host_ascii_detail=r["host_ascii"],
-                                      api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
-                                               "api = n x sketch() + query(); host_ascii = sketch_many() (pinned, double-buffered H2D pipeline) + query()")
-            if args.cpu_sample > 0:
-                ns = min(args.cpu_sample, n_refs)
-                threads = os.cpu_count() or 1
-                v1, secs1, nh, vall, secs_all = cpu_baseline(fetch, ns, threads)
-                line["cpu_baseline"] = {"value": v1, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
-                                        "sample": f"1 query vs the first {ns} of {n_refs} refs of the same workload (sketch {ns + 1} genomes + {ns} screens + {nh} chained hits), {secs1:.1f} s of oracle time",
-                                        "all_cores": {"value": vall, "cores": threads, "seconds": secs_all,
-                                                      "how": "same sample, one reference (sketch + screen + chain) per thread over every hardware thread of the host"},
-                                        "note": "the repo's own C restatement (the Rust reference cannot be built here); it keeps seeds in flat arrays where skani inserts "
-                                                "into hash maps, so it is if anything faster than the Rust path: a conservative floor for the speed-up"}
-        if world == 1 and args.workload == "allvsall" and args.cpu_sample > 0:
-            host = buf.cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline_allvsall(lambda i: host[offs[i]:offs[i] + lens[i]].tobytes(), n_refs,
-                                                         min(args.cpu_sample, 256, n_refs), os.cpu_count() or 1)
+        e = run_mammalian(job, args.steps, args.warmup, args.refs or 8, args.contig_mb, 2 if cpu_n > 0 else 0)
+        line = as_line(e, "mammalian") if rank == 0 else None
+    if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
-    if meta_state.get("db"):
-        eng.lib.psk_db_destroy(meta_state["db"])
     if world > 1:
         dist.destroy_process_group()
 

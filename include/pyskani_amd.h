@@ -105,6 +105,9 @@ psk_status psk_ctx_set_timing(psk_ctx* ctx, int on);
  * wave64 instruction on gfx950) timed with HIP events; *mhz = cycles / duration, *ms = the duration (may be NULL). */
 psk_status psk_ctx_clock_probe(psk_ctx* ctx, double* mhz, double* ms);
 psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+/* Work of the chain stage since the last reset: pairs that reached chain_seeds (lib.rs:652-653), (pair, query seed) items joined,
+ * anchors emitted. The per-kernel algorithmic bytes of bench.py are counted from these. Any pointer may be NULL. */
+psk_status psk_ctx_work(psk_ctx* ctx, uint64_t* pairs, uint64_t* items, uint64_t* anchors, int reset);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
 psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
 psk_status psk_device_free(psk_ctx* ctx, void* dptr);

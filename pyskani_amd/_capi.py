@@ -52,7 +52,7 @@ SYMBOLS = [
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
-    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe",
+    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe", "psk_ctx_work",
     "psk_comm_unique_id", "psk_comm_create", "psk_comm_destroy", "psk_comm_info", "psk_gather_hits", "psk_gather_sketches",
     "psk_model_create", "psk_model_load_json", "psk_model_load_file", "psk_model_free", "psk_model_info", "psk_model_predict",
 ]
@@ -112,6 +112,7 @@ def load():
     lib.psk_sketch_unpack.argtypes = [vp, vp, C.POINTER(u64), u32, C.POINTER(vp)]
     lib.psk_sketch_pack_many.argtypes = [C.POINTER(vp), u32, vp, C.POINTER(u64), u64]
     lib.psk_ctx_clock_probe.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.psk_ctx_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_int]
     lib.psk_comm_unique_id.argtypes = [vp]
     lib.psk_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.psk_comm_destroy.argtypes = [vp]

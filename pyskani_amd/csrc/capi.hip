@@ -159,6 +159,15 @@ psk_status psk_ctx_clock_probe(psk_ctx* c, double* mhz, double* ms_out) {
     return PSK_OK;
 }
 
+psk_status psk_ctx_work(psk_ctx* c, uint64_t* pairs, uint64_t* items, uint64_t* anchors, int reset) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    if (pairs) *pairs = c->w_pairs.load();
+    if (items) *items = c->w_items.load();
+    if (anchors) *anchors = c->w_anchors.load();
+    if (reset) { c->w_pairs = 0; c->w_items = 0; c->w_anchors = 0; }
+    return PSK_OK;
+}
+
 psk_status psk_device_alloc(psk_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) { psk_set_error("device_alloc: NULL argument"); return PSK_EINVAL; }
     PSK_HIP(hipSetDevice(c->device));

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <sys/mman.h>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -85,6 +86,8 @@ struct psk_ctx {
     std::mutex stat_mu;
     double acc_ms[K_COUNT] = {0};
     uint64_t acc_n[K_COUNT] = {0};
+    // work done by the chain stage since the last reset (psk_ctx_work): what the algorithmic bytes of its kernels are counted from
+    std::atomic<uint64_t> w_pairs{0}, w_items{0}, w_anchors{0};
     // lanes: created on demand, at most max_lanes; a call takes a free one (LaneGuard) and gives it back
     std::mutex lanes_mu;
     std::condition_variable lanes_cv;

@@ -2866,7 +2866,7 @@ static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, c
         ctx->huge_release();
         bool retry;
         PSK_TRY(chain_check(*T, n_pairs, &cap, &wide, &retry));
-        if (!retry) break;
+        if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
         if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
     }
     for (uint32_t p = 0; p < n_pairs; p++) { out[p] = h_hits[p]; out[p].reserved = 0; }
@@ -3292,7 +3292,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
-                    if (!retry) break;
+                    if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
                     if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position

@@ -503,6 +503,31 @@ class Database:
                 self._resident.append(True)
         return None
 
+    def sketch_many_device(self, names, device_ptr, contig_offsets, contig_lengths, genome_first_contig=None, *, seed=True):
+        """Add many reference genomes whose ASCII already sits in HBM (psk_sketch_batch_device + psk_db_add_batch): contig i is
+        bytes [contig_offsets[i], +contig_lengths[i]) of the device allocation at `device_ptr` (offsets 16-byte aligned, 16 bytes
+        of slack after the last contig); genome g owns contigs [genome_first_contig[g], genome_first_contig[g+1]) (default: one
+        contig per genome). For callers that stage genomes on the GPU themselves (bench.py, a multi-GPU shard)."""
+        n = len(names)
+        nc = len(contig_offsets)
+        gfc = list(genome_first_contig) if genome_first_contig is not None else list(range(n + 1))
+        if len(gfc) != n + 1 or gfc[-1] != nc or len(contig_lengths) != nc:
+            raise ValueError("genome_first_contig must hold len(names) + 1 entries ending at the number of contigs")
+        with Database._Borrow(self, True):
+            c_off = (C.c_uint64 * max(nc, 1))(*[int(x) for x in contig_offsets])
+            c_len = (C.c_uint64 * max(nc, 1))(*[int(x) for x in contig_lengths])
+            c_gfc = (C.c_uint32 * (n + 1))(*gfc)
+            out = (C.c_void_p * max(n, 1))()
+            _capi.check(self._lib.psk_sketch_batch_device(self._ctx._h, C.byref(self._params), C.c_void_p(device_ptr), c_off, c_len, c_gfc, n, int(bool(seed)), out))
+            if self._storage is not None:
+                for i in range(n):
+                    self._storage.store(Sketch(self._ctx, C.c_void_p(out[i]), names[i], owned=False).to_record())
+            c_names = (C.c_char_p * max(n, 1))(*[nm.encode("utf-8") for nm in names])
+            _capi.check(self._lib.psk_db_add_batch(self._h, c_names, out, n))
+            self._names.extend(names)
+            self._resident.extend([True] * n)
+        return None
+
     def sketch(self, name, *contigs, seed=True):
         """Add a reference genome to the database (lib.rs:477-510)."""
         if not isinstance(name, str):
@@ -585,6 +610,38 @@ class Database:
         n = len(sketches)
         with Database._Borrow(self, False):
             return self._query_sketches(sketches, opts, n)
+
+    # ---- record-level entry points (no Python object per hit): what parallel.ShardedDatabase and bench.py use
+    def sketch_handles(self):
+        """ctypes array of the psk_sketch* of every reference, in insertion order (borrowed: the database owns them)."""
+        if not all(self._resident):
+            raise RuntimeError("sketch_handles needs a memory-resident database")
+        n = len(self._names)
+        return (C.c_void_p * max(n, 1))(*[self._lib.psk_db_sketch(self._h, i) for i in range(n)])
+
+    def query_handles(self, handles, n, *, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False):
+        """psk_query_many over n raw sketch handles -> (records, offsets): a numpy array of psk_hit (own memory) and the n+1
+        int64 offsets of every query's hits in it."""
+        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
+        with Database._Borrow(self, False):
+            hits_p = C.POINTER(_capi.Hit)()
+            offs = (C.c_uint64 * (n + 1))()
+            _capi.check(self._lib.psk_query_many(self._h, handles, n, C.byref(opts), C.byref(hits_p), offs))
+            try:
+                total = int(offs[n])
+                recs = (np.frombuffer((_capi.Hit * total).from_address(C.addressof(hits_p.contents)), dtype=self._HIT_DTYPE).copy()
+                        if total else np.zeros(0, self._HIT_DTYPE))
+            finally:
+                if hits_p:
+                    self._lib.psk_free(hits_p)
+        return recs, np.frombuffer(offs, dtype=np.uint64).astype(np.int64)
+
+    def query_records(self, name, *contigs, seed=True, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False):
+        """Database.query returning the psk_hit records (numpy structured array, ref_index = insertion index) instead of `Hit`s."""
+        with Database._Borrow(self, False):
+            q = self._sketch(name, contigs, seed)
+        recs, _ = self.query_handles((C.c_void_p * 1)(q._h), 1, learned_ani=learned_ani, median=median, robust=robust, cutoff=cutoff, faster_small=faster_small)
+        return recs
 
     def _query_sketches(self, sketches, opts, n):
         if not all(self._resident):      # `open`ed database: sketches come from disk per query

@@ -1,12 +1,27 @@
-"""Multi-GPU plumbing for the query path: one process per GPU, references sharded across ranks,
-one exchange step — an all-gather of the per-shard hit lists. The collective runs
-through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests);
-nothing else on the data path is collective: every (query, ref) pair is independent (lib.rs:617-657).
+"""Multi-GPU plumbing for the query path: one process per GPU, references sharded across ranks.
+
+Every (query, ref) pair is independent (lib.rs:617-657), so the path has exactly two exchange steps and nothing else is
+collective: the all-gather of the per-shard HIT LISTS (search and all-vs-all), and — all-vs-all only — the all-gather of the
+shards' SKETCHES as the query side, moved as packed device records HBM -> xGMI -> HBM.
+
+Two interchangeable transports carry them:
+  TorchComm   torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests and one-GPU dry runs)
+  CapiComm    the library's own RCCL communicator behind the C-ABI (psk_comm_create / psk_gather_hits / psk_gather_sketches,
+              include/pyskani_amd.h): what a non-Python host binds; torch.distributed (any backend) only hands the 128-byte id round
+Hits travel as the library's 80-byte psk_hit records (numpy structured arrays): the GLOBAL reference index in `ref_index`, the
+global query index in `reserved`. No Python object exists per hit until a caller asks for `Hit`s at the very end.
 """
+import ctypes as C
+import time
+
 import numpy as np
 import torch  # noqa: F401  (before the HIP library: torch bundles its own HIP runtime, which must initialise first)
 
+from . import _capi
+
 HIT_VALS = 3  # ani, af_query, af_ref
+HIT_DTYPE = np.dtype(_capi.Hit)
+HIT_BYTES = HIT_DTYPE.itemsize
 
 
 def shard_bounds(n_items, rank, world):
@@ -34,90 +49,194 @@ def weighted_shard_cuts(weights, world):
     return cuts + [n]
 
 
-_HIT_CAP = {}      # rows the gathered buffer held last time, per process group: the next call sends that many (+ the header row)
+def _al16(x):
+    return (int(x) + 15) & ~15
 
 
-def all_gather_hits(idx, vals, dist, device="cpu", group=None):
-    """All-gather ragged per-shard hit lists.
+def all_gather_hit_records(recs, dist, device="cpu", group=None, state=None):
+    """All-gather ragged per-shard arrays of psk_hit records. Returns (all records in rank order, per-rank counts), identical on
+    every rank.
 
-    idx:  int64 [n_local, 2] = (global query index, global ref index) — integers travel as integers (exact for any
-          database size); vals: float32 [n_local, 3] = (ani, af_query, af_ref).
-    Returns (idx, vals) concatenated over ranks in rank order, identical on every rank.
-
-    ONE collective in the steady state: every rank sends a fixed number of int64 rows — row 0 carries its true count, the
-    others (query, ref, the three floats bit-cast into two int64) — sized by the largest count seen so far. If a count does
-    not fit (every rank sees every header, so all agree), the capacity grows and the gather is repeated once; the first
-    call therefore exchanges the counts alone and then the lists.
-    """
-    import torch
+    ONE collective in the steady state: every rank sends a fixed number of 80-byte rows — row 0 carries its true count — sized by
+    `state["cap"]`, the largest count seen lately. If a count does not fit (every rank sees every header, so all agree), the
+    capacity grows and the gather is repeated once. The capacity decays (halves towards the latest maximum), so one large exchange
+    does not tax every later small one. `state` is a dict the CALLER owns (one per ShardedDatabase); without it every call
+    exchanges the counts first."""
     world = dist.get_world_size(group)
-    idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1, 2)
-    vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1, HIT_VALS)
-    assert len(idx) == len(vals)
-    n = idx.shape[0]
-    rows = np.zeros((n, 4), dtype=np.int64)
-    rows[:, :2] = idx
-    v4 = np.zeros((n, 4), dtype=np.float32)
-    v4[:, :HIT_VALS] = vals
-    rows[:, 2:] = v4.view(np.int64)
-    key = id(group) if group is not None else 0
-    cap = _HIT_CAP.get(key, 0)
+    recs = np.ascontiguousarray(recs, dtype=HIT_DTYPE).reshape(-1)
+    n = recs.shape[0]
+    cap = int(state.get("cap", 0)) if state is not None else 0
+    raw = recs.view(np.uint8).reshape(n, HIT_BYTES)
     while True:
-        mine = torch.zeros((cap + 1, 4), dtype=torch.int64, device=device)
-        mine[0, 0] = n
+        mine = torch.empty((cap + 1, HIT_BYTES), dtype=torch.uint8, device=device)
+        head = np.zeros(HIT_BYTES, np.uint8)
+        head[:8] = np.frombuffer(np.int64(n).tobytes(), np.uint8)
         k = min(n, cap)
-        if k:
-            mine[1:1 + k] = torch.from_numpy(rows[:k]).to(device)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
+        host = np.concatenate([head[None, :], raw[:k]], axis=0) if k else head[None, :]
+        mine[:1 + k] = torch.from_numpy(host).to(device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
-        host = [p.cpu().numpy() for p in parts]
-        counts = [int(h[0, 0]) for h in host]
+        heads = torch.stack([p[0, :8] for p in parts]).cpu().numpy()
+        counts = [int(np.frombuffer(heads[r].tobytes(), np.int64)[0]) for r in range(world)]
         if max(counts) <= cap:
             break
         cap = max(counts)      # the same on every rank: they all saw the same headers
-    _HIT_CAP[key] = cap
-    got = np.concatenate([h[1:1 + c] for h, c in zip(host, counts)], axis=0) if sum(counts) else np.zeros((0, 4), np.int64)
-    out_idx = np.ascontiguousarray(got[:, :2])
-    out_vals = np.ascontiguousarray(got[:, 2:]).view(np.float32).reshape(-1, 4)[:, :HIT_VALS].copy()
+    if state is not None:
+        state["cap"] = max(max(counts), cap // 2)
+    if sum(counts):
+        got = np.concatenate([p[1:1 + c].cpu().numpy() for p, c in zip(parts, counts) if c], axis=0)
+        out = np.ascontiguousarray(got).view(HIT_DTYPE).reshape(-1)
+    else:
+        out = np.zeros(0, HIT_DTYPE)
+    return out, counts
+
+
+def all_gather_hits(idx, vals, dist, device="cpu", group=None, state=None):
+    """All-gather ragged per-shard hit lists given as plain arrays.
+
+    idx:  int64 [n_local, 2] = (global query index, global ref index), both below 2^32; vals: float32 [n_local, 3] =
+    (ani, af_query, af_ref). Returns (idx, vals) concatenated over ranks in rank order, identical on every rank. A thin front
+    of all_gather_hit_records: integers travel as integers (exact for any database size)."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1, 2)
+    vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1, HIT_VALS)
+    assert len(idx) == len(vals)
+    recs = np.zeros(len(idx), HIT_DTYPE)
+    recs["reserved"] = idx[:, 0]; recs["ref_index"] = idx[:, 1]
+    recs["ani"] = vals[:, 0]; recs["af_query"] = vals[:, 1]; recs["af_ref"] = vals[:, 2]
+    got, _ = all_gather_hit_records(recs, dist, device=device, group=group, state=state)
+    out_idx = np.stack([got["reserved"].astype(np.int64), got["ref_index"].astype(np.int64)], axis=1).reshape(-1, 2)
+    out_vals = np.stack([got["ani"], got["af_query"], got["af_ref"]], axis=1).astype(np.float32).reshape(-1, HIT_VALS)
     return out_idx, out_vals
 
 
-def all_gather_sketches(sketches, ctx, dist, device, group=None):
-    """The exchange step of an all-vs-all: every rank contributes a list of device-resident sketches
-    and receives everybody's, as device-resident sketches on ITS GPU. Records are packed into one uint8 device tensor
-    (psk_sketch_pack), moved by ONE all-gather of that tensor (RCCL over xGMI with backend "nccl"; no host hop),
-    and unpacked in place (psk_sketch_unpack). A second, small all-gather carries the record sizes.
-    Returns a list over ranks of lists of `Sketch`."""
-    import torch
-    from .database import Sketch
-    world = dist.get_world_size(group)
-    sizes = [s.pack_size() for s in sketches]
-    n = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
-    ns = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(ns, n, group=group)
-    counts = [int(x.item()) for x in ns]
-    m = max(max(counts), 1)
-    mine = torch.zeros(m, dtype=torch.int64, device=device)
-    if sizes:
-        mine[:len(sizes)] = torch.tensor(sizes, dtype=torch.int64)
-    all_sizes = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(all_sizes, mine, group=group)
-    all_sizes = [t.cpu().numpy()[:c] for t, c in zip(all_sizes, counts)]
-    offs = [np.concatenate([[0], np.cumsum(sz)]).astype(np.int64) for sz in all_sizes]     # record sizes are multiples of 16
-    width = max(int(max(o[-1] for o in offs)), 16)
-    buf = torch.empty(width, dtype=torch.uint8, device=device)      # pad bytes are never read; a fill kernel on torch's stream
-    torch.cuda.current_stream(device).synchronize()                   # would race the library's own (non-blocking) stream
-    rank = dist.get_rank(group)
-    for s, o, sz in zip(sketches, offs[rank][:-1], sizes):
-        s.pack_into(buf.data_ptr() + int(o), int(sz))
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
-    torch.cuda.synchronize(device)              # the library reads the gathered tensors on its own stream
-    out = []
-    for r in range(world):
-        names = [f"rank{r}_{j}" for j in range(counts[r])]
-        out.append(Sketch.unpack(ctx, parts[r].data_ptr(), offs[r][:-1], names) if counts[r] else [])
-    return out
+class TorchComm:
+    """The two exchange steps over torch.distributed."""
+
+    kind = "torch"
+
+    def __init__(self, dist, group=None, device="cpu"):
+        self.dist, self.group, self.device = dist, group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._hit_state = {}
+        self.bytes_sent = 0
+
+    def gather_hit_records(self, recs):
+        out, counts = all_gather_hit_records(recs, self.dist, device=self.device, group=self.group, state=self._hit_state)
+        self.bytes_sent += (self._hit_state.get("cap", 0) + 1) * HIT_BYTES * (self.world - 1)
+        return out, counts
+
+    def gather_sketch_handles(self, ctx, handles, cuda_device):
+        """handles: ctypes array of this rank's psk_sketch* -> (ctypes array of everybody's handles on this GPU, counts per rank).
+        TWO collectives: (count, bytes) of every rank, then one uint8 device tensor per rank = [u64 sizes[n]] pad16 [records],
+        packed by ONE psk_sketch_pack_many, moved by one all-gather (HBM -> xGMI -> HBM with backend "nccl"), unpacked by ONE
+        psk_sketch_unpack."""
+        lib, dist, world = ctx._lib, self.dist, self.world
+        n = len(handles)
+        sizes = np.zeros(n, np.uint64)
+        sz = C.c_uint64()
+        for i in range(n):
+            _capi.check(lib.psk_sketch_pack_size(handles[i], C.byref(sz))); sizes[i] = sz.value
+        table = _al16(8 * n)
+        offs = table + np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        mybytes = int(offs[-1])
+        nb = torch.tensor([n, mybytes], dtype=torch.int64, device=self.device)
+        nbs = [torch.empty_like(nb) for _ in range(world)]
+        dist.all_gather(nbs, nb, group=self.group)
+        nbs = torch.stack(nbs).cpu().numpy()
+        counts = [int(x) for x in nbs[:, 0]]
+        width = max(16, _al16(int(nbs[:, 1].max())))
+        big = torch.empty((world + 1, width), dtype=torch.uint8, device=cuda_device)      # pad bytes are never read
+        send = big[world]
+        if n:
+            send[:8 * n] = torch.from_numpy(sizes.view(np.uint8)).to(cuda_device)
+        torch.cuda.current_stream(cuda_device).synchronize()      # the library packs on its own (non-blocking) stream
+        if n:
+            c_offs = (C.c_uint64 * n)(*[int(o) for o in offs[:-1]])
+            _capi.check(lib.psk_sketch_pack_many(handles, n, C.c_void_p(send.data_ptr()), c_offs, mybytes))
+        if self.device == "cpu":      # gloo: the records take the host hop (CPU tests, one-GPU dry runs)
+            hsend = send.cpu()
+            hparts = [torch.empty_like(hsend) for _ in range(world)]
+            dist.all_gather(hparts, hsend, group=self.group)
+            for r in range(world):
+                big[r].copy_(hparts[r])
+        else:
+            dist.all_gather(list(big[:world].unbind(0)), send, group=self.group)
+        self.bytes_sent += width * (world - 1)
+        maxn = max(counts) if counts else 0
+        tables = big[:world, :8 * maxn].cpu().numpy() if maxn else np.zeros((world, 0), np.uint8)
+        torch.cuda.synchronize(cuda_device)              # the library reads the gathered tensor on its own stream
+        roffs = []
+        for r in range(world):
+            sz_r = np.ascontiguousarray(tables[r, :8 * counts[r]]).view(np.uint64)
+            o = r * width + _al16(8 * counts[r])
+            for s in sz_r:
+                roffs.append(o); o += int(s)
+        total = len(roffs)
+        out = (C.c_void_p * max(total, 1))()
+        if total:
+            c_roffs = (C.c_uint64 * total)(*roffs)
+            _capi.check(lib.psk_sketch_unpack(ctx._h, C.c_void_p(big.data_ptr()), c_roffs, total, out))
+        return out, counts
+
+
+class CapiComm:
+    """The two exchange steps through the library's own RCCL communicator (psk_comm_*): the id is made by rank 0 and handed
+    round with torch.distributed's broadcast_object_list (any backend — it is the host program's bootstrap channel, not the
+    data path)."""
+
+    kind = "capi"
+
+    def __init__(self, ctx, dist, group=None):
+        lib = ctx._lib
+        self._lib, self.ctx = lib, ctx
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_uint8 * _capi.COMM_ID_BYTES)()
+        if self.rank == 0:
+            _capi.check(lib.psk_comm_unique_id(ident))
+        box = [bytes(ident)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ident = (C.c_uint8 * _capi.COMM_ID_BYTES).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _capi.check(lib.psk_comm_create(ctx._h, self.rank, self.world, ident, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.psk_comm_destroy(self._h)
+            self._h = None
+
+    @property
+    def bytes_sent(self):
+        b = C.c_uint64()
+        _capi.check(self._lib.psk_comm_info(self._h, None, None, C.byref(b), None))
+        return b.value
+
+    def gather_hit_records(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=HIT_DTYPE).reshape(-1)
+        out_p = C.POINTER(_capi.Hit)()
+        n_all = C.c_uint64()
+        counts = (C.c_uint64 * self.world)()
+        _capi.check(self._lib.psk_gather_hits(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), C.byref(out_p), C.byref(n_all), counts))
+        try:
+            n = n_all.value
+            out = np.frombuffer((_capi.Hit * n).from_address(C.addressof(out_p.contents)), dtype=HIT_DTYPE).copy() if n else np.zeros(0, HIT_DTYPE)
+        finally:
+            if out_p:
+                self._lib.psk_free(out_p)
+        return out, [int(c) for c in counts]
+
+    def gather_sketch_handles(self, ctx, handles, cuda_device=None):
+        n = len(handles)
+        out_pp = C.POINTER(C.c_void_p)()
+        counts = (C.c_uint32 * self.world)()
+        _capi.check(self._lib.psk_gather_sketches(self._h, handles, n, C.byref(out_pp), counts))
+        total = sum(counts)
+        out = (C.c_void_p * max(total, 1))()
+        for i in range(total):
+            out[i] = out_pp[i]
+        self._lib.psk_free(out_pp)
+        return out, [int(c) for c in counts]
 
 
 class ShardedDatabase:
@@ -130,9 +249,12 @@ class ShardedDatabase:
     other exchange the path has: the shards' sketches, all-gathered in batches as the query side.
 
     `local` is any object with the `Database` interface; by default a `pyskani_amd.Database` on this rank's GPU.
+    `comm`: "torch" (collectives through torch.distributed), "capi" (the library's RCCL communicator, psk_comm_*), or an instance.
+    `stats` accumulates where the wall time of the exchange-carrying calls went: seconds inside psk_* calls, inside collectives,
+    and in Python around them.
     """
 
-    def __init__(self, dist, local=None, device=None, group=None, **params):
+    def __init__(self, dist, local=None, device=None, group=None, comm="torch", **params):
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.coll_device = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
@@ -140,10 +262,19 @@ class ShardedDatabase:
             from .database import Database
             local = Database(device=(device.index if device is not None and device.index is not None else 0), **params)
         self.local = local
+        if comm == "capi":
+            self.comm = CapiComm(local._ctx, dist, group)
+        elif comm == "torch":
+            self.comm = TorchComm(dist, group, self.coll_device)
+        elif hasattr(comm, "gather_hit_records"):
+            self.comm = comm           # a transport the caller made once and reuses (creating an RCCL communicator is not free)
+        else:
+            raise ValueError("comm must be 'torch', 'capi' or a TorchComm / CapiComm instance")
         self.names = []          # GLOBAL reference names, identical on every rank
         self._lo = 0
         self._cuts = None        # shard cut points (world + 1), identical on every rank
         self.device = device
+        self.stats = {"psk_s": 0.0, "collective_s": 0.0, "total_s": 0.0}
 
     def __len__(self):
         return len(self.names)
@@ -160,56 +291,102 @@ class ShardedDatabase:
         contiguous shards on seed count instead of genome count."""
         if self.names:
             raise RuntimeError("ShardedDatabase.sketch_all may be called once: shards are contiguous")
+        self._set_names(names, weights)
+        hi = self._shard(self.rank)[1]
+        for i in range(self._lo, hi):
+            self.local.sketch(self.names[i], *fetch(i))
+        return hi - self._lo
+
+    def _set_names(self, names, weights=None):
         self.names = list(names)
         if weights is not None:
             if len(weights) != len(self.names):
                 raise ValueError("weights must hold one entry per reference")
             self._cuts = weighted_shard_cuts(weights, self.world)
-        self._lo, hi = self._shard(self.rank)
-        for i in range(self._lo, hi):
-            self.local.sketch(self.names[i], *fetch(i))
-        return hi - self._lo
+        self._lo = self._shard(self.rank)[0]
 
-    def _global_index(self, h, by_name):
-        raw = getattr(h, "_raw", None)        # the library's own reference index when the hit carries it; else by name
-        return self._lo + int(raw["ref_index"]) if raw is not None else by_name[h.reference_name]
+    def adopt_local(self, names, weights=None):
+        """For callers that filled `local` themselves (e.g. from device-resident genomes, psk_sketch_batch_device): declare the
+        GLOBAL name list; this rank's shard must already hold exactly its share, in order."""
+        self._set_names(names, weights)
+        lo, hi = self._shard(self.rank)
+        if len(self.local) != hi - lo:
+            raise ValueError(f"rank {self.rank}: the local database holds {len(self.local)} references, its shard is {hi - lo}")
+
+    def _timed(self, key, fn, *a, **kw):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **kw)
+        finally:
+            self.stats[key] += time.perf_counter() - t0
 
     def query(self, name, *contigs, **opts):
         from .database import Hit
-        by_name = {n: self._lo + j for j, n in enumerate(self.names[self._lo:self._lo + len(self.local)])}
-        local = self.local.query(name, *contigs, **opts)
-        idx = np.array([[0, self._global_index(h, by_name)] for h in local], dtype=np.int64).reshape(-1, 2)
-        vals = np.array([[h.identity, h.query_fraction, h.reference_fraction] for h in local], dtype=np.float32).reshape(-1, HIT_VALS)
-        idx, vals = all_gather_hits(idx, vals, self.dist, device=self.coll_device, group=self.group)
-        return [Hit(float(v[0]), name, float(v[1]), self.names[int(i[1])], float(v[2])) for i, v in zip(idx, vals)]
+        t0 = time.perf_counter()
+        if hasattr(self.local, "query_records"):
+            recs = self._timed("psk_s", self.local.query_records, name, *contigs, **opts)
+        else:       # a stand-in local database (tests): Hit objects in, records out
+            by_name = {n: j for j, n in enumerate(self.names[self._lo:self._lo + len(self.local)])}
+            local = self.local.query(name, *contigs, **opts)
+            recs = np.zeros(len(local), HIT_DTYPE)
+            for i, h in enumerate(local):
+                raw = getattr(h, "_raw", None)
+                recs[i]["ref_index"] = int(raw["ref_index"]) if raw is not None else by_name[h.reference_name]
+                recs[i]["ani"], recs[i]["af_query"], recs[i]["af_ref"] = h.identity, h.query_fraction, h.reference_fraction
+        recs = recs.copy()
+        recs["ref_index"] += self._lo
+        recs["reserved"] = 0
+        got, _ = self._timed("collective_s", self.comm.gather_hit_records, recs)
+        self.stats["total_s"] += time.perf_counter() - t0
+        return [Hit(float(r["ani"]), name, float(r["af_query"]), self.names[int(r["ref_index"])], float(r["af_ref"])) for r in got]
 
-    def all_vs_all(self, batch=256, **opts):
-        """Every genome of the job against every other (and itself). Each rank's shard IS its share of the genomes,
-        so the query side is the all-gather of the shards' sketches, `batch` genomes per rank at a time, as packed
-        device records (`all_gather_sketches`: HBM -> xGMI -> HBM); each received batch is queried against the local
-        shard with `Database.query_sketches`, and the hit lists are all-gathered at the end. Returns
-        {query_name: [Hit, ...]}, identical on every rank, hits in global reference order."""
-        import torch
-        from .database import Hit
+    def all_vs_all_records(self, batch=256, **opts):
+        """Every genome of the job against every other (and itself), as RECORDS: a numpy array of psk_hit sorted by (query,
+        reference) with GLOBAL indices (`reserved` = query, `ref_index` = reference), identical on every rank.
+
+        Each rank's shard IS its share of the genomes, so the query side is the all-gather of the shards' sketches, `batch`
+        genomes per rank at a time, as packed device records (HBM -> xGMI -> HBM); each received batch is queried against
+        the local shard in one psk_query_many, the hits get their global indices with numpy, and ONE all-gather of the hit
+        records ends the call. No Python object per hit or per pair anywhere."""
+        t_all = time.perf_counter()
         local = self.local
         n_local = len(local)
-        by_name = {n: self._lo + j for j, n in enumerate(self.names[self._lo:self._lo + n_local])}
         sizes = [self._shard(r)[1] - self._shard(r)[0] for r in range(self.world)]
         dev = self.device if self.device is not None else torch.device("cuda", local._device)
-        rows_i, rows_v = [], []
+        lib = local._lib
+        mine_all = local.sketch_handles()            # ctypes array of the shard's psk_sketch*
+        chunks = []
         for b in range((max(sizes) + batch - 1) // batch if sizes else 0):
             i0, i1 = min(b * batch, n_local), min((b + 1) * batch, n_local)
-            mine = [local._full_sketch(i) for i in range(i0, i1)]
-            for r, sketches in enumerate(all_gather_sketches(mine, local._ctx, self.dist, dev, group=self.group)):
-                qbase = self._shard(r)[0] + b * batch
-                for j, hits in enumerate(local.query_sketches(sketches, **opts) if sketches else []):
-                    for h in hits:
-                        rows_i.append([qbase + j, self._global_index(h, by_name)])
-                        rows_v.append([h.identity, h.query_fraction, h.reference_fraction])
-        idx, vals = all_gather_hits(np.array(rows_i, dtype=np.int64).reshape(-1, 2), np.array(rows_v, dtype=np.float32).reshape(-1, HIT_VALS),
-                                    self.dist, device=self.coll_device, group=self.group)
+            mine_n = (C.c_void_p * (i1 - i0))(*[mine_all[i] for i in range(i0, i1)])
+            handles, counts = self._timed("collective_s", self.comm.gather_sketch_handles, local._ctx, mine_n, dev)
+            total = sum(counts)
+            try:
+                if total:
+                    recs, offs = self._timed("psk_s", local.query_handles, handles, total, **opts)
+                    # global query index of every hit: the batch's queries are rank-major, rank r contributes counts[r]
+                    qglob = np.concatenate([self._shard(r)[0] + b * batch + np.arange(counts[r], dtype=np.int64) for r in range(self.world)])
+                    per_q = np.diff(offs)
+                    recs["reserved"] = np.repeat(qglob, per_q).astype(np.uint32)
+                    recs["ref_index"] += self._lo
+                    chunks.append(recs)
+            finally:
+                for i in range(total):
+                    lib.psk_sketch_free(handles[i])
+        mine_recs = np.concatenate(chunks) if chunks else np.zeros(0, HIT_DTYPE)
+        got, _ = self._timed("collective_s", self.comm.gather_hit_records, mine_recs)
+        order = np.lexsort((got["ref_index"], got["reserved"]))
+        out = got[order]
+        self.stats["total_s"] += time.perf_counter() - t_all
+        return out
+
+    def all_vs_all(self, batch=256, **opts):
+        """`all_vs_all_records` as {query_name: [Hit, ...]}, identical on every rank, hits in global reference order."""
+        recs = self.all_vs_all_records(batch=batch, **opts)
+        from .database import Hit
         out = {n: [] for n in self.names}
-        for t in np.lexsort((idx[:, 1], idx[:, 0])):
-            qn = self.names[int(idx[t, 0])]
-            out[qn].append(Hit(float(vals[t, 0]), qn, float(vals[t, 1]), self.names[int(idx[t, 1])], float(vals[t, 2])))
+        names = self.names
+        for q, r, ani, afq, afr in zip(recs["reserved"].tolist(), recs["ref_index"].tolist(), recs["ani"].tolist(), recs["af_query"].tolist(), recs["af_ref"].tolist()):
+            qn = names[q]
+            out[qn].append(Hit(ani, qn, afq, names[r], afr))
         return out

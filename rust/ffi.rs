@@ -50,6 +50,7 @@ extern "C" {
     pub fn psk_ctx_set_timing(ctx: *mut PskCtx, on: c_int) -> c_int;
     pub fn psk_ctx_timing(ctx: *mut PskCtx, kernel: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn psk_ctx_clock_probe(ctx: *mut PskCtx, mhz: *mut f64, ms: *mut f64) -> c_int;
+    pub fn psk_ctx_work(ctx: *mut PskCtx, pairs: *mut u64, items: *mut u64, anchors: *mut u64, reset: c_int) -> c_int;
     pub fn psk_device_alloc(ctx: *mut PskCtx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
     pub fn psk_device_free(ctx: *mut PskCtx, dptr: *mut c_void) -> c_int;
     pub fn psk_memcpy_h2d(ctx: *mut PskCtx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;

@@ -93,9 +93,11 @@ def test_group_selection_matches_solo_and_serial():
         "    print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (root,)
     outs = {}
-    for name, extra in (("solo", {}), ("group", {"PSK_BIG_SOLO": "1024"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
+    # "few_slots": the group selection on a device that reports 6 co-resident workgroups (a small partition, a CU mask): the occupancy
+    # query must size the launch down to one workgroup per pair instead of spinning at a barrier nobody else reaches
+    for name, extra in (("solo", {}), ("group", {"PSK_BIG_SOLO": "1024"}), ("few_slots", {"PSK_BIG_SOLO": "1024", "PSK_HUGE_SLOTS": "6"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
         env = dict(os.environ)
-        for k in ("PSK_BIG_SOLO", "PSK_CHAIN_SERIAL"):
+        for k in ("PSK_BIG_SOLO", "PSK_CHAIN_SERIAL", "PSK_HUGE_SLOTS"):
             env.pop(k, None)
         env.update(extra)
         outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().strip()

@@ -293,3 +293,65 @@ def test_many_small_pairs_against_oracle(psk, oracle, kw, monkeypatch):
             alt = db.query_many(contigs, learned_ani=False)
             monkeypatch.delenv(var)
             assert [[(h.reference_name, h.identity, h._raw["n_anchors"]) for h in hs] for hs in alt] == ref, var
+
+
+def test_pack_many_and_device_sketching(psk):
+    """psk_sketch_pack_many: one call packs a batch (one header upload, one copy launch, one synchronisation); the records unpack to
+    byte-identical sketches. Database.sketch_many_device: genomes staged in HBM by the caller give the same sketches as sketch()."""
+    import ctypes as C
+    import torch
+    from pyskani_amd import _capi
+    rng = np.random.default_rng(33)
+    g = random_genome(rng, 150_000)
+    genomes = [[g[:60_000], g[60_000:60_400], g[60_400:]], [mutate(rng, g, 0.03)], [random_genome(rng, 20_000)] * 3, [b"ACGT" * 40]]
+    db = psk.Database()
+    sketches = [db._sketch(f"s{i}", c, True) for i, c in enumerate(genomes)]
+    sizes = [s.pack_size() for s in sketches]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    buf = torch.empty(int(offs[-1]), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    lib = db._lib
+    handles = (C.c_void_p * len(sketches))(*[s._h for s in sketches])
+    c_offs = (C.c_uint64 * len(sketches))(*[int(o) for o in offs[:-1]])
+    _capi.check(lib.psk_sketch_pack_many(handles, len(sketches), C.c_void_p(buf.data_ptr()), c_offs, int(offs[-1])))
+    assert lib.psk_sketch_pack_many(handles, len(sketches), C.c_void_p(buf.data_ptr()), c_offs, int(offs[-1]) - 16) == _capi.PSK_EINVAL
+    got = psk.Sketch.unpack(db._ctx, buf.data_ptr(), offs[:-1], [s.name for s in sketches])
+    for a, b in zip(sketches, got):
+        sa, ma = a.export(); sb, mb = b.export()
+        assert sa.tobytes() == sb.tobytes() and ma.tobytes() == mb.tobytes()
+    # device-resident ingest through the Database class
+    flat, coffs, clens, gfc = [], [], [], [0]
+    total = 0
+    for cs in genomes:
+        for c in cs:
+            coffs.append(total); clens.append(len(c)); flat.append(np.frombuffer(c, np.uint8)); total += (len(c) + 31) & ~15
+            pad = ((len(c) + 31) & ~15) - len(c)
+            flat.append(np.zeros(pad, np.uint8))
+        gfc.append(len(coffs))
+    dev = torch.from_numpy(np.concatenate(flat + [np.zeros(64, np.uint8)])).cuda()
+    torch.cuda.synchronize()
+    db2 = psk.Database()
+    db2.sketch_many_device([f"s{i}" for i in range(len(genomes))], dev.data_ptr(), coffs, clens, gfc)
+    assert len(db2) == len(genomes)
+    for i, a in enumerate(sketches):
+        sa, ma = a.export(); sb, mb = db2._full_sketch(i).export()
+        assert sa.tobytes() == sb.tobytes() and ma.tobytes() == mb.tobytes()
+
+
+def test_clock_probe_and_work_counters(psk):
+    import ctypes as C
+    from pyskani_amd import _capi
+    rng = np.random.default_rng(4)
+    db = psk.Database()
+    lib, ctx = db._lib, db._ctx._h
+    mhz, ms = C.c_double(), C.c_double()
+    _capi.check(lib.psk_ctx_clock_probe(ctx, C.byref(mhz), C.byref(ms)))
+    assert 500.0 < mhz.value < 3000.0 and 0.1 < ms.value < 20.0, (mhz.value, ms.value)      # MI355X: up to 2.4 GHz
+    g = random_genome(rng, 200_000)
+    db.sketch("a", g); db.sketch("b", mutate(rng, g, 0.02)); db.sketch("z", random_genome(rng, 200_000))
+    p, i, a = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _capi.check(lib.psk_ctx_work(ctx, None, None, None, 1))
+    hits = db.query("q", mutate(rng, g, 0.01), learned_ani=False)
+    _capi.check(lib.psk_ctx_work(ctx, C.byref(p), C.byref(i), C.byref(a), 0))
+    assert len(hits) == 2 and p.value == 2 and a.value == sum(int(h._raw["n_anchors"]) for h in hits)
+    assert i.value > 0 and i.value % 2 == 0      # two pairs of the same query: 2 x its seed count

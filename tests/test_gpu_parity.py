@@ -524,6 +524,20 @@ db = psk.Database()
 for n, r in zip(names, refs): db.sketch(n, r)
 want = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in db.query("q", q, learned_ani=False)]
 assert got == want and len(got) == 3, (got, want)
+# the same exchange steps through the library's OWN RCCL communicator (psk_comm_create / psk_gather_hits / psk_gather_sketches)
+sdb2 = ShardedDatabase(dist, device=dev, comm="capi")
+sdb2.sketch_all(names, lambda i: (refs[i],))
+got2 = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in sdb2.query("q", q, learned_ani=False)]
+assert got2 == want, (got2, want)
+for s in (sdb, sdb2):
+    ava = s.all_vs_all(batch=3, learned_ani=False)
+    full = db.query_many(list(zip(names, refs)), learned_ani=False)
+    for n, hits in zip(names, full):
+        w = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in hits]
+        g = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in ava[n]]
+        assert g == w, (s.comm.kind, n, g, w)
+assert sdb2.comm.kind == "capi" and sdb2.stats["collective_s"] > 0
+sdb2.comm.close()
 dist.destroy_process_group()
 print("sharded ok")
 ''' % (ROOT, ROOT)

@@ -1,7 +1,8 @@
 """GPU: the paths that only large batches take - one-workgroup-per-pair emit with the chunk table (>= 1 024 mid-sized pairs),
 XCD turns in the join, two-tier selection, 2^29-seed batches, the seed prefilter of rescued contigs (>= 2^20 pairs) - against
 the same batch with each of them switched off. Every hit (reference, all chaining integers, ANI, AF) must be identical.
-(The small-batch paths are held to the oracle in test_gpu_parity / test_gpu_fuzz; these runs are held to those paths.)"""
+(The small-batch paths are held to the oracle in test_gpu_parity / test_gpu_fuzz; these runs are held to those paths, and a random
+sample of the large all-vs-all batch's hits is held to the oracle directly: test_large_batch_sample_matches_oracle.)"""
 import hashlib
 import os
 import subprocess
@@ -74,3 +75,60 @@ def test_rescue_prefilter_agrees_at_scale():
     assert base[0] > 4800 * 20
     for extra in ({"PSK_PREFILTER": "0"}, {"PSK_PREFILTER": "1"}, {"PSK_PREFILTER": "1", "PSK_JOIN_PAIRS": "0"}):
         assert _run(RESCUE, extra) == base, extra
+
+
+def test_large_batch_sample_matches_oracle(oracle):
+    """Closes the transitive link: 40 random (query, reference) pairs of the SAME 320-genome all-vs-all batch the
+    digest tests run - i.e. hits produced by the large-batch paths (per-pair emit with the chunk table, XCD turns, live lists) -
+    recomputed by the CPU oracle, every chaining integer and ANI / AF compared."""
+    import numpy as np
+    import pyskani_amd as psk
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(77)
+
+    def mutate(a, d):
+        b = a.copy(); m = rng.random(len(a)) < d; b[m] = (b[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3; return b
+    anc = [rng.integers(0, 4, 600_000, dtype=np.uint8) for _ in range(8)]
+    genomes = [(f"g{f}_{j}", lut[mutate(anc[f], 0.002 * j)].tobytes()) for f in range(8) for j in range(40)]
+    db = psk.Database()
+    db.sketch_many(genomes)
+    res = db.query_many(genomes, learned_ani=False)
+    assert sum(len(h) for h in res) >= 320 * 40
+    by_name = {n: g for n, g in genomes}
+    pick = np.random.default_rng(5)
+    checked = 0
+    for qi in pick.choice(len(genomes), 40, replace=False):
+        hits = res[int(qi)]
+        h = hits[int(pick.integers(0, len(hits)))]
+        want = oracle.chain(oracle.Sketch([by_name[h.reference_name]]), oracle.Sketch([genomes[int(qi)][1]]))
+        for f in ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds"):
+            assert int(h._raw[f]) == int(getattr(want, f)), (genomes[int(qi)][0], h.reference_name, f, int(h._raw[f]), int(getattr(want, f)))
+        assert abs(h.identity - want.ani) < 1e-6 and abs(h.query_fraction - want.af_query) < 1e-6 and abs(h.reference_fraction - want.af_ref) < 1e-6
+        checked += 1
+    assert checked == 40
+
+
+def test_prefilter_scratch_returns_to_the_pool():
+    """the seed prefilter's scratch block was a PoolScratch local without a destructor and leaked one block per
+    query_many round. Free device memory must stay flat over repeated calls with the prefilter forced on."""
+    code = COMMON + r"""
+import torch
+anc = [rng.integers(0, 4, 300_000, dtype=np.uint8) for _ in range(4)]
+refs = [(f"r{f}_{j}", lut[mutate(anc[f], 0.004 * j)].tobytes()) for f in range(4) for j in range(10)]
+contigs = []
+for i in range(600):
+    a = anc[i % 4]; L = int(rng.integers(1200, 3000)); st = int(rng.integers(0, len(a) - L))
+    contigs.append((f"c{i}", lut[mutate(a[st:st + L], 0.01)].tobytes()))
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many(refs)
+n0 = sum(len(h) for h in db.query_many(contigs, learned_ani=False))
+db.query_many(contigs, learned_ani=False)
+free0 = torch.cuda.mem_get_info()[0]
+for _ in range(12):
+    assert sum(len(h) for h in db.query_many(contigs, learned_ani=False)) == n0
+free1 = torch.cuda.mem_get_info()[0]
+print(n0, free0 - free1)
+"""
+    env = dict(os.environ, PSK_PREFILTER="1")
+    out = subprocess.check_output([sys.executable, "-c", "import torch\n" + code], env=env, timeout=900).decode().split()
+    assert int(out[0]) > 600 and int(out[1]) < (8 << 20), out      # the leak was the prefilter block (tens of MB) per call

@@ -32,17 +32,21 @@ ei, ev = all_gather_hits(np.zeros((0, 2), np.int64) if rank == 1 else idx, np.ze
 n0 = len([g for g in range(*shard_bounds(n_refs, 0, world)) if g %% 3 == 0])
 assert len(ei) == len(ev) == n0 and np.array_equal(ei[:, 1], want[:n0] + BIG)
 # the one-collective exchange keeps a capacity from call to call: a larger list (capacity grows, second gather), then a smaller one
+st = {}                                                                # the caller owns the capacity (one per ShardedDatabase)
+caps = []
 for n_each in (40, 3, 0, 17):
     bi = np.stack([np.arange(n_each, dtype=np.int64) + 1000 * rank, np.arange(n_each, dtype=np.int64) * 7 + rank], axis=1).reshape(-1, 2)
     bv = (np.arange(3 * n_each, dtype=np.float32).reshape(-1, 3) + rank) / 8
     n_mine = n_each if rank == 0 else n_each // 2                      # ragged: rank 1 sends half
-    oi, ov = all_gather_hits(bi[:n_mine], bv[:n_mine], dist)
+    oi, ov = all_gather_hits(bi[:n_mine], bv[:n_mine], dist, state=st)
+    caps.append(st["cap"])
     w0 = np.stack([np.arange(n_each, dtype=np.int64), np.arange(n_each, dtype=np.int64) * 7], axis=1).reshape(-1, 2)
     w1 = np.stack([np.arange(n_each // 2, dtype=np.int64) + 1000, np.arange(n_each // 2, dtype=np.int64) * 7 + 1], axis=1).reshape(-1, 2)
     assert np.array_equal(oi, np.concatenate([w0, w1])), (n_each, oi)
     v0 = np.arange(3 * n_each, dtype=np.float32).reshape(-1, 3) / 8
     v1 = ((np.arange(3 * n_each, dtype=np.float32).reshape(-1, 3) + 1) / 8)[:n_each // 2]
     assert ov.dtype == np.float32 and np.array_equal(ov, np.concatenate([v0, v1])), n_each
+assert caps == [40, 20, 10, 17], caps                                  # grows to fit, decays by halves: one big exchange does not tax later ones
 # ShardedDatabase over a stand-in local database (no GPU here): hits = refs whose name ends in an even digit
 from pyskani_amd.parallel import ShardedDatabase
 from pyskani_amd.database import Hit
