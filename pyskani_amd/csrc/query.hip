@@ -321,6 +321,7 @@ struct PairDesc {
     uint64_t q_total_len, r_total_len;
     uint32_t r_n, q_n;
     const uint32_t* r_bucket; uint32_t r_bshift;                              // ref index bucket table (IndexStore::bucket)
+    uint32_t r_tab_lines; const ProbeLine* r_tab;                             // ref probe table (null until built: ensure_probe)
 };
 // sbase[p] = first (pair, query seed) item of pair p in lb/cnt/aoff; cbase[p] = first row of pair p in the chunk table
 
@@ -966,6 +967,158 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
             if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, pend); else atomicOr(err, 1u);
             n_chunks[p] = n_rows + 1 < max_chunks ? n_rows + 1 : max_chunks;
         }
+    }
+}
+
+// ---- position-ordered join: no records, no scan, no separate emit ------------------------------------------------------------
+// For batches of many mid-sized pairs whose references carry a PROBE TABLE (ProbeLine, common.h). One wave per pair walks the
+// query's seeds in (contig, position) order, JT x 64 at a time: every lane looks its k-mer up in the reference's table - ONE
+// 64-byte line read; the entry holds exactly what anchor_join4_kernel's 8-byte record holds - and the round's matches are
+// ranked with shuffles and written as anchors at once, the chunk table built on the way exactly as anchor_emit_pairs_kernel
+// builds it. What the k-mer-ordered join pays to turn k-mer order into position order - one scattered 8-byte record store per
+// (pair, query seed), the records read back, a scan over the pairs' counts - does not exist here: the query is never left.
+// The price is one random line read per item where the merge streams 4 bytes of sorted reference k-mers; the lines of one
+// reference (~1 MB per 5 Mb genome) are shared by the ~100 pairs of its family in flight and sit in L2 / the memory-side cache.
+// A pair's anchors go to [sbase[p], sbase[p+1]) - its own items' worth of space: a pair never holds more anchors than query
+// seeds unless k-mers repeat; then it raises err bit 4 and the host reruns the batch through the k-mer-ordered join.
+// Loads are software-pipelined: k-mers two rounds ahead, table lines and the query side one round ahead.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void anchor_probe_pairs_kernel(
+    const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t kshift,
+    uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err, uint32_t* __restrict__ need_wide,
+    const uint32_t* __restrict__ cbase, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+    uint32_t* __restrict__ pcount, unsigned long long* __restrict__ bsum) {
+    __shared__ unsigned long long s_key[JT * 64];     // (q contig << 32 | q pos) + 1 of the items with a match, 0 otherwise
+    __shared__ uint32_t s_pre[JT * 64];               // anchors of the round before the item
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
+    const uint32_t n = s1 - s0;
+    if (n == 0) { if (lane == 0) { pcount[p] = 0; bsum[p] = 0; n_chunks[p] = 0; } return; }
+    const PairDesc& P = pairs[p];
+    const uint32_t* __restrict__ q_kmer = P.q_kmer; const uint32_t* __restrict__ q_pos = P.q_pos; const uint32_t* __restrict__ q_meta = P.q_meta;
+    const ProbeLine* __restrict__ tab = P.r_tab;
+    const uint32_t lines = P.r_tab_lines;
+    const uint32_t lim = s1 < cap ? s1 : cap;          // end of the pair's anchor space
+    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
+    unsigned long long run = s0;                        // next anchor slot
+    unsigned long long lim1 = 0; uint32_t h = 0, n_rows = 0; bool have = false, over = false;
+    // pipeline state: k-mers of round r+1 (km1) with their lines (ln1), key quads (kq1) and query side (qp1, qm1) in flight
+    uint32_t km1[JT], ln1[JT], qp1[JT], qm1[JT], km2[JT];
+    uint4 kq1[JT];
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        const uint32_t j = t * 64u + lane;
+        km1[t] = j < n ? q_kmer[j] : 0u;
+        const uint32_t j2 = (JT + t) * 64u + lane;
+        km2[t] = j2 < n ? q_kmer[j2] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < JT; t++) {
+        const uint32_t j = t * 64u + lane;
+        ln1[t] = lines ? probe_line(km1[t], kshift, lines) : 0u;
+        kq1[t] = (j < n && lines) ? *(const uint4*)(tab + ln1[t]) : make_uint4(PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY);
+        qp1[t] = j < n ? q_pos[j] : 0u; qm1[t] = j < n ? q_meta[j] : 0u;
+    }
+    for (uint32_t c0 = 0; c0 < n; c0 += JT * 64u) {
+        uint32_t km[JT], ln[JT], qp[JT], qm[JT];
+        uint4 kq[JT];
+#pragma unroll
+        for (int t = 0; t < JT; t++) { km[t] = km1[t]; ln[t] = ln1[t]; kq[t] = kq1[t]; qp[t] = qp1[t]; qm[t] = qm1[t]; km1[t] = km2[t]; }
+        // next rounds' loads first: they are in flight while this round resolves
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            const uint32_t j2 = c0 + (2 * JT + t) * 64u + lane;
+            km2[t] = j2 < n ? q_kmer[j2] : 0u;
+            const uint32_t j1 = c0 + (JT + t) * 64u + lane;
+            ln1[t] = lines ? probe_line(km1[t], kshift, lines) : 0u;
+            kq1[t] = (j1 < n && lines) ? *(const uint4*)(tab + ln1[t]) : make_uint4(PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY);
+            qp1[t] = j1 < n ? q_pos[j1] : 0u; qm1[t] = j1 < n ? q_meta[j1] : 0u;
+        }
+        // this round: the slot of every k-mer (fifth slot / next line only where the first four are taken), then the entries
+        int slot[JT];
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            const uint32_t j = c0 + t * 64u + lane;
+            slot[t] = -1;
+            if (j < n) {
+                uint4 K = kq[t];
+                for (;;) {
+                    int sl = K.x == km[t] ? 0 : K.y == km[t] ? 1 : K.z == km[t] ? 2 : K.w == km[t] ? 3 : -1;
+                    if (sl < 0 && K.w != PROBE_EMPTY) {
+                        const uint32_t k4 = tab[ln[t]].k[4];
+                        if (k4 == km[t]) sl = 4;
+                        else if (k4 != PROBE_EMPTY) { ln[t] = ln[t] + 1 < lines ? ln[t] + 1 : 0; K = *(const uint4*)(tab + ln[t]); continue; }
+                    }
+                    slot[t] = sl;
+                    break;
+                }
+            }
+        }
+        uint2 rec[JT];
+#pragma unroll
+        for (int t = 0; t < JT; t++) rec[t] = slot[t] >= 0 ? tab[ln[t]].v[slot[t]] : make_uint2(0u, 0u);
+        uint32_t c[JT], incl[JT];
+        uint32_t agg = 0;
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            c[t] = rec[t].y >> 24;
+            if (c[t] == 255u) { atomicOr(need_wide, 1u); c[t] = 0; }      // a count or contig number the packed entry cannot hold: the host reruns the batch in the wide format
+            uint32_t v = c[t];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(v, o); if (lane >= o) v += x; }
+            incl[t] = v;
+            const uint32_t tot = __shfl(v, 63);
+            s_key[t * 64 + lane] = c[t] ? ((((unsigned long long)(qm[t] >> 1)) << 32) | qp[t]) + 1ull : 0ull;
+            s_pre[t * 64 + lane] = agg + (v - c[t]);
+            incl[t] = agg + v;
+            agg += tot;
+        }
+        lds_wave_sync();
+        if (run + agg > lim) { over = true; break; }      // more anchors than query seeds (repeats): the k-mer-ordered join takes the batch
+#pragma unroll
+        for (int t = 0; t < JT; t++) {
+            if (!c[t]) continue;
+            const uint32_t d = (uint32_t)run + (incl[t] - c[t]);
+            if (c[t] == 1) {
+                anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
+            } else {      // a repeat: its run in the reference index (rare)
+                uint32_t l, c2;
+                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km[t], l, c2);
+                for (uint32_t jj = 0; jj < c[t]; jj++) {
+                    const uint64_t pm = P.r_pms[l + jj];
+                    const uint32_t rmeta = (uint32_t)pm;
+                    anc[d + jj] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
+                }
+            }
+        }
+        {      // heads among this round's items: the first item with a match and a key beyond the current head's reach, again and again
+            uint32_t sp = 0;
+            while (sp < (uint32_t)(JT * 64)) {
+                const uint32_t idx = sp + lane;
+                const unsigned long long k1 = idx < (uint32_t)(JT * 64) ? s_key[idx] : 0ull;
+                const unsigned long long bal = __ballot(k1 > lim1);      // lim1 = 0 before the pair's first anchor: any match starts the first chunk
+                if (!bal) { sp += 64; continue; }
+                const uint32_t j = sp + (uint32_t)__ffsll((long long)bal) - 1;
+                const uint32_t b = (uint32_t)run + s_pre[j];
+                if (have) {
+                    if (lane == 0) { if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, b); else atomicOr(err, 1u); }
+                    n_rows++;
+                }
+                have = true; h = b; lim1 = s_key[j] + FRAGMENT_LENGTH;
+                sp = j + 1;
+            }
+        }
+        run += agg;
+        lds_wave_sync();      // the next round overwrites s_key / s_pre
+    }
+    const uint32_t total = over ? 0u : (uint32_t)(run - s0);
+    if (lane == 0) {
+        if (over) atomicOr(err, 4u);
+        pcount[p] = total; bsum[p] = total;
+        if (!over && have && total >= MIN_ANCHORS) {      // fewer: no chain can form, no chunk table, every later kernel skips the pair
+            if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, (uint32_t)run); else atomicOr(err, 1u);
+            n_chunks[p] = n_rows + 1 < max_chunks ? n_rows + 1 : max_chunks;
+        } else n_chunks[p] = 0;
     }
 }
 
@@ -2157,6 +2310,7 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
 
 // ------------------------------------------------------------------ per-pair ANI / AF
 struct ReduceArgs {
+    const uint32_t* pcount;      // anchors per pair where the pairs' anchor ranges are not contiguous (probe path); else null: pstart[p + 1] - pstart[p]
     const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
     const uint32_t* pstart; const PairDesc* pairs;
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
@@ -2176,7 +2330,7 @@ __global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t 
     psk_hit h{};
     h.ani = -1.0f; h.ani_raw = -1.0f;
     h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+    h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
     R.hits[p] = h;
 }
 
@@ -2196,7 +2350,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
             psk_hit h{};
             h.ani = -1.0f; h.ani_raw = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
             R.hits[p] = h;
         }
         return;
@@ -2314,7 +2468,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     if (threadIdx.x == 0) {
         h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
-        h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+        h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
         h.covered_query = s_acc[0]; h.covered_ref = s_acc[1]; h.sum_chain_anchors = s_acc[2]; h.sum_chunk_seeds = s_acc[3];
         if (m > 0) {
             double ani;
@@ -2408,7 +2562,7 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
             h.ani = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
             h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
-            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
             h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
             if (m > 0) {
                 double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
@@ -2462,12 +2616,13 @@ static SketchDesc make_desc(const psk_sketch* s) {
     if (d.n) for (uint32_t len : s->contig_len) rows += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
     d.rows = (uint32_t)std::min<uint64_t>(rows, 0xFFFFFFFFu);
     s->len_quantiles(d.lenq);
+    d.tab = (ix && s->ptab) ? (const ProbeLine*)s->ptab->base + s->ptab_off : nullptr; d.tab_lines = (ix && s->ptab) ? s->ptab_lines : 0;
     return d;
 }
 
 __device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
     PairDesc P;
-    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
+    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift; P.r_tab = R.tab; P.r_tab_lines = R.tab_lines;
     P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer; P.q_nc = Q.n_contigs; P.pad_ = 0;
     P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
     P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
@@ -2569,21 +2724,44 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
 // Everything between "pairs / sbase / cbase are on the device" and "hits are on the device": no host synchronisation.
 // Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
 // reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
+// `probe_ok`: every reference of the batch carries a probe table (ensure_probe) - the position-ordered join may take the batch.
+static bool probe_shape(uint32_t n_pairs, size_t n_items) {      // many mid-sized pairs (all-vs-all): the shapes anchor_emit_pairs_kernel takes
+    return n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17);
+}
 static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
-                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
+                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide, bool probe_ok = false) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
     PSK_HIP(hipMemsetAsync(L.misc, 0, 256, st));     // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[32..47] its group barriers
     PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
     const uint32_t gi = L.gi;
     hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair);
-    ctx->t_begin(K_ANCHOR);
-    if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
+    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
+    const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
+    PSK_TRY(ctx->q_d.reserve(4 * na * 16));
+    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
+    uint32_t* D = (uint32_t*)ctx->q_d.p;
+    uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
+    uint32_t* a_nxt = D + 4 * na;
+    // position-ordered join (anchor_probe_pairs_kernel): anchors and chunk table straight from the query walk; PSK_PROBE=0 forbids it,
+    // PSK_PROBE=1 takes it for any batch whose references carry tables (tests)
+    const char* pb_env = getenv("PSK_PROBE");
+    const bool probe = probe_ok && !wide && cap >= n_items && !(pb_env && pb_env[0] == '0') && ((pb_env && pb_env[0] == '1') ? n_pairs >= 1 : probe_shape(n_pairs, n_items));
+    uint32_t* pcount = probe ? L.aoff : nullptr;      // anchors per pair (the per-item offsets array is not used then)
+    if (probe) {
+        PSK_HIP(hipMemcpyAsync(L.pstart, L.sbase, 4 * ((size_t)n_pairs + 1), hipMemcpyDeviceToDevice, st));      // a pair's anchors live in its own items' worth of space
+        ctx->t_begin(K_ANCHOR);
+        hipLaunchKernelGGL(anchor_probe_pairs_kernel, dim3(n_pairs), dim3(64), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)(32 - 2 * prm.k), anc, (uint32_t)cap, L.misc, L.misc + 5,
+                           L.cbase, L.chunks, L.nch, pcount, L.bsum);
+        ctx->t_end();
+    }
+    if (!probe) ctx->t_begin(K_ANCHOR);
+    if (wide && !probe) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
     static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
-    const bool join_pairs = !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
+    const bool join_pairs = !probe && !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
     if (join_pairs) {
         // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys
         size_t ts = 0;
@@ -2599,19 +2777,20 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
         n_sum = nb;
     }
-    else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
+    else if (!probe && !wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
     // many mid-sized pairs (all-vs-all): the join counts every pair's anchors, one workgroup per pair then emits with a running offset
     // (anchor_emit_pairs_kernel) instead of a scan over all items; PSK_EMIT_PAIRS=1 / 0 force / forbid it (tests, A/B)
     const char* ep_env = getenv("PSK_EMIT_PAIRS");
-    const bool emit_pairs = !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
+    const bool emit_pairs = !probe && !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
                             (ep_env ? ep_env[0] == '1' : (n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17)));
     uint32_t* pair_cnt = L.live;      // free until the live list is built
     if (emit_pairs) PSK_HIP(hipMemsetAsync(pair_cnt, 0, 4 * ((size_t)n_pairs + 1), st));
     // workgroups of one pair per XCD turn (0 = contiguous eighths of the grid; PSK_XCD_GROUP overrides): see xcd_group_block_id
     static const int xg_env = getenv("PSK_XCD_GROUP") ? atoi(getenv("PSK_XCD_GROUP")) : -1;
     const uint32_t xcd_group = xg_env >= 0 ? (uint32_t)xg_env : (n_pairs >= 64 ? (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, 4 * (n_items / n_pairs) / (JT * 256))) : 0u);      // four pairs per turn (measured: 1 pair 38.5, 2: 37.4, 4 and more: 36.8 ms of join per 10^5 pairs; contiguous eighths: 44.0)
-    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
-    ctx->t_end();
+    if (!probe && !wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
+    if (!probe) ctx->t_end();
+    if (probe) n_sum = n_pairs;      // bsum[p] = anchors of pair p
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
     hipcub::TransformInputIterator<uint32_t, PackedCount, const uint2*> pcnt_it(L.lbcnt, PackedCount());
@@ -2629,20 +2808,14 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
         hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap);
     }
+    else if (probe) { /* no per-item offsets: the probe kernel placed the anchors itself */ }
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
     if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + L.gi_sum, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
-    if (!emit_pairs || small_sum)
-        hipLaunchKernelGGL(pair_start_kernel, dim3(emit_pairs ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, emit_pairs ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
+    if ((!emit_pairs && !probe) || small_sum)
+        hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
-    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
-    const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
-    PSK_TRY(ctx->q_d.reserve(4 * na * 16));
-    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
-    uint32_t* D = (uint32_t*)ctx->q_d.p;
-    uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
-    uint32_t* a_nxt = D + 4 * na;
     ChainArgs A{};
     A.anc = anc;
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
@@ -2659,14 +2832,16 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool use_hops = hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20));
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
-    ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
-    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table (nothing on the probe path: its join wrote both)
+    if (probe) { /* anchors and chunk table exist */ }
+    else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
     else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    if (use_hops) {
+    if (probe) { /* chunk table exists */ }
+    else if (use_hops) {
         hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
         if (n_items / n_pairs > (1u << 20) && !getenv("PSK_HOPS_UNSLICED")) {      // Gb-scale pairs: HOP_SLICES waves per pair, count then write
             PSK_TRY(ctx->q_g.reserve(4 * (size_t)n_pairs * HOP_SLICES + 256));
@@ -2774,6 +2949,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     ctx->t_end();
     hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
+    R.pcount = pcount;
     R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
     R.k = prm.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = L.hits;
@@ -2807,8 +2983,9 @@ static uint64_t anchor_cap_for(Lane* ctx, size_t n_items) {
 // outcome of a launch sequence, read back with the hits
 struct ChainTail { uint32_t misc[16]; unsigned long long total64; };
 static bool join_wide_default() { const char* e = getenv("PSK_JOIN"); return e && !strcmp(e, "wide"); }
-static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry) {
+static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry, bool* probe_ok = nullptr) {
     *retry = false;
+    if (probe_ok && *probe_ok && (T.misc[0] & 4u)) { *probe_ok = false; *retry = true; return PSK_OK; }   // a pair with more anchors than query seeds (repeats): the k-mer-ordered join takes the batch
     if (!*wide && T.misc[5]) { *wide = true; *retry = true; return PSK_OK; }   // a count or contig number the packed join format cannot hold: rerun in the wide format
     if (T.total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
         psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, T.total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
@@ -3022,10 +3199,15 @@ __global__ __launch_bounds__(256) void pref_apply_kernel(const uint32_t* __restr
     if (cnt[cell] < MIN_ANCHORS) pass[(size_t)rq[j] * n_refs + r] = 0;
 }
 
+// how many references carry a k-mer index (low word) / a probe table (high word): the descriptor table is stale when this moves
+static uint64_t index_stamp(const psk_db* db) {
+    uint64_t v = 0;
+    for (const psk_sketch* r : db->refs) v += (uint64_t)(r->idx != nullptr) + ((uint64_t)(r->ptab != nullptr) << 32);
+    return v;
+}
 static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
-    uint64_t indexed = 0;
-    for (const psk_sketch* r : db->refs) indexed += r->idx != nullptr;
+    const uint64_t indexed = index_stamp(db);
     if (!db->desc_dirty && db->desc_indexed == indexed && db->desc_n == n) return PSK_OK;
     std::vector<SketchDesc>& h = db->h_refdesc;     // stays alive until the copy has drained (every query ends with a synchronisation)
     h.resize(n);
@@ -3109,9 +3291,8 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
             if (refs_ok) {
                 bool all_idx = !db->desc_dirty && db->desc_n == n;
-                uint64_t indexed = 0;
-                for (const psk_sketch* rs : db->refs) { indexed += rs->idx != nullptr; if (!rs->idx && rs->n_seeds && rs->store) all_idx = false; }
-                if (!all_idx || indexed != db->desc_indexed)
+                for (const psk_sketch* rs : db->refs) if (!rs->idx && rs->n_seeds && rs->store) all_idx = false;
+                if (!all_idx || index_stamp(db) != db->desc_indexed)
                     PSK_TRY(exclusive([&]() -> psk_status {
                         std::vector<const psk_sketch*> all_refs(db->refs.begin(), db->refs.end());
                         PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
@@ -3189,9 +3370,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
         {   // references first (shared state: exclusive), then this call's own query sketches
             bool refs_stale = db->desc_dirty || db->desc_n != n;
-            uint64_t indexed = 0;
-            for (const psk_sketch* rs : db->refs) indexed += rs->idx != nullptr;
-            refs_stale = refs_stale || indexed != db->desc_indexed;
+            refs_stale = refs_stale || index_stamp(db) != db->desc_indexed;
             for (size_t i = 0; i < n_need_refs && !refs_stale; i++) refs_stale = !need[i]->idx && need[i]->n_seeds && need[i]->store;
             if (refs_stale)     // one index launch for the references AND this call's queries (a fresh database: the headline step)
                 PSK_TRY(exclusive([&]() -> psk_status {
@@ -3199,6 +3378,28 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     return refresh_ref_descs(ctx, db);
                 }));
             else if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
+        }
+        // large rounds of mid-sized pairs (all-vs-all) take the position-ordered join: every reference about to be chained needs its
+        // probe table (built once per reference, like the k-mer index; PSK_PROBE=0 never, =1 whenever the references allow it)
+        bool round_probe = false;
+        {
+            const char* pb_env = getenv("PSK_PROBE");
+            const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
+            uint64_t round_items = 0;
+            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
+            if (!pb_off && db->params.k <= 16 && (pb_force ? round_pairs >= 1 : probe_shape((uint32_t)std::min<uint64_t>(round_pairs, 0xFFFFFFFFu), (size_t)round_items))) {
+                round_probe = true;
+                bool missing = false;
+                for (size_t i = 0; i < n_need_refs; i++) {
+                    if (need[i]->n_seeds < 256 || need[i]->n_seeds > (1u << 20)) { round_probe = false; break; }
+                    missing = missing || !need[i]->ptab;
+                }
+                if (round_probe && missing)
+                    PSK_TRY(exclusive([&]() -> psk_status {
+                        PSK_TRY(ensure_probe(ctx, need.data(), (uint32_t)n_need_refs));
+                        return refresh_ref_descs(ctx, db);
+                    }));
+            }
         }
         h_qd.resize(m);
         for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
@@ -3271,9 +3472,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
-                bool too_big = false, wide = join_wide_default();
+                bool too_big = false, wide = join_wide_default(), probe_ok = round_probe;
                 for (int attempt = 0;; attempt++) {
-                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide);
+                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, probe_ok);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
                     const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
@@ -3289,11 +3490,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     ctx->huge_release();
                     bool retry;
-                    psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
+                    psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry, &probe_ok);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
                     if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
-                    if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+                    if (attempt >= 4) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
                 n_sel = T->misc[12];
