@@ -267,6 +267,7 @@ struct IndexStore {
     size_t bytes = 0;
     uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
     uint32_t* perm = nullptr;  // index of the seed in the sketch's (contig,pos)-ordered arrays
+    uint32_t* iperm = nullptr; // the inverse: index entry of every seed (the per-pair emit of large batches walks positions through it)
     uint64_t* pms = nullptr;   // pos<<32 | meta of the seed at each index position (saves the perm -> seed_pm hop)
     uint32_t* km32 = nullptr;  // the sorted k-mers alone (low word of key): what the join streams, half the bytes
     uint32_t* bucket = nullptr; // per sketch nb+1 offsets: bucket b = entries whose k-mer >> bshift == b (a lookup is one
@@ -280,8 +281,7 @@ inline IndexStore::~IndexStore() { if (ctx) ctx->pool_release(base, bytes); else
 // (anchor_probe_pairs_kernel). One 64-byte line holds up to PROBE_SLOTS distinct k-mers and, for each, what the packed join
 // record holds (reference position of the first match; ref contig << 1 | strand, count << 24): a lookup is ONE line read where the
 // k-mer-sorted index needs a bucket-table read, a key scan and a position read. line(km) = mulhi(km left-aligned, lines) is
-// monotone in the k-mer (hash-selected k-mers are uniform over the 2k-bit space: ~2.5 per line); a k-mer whose line is full
-// sits in the next line with room.
+// a multiplicative hash of the k-mer (~2.5 k-mers per line); a k-mer whose line is full sits in the next line with room.
 constexpr uint32_t PROBE_SLOTS = 5;
 constexpr uint32_t PROBE_EMPTY = 0xFFFFFFFFu;      // no canonical k-mer of k <= 16 (its reverse complement, 0, is smaller)
 struct ProbeLine { uint32_t k[PROBE_SLOTS]; uint32_t pad; uint2 v[PROBE_SLOTS]; };
@@ -316,6 +316,7 @@ struct SketchStore {
 // plus the per-sketch inputs of the learned-ANI regression. Pairs are assembled from two of these ON THE DEVICE.
 struct SketchDesc {
     const uint32_t* key; const uint64_t* pms; const uint32_t* perm; const uint32_t* bucket;   // k-mer index (null until built)
+    const uint32_t* iperm;
     const uint32_t* pos; const uint32_t* meta; const uint32_t* seed_pos_base; const uint32_t* contig_start;
     const uint32_t* kmer;   // seed k-mers in (contig,pos) order
     uint64_t total_len;
@@ -462,7 +463,13 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
 psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
 // builds the probe table of every indexed sketch of the list that lacks one (sketches of 256 .. 2^20 seeds)
 psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
-__device__ __forceinline__ uint32_t probe_line(uint32_t km, uint32_t kshift, uint32_t lines) { return __umulhi(km << kshift, lines); }      // kshift = 32 - 2k
+// line of a k-mer: multiplicative hash, then scaled to the table. (NOT the k-mer's own top bits: canonical k-mers are the smaller of a
+// k-mer and its reverse complement, so their density falls linearly from 2 at zero - twice the average load per line at the low end
+// and probe chains hundreds of lines long; measured: 60 x slower.)
+__device__ __forceinline__ uint32_t probe_line(uint32_t km, uint32_t lines) { return __umulhi(km * 2654435761u, lines); }
+// first anchor slot of pair p on the probe path: its items' worth of space plus an eighth (a k-mer that occurs twice on both sides
+// yields four anchors for two query seeds: a genome against itself already holds a few more anchors than seeds)
+__host__ __device__ __forceinline__ uint64_t probe_slot(uint32_t item_base) { return (uint64_t)item_base + (item_base >> 3); }
 psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,

@@ -752,6 +752,12 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
 // sketches that need one; LSD radix sort is stable, so equal k-mers keep their (contig,pos) order ----
 struct IdxSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t out_off; uint32_t bshift, nb, boff; };
 
+// iperm[seed] = index entry of the seed (the inverse of perm), per sketch
+__global__ __launch_bounds__(256) void index_iperm_kernel(const IdxSeg* __restrict__ segs, const uint32_t* __restrict__ perm, uint32_t* __restrict__ iperm) {
+    const IdxSeg sg = segs[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) iperm[sg.out_off + perm[sg.out_off + i]] = i;
+}
+
 __global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const IdxSeg sg = segs[blockIdx.y];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) {
@@ -942,10 +948,11 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
         auto ix = std::make_shared<IndexStore>();
         ix->ctx = ctx->dev;
         size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256), bb = align_up(4 * (size_t)boff, 256);
-        PSK_TRY(ctx->pool_alloc(2 * kb + 2 * vb + bb, &ix->base, &ix->bytes));
+        PSK_TRY(ctx->pool_alloc(2 * kb + 3 * vb + bb, &ix->base, &ix->bytes));
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
         ix->km32 = (uint32_t*)((char*)ix->base + 2 * kb + vb);
         ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb);
+        ix->iperm = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb + bb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
         PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         if (small) {
@@ -957,6 +964,7 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
             if (tiny) hipLaunchKernelGGL((index_block_kernel<256, IDXT_MAX_LB>), dim3(m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, 1u, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
             else hipLaunchKernelGGL((index_block_kernel<IDXB_THREADS, IDXB_MAX_LB>), dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
+            hipLaunchKernelGGL(index_iperm_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint32_t*)ix->perm, ix->iperm);
             ctx->t_end();
             PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {
@@ -976,6 +984,7 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
         PSK_TRY(ctx->s_tmp.reserve(tmp));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms, ix->km32);
+        hipLaunchKernelGGL(index_iperm_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint32_t*)ix->perm, ix->iperm);
         ctx->t_end();
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) {
@@ -988,7 +997,7 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
 }
 
 // ------------------------------------------------------------------ probe tables (position-ordered join of large all-vs-all batches)
-struct ProbeSeg { const uint32_t* key; const uint64_t* pms; ProbeLine* tab; uint32_t n, lines, kshift, pad; };
+struct ProbeSeg { const uint32_t* key; const uint64_t* pms; ProbeLine* tab; uint32_t n, lines; };
 // one thread per index entry; the head of every run of equal k-mers inserts (k-mer, first position, meta | count << 24)
 __global__ __launch_bounds__(256) void probe_build_kernel(const ProbeSeg* __restrict__ segs) {
     const ProbeSeg S = segs[blockIdx.y];
@@ -1002,7 +1011,7 @@ __global__ __launch_bounds__(256) void probe_build_kernel(const ProbeSeg* __rest
     const uint32_t rmeta = (uint32_t)pm;
     // same packing as the join's record: counts >= 255 or reference contig numbers >= 2^23 read as 255 ("rerun in the wide format")
     const uint32_t y = (cnt >= 255u || (rmeta >> 24)) ? ((rmeta & 0xFFFFFFu) | (255u << 24)) : (rmeta | (cnt << 24));
-    uint32_t L = probe_line(km, S.kshift, S.lines);
+    uint32_t L = probe_line(km, S.lines);
     for (;;) {
         ProbeLine* ln = S.tab + L;
         for (uint32_t s = 0; s < PROBE_SLOTS; s++) {
@@ -1028,7 +1037,7 @@ psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             const psk_sketch* s = todo[i1];
             const uint32_t ln = (uint32_t)((s->n_seeds * 2 + 4) / 5);              // ~2.5 k-mers per line of 5 slots
             loff.push_back(lines);
-            segs.push_back(ProbeSeg{s->idx->km32 + s->idx_off, s->idx->pms + s->idx_off, nullptr, (uint32_t)s->n_seeds, ln, (uint32_t)(32 - 2 * s->params.k), 0});
+            segs.push_back(ProbeSeg{s->idx->km32 + s->idx_off, s->idx->pms + s->idx_off, nullptr, (uint32_t)s->n_seeds, ln});
             lines += ln; maxn = std::max(maxn, (uint32_t)s->n_seeds); i1++;
         }
         auto ps = std::make_shared<ProbeStore>();
