@@ -267,7 +267,6 @@ struct IndexStore {
     size_t bytes = 0;
     uint64_t* key = nullptr;   // slot<<32 | kmer, ascending: a sketch's slice is sorted by k-mer, stable in (contig,pos)
     uint32_t* perm = nullptr;  // index of the seed in the sketch's (contig,pos)-ordered arrays
-    uint32_t* iperm = nullptr; // the inverse: index entry of every seed (the per-pair emit of large batches walks positions through it)
     uint64_t* pms = nullptr;   // pos<<32 | meta of the seed at each index position (saves the perm -> seed_pm hop)
     uint32_t* km32 = nullptr;  // the sorted k-mers alone (low word of key): what the join streams, half the bytes
     uint32_t* bucket = nullptr; // per sketch nb+1 offsets: bucket b = entries whose k-mer >> bshift == b (a lookup is one
@@ -276,22 +275,6 @@ struct IndexStore {
 };
 
 inline IndexStore::~IndexStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
-
-// Probe tables of a group of sketches (ensure_probe): the reference side of the POSITION-ordered join of large all-vs-all batches
-// (anchor_probe_pairs_kernel). One 64-byte line holds up to PROBE_SLOTS distinct k-mers and, for each, what the packed join
-// record holds (reference position of the first match; ref contig << 1 | strand, count << 24): a lookup is ONE line read where the
-// k-mer-sorted index needs a bucket-table read, a key scan and a position read. line(km) = mulhi(km left-aligned, lines) is
-// a multiplicative hash of the k-mer (~2.5 k-mers per line); a k-mer whose line is full sits in the next line with room.
-constexpr uint32_t PROBE_SLOTS = 5;
-constexpr uint32_t PROBE_EMPTY = 0xFFFFFFFFu;      // no canonical k-mer of k <= 16 (its reverse complement, 0, is smaller)
-struct ProbeLine { uint32_t k[PROBE_SLOTS]; uint32_t pad; uint2 v[PROBE_SLOTS]; };
-static_assert(sizeof(ProbeLine) == 64, "one probe line = one 64-byte cache line");
-struct ProbeStore {
-    psk_ctx* ctx = nullptr;
-    void* base = nullptr;
-    size_t bytes = 0;
-    ~ProbeStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
-};
 
 // Storage shared by the sketches of one batch: one device allocation, sliced.
 struct SketchStore {
@@ -316,7 +299,6 @@ struct SketchStore {
 // plus the per-sketch inputs of the learned-ANI regression. Pairs are assembled from two of these ON THE DEVICE.
 struct SketchDesc {
     const uint32_t* key; const uint64_t* pms; const uint32_t* perm; const uint32_t* bucket;   // k-mer index (null until built)
-    const uint32_t* iperm;
     const uint32_t* pos; const uint32_t* meta; const uint32_t* seed_pos_base; const uint32_t* contig_start;
     const uint32_t* kmer;   // seed k-mers in (contig,pos) order
     uint64_t total_len;
@@ -324,8 +306,7 @@ struct SketchDesc {
     uint32_t bshift, rows;  // bucket shift; rows of the chunk table a pair with this sketch as the query needs
     uint32_t n_contigs;
     float lenq[3];          // contig-length quantiles {q90, q50, q10}
-    uint32_t tab_lines;     // probe table (null / 0 until built: ensure_probe)
-    const ProbeLine* tab;
+    uint32_t pad;
 };
 
 struct psk_sketch {
@@ -353,9 +334,6 @@ struct psk_sketch {
     mutable uint64_t idx_off = 0;
     mutable uint64_t idx_boff = 0;      // first entry of this sketch's bucket table in idx->bucket
     mutable uint32_t idx_bshift = 0;
-    mutable std::shared_ptr<ProbeStore> ptab;  // built on first use by a large all-vs-all batch (ensure_probe)
-    mutable uint64_t ptab_off = 0;      // first line of this sketch in ptab
-    mutable uint32_t ptab_lines = 0;
 };
 
 struct psk_db {
@@ -461,15 +439,6 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
                              int want_seeds, psk_sketch** out);
 // sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
 psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
-// builds the probe table of every indexed sketch of the list that lacks one (sketches of 256 .. 2^20 seeds)
-psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
-// line of a k-mer: multiplicative hash, then scaled to the table. (NOT the k-mer's own top bits: canonical k-mers are the smaller of a
-// k-mer and its reverse complement, so their density falls linearly from 2 at zero - twice the average load per line at the low end
-// and probe chains hundreds of lines long; measured: 60 x slower.)
-__device__ __forceinline__ uint32_t probe_line(uint32_t km, uint32_t lines) { return __umulhi(km * 2654435761u, lines); }
-// first anchor slot of pair p on the probe path: its items' worth of space plus an eighth (a k-mer that occurs twice on both sides
-// yields four anchors for two query seeds: a genome against itself already holds a few more anchors than seeds)
-__host__ __device__ __forceinline__ uint64_t probe_slot(uint32_t item_base) { return (uint64_t)item_base + (item_base >> 3); }
 psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,

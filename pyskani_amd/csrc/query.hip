@@ -315,14 +315,12 @@ struct PairDesc {
     const uint32_t* q_key; const uint32_t* q_perm;                            // query index slice: the join walks the query in k-mer order
     const uint32_t* q_pos; const uint32_t* q_meta;                            // query seeds, (contig,pos) order
     const uint32_t* q_kmer;                                                   // their k-mers, same order
-    const uint32_t* q_iperm;                                                  // index entry of every query seed (inverse of q_perm)
     uint32_t q_nc, pad_;                                                      // kept contigs of the query
     const uint32_t* q_seed_pos_base;   // base of the query's store (q_contig_start holds offsets into it)
     const uint32_t* q_contig_start;
     uint64_t q_total_len, r_total_len;
     uint32_t r_n, q_n;
     const uint32_t* r_bucket; uint32_t r_bshift;                              // ref index bucket table (IndexStore::bucket)
-    uint32_t r_tab_lines; const ProbeLine* r_tab;                             // ref probe table (null until built: ensure_probe)
 };
 // sbase[p] = first (pair, query seed) item of pair p in lb/cnt/aoff; cbase[p] = first row of pair p in the chunk table
 
@@ -971,429 +969,6 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     }
 }
 
-// ---- position-ordered join: no records, no scan, no separate emit ------------------------------------------------------------
-// For batches of many mid-sized pairs whose references carry a PROBE TABLE (ProbeLine, common.h). One wave per pair walks the
-// query's seeds in (contig, position) order, JT x 64 at a time: every lane looks its k-mer up in the reference's table - ONE
-// 64-byte line read; the entry holds exactly what anchor_join4_kernel's 8-byte record holds - and the round's matches are
-// ranked with shuffles and written as anchors at once, the chunk table built on the way exactly as anchor_emit_pairs_kernel
-// builds it. What the k-mer-ordered join pays to turn k-mer order into position order - one scattered 8-byte record store per
-// (pair, query seed), the records read back, a scan over the pairs' counts - does not exist here: the query is never left.
-// The price is one random line read per item where the merge streams 4 bytes of sorted reference k-mers; the lines of one
-// reference (~1 MB per 5 Mb genome) are shared by the ~100 pairs of its family in flight and sit in L2 / the memory-side cache.
-// A pair's anchors go to [probe_slot(sbase[p]), probe_slot(sbase[p+1])) - its own items' worth of space plus an eighth: only a
-// repeat-rich pair holds more anchors than that; it raises err bit 4 and the host reruns the batch through the k-mer-ordered join.
-// Loads are software-pipelined two rounds deep: when a round's entries are consumed, the next round's key quads have arrived and its
-// entries are requested, and the round after that has its k-mers and its lines on the way - an iteration waits for what the previous
-// one asked for, never for its own requests.
-// Pairs are visited in the order of `order[]` (pair ids sorted by REFERENCE), each XCD taking a contiguous run of it: the ~100 pairs
-// of one reference that a batch holds are probed back to back on ONE XCD, whose L2 keeps that reference's lines (1 MB) while the
-// queries stream past (coalesced); in the batch's own query-major order every XCD would have a quarter of a family's tables in flight.
-__device__ __forceinline__ int probe_slot_of(const ProbeLine* __restrict__ tab, uint32_t lines, uint32_t km, uint4 K, uint32_t& ln) {
-    for (;;) {      // the fifth slot / the next line only where the first four are taken (a fifth of the lookups; a next line one in ten)
-        int sl = K.x == km ? 0 : K.y == km ? 1 : K.z == km ? 2 : K.w == km ? 3 : -1;
-        if (sl < 0 && K.w != PROBE_EMPTY) {
-            const uint32_t k4 = tab[ln].k[4];
-            if (k4 == km) sl = 4;
-            else if (k4 != PROBE_EMPTY) { ln = ln + 1 < lines ? ln + 1 : 0; K = *(const uint4*)(tab + ln); continue; }
-        }
-        return sl;
-    }
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void anchor_probe_pairs_kernel(
-    const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, const uint32_t* __restrict__ order, uint32_t n_pairs,
-    uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err, uint32_t* __restrict__ need_wide,
-    const uint32_t* __restrict__ cbase, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
-    uint32_t* __restrict__ pcount, unsigned long long* __restrict__ bsum) {
-    __shared__ unsigned long long s_key[JT * 64];     // (q contig << 32 | q pos) + 1 of the items with a match, 0 otherwise
-    __shared__ uint32_t s_pre[JT * 64];               // anchors of the round before the item
-    const uint32_t p = order ? order[xcd_block_id()] : blockIdx.x;
-    const int lane = threadIdx.x;
-    const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
-    const uint32_t n = s1 - s0;
-    if (n == 0) { if (lane == 0) { pcount[p] = 0; bsum[p] = 0; n_chunks[p] = 0; } return; }
-    const PairDesc& P = pairs[p];
-    const uint32_t* __restrict__ q_kmer = P.q_kmer; const uint32_t* __restrict__ q_pos = P.q_pos; const uint32_t* __restrict__ q_meta = P.q_meta;
-    const ProbeLine* __restrict__ tab = P.r_tab;
-    const uint32_t lines = P.r_tab_lines;
-    const unsigned long long a0 = probe_slot(s0), a1 = probe_slot(s1);      // the pair's anchor space
-    const unsigned long long lim = a1 < cap ? a1 : cap;
-    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
-    unsigned long long run = a0;                        // next anchor slot
-    unsigned long long lim1 = 0; uint32_t h = 0, n_rows = 0; bool have = false, over = false;
-    const uint4 NOKEYS = make_uint4(PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY);
-    // pipeline state. Round r (being consumed): km0, qp0, qm0, rec0 (entries, requested). Round r+1: km1, ln1, kq1 (key quads,
-    // requested), qp1, qm1. Round r+2: km2 (requested).
-    uint32_t km0[JT], qp0[JT], qm0[JT], km1[JT], ln1[JT], qp1[JT], qm1[JT], km2[JT];
-    uint2 rec0[JT];
-    uint4 kq1[JT];
-    auto item = [&](uint32_t round, int t) { return (round * JT + (uint32_t)t) * 64u + (uint32_t)lane; };
-    {   // prologue: rounds 0 and 1
-        uint32_t ln0[JT]; uint4 kq0[JT];
-#pragma unroll
-        for (int t = 0; t < JT; t++) { const uint32_t j0 = item(0, t), j1 = item(1, t); km0[t] = j0 < n ? q_kmer[j0] : 0u; km1[t] = j1 < n ? q_kmer[j1] : 0u; }
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            const uint32_t j0 = item(0, t);
-            ln0[t] = lines ? probe_line(km0[t], lines) : 0u;
-            kq0[t] = (j0 < n && lines) ? *(const uint4*)(tab + ln0[t]) : NOKEYS;
-            qp0[t] = j0 < n ? q_pos[j0] : 0u; qm0[t] = j0 < n ? q_meta[j0] : 0u;
-        }
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            const int sl = item(0, t) < n ? probe_slot_of(tab, lines, km0[t], kq0[t], ln0[t]) : -1;
-            rec0[t] = sl >= 0 ? tab[ln0[t]].v[sl] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            const uint32_t j1 = item(1, t), j2 = item(2, t);
-            ln1[t] = lines ? probe_line(km1[t], lines) : 0u;
-            kq1[t] = (j1 < n && lines) ? *(const uint4*)(tab + ln1[t]) : NOKEYS;
-            qp1[t] = j1 < n ? q_pos[j1] : 0u; qm1[t] = j1 < n ? q_meta[j1] : 0u;
-            km2[t] = j2 < n ? q_kmer[j2] : 0u;
-        }
-    }
-    for (uint32_t r = 0; r * (JT * 64u) < n; r++) {
-        // ---- consume round r: its entries were requested by the previous iteration
-        uint32_t c[JT], incl[JT], km[JT], qp[JT], qm[JT];
-        uint2 rec[JT];
-        uint32_t agg = 0;
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            rec[t] = rec0[t]; km[t] = km0[t]; qp[t] = qp0[t]; qm[t] = qm0[t];
-            c[t] = rec[t].y >> 24;
-            if (c[t] == 255u) { atomicOr(need_wide, 1u); c[t] = 0; }      // a count or contig number the packed entry cannot hold: the host reruns the batch in the wide format
-            uint32_t v = c[t];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(v, o); if (lane >= o) v += x; }
-            const uint32_t tot = __shfl(v, 63);
-            s_key[t * 64 + lane] = c[t] ? ((((unsigned long long)(qm[t] >> 1)) << 32) | qp[t]) + 1ull : 0ull;
-            s_pre[t * 64 + lane] = agg + (v - c[t]);
-            incl[t] = agg + v;
-            agg += tot;
-        }
-        // ---- round r+1: slots from the key quads that have arrived, entries requested; round r+2: lines + query side requested; round r+3: k-mers
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            const int sl = item(r + 1, t) < n ? probe_slot_of(tab, lines, km1[t], kq1[t], ln1[t]) : -1;
-            rec0[t] = sl >= 0 ? tab[ln1[t]].v[sl] : make_uint2(0u, 0u);
-            km0[t] = km1[t]; qp0[t] = qp1[t]; qm0[t] = qm1[t]; km1[t] = km2[t];
-        }
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            const uint32_t j2 = item(r + 2, t), j3 = item(r + 3, t);
-            ln1[t] = lines ? probe_line(km1[t], lines) : 0u;
-            kq1[t] = (j2 < n && lines) ? *(const uint4*)(tab + ln1[t]) : NOKEYS;
-            qp1[t] = j2 < n ? q_pos[j2] : 0u; qm1[t] = j2 < n ? q_meta[j2] : 0u;
-            km2[t] = j3 < n ? q_kmer[j3] : 0u;
-        }
-        lds_wave_sync();
-        if (run + agg > lim) { over = true; break; }      // more anchors than the pair's space (repeats): the k-mer-ordered join takes the batch
-#pragma unroll
-        for (int t = 0; t < JT; t++) {
-            if (!c[t]) continue;
-            const uint32_t d = (uint32_t)run + (incl[t] - c[t]);
-            if (c[t] == 1) {
-                anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
-            } else {      // a repeat: its run in the reference index (rare)
-                uint32_t l, c2;
-                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km[t], l, c2);
-                for (uint32_t jj = 0; jj < c[t]; jj++) {
-                    const uint64_t pm = P.r_pms[l + jj];
-                    const uint32_t rmeta = (uint32_t)pm;
-                    anc[d + jj] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
-                }
-            }
-        }
-        {      // heads among this round's items: the first item with a match and a key beyond the current head's reach, again and again
-            uint32_t sp = 0;
-            while (sp < (uint32_t)(JT * 64)) {
-                const uint32_t idx = sp + lane;
-                const unsigned long long k1 = idx < (uint32_t)(JT * 64) ? s_key[idx] : 0ull;
-                const unsigned long long bal = __ballot(k1 > lim1);      // lim1 = 0 before the pair's first anchor: any match starts the first chunk
-                if (!bal) { sp += 64; continue; }
-                const uint32_t j = sp + (uint32_t)__ffsll((long long)bal) - 1;
-                const uint32_t b = (uint32_t)run + s_pre[j];
-                if (have) {
-                    if (lane == 0) { if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, b); else atomicOr(err, 1u); }
-                    n_rows++;
-                }
-                have = true; h = b; lim1 = s_key[j] + FRAGMENT_LENGTH;
-                sp = j + 1;
-            }
-        }
-        run += agg;
-        lds_wave_sync();      // the next round overwrites s_key / s_pre
-    }
-    const uint32_t total = over ? 0u : (uint32_t)(run - a0);
-    if (lane == 0) {
-        if (over) atomicOr(err, 4u);
-        pcount[p] = total; bsum[p] = total;
-        if (!over && have && total >= MIN_ANCHORS) {      // fewer: no chain can form, no chunk table, every later kernel skips the pair
-            if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, (uint32_t)run); else atomicOr(err, 1u);
-            n_chunks[p] = n_rows + 1 < max_chunks ? n_rows + 1 : max_chunks;
-        } else n_chunks[p] = 0;
-    }
-}
-
-// one entry of a query_many batch: the pairs of query q with screen ranks [rank_lo, rank_hi) (pair_build_rows_kernel)
-struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; uint32_t rec_off, m_pad, word_off, nxt_off; };      // rec_off / m_pad: the entry's block of join rows (anchor_join_rows_kernel); word_off / nxt_off: its match-mask words and its next-head table
-// ---- row-major join + lane-per-pair emit: no scattered record stores ----------------------------------------------------------
-// What the k-mer-ordered join pays for (profiles/r3/r3a_chain_lane20_counters.md, r2e_pmc_join_kernels_sq.txt) is not bytes but
-// REQUESTS: one scattered 8-byte record store per (pair, query seed) - 4 x 10^9 per 10^5 pairs, each its own L2 transaction - to turn
-// k-mer order into position order pair by pair. But that permutation belongs to the QUERY, and a batch of an all-vs-all holds ~100
-// pairs of every query. So the records of one query are laid out ITEM-major: row i = the records of the query's i-th seed in K-MER
-// order against each of its m references, m_pad (a multiple of 8) records = whole 64-byte lines.
-//   anchor_join_rows_kernel  one wave per 64 consecutive k-mer-order seeds of a query, looping over the query's references 8 at a
-//                            time: the merge of anchor_join_kernel against each (stretch of sorted reference k-mers staged in LDS,
-//                            binary search per lane), the 64 x 8 records transposed through LDS and written as 64-byte lines - 16
-//                            full lines per store instruction. The query's k-mers are read once per 100 pairs, not once per pair.
-//   anchor_emit_rows_kernel  anchor_emit_pairs_kernel for EIGHT pairs at once - the eight references of one line, one wave each -
-//                            walking the query's seeds in (contig, position) order: seed j's row is row iperm[j], the workgroup
-//                            gathers the round's 256 lines whole (four lanes per line) into LDS and every wave reads its own
-//                            column there: the gather that puts a pair's records into position order moves 64 bytes per request
-//                            and serves eight pairs. Anchors and chunk table as the per-pair emit writes them.
-//                            (A lane-per-pair walk - 64 pairs per wave, rows read 512 contiguous bytes at a time - was built
-//                            first: 265 ms per 10^5 pairs. A batch holds ~13 000 pairs = 200 such waves for 1 024 SIMDs.)
-// Anchors of pair p go to [probe_slot(sbase[p]), probe_slot(sbase[p + 1])) as on the probe path (err bit 4 -> the batch is rerun
-// through the per-pair join).
-constexpr int JR_G = 8;      // references per flush = records per 64-byte line
-__global__ __launch_bounds__(256) void anchor_join_rows_kernel(const BatchQ* __restrict__ bq, uint32_t n_bq, const PairDesc* __restrict__ pairs,
-                                                               uint2* __restrict__ rows, uint32_t* __restrict__ need_wide) {
-    __shared__ uint32_t s_key[4][JOIN_WIN];
-    __shared__ __attribute__((aligned(16))) uint2 s_rec[4][64][JR_G];      // 4 KB per wave
-    // workgroup -> (tile, batch entry), entries fastest: the same k-mer range of neighbouring queries (one family) probes the same
-    // stretches of the same reference indices at the same time
-    const uint32_t b = blockIdx.x % n_bq, tile = blockIdx.x / n_bq;
-    const BatchQ B = bq[b];
-    const uint32_t m = B.rank_hi - B.rank_lo;
-    const PairDesc& P0 = pairs[B.pair_off];
-    const uint32_t qn = P0.q_n;
-    if (tile * 256u >= qn) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t i0 = tile * 256u + wave * 64u;      // the wave's first seed (k-mer order)
-    if (i0 >= qn) return;
-    const uint32_t i = i0 + lane;
-    const bool valid = i < qn;
-    const uint32_t km = valid ? P0.q_key[i] : 0u;
-    const unsigned long long vm = __ballot(valid);
-    const int l1 = 63 - __clzll((long long)vm);
-    const uint32_t km_a = __shfl(km, 0), km_b = __shfl(km, l1);
-    uint32_t* sk = s_key[wave];
-    uint2 (*sr)[JR_G] = s_rec[wave];
-    uint2* __restrict__ out = rows + (size_t)B.rec_off + (size_t)i0 * B.m_pad;      // row of the wave's first seed
-    for (uint32_t j0 = 0; j0 < m; j0 += JR_G) {
-#pragma unroll 2
-        for (uint32_t g = 0; g < (uint32_t)JR_G; g++) {
-            uint32_t x = 0, y = 0;
-            if (j0 + g < m) {
-                const PairDesc& P = pairs[B.pair_off + j0 + g];
-                const uint32_t rn = P.r_n;
-                uint32_t lo = 0, cnt = 0;
-                if (rn) {
-                    const uint32_t w_lo = P.r_bucket[km_a >> P.r_bshift], wn = P.r_bucket[(km_b >> P.r_bshift) + 1] - w_lo;
-                    if (wn <= (uint32_t)JOIN_WIN) {
-                        const uint32_t* __restrict__ rk = P.r_key;
-                        lds_wave_sync();      // the previous reference's stretch has been searched
-                        for (uint32_t t = lane; t < wn; t += 64) sk[t] = rk[w_lo + t];
-                        lds_wave_sync();
-                        if (valid) {
-                            uint32_t a = 0, e = wn;
-                            while (a < e) { const uint32_t mid = (a + e) >> 1; if (sk[mid] < km) a = mid + 1; else e = mid; }
-                            lo = w_lo + a;
-                            uint32_t z = a;
-                            while (z < wn && sk[z] == km) z++;      // equal k-mers share a bucket: the run ends inside the stretch
-                            cnt = z - a;
-                        }
-                    } else if (valid) lookup_lane(P.r_key, rn, P.r_bucket, P.r_bshift, km, lo, cnt);      // a sparse query on a dense reference
-                }
-                if (cnt) {
-                    const uint64_t pm = P.r_pms[lo];
-                    const uint32_t rmeta = (uint32_t)pm;
-                    x = (uint32_t)(pm >> 32);
-                    if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
-                    else y = rmeta | (cnt << 24);
-                }
-            }
-            sr[lane][g] = make_uint2(x, y);
-        }
-        lds_wave_sync();
-        // 64 rows x 64 bytes: four consecutive lanes cover one row's line
-#pragma unroll
-        for (int pass = 0; pass < 4; pass++) {
-            const uint32_t it = pass * 16u + ((uint32_t)lane >> 2), seg = (uint32_t)lane & 3u;
-            if (i0 + it < qn && j0 + seg * 2u < B.m_pad)
-                *(uint4*)(out + (size_t)it * B.m_pad + j0 + seg * 2u) = *(const uint4*)&sr[it][seg * 2];
-        }
-        lds_wave_sync();
-    }
-}
-
-// ---- emit over the rows: one LANE per pair, the query cut into segments ------------------------------------------------------------
-// 64 pairs of one query per wave; seed j's row is row iperm[j] (a scalar load: the query is the wave's), the 64 lanes read 512
-// contiguous bytes of it. Query position and contig are scalars, there is no scan, no LDS and no cross-lane traffic: every lane
-// appends to its own pair. A pair's walk is split into segments of ER_SEG seeds so that a batch of ~13 000 pairs fills the chip:
-//   pass 0 (count)   anchors of every (pair, segment)
-//   pass 1 (write)   anchors, starting at the pair's slot + the counts of its earlier segments; per 32 seeds one match mask and
-//                    the anchor offset of the word's first seed (bit 31: a seed of the word matches more than once)
-//   anchor_heads_rows_kernel   the chunk table, one lane per pair: from a head seed j the next head is the first MATCHING seed at or
-//                    after nxt[j] (the query's first seed more than FRAGMENT_LENGTH further on - one table per query, built once per
-//                    batch): one table read, one or two mask words, one offset word per chunk instead of a walk over all anchors.
-constexpr uint32_t ER_SEG = 2048;      // seeds per segment (64 mask words)
-struct RowsAux { uint32_t* segcnt; uint32_t* mask; uint32_t* wpre; uint32_t* nxt; uint32_t s_max; };      // segcnt[pair][s_max]; mask / wpre: per entry [word][m_pad] at word_off[entry]; nxt: per entry [seed] at nxt_off[entry]
-template <int PASS>
-__global__ __launch_bounds__(64) void anchor_emit_rows_kernel(const BatchQ* __restrict__ bq, uint32_t n_bq, uint32_t g_max, const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
-                                                              const uint2* __restrict__ rows, RowsAux X,
-                                                              uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err, uint32_t* __restrict__ need_wide,
-                                                              uint32_t* __restrict__ pcount, unsigned long long* __restrict__ bsum) {
-    const uint32_t b = blockIdx.x % n_bq, rest = blockIdx.x / n_bq, grp = rest % g_max, seg = rest / g_max;
-    const BatchQ B = bq[b];
-    const uint32_t m = B.rank_hi - B.rank_lo;
-    const PairDesc& P0 = pairs[B.pair_off];
-    const uint32_t qn = P0.q_n;
-    if (grp * 64u >= m || seg * ER_SEG >= qn) return;
-    const uint32_t rank = grp * 64u + threadIdx.x;
-    const bool mine = rank < m;
-    const uint32_t p = B.pair_off + (mine ? rank : 0u);
-    const uint32_t* __restrict__ iperm = P0.q_iperm; const uint32_t* __restrict__ q_pos = P0.q_pos; const uint32_t* __restrict__ q_meta = P0.q_meta;
-    const uint2* __restrict__ col = rows + (size_t)B.rec_off + (mine ? rank : 0u);      // this pair's column of the rows
-    const uint32_t m_pad = B.m_pad;
-    const uint32_t j_lo = seg * ER_SEG, j_hi = j_lo + ER_SEG < qn ? j_lo + ER_SEG : qn;
-    uint32_t run = 0;                  // anchors of the segment so far
-    unsigned long long base = 0;       // PASS 1: first anchor slot of the segment
-    bool over = false;
-    if (PASS == 1 && mine) {
-        const unsigned long long a0 = probe_slot(sbase[p]), a1 = probe_slot(sbase[p + 1]);
-        const unsigned long long lim = a1 < cap ? a1 : cap;
-        const uint32_t ns = (qn + ER_SEG - 1) / ER_SEG;
-        unsigned long long before = 0, total = 0;
-        for (uint32_t s2 = 0; s2 < ns; s2++) { const uint32_t c = X.segcnt[(size_t)p * X.s_max + s2]; total += c; if (s2 < seg) before += c; }
-        over = a0 + total > lim;       // more anchors than the pair's space (repeats): the per-pair join takes the batch
-        base = a0 + before;
-        if (seg == 0) { pcount[p] = over ? 0u : (uint32_t)total; bsum[p] = over ? 0ull : total; if (over) atomicOr(err, 4u); }
-    }
-    uint32_t* __restrict__ mask_w = PASS == 1 ? X.mask + B.word_off + (mine ? rank : 0u) : nullptr;
-    uint32_t* __restrict__ wpre_w = PASS == 1 ? X.wpre + B.word_off + (mine ? rank : 0u) : nullptr;
-    constexpr int U = 8;               // seeds in flight per lane
-    for (uint32_t w0 = j_lo; w0 < j_hi; w0 += 32) {      // one 32-seed word at a time
-        uint32_t bits = 0, multi = 0;
-        const uint32_t run_w = run;
-#pragma unroll
-        for (int q4 = 0; q4 < 32; q4 += U) {
-            uint2 rec[U]; uint32_t qp[U], qm[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t j = w0 + q4 + u;
-                const bool in = j < j_hi;
-                const uint32_t i = in ? iperm[j] : 0u;      // uniform over the wave: scalar loads
-                if (PASS == 1) { qp[u] = in ? q_pos[j] : 0u; qm[u] = in ? q_meta[j] : 0u; }
-                rec[u] = (in && mine) ? col[(size_t)i * m_pad] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint32_t c = rec[u].y >> 24;
-                if (c == 255u) { if (PASS == 0) atomicOr(need_wide, 1u); c = 0; }      // a count or contig number the packed record cannot hold: the host reruns the batch in the wide format
-                if (!c) continue;
-                if (PASS == 1 && !over) {
-                    bits |= 1u << (q4 + u); if (c > 1) multi = 0x80000000u;
-                    const uint32_t d = (uint32_t)(base + run);
-                    if (c == 1) {
-                        anc[d] = make_uint4(qp[u], rec[u].x, (rec[u].y & 0xFFFFFEu) | ((rec[u].y ^ qm[u]) & 1u), qm[u] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
-                    } else {      // a repeat: its run in the reference index (rare)
-                        const PairDesc& P = pairs[p];
-                        uint32_t l, c2;
-                        lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[w0 + q4 + u], l, c2);
-                        for (uint32_t jj = 0; jj < c; jj++) {
-                            const uint64_t pm = P.r_pms[l + jj];
-                            const uint32_t rmeta = (uint32_t)pm;
-                            anc[d + jj] = make_uint4(qp[u], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[u]) & 1u), qm[u] >> 1);
-                        }
-                    }
-                }
-                run += c;
-            }
-        }
-        if (PASS == 1 && mine) {
-            const size_t o = (size_t)(w0 >> 5) * m_pad;
-            mask_w[o] = over ? 0u : bits;
-            wpre_w[o] = (uint32_t)(base + run_w - probe_slot(sbase[p])) | multi;      // anchors of the pair before the word's first seed
-        }
-    }
-    if (PASS == 0 && mine) X.segcnt[(size_t)p * X.s_max + seg] = run;
-}
-
-// nxt[j] = first seed of the query whose (contig, position) key exceeds seed j's by more than FRAGMENT_LENGTH (qn: none)
-__global__ __launch_bounds__(256) void rows_next_kernel(const BatchQ* __restrict__ bq, const PairDesc* __restrict__ pairs, uint32_t* __restrict__ nxt) {
-    const BatchQ B = bq[blockIdx.y];
-    const PairDesc& P0 = pairs[B.pair_off];
-    const uint32_t qn = P0.q_n;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < qn; j += gridDim.x * blockDim.x) {
-        const unsigned long long want = ((((unsigned long long)(P0.q_meta[j] >> 1)) << 32) | P0.q_pos[j]) + FRAGMENT_LENGTH;
-        uint32_t a = j + 1, e = qn;
-        while (a < e) {
-            const uint32_t mid = (a + e) >> 1;
-            const unsigned long long k = (((unsigned long long)(P0.q_meta[mid] >> 1)) << 32) | P0.q_pos[mid];
-            if (k <= want) a = mid + 1; else e = mid;
-        }
-        nxt[B.nxt_off + j] = a;
-    }
-}
-
-__global__ __launch_bounds__(64) void anchor_heads_rows_kernel(const BatchQ* __restrict__ bq, uint32_t n_bq, const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
-                                                               const uint2* __restrict__ rows, RowsAux X,
-                                                               const uint32_t* __restrict__ pcount, uint32_t* __restrict__ err,
-                                                               const uint32_t* __restrict__ cbase, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks) {
-    const uint32_t b = blockIdx.x % n_bq, grp = blockIdx.x / n_bq;
-    const BatchQ B = bq[b];
-    const uint32_t m = B.rank_hi - B.rank_lo;
-    const uint32_t rank = grp * 64u + threadIdx.x;
-    if (rank >= m) return;
-    const uint32_t p = B.pair_off + rank;
-    const uint32_t qn = pairs[B.pair_off].q_n, m_pad = B.m_pad;
-    const uint32_t total = pcount[p];
-    if (total < MIN_ANCHORS) { n_chunks[p] = 0; return; }      // fewer: no chain can form, no chunk table, every later kernel skips the pair
-    const uint32_t* __restrict__ mask = X.mask + B.word_off + rank;
-    const uint32_t* __restrict__ wpre = X.wpre + B.word_off + rank;
-    const uint32_t* __restrict__ nxt = X.nxt + B.nxt_off;
-    const uint32_t nw = (qn + 31) / 32;
-    const uint32_t a0 = (uint32_t)probe_slot(sbase[p]);
-    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
-    uint32_t n_rows = 0, h = 0, j = 0;
-    bool have = false;
-    for (;;) {
-        // first matching seed at or after j
-        uint32_t w = j >> 5;
-        if (w >= nw) break;
-        uint32_t mm = mask[(size_t)w * m_pad] & (0xFFFFFFFFu << (j & 31u));
-        while (!mm && ++w < nw) mm = mask[(size_t)w * m_pad];
-        if (!mm) break;
-        const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
-        j = w * 32u + bit;
-        const uint32_t wp = wpre[(size_t)w * m_pad];
-        const uint32_t below = mask[(size_t)w * m_pad] & ((1u << bit) - 1u);
-        uint32_t off = (wp & 0x7FFFFFFFu) + (uint32_t)__popc(below);
-        if ((wp >> 31) && below) {      // a seed of the word matches more than once: the counts of the seeds before j from their records (rare)
-            const uint32_t* __restrict__ iperm = pairs[B.pair_off].q_iperm;
-            const uint2* __restrict__ col = rows + (size_t)B.rec_off + rank;
-            uint32_t bb = below;
-            while (bb) { const uint32_t t = (uint32_t)__ffs((int)bb) - 1u; bb &= bb - 1u; off += (col[(size_t)iperm[w * 32u + t] * m_pad].y >> 24) - 1u; }
-        }
-        const uint32_t a = a0 + off;      // the head's first anchor
-        if (have) { if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, a); else atomicOr(err, 1u); n_rows++; }
-        have = true; h = a;
-        j = nxt[j];
-        if (j >= qn) break;
-    }
-    if (have) {
-        if (n_rows < max_chunks) chunks[(size_t)row0 + n_rows] = make_uint2(h, a0 + total); else atomicOr(err, 1u);
-        n_chunks[p] = n_rows + 1 < max_chunks ? n_rows + 1 : max_chunks;
-    } else n_chunks[p] = 0;
-}
-
-__global__ __launch_bounds__(256) void probe_start_kernel(const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= n_pairs) { const uint64_t a = probe_slot(sbase[p]); pstart[p] = a < cap ? (uint32_t)a : cap; }
-}
-
 // pstart from the 64-bit prefix of the pairs' anchor counts (clamped into the optimistically sized anchor arrays)
 __global__ __launch_bounds__(256) void pair_start64_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1648,11 +1223,12 @@ struct LaneAnchor { uint32_t q, u, m; int32_t f; };
 __device__ __forceinline__ uint32_t lane_diag(uint32_t qx, uint32_t rx, uint32_t sg) { return qx - ((rx ^ sg) - sg); }
 
 // key of predecessor y for anchor x at distance d, NEGATIVE when y is not chainable; same rule as the wave kernel and the oracle.
-// The DP kernel's time is its VALU instruction count (profiles/r3/r3a_chain_lane20_counters.md: 65 % of all issue cycles, three
-// waves per SIMD), so the step is written for it: a predecessor is kept as (q + 1, diagonal, contig | strand, score - 1) - the two
-// "- 1" of the range tests are paid once per anchor instead of once per pair -, every requirement is a sign bit, and the verdict is
-// the key's own sign (one v_and_or) so that the running maximum, taken signed, skips what is not chainable: 15 two-cycle and
-// 4 four-cycle instructions per (anchor, predecessor) pair where the first version issued 21 + 3.
+// The DP kernel's time is its VALU instruction count (profiles/r3/r3a_chain_lane20_counters.md: 65 % of all issue cycles at three
+// waves per SIMD, the rest waits), so the step is written for it: a predecessor is kept as (q + 1, diagonal, contig | strand,
+// score - 1) - the two "- 1" of the range tests are paid once per anchor instead of once per pair -, every requirement is a sign
+// bit, and the verdict is the key's own sign (one v_and_or) so that the running maximum, taken signed, skips what is not chainable.
+// ISA per (anchor, predecessor) pair: 8 v_sub, 3 v_or3, v_xor, v_lshl_add, v_and_or, 2 v_max = 17 instructions / 46 issue cycles;
+// the first version had 20 / 70 (its mask came out as v_cmp + v_cndmask, the slowest VALU instruction there is: 32.8 -> 29.3 ms).
 struct LanePred { uint32_t q1, u, m; int32_t f1; };
 __device__ __forceinline__ int32_t lane_eval2(uint32_t qx, uint32_t ux, uint32_t mx, const LanePred& y, int d) {
     const int32_t a = (int32_t)(qx - y.q1);                               // dq - 1
@@ -1666,6 +1242,7 @@ __device__ __forceinline__ int32_t lane_eval2(uint32_t qx, uint32_t ux, uint32_t
     const uint32_t key = ((uint32_t)s1 << 7) + ((((uint32_t)ANCHOR_SCORE2 + 1u) << 7) | (127u - (uint32_t)d));      // scores stay below 2^20 (a chunk holds < 16 384 anchors): the key's sign bit is free
     return (int32_t)(key | (bad & 0x80000000u));
 }
+
 template <int W>      // window depth: the band rounded up to a multiple of four (20 at c = 125; 24 covers c >= 105)
 __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32_t rows_per_wave) {
     __shared__ uint32_t s_rd[LANE_WAVES][32][64];     // tree id << 14 | depth of the last 32 anchors, per lane
@@ -2586,7 +2163,6 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
 
 // ------------------------------------------------------------------ per-pair ANI / AF
 struct ReduceArgs {
-    const uint32_t* pcount;      // anchors per pair where the pairs' anchor ranges are not contiguous (probe path); else null: pstart[p + 1] - pstart[p]
     const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
     const uint32_t* pstart; const PairDesc* pairs;
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
@@ -2606,7 +2182,7 @@ __global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t 
     psk_hit h{};
     h.ani = -1.0f; h.ani_raw = -1.0f;
     h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-    h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
+    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
     R.hits[p] = h;
 }
 
@@ -2626,7 +2202,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
             psk_hit h{};
             h.ani = -1.0f; h.ani_raw = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-            h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
             R.hits[p] = h;
         }
         return;
@@ -2744,7 +2320,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     if (threadIdx.x == 0) {
         h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
-        h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
+        h.n_anchors = R.pstart[p + 1] - R.pstart[p];
         h.covered_query = s_acc[0]; h.covered_ref = s_acc[1]; h.sum_chain_anchors = s_acc[2]; h.sum_chunk_seeds = s_acc[3];
         if (m > 0) {
             double ani;
@@ -2838,7 +2414,7 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
             h.ani = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
             h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
-            h.n_anchors = R.pcount ? R.pcount[p] : R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
             h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
             if (m > 0) {
                 double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
@@ -2881,7 +2457,6 @@ static SketchDesc make_desc(const psk_sketch* s) {
     SketchDesc d{};
     const bool ix = s->idx != nullptr;
     d.key = ix ? s->idx->km32 + s->idx_off : nullptr; d.pms = ix ? s->idx->pms + s->idx_off : nullptr;
-    d.iperm = ix ? s->idx->iperm + s->idx_off : nullptr;
     d.perm = ix ? s->idx->perm + s->idx_off : nullptr; d.bucket = ix ? s->idx->bucket + s->idx_boff : nullptr;
     d.bshift = ix ? s->idx_bshift : 0; d.n = ix ? (uint32_t)s->n_seeds : 0;
     d.pos = s->store ? s->store->seed_pos + s->seed_off : nullptr; d.meta = s->store ? s->store->seed_meta + s->seed_off : nullptr;
@@ -2893,14 +2468,13 @@ static SketchDesc make_desc(const psk_sketch* s) {
     if (d.n) for (uint32_t len : s->contig_len) rows += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
     d.rows = (uint32_t)std::min<uint64_t>(rows, 0xFFFFFFFFu);
     s->len_quantiles(d.lenq);
-    d.tab = (ix && s->ptab) ? (const ProbeLine*)s->ptab->base + s->ptab_off : nullptr; d.tab_lines = (ix && s->ptab) ? s->ptab_lines : 0;
     return d;
 }
 
 __device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
     PairDesc P;
-    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift; P.r_tab = R.tab; P.r_tab_lines = R.tab_lines;
-    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer; P.q_iperm = Q.iperm; P.q_nc = Q.n_contigs; P.pad_ = 0;
+    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
+    P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer; P.q_nc = Q.n_contigs; P.pad_ = 0;
     P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
     P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
     return P;
@@ -2916,6 +2490,7 @@ __global__ __launch_bounds__(256) void pair_build_list_kernel(const uint2* __res
 // Device-side shortlist: one workgroup per batch entry walks its query's row of the pass matrix and turns the passing
 // references with rank in [rank_lo, rank_hi) into pairs. Every pair of one query has the same item and row count, so the
 // item / row offsets follow from the rank: no scan, no pass[] on the host (lib.rs:617-637 + 640-645 in one kernel).
+struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
 __global__ __launch_bounds__(256) void pair_build_rows_kernel(const BatchQ* __restrict__ bq, const uint8_t* __restrict__ pass, uint32_t n_refs,
                                                               const SketchDesc* __restrict__ qd, const SketchDesc* __restrict__ rd,
                                                               PairDesc* __restrict__ pairs, uint32_t* __restrict__ sbase, uint32_t* __restrict__ cbase,
@@ -2974,13 +2549,12 @@ struct ChainBufs {
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
     uint32_t *blk_pair, *row_pair, *live, *big_list, *huge_list;
     uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum (the 64-bit total sits at bsum[gi_sum])
-    uint32_t n_bq = 0, t_max = 0, g_max = 0, s_max = 0, q_max = 0; size_t n_recs = 0, n_words = 0, n_nxt = 0;      // batch entries (query_many batches), their largest tile / pair-group counts, join rows: what the row-major join needs
 };
-static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L, size_t n_recs = 0) {
+static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
     const size_t gi = (n_items + 255) / 256, gi_sum = std::max(gi, (n_pairs + 3) / 4);
     size_t o_pairs = 0, o_sbase = al256(o_pairs + sizeof(PairDesc) * n_pairs), o_cbase = al256(o_sbase + 4 * (n_pairs + 1)),
            o_pstart = al256(o_cbase + 4 * (n_pairs + 1)), o_lb = al256(o_pstart + 4 * (n_pairs + 1)),
-           o_aoff = al256(o_lb + 8 * (std::max(n_items, n_recs) + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
+           o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
            o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
            o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 256), o_bsum = al256(o_ovf + 4 * n_rows),
@@ -3001,85 +2575,21 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
 // Everything between "pairs / sbase / cbase are on the device" and "hits are on the device": no host synchronisation.
 // Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
 // reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
-// `probe_ok`: every reference of the batch carries a probe table (ensure_probe) - the position-ordered join may take the batch.
-static bool probe_shape(uint32_t n_pairs, size_t n_items) {      // many mid-sized pairs (all-vs-all): the shapes anchor_emit_pairs_kernel takes
-    return n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17);
-}
 static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
-                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide, bool probe_ok = false, bool rows_ok = false) {
+                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
     PSK_HIP(hipMemsetAsync(L.misc, 0, 256, st));     // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[32..47] its group barriers
     PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
     const uint32_t gi = L.gi;
     hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair);
-    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
-    const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
-    PSK_TRY(ctx->q_d.reserve(4 * na * 16));
-    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
-    uint32_t* D = (uint32_t*)ctx->q_d.p;
-    uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
-    uint32_t* a_nxt = D + 4 * na;
-    // position-ordered join (anchor_probe_pairs_kernel): anchors and chunk table straight from the query walk; PSK_PROBE=0 forbids it,
-    // PSK_PROBE=1 takes it for any batch whose references carry tables (tests)
-    // row-major join + lane-per-pair emit (anchor_join_rows_kernel / anchor_emit_rows_kernel): batches of query_many whose entries hold
-    // many pairs per query; PSK_ROWS=0 forbids it, PSK_ROWS=1 takes it for any such batch (tests)
-    // PSK_ROWS: 0 never; 1 for any such batch (tests); default: all-vs-all shapes whose rows cost at most a quarter more than the records
-    const char* rw_env = getenv("PSK_ROWS");
-    const bool rows = rows_ok && L.n_bq && !wide && cap >= probe_slot((uint32_t)n_items) && !(rw_env && rw_env[0] == '0') && L.n_words < 0xFFFFFF00ull &&
-                      ((rw_env && rw_env[0] == '1') ? true : (probe_shape(n_pairs, n_items) && L.n_recs <= n_items + n_items / 4));
-    const char* pb_env = getenv("PSK_PROBE");
-    const bool probe = !rows && probe_ok && !wide && cap >= probe_slot((uint32_t)n_items) && !(pb_env && pb_env[0] == '0') && ((pb_env && pb_env[0] == '1') ? n_pairs >= 1 : probe_shape(n_pairs, n_items));
-    uint32_t* pcount = (probe || rows) ? L.aoff : nullptr;      // anchors per pair (the per-item offsets array is not used then)
-    if (rows) {
-        const size_t o_seg = 0, o_mask = al256(4 * (size_t)n_pairs * L.s_max), o_wpre = al256(o_mask + 4 * L.n_words), o_nxt = al256(o_wpre + 4 * L.n_words), o_endx = o_nxt + 4 * L.n_nxt + 256;
-        PSK_TRY(ctx->q_g.reserve(o_endx));
-        char* G = (char*)ctx->q_g.p;
-        RowsAux X{(uint32_t*)(G + o_seg), (uint32_t*)(G + o_mask), (uint32_t*)(G + o_wpre), (uint32_t*)(G + o_nxt), L.s_max};
-        hipLaunchKernelGGL(probe_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.sbase, n_pairs, L.pstart, (uint32_t)cap);
-        ctx->t_begin(K_ANCHOR);
-        hipLaunchKernelGGL(anchor_join_rows_kernel, dim3(L.t_max * L.n_bq), dim3(256), 0, st, (const BatchQ*)L.bq, L.n_bq, (const PairDesc*)L.pairs, L.lbcnt, L.misc + 5);
-        ctx->t_end();
-        ctx->t_begin(K_ANCHOR_EMIT);
-        const dim3 eg(L.n_bq * L.g_max * L.s_max);
-        hipLaunchKernelGGL(anchor_emit_rows_kernel<0>, eg, dim3(64), 0, st, (const BatchQ*)L.bq, L.n_bq, L.g_max, (const PairDesc*)L.pairs, (const uint32_t*)L.sbase, (const uint2*)L.lbcnt, X,
-                           anc, (uint32_t)cap, L.misc, L.misc + 5, pcount, L.bsum);
-        hipLaunchKernelGGL(anchor_emit_rows_kernel<1>, eg, dim3(64), 0, st, (const BatchQ*)L.bq, L.n_bq, L.g_max, (const PairDesc*)L.pairs, (const uint32_t*)L.sbase, (const uint2*)L.lbcnt, X,
-                           anc, (uint32_t)cap, L.misc, L.misc + 5, pcount, L.bsum);
-        hipLaunchKernelGGL(rows_next_kernel, dim3(std::min<uint32_t>((L.q_max + 255) / 256, 64u), L.n_bq), dim3(256), 0, st, (const BatchQ*)L.bq, (const PairDesc*)L.pairs, X.nxt);
-        hipLaunchKernelGGL(anchor_heads_rows_kernel, dim3(L.n_bq * L.g_max), dim3(64), 0, st, (const BatchQ*)L.bq, L.n_bq, (const PairDesc*)L.pairs, (const uint32_t*)L.sbase, (const uint2*)L.lbcnt, X,
-                           (const uint32_t*)pcount, L.misc, (const uint32_t*)L.cbase, L.chunks, L.nch);
-        ctx->t_end();
-    }
-    if (probe) {
-        hipLaunchKernelGGL(probe_start_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, L.sbase, n_pairs, L.pstart, (uint32_t)cap);      // a pair's anchors live in its own items' worth of space (+ 1/8)
-        ctx->t_begin(K_ANCHOR);
-        // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys (PSK_PROBE_ORDER=0: batch order)
-        static const bool pb_order = !(getenv("PSK_PROBE_ORDER") && getenv("PSK_PROBE_ORDER")[0] == '0');
-        uint32_t* order = nullptr;
-        if (pb_order) {
-            size_t ts = 0;
-            uint32_t* keys_in = L.big_list;                     // free until select runs
-            uint32_t* vals_in = L.live;                         // free until the live list is built
-            uint32_t* keys_out = (uint32_t*)L.hits_sel;         // free until the hits are selected
-            order = keys_out + n_pairs;
-            hipLaunchKernelGGL(pair_ref_keys_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, L.pair_qr, n_pairs, keys_in, vals_in);
-            PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
-            PSK_TRY(ctx->q_g.reserve(ts + 256));
-            PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_g.p, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
-        }
-        hipLaunchKernelGGL(anchor_probe_pairs_kernel, dim3(n_pairs), dim3(64), 0, st, L.pairs, L.sbase, (const uint32_t*)order, n_pairs, anc, (uint32_t)cap, L.misc, L.misc + 5,
-                           L.cbase, L.chunks, L.nch, pcount, L.bsum);
-        ctx->t_end();
-    }
-    const bool placed = probe || rows;      // anchors, chunk table and per-pair counts exist: no join records, no scan, no emit
-    if (!placed) ctx->t_begin(K_ANCHOR);
-    if (wide && !placed) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
+    ctx->t_begin(K_ANCHOR);
+    if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
     static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
-    const bool join_pairs = !placed && !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
+    const bool join_pairs = !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
     if (join_pairs) {
         // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys
         size_t ts = 0;
@@ -3095,20 +2605,19 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
         n_sum = nb;
     }
-    else if (!placed && !wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
+    else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
     // many mid-sized pairs (all-vs-all): the join counts every pair's anchors, one workgroup per pair then emits with a running offset
     // (anchor_emit_pairs_kernel) instead of a scan over all items; PSK_EMIT_PAIRS=1 / 0 force / forbid it (tests, A/B)
     const char* ep_env = getenv("PSK_EMIT_PAIRS");
-    const bool emit_pairs = !placed && !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
+    const bool emit_pairs = !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
                             (ep_env ? ep_env[0] == '1' : (n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17)));
     uint32_t* pair_cnt = L.live;      // free until the live list is built
     if (emit_pairs) PSK_HIP(hipMemsetAsync(pair_cnt, 0, 4 * ((size_t)n_pairs + 1), st));
     // workgroups of one pair per XCD turn (0 = contiguous eighths of the grid; PSK_XCD_GROUP overrides): see xcd_group_block_id
     static const int xg_env = getenv("PSK_XCD_GROUP") ? atoi(getenv("PSK_XCD_GROUP")) : -1;
     const uint32_t xcd_group = xg_env >= 0 ? (uint32_t)xg_env : (n_pairs >= 64 ? (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, 4 * (n_items / n_pairs) / (JT * 256))) : 0u);      // four pairs per turn (measured: 1 pair 38.5, 2: 37.4, 4 and more: 36.8 ms of join per 10^5 pairs; contiguous eighths: 44.0)
-    if (!placed && !wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
-    if (!placed) ctx->t_end();
-    if (placed) n_sum = n_pairs;      // bsum[p] = anchors of pair p
+    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
+    ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
     hipcub::TransformInputIterator<uint32_t, PackedCount, const uint2*> pcnt_it(L.lbcnt, PackedCount());
@@ -3126,14 +2635,20 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
         hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap);
     }
-    else if (placed) { /* no per-item offsets: the probe kernel placed the anchors itself */ }
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
     if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + L.gi_sum, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
-    if ((!emit_pairs && !placed) || small_sum)
-        hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || placed) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || placed) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
+    if (!emit_pairs || small_sum)
+        hipLaunchKernelGGL(pair_start_kernel, dim3(emit_pairs ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, emit_pairs ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
+    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
+    const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
+    PSK_TRY(ctx->q_d.reserve(4 * na * 16));
+    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
+    uint32_t* D = (uint32_t*)ctx->q_d.p;
+    uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
+    uint32_t* a_nxt = D + 4 * na;
     ChainArgs A{};
     A.anc = anc;
     A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
@@ -3150,16 +2665,14 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool use_hops = hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20));
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
-    if (!placed) ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
-    if (placed) { /* anchors and chunk table exist */ }
-    else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
+    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
     else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    if (placed) { /* chunk table exists */ }
-    else if (use_hops) {
+    if (use_hops) {
         hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
         if (n_items / n_pairs > (1u << 20) && !getenv("PSK_HOPS_UNSLICED")) {      // Gb-scale pairs: HOP_SLICES waves per pair, count then write
             PSK_TRY(ctx->q_g.reserve(4 * (size_t)n_pairs * HOP_SLICES + 256));
@@ -3170,7 +2683,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else if (!emit_heads)
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
-    if (!placed) ctx->t_end();
+    ctx->t_end();
     ctx->t_begin(K_CHAIN_CHUNK);
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
@@ -3267,7 +2780,6 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     ctx->t_end();
     hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
-    R.pcount = pcount;
     R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
     R.k = prm.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = L.hits;
@@ -3301,9 +2813,8 @@ static uint64_t anchor_cap_for(Lane* ctx, size_t n_items) {
 // outcome of a launch sequence, read back with the hits
 struct ChainTail { uint32_t misc[16]; unsigned long long total64; };
 static bool join_wide_default() { const char* e = getenv("PSK_JOIN"); return e && !strcmp(e, "wide"); }
-static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry, bool* probe_ok = nullptr, bool* rows_ok = nullptr) {
+static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry) {
     *retry = false;
-    if (probe_ok && rows_ok && (*probe_ok || *rows_ok) && (T.misc[0] & 4u)) { *probe_ok = false; *rows_ok = false; *retry = true; return PSK_OK; }   // a pair with more anchors than query seeds (repeats): the k-mer-ordered join takes the batch
     if (!*wide && T.misc[5]) { *wide = true; *retry = true; return PSK_OK; }   // a count or contig number the packed join format cannot hold: rerun in the wide format
     if (T.total64 >= 0x7FFFFFF0ull) {   // the 32-bit offsets wrapped (or would not fit the per-anchor arrays): the caller splits the batch
         psk_set_error("%u pair(s) yield %llu anchors, more than one launch takes (2^31)%s", n_pairs, T.total64, n_pairs > 1 ? "" : ": the pair is too repetitive to chain");
@@ -3517,15 +3028,10 @@ __global__ __launch_bounds__(256) void pref_apply_kernel(const uint32_t* __restr
     if (cnt[cell] < MIN_ANCHORS) pass[(size_t)rq[j] * n_refs + r] = 0;
 }
 
-// how many references carry a k-mer index (low word) / a probe table (high word): the descriptor table is stale when this moves
-static uint64_t index_stamp(const psk_db* db) {
-    uint64_t v = 0;
-    for (const psk_sketch* r : db->refs) v += (uint64_t)(r->idx != nullptr) + ((uint64_t)(r->ptab != nullptr) << 32);
-    return v;
-}
 static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
-    const uint64_t indexed = index_stamp(db);
+    uint64_t indexed = 0;
+    for (const psk_sketch* r : db->refs) indexed += r->idx != nullptr;
     if (!db->desc_dirty && db->desc_indexed == indexed && db->desc_n == n) return PSK_OK;
     std::vector<SketchDesc>& h = db->h_refdesc;     // stays alive until the copy has drained (every query ends with a synchronisation)
     h.resize(n);
@@ -3609,8 +3115,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
             if (refs_ok) {
                 bool all_idx = !db->desc_dirty && db->desc_n == n;
-                for (const psk_sketch* rs : db->refs) if (!rs->idx && rs->n_seeds && rs->store) all_idx = false;
-                if (!all_idx || index_stamp(db) != db->desc_indexed)
+                uint64_t indexed = 0;
+                for (const psk_sketch* rs : db->refs) { indexed += rs->idx != nullptr; if (!rs->idx && rs->n_seeds && rs->store) all_idx = false; }
+                if (!all_idx || indexed != db->desc_indexed)
                     PSK_TRY(exclusive([&]() -> psk_status {
                         std::vector<const psk_sketch*> all_refs(db->refs.begin(), db->refs.end());
                         PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
@@ -3688,7 +3195,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
         {   // references first (shared state: exclusive), then this call's own query sketches
             bool refs_stale = db->desc_dirty || db->desc_n != n;
-            refs_stale = refs_stale || index_stamp(db) != db->desc_indexed;
+            uint64_t indexed = 0;
+            for (const psk_sketch* rs : db->refs) indexed += rs->idx != nullptr;
+            refs_stale = refs_stale || indexed != db->desc_indexed;
             for (size_t i = 0; i < n_need_refs && !refs_stale; i++) refs_stale = !need[i]->idx && need[i]->n_seeds && need[i]->store;
             if (refs_stale)     // one index launch for the references AND this call's queries (a fresh database: the headline step)
                 PSK_TRY(exclusive([&]() -> psk_status {
@@ -3696,29 +3205,6 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     return refresh_ref_descs(ctx, db);
                 }));
             else if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
-        }
-        // large rounds of mid-sized pairs (all-vs-all) take the position-ordered join: every reference about to be chained needs its
-        // probe table (built once per reference, like the k-mer index; PSK_PROBE=0 never, =1 whenever the references allow it)
-        bool round_probe = false;
-        {
-            const char* pb_env = getenv("PSK_PROBE");
-            const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
-            uint64_t round_items = 0;
-            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
-            (void)round_items;
-            if (!pb_off && db->params.k <= 16 && pb_force && round_pairs >= 1) {      // opt-in (PSK_PROBE=1): measured slower than the row-major join, DESIGN.md section 5
-                round_probe = true;
-                bool missing = false;
-                for (size_t i = 0; i < n_need_refs; i++) {
-                    if (need[i]->n_seeds < 256 || need[i]->n_seeds > (1u << 20)) { round_probe = false; break; }
-                    missing = missing || !need[i]->ptab;
-                }
-                if (round_probe && missing)
-                    PSK_TRY(exclusive([&]() -> psk_status {
-                        PSK_TRY(ensure_probe(ctx, need.data(), (uint32_t)n_need_refs));
-                        return refresh_ref_descs(ctx, db);
-                    }));
-            }
         }
         h_qd.resize(m);
         for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
@@ -3757,7 +3243,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (rank >= h_cnt[qi]) { qi++; rank = 0; continue; }
             // plan one batch from (qi, rank)
             bqs.clear();
-            uint64_t pairs = 0, items = 0, rows = 0, recs = 0, words = 0, nxts = 0, t_max = 0, g_max = 0, q_max = 0;      // recs: join rows (take padded to whole 64-byte lines per query seed)
+            uint64_t pairs = 0, items = 0, rows = 0;
             uint32_t pq = qi, pr = rank;
             while (pq < m) {
                 const uint32_t left = h_cnt[pq] - pr;
@@ -3767,11 +3253,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 if (qn) take = std::min<uint64_t>(take, (max_items - items) / qn);
                 if (qrows) take = std::min<uint64_t>(take, (max_rows - rows) / qrows);
                 if (take == 0) { if (pairs == 0) take = 1; else break; }      // a single pair always goes through (chain_check refuses what cannot fit)
-                const uint32_t m_pad = ((uint32_t)take + 7u) & ~7u;
-                bqs.push_back(BatchQ{pq, pr, pr + (uint32_t)take, (uint32_t)pairs, (uint32_t)items, (uint32_t)rows, (uint32_t)std::min<uint64_t>(recs, 0xFFFFFFFFu), m_pad,
-                                     (uint32_t)std::min<uint64_t>(words, 0xFFFFFFFFu), (uint32_t)std::min<uint64_t>(nxts, 0xFFFFFFFFu)});
-                recs += qn * m_pad; words += ((qn + 31) / 32) * m_pad; nxts += qn;
-                t_max = std::max<uint64_t>(t_max, (qn + 255) / 256); g_max = std::max<uint64_t>(g_max, (take + 63) / 64); q_max = std::max<uint64_t>(q_max, qn);
+                bqs.push_back(BatchQ{pq, pr, pr + (uint32_t)take, (uint32_t)pairs, (uint32_t)items, (uint32_t)rows});
                 pairs += take; items += take * qn; rows += take * qrows;
                 pr += (uint32_t)take;
                 if (pairs >= max_pairs || items >= max_items || rows >= max_rows) break;
@@ -3784,10 +3266,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 // nothing to chain (queries without seeds): no hits
             } else {
                 ChainBufs L;
-                const bool recs_fit = recs < 0xFFFFFF00ull && recs <= items + items / 4 + 65536;
-                psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L, recs_fit ? (size_t)recs : 0);
-                L.n_bq = (uint32_t)bqs.size(); L.t_max = (uint32_t)t_max; L.g_max = (uint32_t)g_max; L.n_recs = (size_t)recs;
-                L.q_max = (uint32_t)q_max; L.s_max = (uint32_t)((q_max + ER_SEG - 1) / ER_SEG); L.n_words = (size_t)words; L.n_nxt = (size_t)nxts;
+                psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
                 PSK_TRY(lrc);
                 PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
@@ -3798,9 +3277,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
-                bool too_big = false, wide = join_wide_default(), probe_ok = round_probe, rows_ok = recs_fit;
+                bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
-                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, probe_ok, rows_ok);
+                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
                     const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
@@ -3816,11 +3295,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     ctx->huge_release();
                     bool retry;
-                    psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry, &probe_ok, &rows_ok);
+                    psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
                     if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
-                    if (attempt >= 4) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+                    if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
                 n_sel = T->misc[12];

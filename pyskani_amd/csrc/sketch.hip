@@ -752,12 +752,6 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
 // sketches that need one; LSD radix sort is stable, so equal k-mers keep their (contig,pos) order ----
 struct IdxSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n; uint32_t out_off; uint32_t bshift, nb, boff; };
 
-// iperm[seed] = index entry of the seed (the inverse of perm), per sketch
-__global__ __launch_bounds__(256) void index_iperm_kernel(const IdxSeg* __restrict__ segs, const uint32_t* __restrict__ perm, uint32_t* __restrict__ iperm) {
-    const IdxSeg sg = segs[blockIdx.y];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) iperm[sg.out_off + perm[sg.out_off + i]] = i;
-}
-
 __global__ __launch_bounds__(256) void index_gather_kernel(const IdxSeg* __restrict__ segs, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const IdxSeg sg = segs[blockIdx.y];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) {
@@ -948,11 +942,10 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
         auto ix = std::make_shared<IndexStore>();
         ix->ctx = ctx->dev;
         size_t kb = align_up(8 * (size_t)T, 256), vb = align_up(4 * (size_t)T, 256), bb = align_up(4 * (size_t)boff, 256);
-        PSK_TRY(ctx->pool_alloc(2 * kb + 3 * vb + bb, &ix->base, &ix->bytes));
+        PSK_TRY(ctx->pool_alloc(2 * kb + 2 * vb + bb, &ix->base, &ix->bytes));
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
         ix->km32 = (uint32_t*)((char*)ix->base + 2 * kb + vb);
         ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb);
-        ix->iperm = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb + bb);
         PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
         PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
         if (small) {
@@ -964,7 +957,6 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
             if (tiny) hipLaunchKernelGGL((index_block_kernel<256, IDXT_MAX_LB>), dim3(m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, 1u, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
             else hipLaunchKernelGGL((index_block_kernel<IDXB_THREADS, IDXB_MAX_LB>), dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
-            hipLaunchKernelGGL(index_iperm_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint32_t*)ix->perm, ix->iperm);
             ctx->t_end();
             PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {
@@ -984,7 +976,6 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
         PSK_TRY(ctx->s_tmp.reserve(tmp));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
         hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms, ix->km32);
-        hipLaunchKernelGGL(index_iperm_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 64), m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint32_t*)ix->perm, ix->iperm);
         ctx->t_end();
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) {
@@ -995,65 +986,3 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
     }
     return PSK_OK;
 }
-
-// ------------------------------------------------------------------ probe tables (position-ordered join of large all-vs-all batches)
-struct ProbeSeg { const uint32_t* key; const uint64_t* pms; ProbeLine* tab; uint32_t n, lines; };
-// one thread per index entry; the head of every run of equal k-mers inserts (k-mer, first position, meta | count << 24)
-__global__ __launch_bounds__(256) void probe_build_kernel(const ProbeSeg* __restrict__ segs) {
-    const ProbeSeg S = segs[blockIdx.y];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S.n) return;
-    const uint32_t km = S.key[i];
-    if (i > 0 && S.key[i - 1] == km) return;
-    uint32_t cnt = 1;
-    while (i + cnt < S.n && cnt < 255u && S.key[i + cnt] == km) cnt++;
-    const uint64_t pm = S.pms[i];
-    const uint32_t rmeta = (uint32_t)pm;
-    // same packing as the join's record: counts >= 255 or reference contig numbers >= 2^23 read as 255 ("rerun in the wide format")
-    const uint32_t y = (cnt >= 255u || (rmeta >> 24)) ? ((rmeta & 0xFFFFFFu) | (255u << 24)) : (rmeta | (cnt << 24));
-    uint32_t L = probe_line(km, S.lines);
-    for (;;) {
-        ProbeLine* ln = S.tab + L;
-        for (uint32_t s = 0; s < PROBE_SLOTS; s++) {
-            if (atomicCAS(&ln->k[s], PROBE_EMPTY, km) == PROBE_EMPTY) { ln->v[s] = make_uint2((uint32_t)(pm >> 32), y); return; }
-        }
-        L = L + 1 < S.lines ? L + 1 : 0;
-    }
-}
-
-psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
-    std::lock_guard<std::mutex> index_lock(ctx->dev->index_mu);
-    hipStream_t st = ctx->stream;
-    std::vector<const psk_sketch*> todo;
-    std::unordered_set<const psk_sketch*> seen;
-    for (uint32_t i = 0; i < n; i++)
-        if (refs[i] && refs[i]->idx && !refs[i]->ptab && refs[i]->n_seeds >= 256 && refs[i]->n_seeds <= (1u << 20) && seen.insert(refs[i]).second) todo.push_back(refs[i]);
-    size_t i0 = 0;
-    while (i0 < todo.size()) {
-        size_t i1 = i0; uint64_t lines = 0; uint32_t maxn = 0;
-        std::vector<ProbeSeg> segs;
-        std::vector<uint64_t> loff;
-        while (i1 < todo.size() && i1 - i0 < 65535 && lines < (1ull << 28)) {      // <= 16 GB of lines per store
-            const psk_sketch* s = todo[i1];
-            const uint32_t ln = (uint32_t)((s->n_seeds * 2 + 4) / 5);              // ~2.5 k-mers per line of 5 slots
-            loff.push_back(lines);
-            segs.push_back(ProbeSeg{s->idx->km32 + s->idx_off, s->idx->pms + s->idx_off, nullptr, (uint32_t)s->n_seeds, ln});
-            lines += ln; maxn = std::max(maxn, (uint32_t)s->n_seeds); i1++;
-        }
-        auto ps = std::make_shared<ProbeStore>();
-        ps->ctx = ctx->dev;
-        PSK_TRY(ctx->pool_alloc(sizeof(ProbeLine) * (size_t)lines, &ps->base, &ps->bytes));
-        for (size_t j = 0; j < segs.size(); j++) segs[j].tab = (ProbeLine*)ps->base + loff[j];
-        PSK_HIP(hipMemsetAsync(ps->base, 0xFF, sizeof(ProbeLine) * (size_t)lines, st));
-        PSK_TRY(ctx->s_offs.reserve(sizeof(ProbeSeg) * segs.size()));
-        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(ProbeSeg) * segs.size(), hipMemcpyHostToDevice, st));
-        ctx->t_begin(K_SKETCH_SORT);
-        hipLaunchKernelGGL(probe_build_kernel, dim3((maxn + 255) / 256, (uint32_t)segs.size()), dim3(256), 0, st, (const ProbeSeg*)ctx->s_offs.p);
-        ctx->t_end();
-        PSK_HIP(hipStreamSynchronize(st));      // segs (host vector) feeds the async copy above
-        for (size_t j = 0; j < segs.size(); j++) { todo[i0 + j]->ptab = ps; todo[i0 + j]->ptab_off = loff[j]; todo[i0 + j]->ptab_lines = segs[j].lines; }
-        i0 = i1;
-    }
-    return PSK_OK;
-}
-

@@ -1,5 +1,4 @@
-"""GPU: the paths that only large batches take - the row-major join with its lane-per-pair emit and, behind it, the per-pair join with the
-one-workgroup-per-pair emit with the chunk table (>= 1 024 mid-sized pairs), the position-ordered join over probe tables,
+"""GPU: the paths that only large batches take - one-workgroup-per-pair emit with the chunk table (>= 1 024 mid-sized pairs),
 XCD turns in the join, two-tier selection, 2^29-seed batches, the seed prefilter of rescued contigs (>= 2^20 pairs) - against
 the same batch with each of them switched off. Every hit (reference, all chaining integers, ANI, AF) must be identical.
 (The small-batch paths are held to the oracle in test_gpu_parity / test_gpu_fuzz; these runs are held to those paths, and a random
@@ -57,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_ROWS"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -67,11 +66,7 @@ def _run(code, extra):
 def test_all_vs_all_batch_paths_agree():
     base = _run(ALL_VS_ALL, {})
     assert base[0] >= 320 * 40                      # every genome finds its family: >= 1 024 chained pairs in one batch
-    # the default walks every QUERY once over all its pairs (anchor_join_rows_kernel: records as whole lines, item-major) and emits with one
-    # lane per pair; PSK_ROWS=0 is the per-pair k-mer-ordered join, whose variants follow; PSK_PROBE=1 the position-ordered join over probe tables
-    C = {"PSK_ROWS": "0"}
-    for extra in (C, dict(C, PSK_PROBE="1"), dict(C, PSK_PROBE="1", PSK_PROBE_ORDER="0"), dict(C, PSK_EMIT_PAIRS="0"), dict(C, PSK_EMIT_HEADS="0"), dict(C, PSK_XCD_GROUP="0"),
-                  {"PSK_BATCH_ITEMS_LOG2": "22"}, dict(C, PSK_BATCH_ITEMS_LOG2="22"), dict(C, PSK_CHUNK_HOPS="1")):
+    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0"}, {"PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_CHUNK_HOPS": "1"}):
         assert _run(ALL_VS_ALL, extra) == base, extra
 
 
