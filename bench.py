@@ -132,6 +132,26 @@ def make_big_genomes(torch, device, n_genomes, n_contigs, contig_len, fam_size, 
     return buf, offs, lens, gfc
 
 
+def fill_big_genome(torch, device, buf, gi, n_contigs, contig_len, fam_size, seed):
+    """Genome gi of the configs[4] family model into `buf` (n_contigs x stride bytes, reused from genome to genome): ancestor contig c of
+    family gi // fam_size drawn from a generator seeded by (seed, family, contig), the member's substitutions from (seed, genome, contig) -
+    any genome can be (re)built alone, so 50 x 3 Gb never has to be resident as ASCII. Returns the contig offsets / lengths."""
+    g = torch.Generator(device=device)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    stride = (contig_len + 15 + 16) & ~15
+    fam, j = gi // fam_size, gi % fam_size
+    d = DIVERGENCE[:4][j % 4]
+    for c in range(n_contigs):
+        g.manual_seed((seed * 1_000_003 + fam) * 1009 + c)
+        a = torch.randint(0, 4, (contig_len,), generator=g, device=device, dtype=torch.uint8)
+        g.manual_seed(((seed + 7) * 1_000_003 + gi) * 1009 + c)
+        mut = torch.rand(a.shape, generator=g, device=device) < d
+        shift = torch.randint(1, 4, a.shape, generator=g, device=device, dtype=torch.uint8)
+        buf[c * stride:c * stride + contig_len] = lut[torch.where(mut, (a + shift) & 3, a).long()]
+        del a, mut, shift
+    return [c * stride for c in range(n_contigs)], [contig_len] * n_contigs
+
+
 def make_contigs(torch, device, buf, offs, lens, n_refs, n_contigs, seed):
     """BASELINE configs[3] / SURVEY.md §8(d) config 4: query contigs = substrings of random references, length
     log-uniform in [2 kb, 50 kb], extra divergence U[0, 5 %]. Built on the GPU; 16-byte aligned offsets."""
@@ -782,15 +802,82 @@ def run_mammalian(job, steps, warmup, n_genomes, contig_mb, verify_pairs):
     return entry
 
 
+def run_mammalian_stream(job, n_genomes, contig_mb, fam_size, verify_pairs):
+    """BASELINE configs[4] at its full count on ONE GPU: n_genomes genomes of 24 x contig_mb Mb (50 x 3 Gb = 150 Gb of sequence) whose ASCII is
+    never resident together - every genome is built into one reused device buffer (untimed), sketched from there (timed) and dropped; what
+    stays in HBM is what the path needs: the sketches and, once chained, the k-mer indexes of all n_genomes. Then one database, every genome
+    against all of them (psk_query_many), hits to the host. ms_per_step = the sum of the sketch calls + database + query: one pass, steps = 1."""
+    torch = job.torch
+    contig_len = contig_mb * 1_000_000
+    stride = (contig_len + 15 + 16) & ~15
+    buf = torch.zeros(24 * stride + 64, dtype=torch.uint8, device=job.device)
+    eng = Engine(job.local_rank)
+    clock = eng.clock_probe()
+    eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 1)); eng.timing("reset"); eng.work(reset=True)
+    handles = (C.c_void_p * n_genomes)()
+    t_sketch, t_gen = 0.0, 0.0
+    for gi in range(n_genomes):
+        t0 = time.perf_counter()
+        offs, lens = fill_big_genome(torch, job.device, buf, gi, 24, contig_len, fam_size, seed=5)
+        torch.cuda.synchronize()
+        t_gen += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        h = eng.sketch_device(buf.data_ptr(), offs, lens, gfc=[0, 24])
+        eng.sync()
+        t_sketch += time.perf_counter() - t0
+        handles[gi] = h[0]
+    names = (C.c_char_p * n_genomes)(*[f"m{i}".encode() for i in range(n_genomes)])
+    free0 = torch.cuda.mem_get_info()[0]
+    t0 = time.perf_counter()
+    db = eng.make_db(names, handles, n_genomes)
+    nh, (recs, qoffs) = eng.query_many(db, handles, n_genomes, keep=True)
+    eng.sync()
+    t_query = time.perf_counter() - t0
+    free1 = torch.cuda.mem_get_info()[0]
+    kern = {k: eng.timing(k) for k in KERNELS}
+    work = eng.work(reset=True)
+    dt = t_sketch + t_query
+    bases = float(n_genomes) * 24 * contig_len
+    table = kernel_rooflines(kern, 1, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+    seeds = C.c_uint64(); n_seeds = 0
+    for gi in range(n_genomes):
+        eng.capi.check(eng.lib.psk_sketch_info(handles[gi], None, C.byref(seeds), None, None, None)); n_seeds += seeds.value
+    entry = {"ms_per_step": dt * 1e3, "steps": 1, "warmup": 0, "value": float(n_genomes) * n_genomes / dt, "unit": "genome-pairs/s",
+             "workload": f"mammalian scale, BASELINE configs[4] at full count on one GPU: all-vs-all of {n_genomes} synthetic genomes of 24 x {contig_mb} Mb contigs "
+                         f"({24 * contig_mb / 1000:.1f} Gb each; families of {fam_size}, substitution rates {DIVERGENCE[:4]}), c=125 marker_c=1000 k=15; ASCII streamed genome by genome "
+                         f"through one device buffer, sketches + k-mer indexes of all {n_genomes} resident",
+             "hits": int(nh), "chain_work_per_step": work, "bases_sketched_per_s": bases / t_sketch,
+             "phases_s": {"sketch_all": t_sketch, "database_and_query": t_query, "generate_untimed": t_gen},
+             "resident": {"seeds": int(n_seeds), "sketch_bytes_est": int(n_seeds) * 20, "index_bytes_est": int(n_seeds) * 24,
+                          "device_free_before_query_GB": free0 / 1e9, "device_free_after_query_GB": free1 / 1e9},
+             "roofline": roofline_of(table, 1), "kernel_roofline": table, "clock": clock}
+    eng.lib.psk_db_destroy(db)
+    if verify_pairs > 0 and nh:
+        # genomes 0 and 1 rebuilt (the generator is per genome), copied to the host and chained by the oracle
+        contigs = {}
+        for gi in (0, 1):
+            offs, lens = fill_big_genome(torch, job.device, buf, gi, 24, contig_len, fam_size, seed=5)
+            contigs[gi] = [buf[o:o + L].cpu().numpy().tobytes() for o, L in zip(offs, lens)]
+        entry["oracle_check"], entry["cpu_baseline"] = mammalian_verify_host(contigs, recs, qoffs, n_genomes, verify_pairs, int(nh))
+    del buf
+    eng.close()
+    torch.cuda.empty_cache()
+    return entry
+
+
 def mammalian_verify(buf, offs, lens, gfc, recs, qoffs, n_genomes, verify_pairs, n_hits):
     """Two genomes of one family -> host -> oracle sketches -> oracle.chain for the ordered pairs between them; the hits of the last
     timed step must carry the same integers. Returns (check record, cpu_baseline extrapolated from the oracle's times)."""
+    qa, qb = 0, 1                       # two members of family 0
+    contigs = {g: [buf[offs[c]:offs[c] + lens[c]].cpu().numpy().tobytes() for c in range(gfc[g], gfc[g + 1])] for g in (qa, qb)}
+    return mammalian_verify_host(contigs, recs, qoffs, n_genomes, verify_pairs, n_hits)
+
+
+def mammalian_verify_host(contigs, recs, qoffs, n_genomes, verify_pairs, n_hits):
+    """contigs = {0: [...], 1: [...]}: two genomes of one family as host bytes."""
     from oracle import oracle as O
     O.build()
-    qa, qb = 0, 1                       # two members of family 0
-    t0 = time.perf_counter()
-    contigs = {g: [buf[offs[c]:offs[c] + lens[c]].cpu().numpy().tobytes() for c in range(gfc[g], gfc[g + 1])] for g in (qa, qb)}
-    t_copy = time.perf_counter() - t0
+    qa, qb = 0, 1
     t0 = time.perf_counter()
     sk = {g: O.Sketch(contigs[g]) for g in (qa, qb)}
     t_sketch = (time.perf_counter() - t0) / 2
@@ -810,7 +897,7 @@ def mammalian_verify(buf, offs, lens, gfc, recs, qoffs, n_genomes, verify_pairs,
         checked.append({"query": q, "ref": r, "ani": float(hit[0]["ani"]), "n_anchors": int(hit[0]["n_anchors"]), "n_chunks": int(hit[0]["n_chunks"])})
     t_chain /= max(1, len(checked))
     secs = n_genomes * t_sketch + n_hits * t_chain      # screens are negligible at this scale
-    check = {"pairs": checked, "fields": list(fields) + ["ani (1e-6)", "af_query (1e-6)"], "result": "bit-exact integers", "d2h_copy_s": t_copy}
+    check = {"pairs": checked, "fields": list(fields) + ["ani (1e-6)", "af_query (1e-6)"], "result": "bit-exact integers"}
     cpu = {"value": float(n_genomes) * n_genomes / secs, "unit": "genome-pairs/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
            "sample": f"2 of the {n_genomes} genomes sketched ({t_sketch:.1f} s each) and {len(checked)} of the {n_hits} chained pairs ({t_chain:.1f} s each) by the oracle on one core; "
                      f"extrapolated to {n_genomes} sketches + {n_hits} chains = {secs:.0f} s",
@@ -831,6 +918,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
     ap.add_argument("--contig-mb", type=int, default=125, help="mammalian: contig length in Mb (24 contigs per genome; 125 = 3 Gb genomes)")
     ap.add_argument("--api-queries", type=int, default=2000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
+    ap.add_argument("--stream", action="store_true", help="mammalian: build and sketch one genome at a time through a reused device buffer (BASELINE configs[4] at full count: --refs 50), families of 10")
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--comm", choices=["torch", "capi"], default="torch", help="N>1: who moves the exchange steps — torch.distributed, or the library's own RCCL communicator (psk_comm_*)")
@@ -901,7 +989,8 @@ def main():
             if m.get("api"):
                 line["extras"]["api"] = m["api"]
     else:
-        e = run_mammalian(job, args.steps, args.warmup, args.refs or 8, args.contig_mb, 2 if cpu_n > 0 else 0)
+        e = (run_mammalian_stream(job, args.refs or 50, args.contig_mb, 10, 2 if cpu_n > 0 else 0) if args.stream
+             else run_mammalian(job, args.steps, args.warmup, args.refs or 8, args.contig_mb, 2 if cpu_n > 0 else 0))
         line = as_line(e, "mammalian") if rank == 0 else None
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
