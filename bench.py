@@ -285,19 +285,20 @@ def timed_loop(eng, step, steps, warmup, fence):
 
 
 def load_pmc():
-    """offline counter passes (rocprofv3 --pmc, separate runs; profiles/scripts/pmc_summary.py writes the JSON): HBM bytes per unit
-    of every profiled kernel, {timer name: {"bytes_per_unit": x, "unit": "base" | "item" | "anchor", "source": ...}}"""
+    """offline counter passes (rocprofv3 --pmc, separate runs; profiles/scripts/pmc_summary.py writes the JSON): HBM bytes per unit of work of
+    the profiled kernels, {workload: {timer name: {"bytes_per_unit": x, "unit": "base" | "item" | "anchor", "source": ...}}}"""
     out = {}
-    for rel in ("profiles/r2/r2n_pmc_sketch_scan.json", "profiles/r3/pmc_kernels.json"):
-        p = os.path.join(ROOT, rel)
-        if not os.path.exists(p):
-            continue
+    p = os.path.join(ROOT, "profiles", "r2", "r2n_pmc_sketch_scan.json")
+    if os.path.exists(p):      # sketch_scan is unchanged since round 2 (same counters in round 1)
         d = json.load(open(p))
-        if "traffic_bytes_per_base" in d:      # round-2 format: sketch_scan only
-            out["sketch_scan"] = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": rel, "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
-        else:
-            for k, v in d.items():
-                out[k] = dict(v, source=rel)
+        ss = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": "profiles/r2/r2n_pmc_sketch_scan.json", "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
+        for wl in ("search", "allvsall", "metagenome", "mammalian"):
+            out.setdefault(wl, {})["sketch_scan"] = ss
+    p = os.path.join(ROOT, "profiles", "r3", "pmc_kernels.json")
+    if os.path.exists(p):
+        for wl, timers in json.load(open(p)).items():
+            for k, v in timers.items():
+                out.setdefault(wl, {})[k] = dict(v, source="profiles/r3/pmc_kernels.json")
     return out
 
 
@@ -312,11 +313,12 @@ def kernel_rooflines(kern, steps, units, pmc):
     Kernels without a stated byte count (screen, select, pair_reduce, the sorts) are reported as time only."""
     bases, items, anchors = units["bases"], units.get("items", 0.0), units.get("anchors", 0.0)
     alg = {"sketch_scan": (1.25 * bases, "L + L/4 per base"),
+           "sketch_sort": ((20.0 / units["c"] + 16.0 / units["marker_c"]) * bases, "k-mer index: 20 B per seed (key, position|meta, order); marker sets: 16 B per marker; per base: 20/c + 16/marker_c"),
            "sketch_emit": ((0.125 + 0.25 + 20.0 / units["c"] + 8.0 / units["marker_c"]) * bases, "L/8 + L/4 + 20 L/c + 8 L/marker_c per base"),
            "anchor": (16.0 * items, "16 B per (pair, query seed) item"),
            "anchor_emit": (8.0 * items + 16.0 * anchors, "8 B per item + 16 B per anchor"),
            "chain_chunk": (16.0 * anchors, "16 B per anchor")}
-    unit_of = {"sketch_scan": ("base", bases), "sketch_emit": ("base", bases), "anchor": ("item", items), "anchor_emit": ("item", items), "chain_chunk": ("anchor", anchors)}
+    unit_of = {"sketch_scan": ("base", bases), "sketch_emit": ("base", bases), "sketch_sort": ("base", bases), "anchor": ("item", items), "anchor_emit": ("item", items), "chain_chunk": ("anchor", anchors)}
     table = {}
     for k in KERNELS:
         ms_total, launches = kern[k]
@@ -532,9 +534,9 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
     line = None
     if rank == 0:
         bases = float(sum(lens))
-        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc.get("search", {}))
         roof = roofline_of(table, steps, prefer="sketch_scan")
-        pm = job.pmc.get("sketch_scan")
+        pm = job.pmc.get("search", {}).get("sketch_scan")
         if pm and "valu_per_base" in pm and roof:
             # VALU issue: SQ_INSTS_VALU per base measured offline (26.8 wave-instructions per 64 bases, 61 % four-cycle and 39 % two-cycle by
             # profiles/micro/valu_rates.hip = 3.2 cycles on average), launch duration measured live, clock probed live
@@ -619,7 +621,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
         recs = last["recs"]
         recs["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(last["offs"]))
         digest = records_digest(recs)
-        table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc)
+        table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                 "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}), c=125 marker_c=1000 k=15",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
@@ -656,7 +658,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
         if rank == 0:
             st = state["stats"]
             other = st["total_s"] - st["psk_s"] - st["collective_s"]
-            table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc)
+            table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
             line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                     "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15; "
                                 f"query side = all-gather of the shards' packed sketch records, {args.exchange_batch} genomes per rank and round; hit records all-gathered once ({args.comm})",
@@ -703,7 +705,7 @@ def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs,
                     eng.lib.psk_sketch_free(h)
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
         dt = job.max_over_ranks(dt)
-        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 30, "marker_c": 200, **work}, job.pmc)
+        table = kernel_rooflines(kern, steps, {"bases": bases, "c": 30, "marker_c": 200, **work}, job.pmc.get("metagenome", {}))
         entry = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": n_queries * job.world * steps / dt, "unit": "queries/s",
                  "pairs_per_s": float(n_queries) * n_refs * job.world * steps / dt,
                  "workload": f"metagenome: {n_queries} contigs (2-50 kb, log-uniform, 0-5 % divergence) vs a resident database of {n_refs} synthetic ~5 Mb refs ({n_families} families), "
@@ -788,7 +790,7 @@ def run_mammalian(job, steps, warmup, n_genomes, contig_mb, verify_pairs):
     dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
     dt = job.max_over_ranks(dt)
     bases = float(sum(lens))
-    table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+    table = kernel_rooflines(kern, steps, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc.get("mammalian", {}))
     entry = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_genomes) * n_genomes * job.world * steps / dt, "unit": "genome-pairs/s",
              "workload": f"mammalian scale (BASELINE configs[4] shape at reduced count): all-vs-all of {n_genomes} synthetic genomes of 24 x {contig_mb} Mb contigs "
                          f"({24 * contig_mb / 1000:.1f} Gb each; families of 4, substitution rates {DIVERGENCE[:4]}), c=125 marker_c=1000 k=15",
@@ -838,7 +840,7 @@ def run_mammalian_stream(job, n_genomes, contig_mb, fam_size, verify_pairs):
     work = eng.work(reset=True)
     dt = t_sketch + t_query
     bases = float(n_genomes) * 24 * contig_len
-    table = kernel_rooflines(kern, 1, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc)
+    table = kernel_rooflines(kern, 1, {"bases": bases, "c": 125, "marker_c": 1000, **work}, job.pmc.get("mammalian", {}))
     seeds = C.c_uint64(); n_seeds = 0
     for gi in range(n_genomes):
         eng.capi.check(eng.lib.psk_sketch_info(handles[gi], None, C.byref(seeds), None, None, None)); n_seeds += seeds.value

@@ -426,9 +426,11 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
     block_total(cnt, lb, block_sum);
 }
 
-// PACKED join format (default): per (pair, query seed) x = reference position of the FIRST match, y = (ref contig << 1 | ref
-// strand bit) | count << 24. An item with one match - nearly all of them - then needs no further look at the reference: the
-// emit kernel reads nothing at random. Counts >= 255 or reference contig numbers >= 2^23 raise `need_wide` and the host
+// PACKED join format (default): per (pair, query seed) y = (ref contig << 1 | ref strand bit) of the first match | count << 24, and
+// x = the reference position of the match when there is ONE - nearly all items: the emit kernel then reads nothing at random -
+// or, for a k-mer with several matches, the index of the run's first entry in the reference's k-mer index (the emit kernel reads
+// the run's positions from there; it used to look the k-mer up again, which is what every item of a Gb-scale pair - six chance
+// 15-mer matches per seed - went through). Counts >= 255 or reference contig numbers >= 2^23 raise `need_wide` and the host
 // reruns the batch in the wide format.
 // The lookup itself is a MERGE: a wave's 64 query k-mers are consecutive in k-mer order, so their matches sit in one short
 // stretch of the reference's sorted k-mers. The wave reads the bucket table twice (its first and last k-mer), stages that
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void anchor_join_kernel(const PairDesc* __rest
         if (cnt) {
             const uint64_t pm = pairs[p].r_pms[lo];
             const uint32_t rmeta = (uint32_t)pm;
-            x = (uint32_t)(pm >> 32);
+            x = cnt > 1 ? lo : (uint32_t)(pm >> 32);      // one match: its reference position; a run: where it starts in the reference index
             if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
             else y = rmeta | (cnt << 24);
         }
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc*
         anc[dst] = make_uint4(qp, it.x, (it.y & 0xFFFFFEu) | ((it.y ^ qm) & 1u), qm >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig): one 16-byte store
         return;
     }
-    uint32_t l, c2;     // a repeat: find its run in the reference index again (rare)
-    lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[j0], l, c2);
+    const uint32_t l = it.x;     // a k-mer with several matches: the record holds where its run starts in the reference index
     for (uint32_t j = 0; j < c; j++) {
         const uint64_t pm = P.r_pms[l + j];
         const uint32_t rmeta = (uint32_t)pm;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void anchor_join4_kernel(const PairDesc* __res
             uint32_t x = 0, y = 0;
             if (cnt[t]) {
                 const uint32_t rmeta = (uint32_t)pm[t];
-                x = (uint32_t)(pm[t] >> 32);
+                x = cnt[t] > 1 ? lo[t] : (uint32_t)(pm[t] >> 32);      // one match: its reference position; a run: where it starts in the reference index
                 if (cnt[t] >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
                 else y = rmeta | (cnt[t] << 24);
             }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(256) void anchor_join_pairs_kernel(const PairDesc* 
                 uint32_t x = 0, y = 0;
                 if (cnt[u]) {
                     const uint32_t rmeta = (uint32_t)pm[u];
-                    x = (uint32_t)(pm[u] >> 32);
+                    x = cnt[u] > 1 ? lo[u] : (uint32_t)(pm[u] >> 32);
                     if (cnt[u] >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
                     else y = rmeta | (cnt[u] << 24);
                 }
@@ -802,15 +803,71 @@ __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc
         if (c[t] == 1) {
             const uint32_t d = dst[t];
             anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
-        } else {      // a repeat: find its run in the reference index again (rare)
+        } else {      // a k-mer with several matches: the record holds where its run starts in the reference index
             const PairDesc& P = pairs[p[t]];
-            uint32_t l, c2;
-            lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[i[t] - sbase[p[t]]], l, c2);
+            const uint32_t l = rec[t].x;
             for (uint32_t j = 0; j < c[t]; j++) {
                 const uint64_t pm = P.r_pms[l + j];
                 const uint32_t rmeta = (uint32_t)pm;
                 anc[dst[t] + j] = make_uint4(qp[t], (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm[t]) & 1u), qm[t] >> 1);
             }
+        }
+    }
+}
+
+// Emit for batches whose k-mers match MANY times (Gb-scale pairs: a 15-mer has ~6 chance matches in 3 Gb, so a pair of 24 M seeds yields
+// 155 M anchors). The item-major kernels above give every item's run to ONE lane - 6.5 sixteen-byte stores a lane at a stride of 104
+// bytes: 64 separate requests per store instruction, 0.57 TB/s for 80 GB of anchors. Here the wave works ANCHOR-major: its 64 items'
+// records, offsets and query sides go to LDS, then lane k takes output slot first + k, first + 64 + k, ...: the owning item by a binary
+// search over the 64 offsets, the match's position from r_pms[run start + j] - consecutive lanes read consecutive entries of a run -
+// and ONE contiguous kilobyte of anchors per store instruction. Same anchors at the same places.
+__global__ __launch_bounds__(256) void anchor_emit_expand_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                                 uint32_t n_pairs, uint32_t n_items,
+                                                                 const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
+                                                                 uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
+                                                                 const uint32_t* __restrict__ blk_pair) {
+    __shared__ uint32_t s_dst[4][64], s_x[4][64], s_y[4][64], s_qp[4][64], s_qm[4][64];
+    __shared__ const uint64_t* s_pms[4][64];
+    const uint32_t lb = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i = lb * 256u + threadIdx.x;
+    const bool act = i < n_items;
+    const uint2 rec = act ? item[i] : make_uint2(0u, 0u);
+    const uint32_t d0 = act ? aoff[i] : 0u;
+    const uint32_t c = rec.y >> 24;
+    uint32_t qp = 0, qm = 0;
+    const uint64_t* pms = nullptr;
+    if (act && c) {
+        const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[lb]);
+        const PairDesc& P = pairs[p];
+        const uint32_t j0 = i - sbase[p];
+        qp = P.q_pos[j0]; qm = P.q_meta[j0]; pms = P.r_pms;
+    }
+    // the wave's items with a match, compacted to the front (offsets ascending): lane l of the compacted list
+    const unsigned long long live = __ballot(act && c != 0);
+    const uint32_t n_live = (uint32_t)__popcll(live);
+    if (n_live == 0) return;
+    if (act && c) {
+        const uint32_t r = (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
+        s_dst[wave][r] = d0; s_x[wave][r] = rec.x; s_y[wave][r] = rec.y; s_qp[wave][r] = qp; s_qm[wave][r] = qm; s_pms[wave][r] = pms;
+    }
+    lds_wave_sync();
+    const uint32_t first = s_dst[wave][0];
+    const uint32_t last_c = s_y[wave][n_live - 1] >> 24;
+    const unsigned long long end = (unsigned long long)s_dst[wave][n_live - 1] + last_c;      // one past the wave's last anchor
+    if (end > cap) { if (lane == 0) atomicOr(err, 2u); }      // beyond the optimistic capacity: the host reruns the batch with the true total
+    const unsigned long long stop = end < cap ? end : cap;
+    for (unsigned long long o = (unsigned long long)first + lane; o < stop; o += 64) {
+        uint32_t a = 0, b = n_live;      // owner = last compacted item with dst <= o
+        while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (s_dst[wave][mid] <= (uint32_t)o) a = mid; else b = mid; }
+        const uint32_t j = (uint32_t)o - s_dst[wave][a];
+        const uint32_t x = s_x[wave][a], y = s_y[wave][a], qpa = s_qp[wave][a], qma = s_qm[wave][a];
+        if ((y >> 24) == 1) {
+            anc[o] = make_uint4(qpa, x, (y & 0xFFFFFEu) | ((y ^ qma) & 1u), qma >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
+        } else {
+            const uint64_t pm = s_pms[wave][a][x + j];      // x = where the k-mer's run starts in the reference index
+            const uint32_t rmeta = (uint32_t)pm;
+            anc[o] = make_uint4(qpa, (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qma) & 1u), qma >> 1);
         }
     }
 }
@@ -925,9 +982,8 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
             const uint32_t d = (uint32_t)dst[t];
             if (c[t] == 1) {
                 anc[d] = make_uint4(qp[t], rec[t].x, (rec[t].y & 0xFFFFFEu) | ((rec[t].y ^ qm[t]) & 1u), qm[t] >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig)
-            } else {      // a repeat: find its run in the reference index again (rare)
-                uint32_t l, c2;
-                lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, P.q_kmer[c0 - s0 + t * (uint32_t)EP_T + threadIdx.x], l, c2);
+            } else {      // a k-mer with several matches: the record holds where its run starts in the reference index
+                const uint32_t l = rec[t].x;
                 for (uint32_t j = 0; j < c[t]; j++) {
                     const uint64_t pm = P.r_pms[l + j];
                     const uint32_t rmeta = (uint32_t)pm;
@@ -1036,17 +1092,32 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
 }
 
 // nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
+// COARSE = 1: the successor of every 64th anchor only, into nxt[a / 64]; COARSE = 2: every anchor, searched between the successors of
+// the two 64th anchors around it (nxt is monotone within a pair: 6-7 probes next to each other instead of 13 across megabytes;
+// 3.9 -> ms per 3 Gb pair of 155 M anchors); COARSE = 0: every anchor on its own (few, small pairs).
+template <int COARSE>
 __global__ __launch_bounds__(256) void anchor_next_kernel(const uint4* __restrict__ anc,
                                                           const uint32_t* __restrict__ pstart, uint32_t n_pairs,
-                                                          uint32_t* __restrict__ nxt) {
-    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= pstart[n_pairs]) return;      // the grid covers the capacity, the device knows the total
+                                                          const uint32_t* __restrict__ coarse, uint32_t* __restrict__ nxt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = pstart[n_pairs];      // the grid covers the capacity, the device knows the total
+    const uint32_t a = COARSE == 1 ? t * 64u : t;
+    if (a >= total) return;
     const uint32_t p = find_le(pstart, n_pairs, a);
-    uint32_t pend = pstart[p + 1];
-    uint64_t key = ((uint64_t)anc[a].w << 32) + (uint64_t)anc[a].x + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
+    const uint32_t pend = pstart[p + 1];
+    const uint64_t key = ((uint64_t)anc[a].w << 32) + (uint64_t)anc[a].x + FRAGMENT_LENGTH;   // first b with (qc,qp) > key
     uint32_t l = a + 1, h = pend;
+    if (COARSE == 2) {
+        const uint32_t g = a >> 6;
+        if (g * 64u >= pstart[p]) { const uint32_t c0 = coarse[g]; l = c0 > l ? c0 : l; }      // the 64th anchor before a is of the same pair: nxt(a) >= its successor
+        if ((g + 1) * 64u < pend) { const uint32_t c1 = coarse[g + 1]; h = c1 < h ? c1 : h; }   // ... and <= the successor of the 64th anchor after it
+    } else if (h - l > 8192u) {
+        // the answer is rarely far: FRAGMENT_LENGTH bases hold a few hundred to a thousand anchors even between Gb-scale genomes, so one
+        // probe 8 192 anchors on usually cuts a 27-step search over a 155 M-anchor pair to 13 steps
+        const uint32_t far = l + 8192u; const uint64_t kf = ((uint64_t)anc[far].w << 32) | anc[far].x; if (kf > key) h = far; else l = far + 1;
+    }
     while (l < h) { uint32_t mid = (l + h) >> 1; uint64_t k2 = ((uint64_t)anc[mid].w << 32) | anc[mid].x; if (k2 <= key) l = mid + 1; else h = mid; }
-    nxt[a] = l;
+    nxt[COARSE == 1 ? t : a] = l;
 }
 
 // Alternative for a few very large pairs (Gb-scale genomes), where one wave walking 50 000 heads is the critical
@@ -1091,27 +1162,41 @@ __device__ __forceinline__ uint32_t first_anchor_of_contig(const uint4* __restri
     while (a < b) { const uint32_t mid = (a + b) >> 1; if (anc[mid].w < c) a = mid + 1; else b = mid; }
     return a;
 }
-// pass 0: count; pass 1: write. slice_cnt[p * HOP_SLICES + w] holds the slice's chunk count between the passes.
+// pass 0: the walk - every slice writes its rows into a scratch table, at the place they would have if every earlier contig held as many
+// chunks as its length allows (last seed position / (FRAGMENT_LENGTH + 1) + 1: the bound the table's rows are sized by), and leaves its
+// count in slice_cnt; pass 1: the slices' rows copied to their dense places, 64 rows per step. (Walking twice - count, then write - was
+// 4.1 ms per 3 Gb pair each time.)
+__device__ __forceinline__ uint32_t contig_row_bound(const PairDesc& P, uint32_t c) {
+    const uint32_t a = P.q_contig_start[c], b = P.q_contig_start[c + 1];
+    return a < b ? P.q_seed_pos_base[b - 1] / (FRAGMENT_LENGTH + 1u) + 1u : 0u;      // a contig without seeds has no anchors and no chunk
+}
 __global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxt, const uint4* __restrict__ anc,
                                                                 const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ cbase, uint32_t n_pairs,
-                                                                uint32_t* __restrict__ slice_cnt, int pass, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
+                                                                uint32_t* __restrict__ slice_cnt, int pass, uint2* __restrict__ scratch, uint2* __restrict__ chunks, uint32_t* __restrict__ n_chunks,
                                                                 uint32_t* __restrict__ err) {
     __shared__ uint32_t s_win[HOP_WIN];
     __shared__ uint32_t s_h, s_n;
     const uint32_t p = blockIdx.x, w = blockIdx.y;
     const int lane = threadIdx.x;
     const uint32_t a = pstart[p], b = pstart[p + 1];
-    const uint32_t nc = pairs[p].q_nc;
+    const PairDesc& P = pairs[p];
+    const uint32_t nc = P.q_nc;
     const uint32_t c_lo = (uint32_t)((uint64_t)nc * w / HOP_SLICES), c_hi = (uint32_t)((uint64_t)nc * (w + 1) / HOP_SLICES);
     const bool dead = b - a < MIN_ANCHORS;
     if (pass == 0 && (dead || c_lo == c_hi)) { if (lane == 0) slice_cnt[p * HOP_SLICES + w] = 0; return; }
     if (pass == 1 && dead) { if (lane == 0 && w == 0) n_chunks[p] = 0; return; }
     const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
-    uint32_t off = 0, total = 0;
+    uint32_t ub = 0;      // rows the contigs before this slice can hold at most: where the slice's scratch rows start
+    for (uint32_t c = lane; c < c_lo; c += 64) ub += contig_row_bound(P, c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ub += __shfl_xor(ub, o);
     if (pass == 1) {
+        uint32_t off = 0, total = 0;
         for (int j = 0; j < HOP_SLICES; j++) { const uint32_t c = slice_cnt[p * HOP_SLICES + j]; if ((uint32_t)j < w) off += c; total += c; }
         if (lane == 0 && w == 0) { n_chunks[p] = total < max_chunks ? total : max_chunks; if (total > max_chunks) atomicOr(err, 1u); }
-        if (c_lo == c_hi) return;
+        const uint32_t n = slice_cnt[p * HOP_SLICES + w];
+        for (uint32_t i = lane; i < n; i += 64) if (off + i < max_chunks && ub + i < max_chunks) chunks[(size_t)row0 + off + i] = scratch[(size_t)row0 + ub + i];
+        return;
     }
     uint32_t h = first_anchor_of_contig(anc, a, b, c_lo);
     const uint32_t hend = c_hi >= nc ? b : first_anchor_of_contig(anc, a, b, c_hi);
@@ -1123,7 +1208,7 @@ __global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* _
         if (lane == 0) {
             while (h < hend && h - w0 < wn) {
                 const uint32_t e = s_win[h - w0];
-                if (pass == 1 && off + n < max_chunks) chunks[(size_t)row0 + off + n] = make_uint2(h, e);
+                if (ub + n < max_chunks) scratch[(size_t)row0 + ub + n] = make_uint2(h, e); else atomicOr(err, 1u);
                 n++; h = e;
             }
             s_h = h; s_n = n;
@@ -1131,7 +1216,7 @@ __global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* _
         lds_wave_sync();
         h = s_h; n = s_n;
     }
-    if (pass == 0 && lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
+    if (lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
 }
 
 // ------------------------------------------------------------------ chaining
@@ -1243,9 +1328,15 @@ __device__ __forceinline__ int32_t lane_eval2(uint32_t qx, uint32_t ux, uint32_t
     return (int32_t)(key | (bad & 0x80000000u));
 }
 
-template <int W>      // window depth: the band rounded up to a multiple of four (20 at c = 125; 24 covers c >= 105)
+// XT: further tree slots per lane in LDS (0, or LANE_XTREES for Gb-scale pairs: there a seed has ~6 chance 15-mer matches beside the
+// true one, the band of 20 ANCHORS reaches back only ~3 seeds, a true chain breaks wherever three seeds in a row do not match and a
+// chunk holds 5-15 qualifying trees - with four slots most chunks went to the wave-per-chunk kernel, 7.7 of 10 ms per 3 Gb pair)
+constexpr int LANE_XTREES = 12;
+template <int W, int XT>      // window depth: the band rounded up to a multiple of four (20 at c = 125; 24 covers c >= 105)
 __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32_t rows_per_wave) {
     __shared__ uint32_t s_rd[LANE_WAVES][32][64];     // tree id << 14 | depth of the last 32 anchors, per lane
+    __shared__ unsigned long long s_xk[LANE_WAVES][XT ? XT : 1][XT ? 64 : 1];     // slots 4 .. 4 + XT - 1: best anchor key
+    __shared__ uint32_t s_xr[LANE_WAVES][XT ? XT : 1][XT ? 64 : 1];               // ... and root
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
     uint32_t s = 0, e = 0;
@@ -1313,8 +1404,14 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
                     found = found || hit;
                     if (hit && k64 > bk[j]) bk[j] = k64;
                 }
+                if (XT && !found && S > (uint32_t)LANE_TREES) {      // the LDS slots (a lane's own column: no other lane touches it)
+                    const uint32_t nx = S - LANE_TREES < (uint32_t)XT ? S - LANE_TREES : (uint32_t)XT;
+                    for (uint32_t j = 0; j < nx; j++)
+                        if (s_xr[wave][j][lane] == ridx) { found = true; if (k64 > s_xk[wave][j][lane]) s_xk[wave][j][lane] = k64; break; }
+                }
                 if (!found) {
-                    if (S >= (uint32_t)LANE_TREES) ovf = true;
+                    if (S >= (uint32_t)(LANE_TREES + XT)) ovf = true;
+                    else if (XT && S >= (uint32_t)LANE_TREES) { s_xr[wave][S - LANE_TREES][lane] = ridx; s_xk[wave][S - LANE_TREES][lane] = k64; }
 #pragma unroll
                     for (int j = 0; j < LANE_TREES; j++) if (S == (uint32_t)j) { sroot[j] = ridx; bk[j] = k64; }
                     S++;
@@ -1335,6 +1432,11 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
 #pragma unroll
                 for (int j = 0; j < LANE_TREES; j++)
                     if (sroot[j] != 0xFFFFFFFFu && (c == 0 || sroot[j] > last) && sroot[j] < pick) { pick = sroot[j]; k = bk[j]; }
+                if (XT && S > (uint32_t)LANE_TREES)
+                    for (uint32_t j = 0; j < S - LANE_TREES; j++) {
+                        const uint32_t rt = s_xr[wave][j][lane];
+                        if ((c == 0 || rt > last) && rt < pick) { pick = rt; k = s_xk[wave][j][lane]; }
+                    }
                 last = pick;
                 const uint32_t xb = s + (16383u - (uint32_t)((k >> 14) & 16383u));      // the tree's best anchor
                 const uint32_t q1 = A.anc[xb].x, rb = A.anc[xb].y;
@@ -1355,8 +1457,9 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
 
 // W = 20 fits three waves per SIMD (168 registers; the 24-deep window needs 192 and runs two): the kernel is VALU-issue bound and
 // a third wave fills issue slots that two leave empty
-__global__ __launch_bounds__(64 * LANE_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8))) void chain_lane20_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<20>(A, rows_per_wave); }
-__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<LANE_N>(A, rows_per_wave); }
+__global__ __launch_bounds__(64 * LANE_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8))) void chain_lane20_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<20, 0>(A, rows_per_wave); }
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane20x_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<20, LANE_XTREES>(A, rows_per_wave); }
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_lane_kernel(ChainArgs A, uint32_t rows_per_wave) { chain_lane_body<LANE_N, 0>(A, rows_per_wave); }
 
 // ---- four lanes per chunk, for launches too small to fill the chip with one lane per chunk -----------------
 // (the headline search: 100 pairs = 22 k chunks). Lane j of a quad owns the anchors whose index is j mod 4: ownership
@@ -2670,15 +2773,28 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
-    else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    else {
+        // k-mers with many matches (Gb-scale pairs): anchor-major emit; PSK_EMIT_EXPAND=1 / 0 force / forbid (tests, A/B)
+        const char* ex_env = getenv("PSK_EMIT_EXPAND");
+        const bool expand = ex_env ? ex_env[0] == '1' : n_items / n_pairs > (1u << 20);
+        if (expand) hipLaunchKernelGGL(anchor_emit_expand_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+        else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    }
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     if (use_hops) {
-        hipLaunchKernelGGL(anchor_next_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, a_nxt);
+        if (n_items / n_pairs > (1u << 20)) {      // Gb-scale: every 64th anchor first (into the spare per-anchor array after a_nxt), then all of them between those
+            uint32_t* coarse = D + 5 * na;          // sc_f's space: the serial path is not running yet
+            hipLaunchKernelGGL(anchor_next_kernel<1>, dim3((uint32_t)((cap / 64 + 1 + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)nullptr, coarse);
+            hipLaunchKernelGGL(anchor_next_kernel<2>, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)coarse, a_nxt);
+        } else
+        hipLaunchKernelGGL(anchor_next_kernel<0>, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)nullptr, a_nxt);
         if (n_items / n_pairs > (1u << 20) && !getenv("PSK_HOPS_UNSLICED")) {      // Gb-scale pairs: HOP_SLICES waves per pair, count then write
-            PSK_TRY(ctx->q_g.reserve(4 * (size_t)n_pairs * HOP_SLICES + 256));
+            const size_t o_scr = al256(4 * (size_t)n_pairs * HOP_SLICES + 256);
+            PSK_TRY(ctx->q_g.reserve(o_scr + sizeof(uint2) * n_rows + 256));
             uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
+            uint2* scratch_rows = (uint2*)((char*)ctx->q_g.p + o_scr);
             for (int pass = 0; pass < 2; pass++)
-                hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, pass, L.chunks, L.nch, L.misc);
+                hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, pass, scratch_rows, L.chunks, L.nch, L.misc);
         } else
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     } else if (!emit_heads)
@@ -2699,9 +2815,14 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             if (quad) {   // small launch: four lanes per chunk, 16 chunks per wave
                 const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
                 hipLaunchKernelGGL(chain_quad_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
-            } else
-            if (A.band <= 20) hipLaunchKernelGGL(chain_lane20_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
-            else hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+            } else {
+                // Gb-scale pairs: sixteen tree slots per chunk (twelve of them in LDS); PSK_LANE_XTREES=1 / 0 force / forbid (tests, A/B)
+                const char* xt_env = getenv("PSK_LANE_XTREES");
+                const bool xtrees = xt_env ? xt_env[0] == '1' : n_items / n_pairs > (1u << 20);
+                if (A.band <= 20 && xtrees) hipLaunchKernelGGL(chain_lane20x_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+                else if (A.band <= 20) hipLaunchKernelGGL(chain_lane20_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+                else hipLaunchKernelGGL(chain_lane_kernel, dim3((waves + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A, rpw);
+            }
             // the few chunks it passes on (more than LANE_TREES trees, >= 16 384 anchors): wave kernel over the list
             const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
             hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);

@@ -95,9 +95,9 @@ def test_group_selection_matches_solo_and_serial():
     outs = {}
     # "few_slots": the group selection on a device that reports 6 co-resident workgroups (a small partition, a CU mask): the occupancy
     # query must size the launch down to one workgroup per pair instead of spinning at a barrier nobody else reaches
-    for name, extra in (("solo", {}), ("group", {"PSK_BIG_SOLO": "1024"}), ("few_slots", {"PSK_BIG_SOLO": "1024", "PSK_HUGE_SLOTS": "6"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
+    for name, extra in (("solo", {}), ("group", {"PSK_BIG_SOLO": "1024"}), ("few_slots", {"PSK_BIG_SOLO": "1024", "PSK_HUGE_SLOTS": "6"}), ("xtrees", {"PSK_LANE_XTREES": "1"}), ("serial", {"PSK_CHAIN_SERIAL": "1"})):
         env = dict(os.environ)
-        for k in ("PSK_BIG_SOLO", "PSK_CHAIN_SERIAL", "PSK_HUGE_SLOTS"):
+        for k in ("PSK_BIG_SOLO", "PSK_CHAIN_SERIAL", "PSK_HUGE_SLOTS", "PSK_LANE_XTREES"):
             env.pop(k, None)
         env.update(extra)
         outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().strip()

@@ -47,10 +47,14 @@ def _case(rng):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PSK_FUZZ_SEEDS", "24"))))   # PSK_FUZZ_SEEDS=1000 for a long sweep
 def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
     rng = np.random.default_rng(5000 + seed)
+    if seed % 4 == 0:
+        monkeypatch.setenv("PSK_LANE_XTREES", "1")  # sixteen tree slots per chunk in the lane DP (twelve in LDS): the Gb-scale variant, forced on small pairs
+        monkeypatch.setenv("PSK_CHAIN_LANE", "64")  # (a small launch would take the four-lanes-per-chunk kernel otherwise)
     if seed % 4 == 3:
         monkeypatch.setenv("PSK_JOIN", "wide")      # the fallback join format gets a quarter of the sweep
     if seed % 4 == 1:
-        monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another
+        monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another,
+        monkeypatch.setenv("PSK_EMIT_EXPAND", "1")  # with the anchor-major emit of Gb-scale pairs behind it
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
