@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: Gb-scale pairs after (a) run starts in the packed records, (b) sixteen tree slots in the lane DP: tests, 8 x 3 Gb, kernel stats, 50 x 3 Gb
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r3f
-timeout 1500 python -m pytest tests/test_gpu_big.py tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/r3f/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3f/pytest.log
+timeout 1500 python -m pytest tests/test_gpu_big.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r3f/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3f/pytest.log
 for xt in 1; do
   PSK_LANE_XTREES=$xt timeout 900 python bench.py --workload mammalian --refs 8 --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/r3f/mammalian_8x3Gb_xt$xt.json 2> gpurun_out/r3f/mammalian_8x3Gb_xt$xt.err; echo "8x xt=$xt rc=$?"
 done

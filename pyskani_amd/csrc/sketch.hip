@@ -305,12 +305,17 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
 }
 
 // dense per-genome marker staging: tile t's markers move from marker_stage[tile_off[t] ..) to dense[tile_moff[t] ..)
+// tile_info != null: every marker is tagged with its genome's number above the 2 x K_MARKER marker bits, so that ONE device radix
+// sort orders all genomes' markers at once (segments stay where they are: the tag is the sort's leading digit)
+constexpr int MARKER_BITS = 2 * K_MARKER;
 __global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t* __restrict__ stage, const uint32_t* __restrict__ tile_off,
-                                                             const uint32_t* __restrict__ tile_moff, uint32_t n_tiles, uint64_t* __restrict__ dense) {
+                                                             const uint32_t* __restrict__ tile_moff, uint32_t n_tiles, uint64_t* __restrict__ dense,
+                                                             const uint4* __restrict__ tile_info) {
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     const uint32_t src = tile_off[tile], dst = tile_moff[tile], n = tile_moff[tile + 1] - dst;
-    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) dense[dst + i] = stage[src + i];
+    const uint64_t tag = tile_info ? (uint64_t)tile_info[tile].y << MARKER_BITS : 0ull;
+    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) dense[dst + i] = stage[src + i] | tag;
 }
 
 // out[i] = tile_off[idx[i]]
@@ -320,6 +325,12 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32
 }
 // one block per genome: write the distinct values of the sorted segment, in order, to `uniq` at the same
 // segment offset; cnt[g] = number of distinct markers (cnt[n_genomes] must be pre-zeroed by the caller's scan input)
+// entries past the batch's last marker (the array is sized by the SEED count, its upper bound) get a tag beyond every genome's: they
+// sort to the end and no segment reads them
+__global__ __launch_bounds__(256) void marker_pad_kernel(uint64_t* __restrict__ dense, const uint32_t* __restrict__ total, uint32_t n, uint64_t sentinel) {
+    const uint32_t i = *total + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dense[i] = sentinel;
+}
 __global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __restrict__ sorted, uint64_t* __restrict__ uniq,
                                                              const uint32_t* __restrict__ beg, const uint32_t* __restrict__ end,
                                                              uint32_t* __restrict__ cnt) {
@@ -330,13 +341,13 @@ __global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __re
     __syncthreads();
     for (uint32_t i0 = b; i0 < e; i0 += 256) {
         uint32_t i = i0 + threadIdx.x;
-        bool f = i < e && (i == b || sorted[i] != sorted[i - 1]);
+        bool f = i < e && (i == b || sorted[i] != sorted[i - 1]);      // (tagged or not: equal within a genome's segment means equal markers)
         unsigned long long bal = __ballot(f);
         if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t off = s_base;
         for (int w = 0; w < wv; w++) off += s_w[w];
-        if (f) uniq[b + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = sorted[i];
+        if (f) uniq[b + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = sorted[i] & ((1ull << MARKER_BITS) - 1ull);
         __syncthreads();
         if (threadIdx.x == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
@@ -639,8 +650,18 @@ struct SketchJob {
     psk_status marker_segsort() {
         const size_t ns = h_goff[n_genomes];
         size_t tmp_bytes = 0;
-        hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense);
-        if (ns > 0) {
+        // Few genomes with millions of markers each (Gb-scale): a segmented sort hands each segment to too few workgroups (60 ms for
+        // 8 x 3 M markers); tagged with the genome number, one device-wide radix sort does all of them (PSK_MARKER_TAGSORT=0: segmented)
+        int gbits = 0; while ((1ull << gbits) < (uint64_t)n_genomes + 1) gbits++;      // tags 0 .. n_genomes - 1, and n_genomes for the padding
+        static const bool tag_off = getenv("PSK_MARKER_TAGSORT") && getenv("PSK_MARKER_TAGSORT")[0] == '0';
+        const bool tagged = !tag_off && MARKER_BITS + gbits <= 64;
+        hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense, tagged ? (const uint4*)d_tinfo : (const uint4*)nullptr);
+        if (ns > 0 && tagged) {
+            hipLaunchKernelGGL(marker_pad_kernel, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, st, d_mdense, d_tmoff + n_tiles, (uint32_t)ns, (uint64_t)n_genomes << MARKER_BITS);
+            JHIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, 0, MARKER_BITS + gbits, st));
+            PSK_TRY(R->s_tmp.reserve(tmp_bytes));
+            JHIP(hipcub::DeviceRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, 0, MARKER_BITS + gbits, st));
+        } else if (ns > 0) {
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
