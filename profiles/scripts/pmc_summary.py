@@ -19,8 +19,8 @@ PLAN = {
                             "chain_chunk": (["chain_lane20_kernel"], "anchor", True)}),
     "metagenome": ("r3_meta", {"anchor": (["anchor_join_pairs_kernel"], "item", False), "anchor_emit": (["anchor_emit_packed4_kernel"], "item", False),
                                "chain_chunk": (["chain_chunk_kernel"], "anchor", False)}),
-    "mammalian": ("r3_mammal", {"anchor": (["anchor_join4_kernel"], "item", False), "anchor_emit": (["anchor_emit_packed4_kernel", "anchor_next_kernel", "chunk_hops_sliced_kernel"], "item", False),
-                                "chain_chunk": (["chain_lane20_kernel", "chain_chunk_list_kernel"], "anchor", True)}),
+    "mammalian": ("r3_mammal", {"anchor": (["anchor_join4_kernel"], "item", False), "anchor_emit": (["anchor_emit_expand_kernel", "anchor_next_kernel", "chunk_hops_sliced_kernel"], "anchor", True),
+                                "chain_chunk": (["chain_lane20x_kernel", "chain_chunk_list_kernel"], "anchor", True)}),
 }
 
 
@@ -29,7 +29,9 @@ def read_counter(tag, counter):
     path = os.path.join(PMC, f"{tag}.{counter}.txt")
     for line in open(path):
         k, n, v = line.rstrip("\n").split("\t")
-        out[k.replace("void ", "").split("<")[0].strip()] = (int(n), float(v) * 1024.0)      # KiB -> bytes
+        name = k.replace("void ", "").split("<")[0].strip()      # template instances of one kernel are summed
+        prev = out.get(name, (0, 0.0))
+        out[name] = (prev[0] + int(n), prev[1] + float(v) * 1024.0)      # KiB -> bytes
     return out
 
 
