@@ -276,6 +276,24 @@ struct IndexStore {
 
 inline IndexStore::~IndexStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
 
+// Probe tables of a group of sketches (ensure_probe): the reference side of the join of batches of MANY SMALL pairs (metagenome
+// contigs: a few hundred query seeds against a reference of 10^5; anchor_join_probe_kernel). One 64-byte line holds up to
+// PROBE_SLOTS distinct k-mers and, for each, exactly what the packed join record holds (x: the reference position of the match, or
+// where the k-mer's run starts in the reference index when it matches more than once; y: ref contig << 1 | strand, count << 24): a
+// lookup is ONE line read where the k-mer-sorted index costs a bucket-table read, a four-step search, two key reads and a position
+// read, each waiting for the one before - and a contig's seeds have nothing to merge with: they fall ~500 index entries apart. line(km) = mulhi(km left-aligned, lines) is
+// a multiplicative hash of the k-mer (~2.5 k-mers per line); a k-mer whose line is full sits in the next line with room.
+constexpr uint32_t PROBE_SLOTS = 5;
+constexpr uint32_t PROBE_EMPTY = 0xFFFFFFFFu;      // no canonical k-mer of k <= 16 (its reverse complement, 0, is smaller)
+struct ProbeLine { uint32_t k[PROBE_SLOTS]; uint32_t pad; uint2 v[PROBE_SLOTS]; };
+static_assert(sizeof(ProbeLine) == 64, "one probe line = one 64-byte cache line");
+struct ProbeStore {
+    psk_ctx* ctx = nullptr;
+    void* base = nullptr;
+    size_t bytes = 0;
+    ~ProbeStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
+};
+
 // Storage shared by the sketches of one batch: one device allocation, sliced.
 struct SketchStore {
     psk_ctx* ctx = nullptr;          // blocks go back to ctx's pool (the ctx must outlive its sketches)
@@ -306,7 +324,8 @@ struct SketchDesc {
     uint32_t bshift, rows;  // bucket shift; rows of the chunk table a pair with this sketch as the query needs
     uint32_t n_contigs;
     float lenq[3];          // contig-length quantiles {q90, q50, q10}
-    uint32_t pad;
+    uint32_t tab_lines;     // probe table (null / 0 until built: ensure_probe)
+    const ProbeLine* tab;
 };
 
 struct psk_sketch {
@@ -334,6 +353,9 @@ struct psk_sketch {
     mutable uint64_t idx_off = 0;
     mutable uint64_t idx_boff = 0;      // first entry of this sketch's bucket table in idx->bucket
     mutable uint32_t idx_bshift = 0;
+    mutable std::shared_ptr<ProbeStore> ptab;  // built on first use by a batch of many small pairs (ensure_probe)
+    mutable uint64_t ptab_off = 0;      // first line of this sketch in ptab
+    mutable uint32_t ptab_lines = 0;
 };
 
 struct psk_db {
@@ -439,6 +461,12 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
                              int want_seeds, psk_sketch** out);
 // sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
 psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
+// builds the probe table of every indexed sketch of the list that lacks one (sketches of 256 .. 2^20 seeds)
+psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
+// line of a k-mer: multiplicative hash, then scaled to the table. (NOT the k-mer's own top bits: canonical k-mers are the smaller of a
+// k-mer and its reverse complement, so their density falls linearly from 2 at zero - twice the average load per line at the low end
+// and probe chains hundreds of lines long; measured: 60 x slower.)
+__device__ __forceinline__ uint32_t probe_line(uint32_t km, uint32_t lines) { return __umulhi(km * 2654435761u, lines); }
 psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double screen_val, int rescue_small,
                        uint8_t* pass, uint32_t* shared);
 psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,

@@ -321,6 +321,7 @@ struct PairDesc {
     uint64_t q_total_len, r_total_len;
     uint32_t r_n, q_n;
     const uint32_t* r_bucket; uint32_t r_bshift;                              // ref index bucket table (IndexStore::bucket)
+    uint32_t r_tab_lines; const ProbeLine* r_tab;                             // ref probe table (null until built: ensure_probe)
 };
 // sbase[p] = first (pair, query seed) item of pair p in lb/cnt/aoff; cbase[p] = first row of pair p in the chunk table
 
@@ -761,6 +762,70 @@ __global__ __launch_bounds__(256) void anchor_join_pairs_kernel(const PairDesc* 
                 }
                 item_out[base + P.q_perm[iq[u]]] = make_uint2(x, y);
                 total += cnt[u];
+            }
+        }
+    }
+    block_total(total, lb, block_sum);
+}
+
+// The same batches - many SMALL pairs, visited reference-major - through the references' PROBE TABLES (common.h): a contig's few hundred
+// seeds fall ~500 entries apart in a 5 Mb reference's index at c = 30, so there is nothing to merge and every (pair, query seed) is an
+// independent lookup - in the k-mer index a chain of eight dependent reads (two bucket bounds, a four-step search, two keys, the
+// position), in the table ONE 64-byte line (a fifth of the lookups a second read of the same line, one in ten the next line). With
+// no order to exploit the query is walked in (contig, position) order: the records land where the emit kernels read them with
+// coalesced stores, the query's index and its scatter are not touched. Four seeds per lane in flight.
+__device__ __forceinline__ int probe_slot_of(const ProbeLine* __restrict__ tab, uint32_t lines, uint32_t km, uint4 K, uint32_t& ln) {
+    for (;;) {      // the fifth slot / the next line only where the first four are taken
+        int sl = K.x == km ? 0 : K.y == km ? 1 : K.z == km ? 2 : K.w == km ? 3 : -1;
+        if (sl < 0 && K.w != PROBE_EMPTY) {
+            const uint32_t k4 = tab[ln].k[4];
+            if (k4 == km) sl = 4;
+            else if (k4 != PROBE_EMPTY) { ln = ln + 1 < lines ? ln + 1 : 0; K = *(const uint4*)(tab + ln); continue; }
+        }
+        return sl;
+    }
+}
+__global__ __launch_bounds__(256) void anchor_join_probe_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
+                                                                const uint32_t* __restrict__ order, uint32_t n_pairs,
+                                                                uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
+                                                                uint32_t* __restrict__ need_wide) {
+    const uint32_t lb = xcd_block_id();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = lb * 4 + wave;
+    uint32_t total = 0;
+    if (w < n_pairs) {
+        const uint32_t p = order[w];
+        const PairDesc& P = pairs[p];
+        const uint32_t qn = P.q_n, lines = P.r_tab_lines;
+        const ProbeLine* __restrict__ tab = P.r_tab;
+        const uint32_t* __restrict__ q_kmer = P.q_kmer;
+        uint2* __restrict__ out = item_out + sbase[p];
+        constexpr int U = 4;
+        for (uint32_t j0 = 0; j0 < qn; j0 += 64 * U) {
+            uint32_t km[U], ln[U];
+            uint4 K[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const uint32_t j = j0 + u * 64 + lane; km[u] = j < qn ? q_kmer[j] : 0u; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t j = j0 + u * 64 + lane;
+                ln[u] = lines ? probe_line(km[u], lines) : 0u;
+                K[u] = (j < qn && lines) ? *(const uint4*)(tab + ln[u]) : make_uint4(PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY, PROBE_EMPTY);
+            }
+            int sl[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) sl[u] = (j0 + u * 64 + lane < qn && lines) ? probe_slot_of(tab, lines, km[u], K[u], ln[u]) : -1;
+            uint2 rec[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) rec[u] = sl[u] >= 0 ? tab[ln[u]].v[sl[u]] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t j = j0 + u * 64 + lane;
+                if (j >= qn) continue;
+                const uint32_t c = rec[u].y >> 24;
+                if (c == 255u) atomicOr(need_wide, 1u);      // a count or contig number the packed entry cannot hold: the host reruns the batch in the wide format
+                out[j] = rec[u];
+                total += c;
             }
         }
     }
@@ -1564,6 +1629,140 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
                 }
             }
         }
+    }
+    if (j == 0 && slot < A.n_rows && real) {
+        if (mine && !ovf) {
+            uint32_t nc = 0, last = 0;
+            for (uint32_t c = 0; c < S; c++) {
+                uint32_t pick = 0xFFFFFFFFu; unsigned long long k = 0; uint32_t q1 = 0, rb = 0;
+#pragma unroll
+                for (int i = 0; i < LANE_TREES; i++)
+                    if (sroot[i] != 0xFFFFFFFFu && (c == 0 || sroot[i] > last) && sroot[i] < pick) { pick = sroot[i]; k = bk[i]; q1 = bq[i]; rb = br[i]; }
+                last = pick;
+                const uint32_t xr = s + pick, ra = A.anc[xr].y, o = s + nc;
+                A.c_score[o] = (int32_t)(uint32_t)(k >> 28); A.c_q0[o] = A.anc[xr].x; A.c_q1[o] = q1;
+                A.c_r0[o] = ra < rb ? ra : rb; A.c_r1[o] = ra < rb ? rb : ra;
+                A.c_n[o] = (uint32_t)(k & 16383u); A.c_rc[o] = A.anc[xr].z >> 1;
+                nc++;
+            }
+            ChunkOut o{};
+            o.n_cand = nc; o.left = 0xFFFFFFFFu; o.right = 0;
+            A.out[slot] = o;
+        } else {
+            A.ovf_list[atomicAdd(A.ovf_count, 1u)] = slot;
+        }
+    }
+}
+
+// ---- four lanes per chunk with DEEP windows: the lane DP for bands beyond its register window ---------------------------------------
+// c = 30 (metagenome mode) means a band of 83 anchors: no lane holds 83 predecessors, and the wave-per-chunk kernel spends ~150 SIMD
+// cycles per anchor on it. Here a quad shares the band: lane j owns the anchors whose index is j mod 4 (as in chain_quad_kernel) and
+// keeps its last QD of them - 4 x 21 = 84 - in the lane kernel's form (q + 1, diagonal, contig | strand, score - 1). Per anchor a
+// lane scores QD predecessors with the sign-bit step of lane_eval2 (the distance's lane-dependent part, j, is added to the lane's
+// best key after its maximum: it is the same for all of a lane's candidates), two quad DPP exchanges give all four lanes the best key.
+// The window moves ONCE per four anchors, by plain register renaming: within a step a lane's newest own anchor is a separate entry
+// that either joins the candidates (u > j) or not, one select per field (v_cndmask is the slowest VALU instruction: the shifting
+// window of chain_quad_kernel would cost 84 of them per anchor). 16 chunks per wave step: ~66 SIMD cycles per anchor.
+constexpr int QD = 21;            // own anchors per lane: bands up to 4 * QD = 84
+constexpr int QD_RING = 128;      // root / depth ring per quad (power of two > 4 * QD + 3)
+__device__ __forceinline__ int32_t quad_eval(uint32_t qx, uint32_t ux, uint32_t mx, uint32_t yq1, uint32_t yu, uint32_t ym, int32_t yf1, int32_t dpj, int32_t bj) {
+    // dpj = the distance of the two anchors PLUS j (a compile-time number for the window entries, one select for the extra entry); bj = band + j
+    const int32_t a = (int32_t)(qx - yq1);
+    const int32_t t = (int32_t)(ux - yu), nt = (int32_t)(yu - ux);
+    const int32_t gap = t > nt ? t : nt;
+    const int32_t b = a - t;
+    const int32_t s1 = yf1 - gap;
+    const uint32_t z = ym ^ mx;
+    const uint32_t bad = (uint32_t)a | (uint32_t)(BP_CHAIN_BAND - 1 - a) | (uint32_t)b | (uint32_t)(MAX_GAP_LENGTH - gap) | (uint32_t)s1 | z | (0u - z) | (uint32_t)(bj - dpj);
+    const uint32_t key = ((uint32_t)s1 << 7) + (((((uint32_t)ANCHOR_SCORE2 + 1u) << 7) | 127u) - (uint32_t)dpj);      // + j after the lane's maximum
+    return (int32_t)(key | (bad & 0x80000000u));
+}
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainArgs A) {
+    __shared__ uint32_t s_rd[LANE_WAVES][QD_RING][16];     // root index << 14 | depth of the last QD_RING anchors, per quad
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2;
+    const int32_t j = lane & 3;
+    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    uint32_t s = 0, e = 0;
+    bool mine = false, real = false;
+    const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
+    if (slot < A.n_rows && slot - A.cbase[pair] < A.n_chunks[pair]) {
+        const uint2 se = A.chunks[slot];
+        s = se.x; e = se.y;
+        real = true;
+        mine = e > s && e - s < 16384;
+    }
+    const uint32_t s_al = s & ~3u;
+    const uint32_t len = mine ? e - s_al : 0;
+    uint32_t Wq[QD], Wu[QD], Wm[QD]; int32_t Wf[QD];      // entry i = this lane's anchor 4 (i + 1) - (u - j) ... before x: its (i + 1)-th latest of EARLIER steps
+#pragma unroll
+    for (int i = 0; i < QD; i++) { Wq[i] = 0; Wu[i] = 0; Wm[i] = 0xFFFFFFFFu; Wf[i] = 0; }
+    unsigned long long bk[LANE_TREES];
+    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
+#pragma unroll
+    for (int k = 0; k < LANE_TREES; k++) { bk[k] = 0; sroot[k] = 0xFFFFFFFFu; bq[k] = br[k] = 0; }
+    uint32_t S = 0;
+    bool ovf = false;
+    uint32_t (*rd)[16] = s_rd[wave];
+    const int32_t bj = A.band + j;
+    for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
+        const uint32_t x0 = s_al + t0;
+        uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
+        if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
+        const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
+        uint32_t nq = 0, nu = 0, nm = 0xFFFFFFFFu; int32_t nf = 0;      // this lane's own anchor of the step (from u = j on)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t x = x0 + u, t = t0 + u;
+            const bool act = x >= s && x < e && mine;
+            const uint32_t qx = qs[u], rx = rs[u], mx = ms[u];
+            const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
+            int32_t best = 0;
+#pragma unroll
+            for (int i = 0; i < QD - 1; i++) {      // own anchors of earlier steps: distance u - j + 4 (i + 1)
+                const int32_t k = quad_eval(qx, ux, mx, Wq[i], Wu[i], Wm[i], Wf[i], u + 4 * (i + 1), bj);
+                best = k > best ? k : best;
+            }
+            {   // the one candidate that depends on the lane: its own anchor of THIS step (u > j, distance u - j) or its oldest (distance u - j + 4 QD)
+                const bool late = u > j;
+                const int32_t k = quad_eval(qx, ux, mx, late ? nq : Wq[QD - 1], late ? nu : Wu[QD - 1], late ? nm : Wm[QD - 1], late ? nf : Wf[QD - 1], late ? u : u + 4 * QD, bj);
+                best = k > best ? k : best;
+            }
+            if (best > 0) best += j;      // the lane-dependent part of 127 - distance
+            {   // all four lanes of the quad get the maximum
+                int32_t o = __builtin_amdgcn_mov_dpp(best, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                best = o > best ? o : best;
+                o = __builtin_amdgcn_mov_dpp(best, 0x4E, 0xF, 0xF, true);            // quad_perm [2,3,0,1]
+                best = o > best ? o : best;
+            }
+            int32_t f = ANCHOR_SCORE2; uint32_t ridx = x - s, dep = 1;
+            if (best > 0) {
+                f = best >> 7;
+                const uint32_t v = rd[(t - (127u - ((uint32_t)best & 127u))) & (uint32_t)(QD_RING - 1)][quad];
+                ridx = v >> 14; dep = (v & 16383u) + 1;
+            }
+            rd[t & (uint32_t)(QD_RING - 1)][quad] = (ridx << 14) | dep;          // four lanes, one value
+            if (j == u) { nq = qx + 1u; nu = ux; nm = act ? mx : 0xFFFFFFFFu; nf = f - 1; }      // x is 4-aligned at u = 0: anchor x belongs to lane u
+            if (act && f >= MIN_SCORE2) {
+                const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < LANE_TREES; k++) {
+                    const bool hit = sroot[k] == ridx;
+                    found = found || hit;
+                    if (hit && k64 > bk[k]) { bk[k] = k64; bq[k] = qx; br[k] = rx; }
+                }
+                if (!found) {
+                    if (S >= (uint32_t)LANE_TREES) ovf = true;
+#pragma unroll
+                    for (int k = 0; k < LANE_TREES; k++) if (S == (uint32_t)k) { sroot[k] = ridx; bk[k] = k64; bq[k] = qx; br[k] = rx; }
+                    S++;
+                }
+            }
+        }
+        // the window moves by one own anchor per step
+#pragma unroll
+        for (int i = QD - 1; i >= 1; i--) { Wq[i] = Wq[i - 1]; Wu[i] = Wu[i - 1]; Wm[i] = Wm[i - 1]; Wf[i] = Wf[i - 1]; }
+        Wq[0] = nq; Wu[0] = nu; Wm[0] = nm; Wf[0] = nf;
     }
     if (j == 0 && slot < A.n_rows && real) {
         if (mine && !ovf) {
@@ -2571,12 +2770,13 @@ static SketchDesc make_desc(const psk_sketch* s) {
     if (d.n) for (uint32_t len : s->contig_len) rows += (uint64_t)len / (FRAGMENT_LENGTH + 1) + 1;
     d.rows = (uint32_t)std::min<uint64_t>(rows, 0xFFFFFFFFu);
     s->len_quantiles(d.lenq);
+    d.tab = (ix && s->ptab) ? (const ProbeLine*)s->ptab->base + s->ptab_off : nullptr; d.tab_lines = (ix && s->ptab) ? s->ptab_lines : 0;
     return d;
 }
 
 __device__ __forceinline__ PairDesc combine_desc(const SketchDesc& Q, const SketchDesc& R) {
     PairDesc P;
-    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift;
+    P.r_key = R.key; P.r_pms = R.pms; P.r_n = R.n; P.r_bucket = R.bucket; P.r_bshift = R.bshift; P.r_tab = R.tab; P.r_tab_lines = R.tab_lines;
     P.q_n = Q.n; P.q_key = Q.key; P.q_perm = Q.perm; P.q_pos = Q.pos; P.q_meta = Q.meta; P.q_kmer = Q.kmer; P.q_nc = Q.n_contigs; P.pad_ = 0;
     P.q_seed_pos_base = Q.seed_pos_base; P.q_contig_start = Q.contig_start;
     P.q_total_len = Q.total_len; P.r_total_len = R.total_len;
@@ -2679,7 +2879,7 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
 // Anchor arrays are sized optimistically (cap anchors); the 64-bit anchor total travels back with the hits and the caller
 // reruns the batch with a larger capacity if it did not fit (emit and every later kernel stay inside cap).
 static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_items, size_t n_rows, const psk_params& prm,
-                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide) {
+                            const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide, bool probe_ok = false) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
     PSK_HIP(hipMemsetAsync(L.misc, 0, 256, st));     // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[32..47] its group barriers
@@ -2705,7 +2905,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_TRY(ctx->q_g.reserve(ts + 256));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_g.p, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
         const uint32_t nb = (n_pairs + 3) / 4;
-        hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
+        // every reference of the batch carries a probe table (ensure_probe): one line read per lookup instead of the index's chain of reads
+        if (probe_ok) hipLaunchKernelGGL(anchor_join_probe_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
+        else hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
         n_sum = nb;
     }
     else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
@@ -2827,6 +3029,18 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
             hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);
         }
+    }
+    // bands beyond the lane kernel's window (c < 105; metagenome mode c = 30: 83): four lanes per chunk with 21-deep windows, its leftovers to
+    // the wave-per-chunk kernel's list form; PSK_CHAIN_QUAD_DEEP=0 keeps the wave-per-chunk kernel for every chunk (tests, A/B)
+    static const bool qd_off = getenv("PSK_CHAIN_QUAD_DEEP") && getenv("PSK_CHAIN_QUAD_DEEP")[0] == '0';
+    const bool quad_deep = !A.lane_dp && !force_serial && !qd_off && A.band <= 4 * QD && !(getenv("PSK_CHAIN_LANE") && getenv("PSK_CHAIN_LANE")[0] == '0');
+    if (quad_deep) {
+        A.ovf_list = L.ovf; A.ovf_count = L.misc + 8;      // misc was zeroed above
+        A.lane_dp = 1;                                     // (chain_chunk_list_kernel walks the list)
+        const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
+        hipLaunchKernelGGL(chain_quad_deep_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
+        const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
+        hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);
     }
     if (!A.lane_dp)
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
@@ -3149,10 +3363,15 @@ __global__ __launch_bounds__(256) void pref_apply_kernel(const uint32_t* __restr
     if (cnt[cell] < MIN_ANCHORS) pass[(size_t)rq[j] * n_refs + r] = 0;
 }
 
+// how many references carry a k-mer index (low word) / a probe table (high word): the descriptor table is stale when this moves
+static uint64_t index_stamp(const psk_db* db) {
+    uint64_t v = 0;
+    for (const psk_sketch* r : db->refs) v += (uint64_t)(r->idx != nullptr) + ((uint64_t)(r->ptab != nullptr) << 32);
+    return v;
+}
 static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     const uint32_t n = (uint32_t)db->refs.size();
-    uint64_t indexed = 0;
-    for (const psk_sketch* r : db->refs) indexed += r->idx != nullptr;
+    const uint64_t indexed = index_stamp(db);
     if (!db->desc_dirty && db->desc_indexed == indexed && db->desc_n == n) return PSK_OK;
     std::vector<SketchDesc>& h = db->h_refdesc;     // stays alive until the copy has drained (every query ends with a synchronisation)
     h.resize(n);
@@ -3236,9 +3455,8 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
             if (refs_ok) {
                 bool all_idx = !db->desc_dirty && db->desc_n == n;
-                uint64_t indexed = 0;
-                for (const psk_sketch* rs : db->refs) { indexed += rs->idx != nullptr; if (!rs->idx && rs->n_seeds && rs->store) all_idx = false; }
-                if (!all_idx || indexed != db->desc_indexed)
+                for (const psk_sketch* rs : db->refs) if (!rs->idx && rs->n_seeds && rs->store) all_idx = false;
+                if (!all_idx || index_stamp(db) != db->desc_indexed)
                     PSK_TRY(exclusive([&]() -> psk_status {
                         std::vector<const psk_sketch*> all_refs(db->refs.begin(), db->refs.end());
                         PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
@@ -3316,9 +3534,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
         {   // references first (shared state: exclusive), then this call's own query sketches
             bool refs_stale = db->desc_dirty || db->desc_n != n;
-            uint64_t indexed = 0;
-            for (const psk_sketch* rs : db->refs) indexed += rs->idx != nullptr;
-            refs_stale = refs_stale || indexed != db->desc_indexed;
+            refs_stale = refs_stale || index_stamp(db) != db->desc_indexed;
             for (size_t i = 0; i < n_need_refs && !refs_stale; i++) refs_stale = !need[i]->idx && need[i]->n_seeds && need[i]->store;
             if (refs_stale)     // one index launch for the references AND this call's queries (a fresh database: the headline step)
                 PSK_TRY(exclusive([&]() -> psk_status {
@@ -3326,6 +3542,28 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     return refresh_ref_descs(ctx, db);
                 }));
             else if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
+        }
+        // rounds of many SMALL pairs (metagenome contigs) join through the references' probe tables: built once per reference, like the
+        // k-mer index, for the references about to be chained (PSK_PROBE=0 never, =1 whatever the round's shape: tests)
+        bool round_probe = false;
+        {
+            const char* pb_env = getenv("PSK_PROBE");
+            const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
+            uint64_t round_items = 0;
+            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
+            if (!pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048))) {
+                round_probe = true;
+                bool missing = false;
+                for (size_t i = 0; i < n_need_refs; i++) {
+                    if (need[i]->n_seeds < 64 || need[i]->n_seeds > (1u << 22)) { round_probe = false; break; }
+                    missing = missing || !need[i]->ptab;
+                }
+                if (round_probe && missing)
+                    PSK_TRY(exclusive([&]() -> psk_status {
+                        PSK_TRY(ensure_probe(ctx, need.data(), (uint32_t)n_need_refs));
+                        return refresh_ref_descs(ctx, db);
+                    }));
+            }
         }
         h_qd.resize(m);
         for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
@@ -3400,7 +3638,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items);
                 bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
-                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide);
+                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
                     const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)

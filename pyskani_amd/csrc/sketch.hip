@@ -1007,3 +1007,65 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
     }
     return PSK_OK;
 }
+
+// ------------------------------------------------------------------ probe tables (join of batches of many small pairs)
+struct ProbeSeg { const uint32_t* key; const uint64_t* pms; ProbeLine* tab; uint32_t n, lines; };
+// one thread per index entry; the head of every run of equal k-mers inserts (k-mer, position or - for a run - its first index entry, meta | count << 24)
+__global__ __launch_bounds__(256) void probe_build_kernel(const ProbeSeg* __restrict__ segs) {
+    const ProbeSeg S = segs[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.n) return;
+    const uint32_t km = S.key[i];
+    if (i > 0 && S.key[i - 1] == km) return;
+    uint32_t cnt = 1;
+    while (i + cnt < S.n && cnt < 255u && S.key[i + cnt] == km) cnt++;
+    const uint64_t pm = S.pms[i];
+    const uint32_t rmeta = (uint32_t)pm;
+    // same packing as the join's record: counts >= 255 or reference contig numbers >= 2^23 read as 255 ("rerun in the wide format")
+    const uint32_t y = (cnt >= 255u || (rmeta >> 24)) ? ((rmeta & 0xFFFFFFu) | (255u << 24)) : (rmeta | (cnt << 24));
+    uint32_t L = probe_line(km, S.lines);
+    for (;;) {
+        ProbeLine* ln = S.tab + L;
+        for (uint32_t s = 0; s < PROBE_SLOTS; s++) {
+            if (atomicCAS(&ln->k[s], PROBE_EMPTY, km) == PROBE_EMPTY) { ln->v[s] = make_uint2(cnt > 1 ? i : (uint32_t)(pm >> 32), y); return; }
+        }
+        L = L + 1 < S.lines ? L + 1 : 0;
+    }
+}
+
+psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
+    std::lock_guard<std::mutex> index_lock(ctx->dev->index_mu);
+    hipStream_t st = ctx->stream;
+    std::vector<const psk_sketch*> todo;
+    std::unordered_set<const psk_sketch*> seen;
+    for (uint32_t i = 0; i < n; i++)
+        if (refs[i] && refs[i]->idx && !refs[i]->ptab && refs[i]->n_seeds >= 64 && refs[i]->n_seeds <= (1u << 22) && seen.insert(refs[i]).second) todo.push_back(refs[i]);
+    size_t i0 = 0;
+    while (i0 < todo.size()) {
+        size_t i1 = i0; uint64_t lines = 0; uint32_t maxn = 0;
+        std::vector<ProbeSeg> segs;
+        std::vector<uint64_t> loff;
+        while (i1 < todo.size() && i1 - i0 < 65535 && lines < (1ull << 28)) {      // <= 16 GB of lines per store
+            const psk_sketch* s = todo[i1];
+            const uint32_t ln = (uint32_t)((s->n_seeds * 2 + 4) / 5);              // ~2.5 k-mers per line of 5 slots
+            loff.push_back(lines);
+            segs.push_back(ProbeSeg{s->idx->km32 + s->idx_off, s->idx->pms + s->idx_off, nullptr, (uint32_t)s->n_seeds, ln});
+            lines += ln; maxn = std::max(maxn, (uint32_t)s->n_seeds); i1++;
+        }
+        auto ps = std::make_shared<ProbeStore>();
+        ps->ctx = ctx->dev;
+        PSK_TRY(ctx->pool_alloc(sizeof(ProbeLine) * (size_t)lines, &ps->base, &ps->bytes));
+        for (size_t j = 0; j < segs.size(); j++) segs[j].tab = (ProbeLine*)ps->base + loff[j];
+        PSK_HIP(hipMemsetAsync(ps->base, 0xFF, sizeof(ProbeLine) * (size_t)lines, st));
+        PSK_TRY(ctx->s_offs.reserve(sizeof(ProbeSeg) * segs.size()));
+        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(ProbeSeg) * segs.size(), hipMemcpyHostToDevice, st));
+        ctx->t_begin(K_SKETCH_SORT);
+        hipLaunchKernelGGL(probe_build_kernel, dim3((maxn + 255) / 256, (uint32_t)segs.size()), dim3(256), 0, st, (const ProbeSeg*)ctx->s_offs.p);
+        ctx->t_end();
+        PSK_HIP(hipStreamSynchronize(st));      // segs (host vector) feeds the async copy above
+        for (size_t j = 0; j < segs.size(); j++) { todo[i0 + j]->ptab = ps; todo[i0 + j]->ptab_off = loff[j]; todo[i0 + j]->ptab_lines = segs[j].lines; }
+        i0 = i1;
+    }
+    return PSK_OK;
+}
+

@@ -55,6 +55,8 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
     if seed % 4 == 1:
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another,
         monkeypatch.setenv("PSK_EMIT_EXPAND", "1")  # with the anchor-major emit of Gb-scale pairs behind it
+        if seed % 8 == 1:
+            monkeypatch.setenv("PSK_PROBE", "1")    # ... through the references' probe tables (the metagenome join)
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
@@ -85,6 +87,9 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
     if seed % 2:
         monkeypatch.setenv("PSK_PREFILTER", "1")      # seed prefilter of rescued queries whatever the batch size
+    else:
+        monkeypatch.setenv("PSK_JOIN_PAIRS", "1")     # the reference-major join of many small pairs, through the references' probe tables,
+        monkeypatch.setenv("PSK_PROBE", "1")          # whatever the batch size
     k = int(rng.integers(11, 17)); c = int(rng.choice([30, 60, 125, 200])); mc = int(c * rng.choice([4, 8]))
     fams = [random_genome(rng, int(rng.integers(60000, 250000))) for _ in range(int(rng.integers(1, 4)))]
     refs = []
