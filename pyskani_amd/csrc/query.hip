@@ -1677,7 +1677,7 @@ __device__ __forceinline__ int32_t quad_eval(uint32_t qx, uint32_t ux, uint32_t 
     const uint32_t key = ((uint32_t)s1 << 7) + (((((uint32_t)ANCHOR_SCORE2 + 1u) << 7) | 127u) - (uint32_t)dpj);      // + j after the lane's maximum
     return (int32_t)(key | (bad & 0x80000000u));
 }
-__global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainArgs A) {
+__global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainArgs A) {      // (255 registers, two waves per SIMD: capped at 168 it spills 83 dwords per lane)
     __shared__ uint32_t s_rd[LANE_WAVES][QD_RING][16];     // root index << 14 | depth of the last QD_RING anchors, per quad
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2;
     const int32_t j = lane & 3;
@@ -2852,6 +2852,7 @@ struct ChainBufs {
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
     uint32_t *blk_pair, *row_pair, *live, *big_list, *huge_list;
     uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum (the 64-bit total sits at bsum[gi_sum])
+    uint32_t rows_pair_max = 0xFFFFFFFFu;      // most chunk-table rows any pair of the batch can have (the host knows its queries): which reduce kernels have work
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
     const size_t gi = (n_items + 255) / 256, gi_sum = std::max(gi, (n_pairs + 3) / 4);
@@ -3130,8 +3131,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool no_small = rs_env && rs_env[0] == '0';
     R.small_done = use_live && !no_small && n_rows / n_pairs < 16;
     if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
-    if (n_rows > (size_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
+    // (the one-wave kernel takes every table of <= 64 rows: when no pair of the batch can have more - contigs have 1-3 chunks - the two
+    // workgroup-per-pair kernels would only walk the live list to find that out: 24 ms per 17 M contig pairs)
+    if (!(R.small_done && L.rows_pair_max <= 64u))
+        hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
+    if (n_rows > (size_t)RED_SMALL && L.rows_pair_max > (uint32_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
     const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
@@ -3602,7 +3606,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (rank >= h_cnt[qi]) { qi++; rank = 0; continue; }
             // plan one batch from (qi, rank)
             bqs.clear();
-            uint64_t pairs = 0, items = 0, rows = 0;
+            uint64_t pairs = 0, items = 0, rows = 0, rows_pair_max = 0;
             uint32_t pq = qi, pr = rank;
             while (pq < m) {
                 const uint32_t left = h_cnt[pq] - pr;
@@ -3613,6 +3617,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 if (qrows) take = std::min<uint64_t>(take, (max_rows - rows) / qrows);
                 if (take == 0) { if (pairs == 0) take = 1; else break; }      // a single pair always goes through (chain_check refuses what cannot fit)
                 bqs.push_back(BatchQ{pq, pr, pr + (uint32_t)take, (uint32_t)pairs, (uint32_t)items, (uint32_t)rows});
+                rows_pair_max = std::max<uint64_t>(rows_pair_max, qrows);
                 pairs += take; items += take * qn; rows += take * qrows;
                 pr += (uint32_t)take;
                 if (pairs >= max_pairs || items >= max_items || rows >= max_rows) break;
@@ -3626,6 +3631,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             } else {
                 ChainBufs L;
                 psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
+                L.rows_pair_max = (uint32_t)std::min<uint64_t>(rows_pair_max, 0xFFFFFFFFu);
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
                 PSK_TRY(lrc);
                 PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
