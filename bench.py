@@ -701,8 +701,7 @@ def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs,
             try:
                 return eng.query_many(db, qh, nq, faster_small)
             finally:
-                for h in qh:
-                    eng.lib.psk_sketch_free(h)
+                eng.lib.psk_sketch_free_many(qh, nq)
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
         dt = job.max_over_ranks(dt)
         table = kernel_rooflines(kern, steps, {"bases": bases, "c": 30, "marker_c": 200, **work}, job.pmc.get("metagenome", {}))

@@ -137,6 +137,8 @@ psk_status psk_sketch_batch_device(psk_ctx* ctx, const psk_params* p, const uint
                                    int want_seeds, psk_sketch** out);
 
 void psk_sketch_free(psk_sketch* s);
+/* n x psk_sketch_free in one call (a host in an interpreted language pays per call: 100 000 contig sketches) */
+void psk_sketch_free_many(psk_sketch* const* sketches, uint32_t n);
 psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds,
                            uint64_t* n_markers, uint64_t* total_len, uint32_t* n_contigs);
 /* copy the sketch back to the host: seeds in (contig,pos) order, markers sorted unique */

@@ -49,7 +49,7 @@ class Seed(C.Structure):
 SYMBOLS = [
     "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
     "psk_ctx_synchronize", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
-    "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_info",
+    "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_free_many", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
     "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe", "psk_ctx_work",
@@ -89,6 +89,8 @@ def load():
     lib.psk_sketch_batch_device.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), u32, C.c_int, C.POINTER(vp)]
     lib.psk_sketch_free.argtypes = [vp]
     lib.psk_sketch_free.restype = None
+    lib.psk_sketch_free_many.argtypes = [C.POINTER(vp), u32]
+    lib.psk_sketch_free_many.restype = None
     lib.psk_sketch_info.argtypes = [vp, C.POINTER(Params), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     lib.psk_sketch_export.argtypes = [vp, vp, vp]
     lib.psk_sketch_contig_lens.argtypes = [vp, vp]

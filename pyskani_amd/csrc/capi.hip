@@ -245,6 +245,7 @@ psk_status psk_sketch_host(psk_ctx* ctx, const psk_params* p, const uint8_t* con
 }
 
 void psk_sketch_free(psk_sketch* s) { delete s; }
+void psk_sketch_free_many(psk_sketch* const* sketches, uint32_t n) { if (sketches) for (uint32_t i = 0; i < n; i++) delete sketches[i]; }
 
 psk_status psk_sketch_info(const psk_sketch* s, psk_params* p, uint64_t* n_seeds, uint64_t* n_markers, uint64_t* total_len, uint32_t* n_contigs) {
     if (!s) { psk_set_error("NULL sketch"); return PSK_EINVAL; }

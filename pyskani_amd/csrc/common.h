@@ -481,6 +481,7 @@ struct HitList {
     // page faults otherwise (~10 ms of the caller's time after the last kernel); pages that are never touched cost nothing
     bool reserve(size_t want) {
         if (want <= cap) return true;
+        if (n && want < 2 * cap) want = 2 * cap;      // a list that already holds hits moves them when it grows: at least double, so a long result is copied O(1) times
         const size_t bytes = sizeof(psk_hit) * want;
         psk_hit* q;
         if (bytes >= ((size_t)8 << 20)) {

@@ -3591,7 +3591,14 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         const size_t half_bytes = al256(sizeof(psk_hit) * half_pairs + 512);
         void* hpin2 = nullptr;
         PSK_TRY(ctx->pinned(2 * half_bytes, &hpin2));
-        if (round_pairs > 4096 && !all.reserve(all.n + (size_t)std::min<uint64_t>(round_pairs, 1ull << 26))) { psk_set_error("out of host memory"); return PSK_ENOMEM; }   // one allocation for the round's hits (untouched pages are free)
+        {   // one allocation for the round's hits (untouched pages are free). Later rounds: the hits so far say how many the whole call will
+            // bring - growing the list round by round copied everything gathered before, 14, 27, 39, ... ms with the GPU idle (a third of the
+            // metagenome step: profiles/r3/r3i_metagenome_gaps.txt)
+            size_t want = all.n + (size_t)std::min<uint64_t>(round_pairs, 1ull << 26);
+            if (b == 0 && n_queries > m) want = std::max(want, (size_t)std::min<double>((double)round_pairs * ((double)n_queries / (double)m) * 1.05, (double)(1ull << 27)));      // every pair yields at most one hit
+            if (b > 0 && all.n) want = std::max(want, (size_t)((double)all.n * ((double)n_queries / (double)b) * 1.1) + 4096);
+            if (round_pairs > 4096 && !all.reserve(want)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+        }
         int parity = 0;
         const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
         auto consume = [&]() -> psk_status {

@@ -371,8 +371,7 @@ class ShardedDatabase:
                     recs["ref_index"] += self._lo
                     chunks.append(recs)
             finally:
-                for i in range(total):
-                    lib.psk_sketch_free(handles[i])
+                lib.psk_sketch_free_many(handles, total)
         mine_recs = np.concatenate(chunks) if chunks else np.zeros(0, HIT_DTYPE)
         got, _ = self._timed("collective_s", self.comm.gather_hit_records, mine_recs)
         order = np.lexsort((got["ref_index"], got["reserved"]))

@@ -65,6 +65,7 @@ extern "C" {
                                    contig_len: *const u64, genome_first_contig: *const u32, n_genomes: u32,
                                    want_seeds: c_int, out: *mut *mut PskSketch) -> c_int;
     pub fn psk_sketch_free(s: *mut PskSketch);
+    pub fn psk_sketch_free_many(sketches: *const *mut PskSketch, n: u32);
     // (de)serialisation hooks for `Database.save/load/open` (lib.rs:249-337): plain arrays in, plain arrays out
     pub fn psk_sketch_info(s: *const PskSketch, p: *mut PskParams, n_seeds: *mut u64, n_markers: *mut u64,
                            total_len: *mut u64, n_contigs: *mut u32) -> c_int;
