@@ -565,6 +565,7 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
             if with_api:
                 import pyskani_amd as psk
                 r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
+                psk.database.release_default_context(job.local_rank)
                 line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"],
                                       api_detail=r["api"], host_ascii_detail=r["host_ascii"],
                                       api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
@@ -720,11 +721,11 @@ def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs,
             entry["cpu_baseline"] = cpu_baseline_metagenome(lambda i: href[offs[i]:offs[i] + lens[i]].tobytes(), n_cpu_refs, n_refs, sample, os.cpu_count() or 1, faster_small)
             del href, chost0
         out["faster_small" if faster_small else "rescue"] = entry
+    eng.lib.psk_db_destroy(db)
+    eng.close()      # the resident database, its indexes, probe tables and scratch go before the API leg builds its own Database
     if job.world == 1 and api_queries > 0 and job.rank == 0:
         out["api"] = metagenome_api(job, buf, offs, lens, n_refs, cbuf, coffs, clens, min(api_queries, n_queries), settings[0])
-    eng.lib.psk_db_destroy(db)
     del buf, cbuf
-    eng.close()
     torch.cuda.empty_cache()
     return out
 
@@ -759,7 +760,10 @@ def metagenome_api(job, buf, offs, lens, n_refs, cbuf, coffs, clens, nq, faster_
     t0 = time.perf_counter()
     pdb.query_many([(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False, faster_small=faster_small)
     t_many = time.perf_counter() - t0
-    del pdb
+    del pdb, many
+    import gc
+    gc.collect()
+    psk.database.release_default_context(job.local_rank)      # its pool would keep tens of GB the next workload needs
     return {"queries": nq, "api_queries_per_s": nq / t_q, "api_query_ms": t_q / nq * 1e3, "api_queries_per_s_8_threads": nq / t_q8, "api_query_many_per_s": nq / t_many,
             "api_db_load_s": t_load, "api_hits": nh, "faster_small": faster_small,
             "note": f"{nq} contigs from host bytes through pyskani_amd.Database: one Database.query() per contig (from one host thread, and from eight), and one Database.query_many() for all of them"}

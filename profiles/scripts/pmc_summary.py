@@ -17,8 +17,8 @@ STEPS = 3      # 1 warm-up + 2 timed steps in every counter pass
 PLAN = {
     "allvsall": ("r3_ava", {"anchor": (["anchor_join4_kernel"], "item", False), "anchor_emit": (["anchor_emit_pairs_kernel"], "item", False),
                             "chain_chunk": (["chain_lane20_kernel"], "anchor", True)}),
-    "metagenome": ("r3_meta", {"anchor": (["anchor_join_pairs_kernel"], "item", False), "anchor_emit": (["anchor_emit_packed4_kernel"], "item", False),
-                               "chain_chunk": (["chain_chunk_kernel"], "anchor", False)}),
+    "metagenome": ("r3_meta", {"anchor": (["anchor_join_probe_kernel"], "item", False), "anchor_emit": (["anchor_emit_packed4_kernel", "chunk_heads_kernel"], "item", False),
+                               "chain_chunk": (["chain_quad_deep_kernel", "chain_chunk_list_kernel"], "anchor", True)}),
     "mammalian": ("r3_mammal", {"anchor": (["anchor_join4_kernel"], "item", False), "anchor_emit": (["anchor_emit_expand_kernel", "anchor_next_kernel", "chunk_hops_sliced_kernel"], "anchor", True),
                                 "chain_chunk": (["chain_lane20x_kernel", "chain_chunk_list_kernel"], "anchor", True)}),
 }

@@ -109,7 +109,13 @@ struct psk_ctx {
             if (best >= 0) { *out = pool[best].p; *got = pool[best].bytes; pool.erase(pool.begin() + best); return PSK_OK; }
         }
         size_t want = bytes + bytes / 16 + 256;
-        PSK_HIP(hipMalloc(out, want));
+        hipError_t e = hipMalloc(out, want);
+        if (e == hipErrorOutOfMemory) {      // blocks the pool keeps for reuse are the first thing to give back
+            (void)hipGetLastError();
+            pool_drain();
+            e = hipMalloc(out, want);
+        }
+        if (e != hipSuccess) { psk_set_error("hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP; }
         *got = want;
         return PSK_OK;
     }

@@ -50,6 +50,15 @@ def default_context(device=0):
         return _ctxs[device]
 
 
+def release_default_context(device=0):
+    """Destroy the shared context of `device` (and with it the device blocks its pool keeps for reuse). Every Database, Sketch and
+    Model made on it must be gone. For programs that run several large jobs one after another in one process (bench.py)."""
+    with _ctx_lock:
+        ctx = _ctxs.pop(device, None)
+    if ctx is not None:
+        ctx.close()
+
+
 def _as_bytes(obj):
     """utils::Text::new (utils.rs:74-102): str -> UTF-8 view, bytes/bytearray -> view, buffers -> copy."""
     if isinstance(obj, str):
