@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
 // nxt[a] = first anchor of the same pair that starts a new chunk if a chunk starts at a
 // COARSE = 1: the successor of every 64th anchor only, into nxt[a / 64]; COARSE = 2: every anchor, searched between the successors of
 // the two 64th anchors around it (nxt is monotone within a pair: 6-7 probes next to each other instead of 13 across megabytes;
-// 3.9 -> ms per 3 Gb pair of 155 M anchors); COARSE = 0: every anchor on its own (few, small pairs).
+// 16.6 -> 8.0 + 1.5 ms per launch over the 8 x 3 Gb step's anchors); COARSE = 0: every anchor on its own (few, small pairs).
 template <int COARSE>
 __global__ __launch_bounds__(256) void anchor_next_kernel(const uint4* __restrict__ anc,
                                                           const uint32_t* __restrict__ pstart, uint32_t n_pairs,
@@ -1953,7 +1953,9 @@ struct SelArgs {
     ChunkOut* out; uint32_t two_c; int force_serial; uint32_t* stats;
     const uint32_t* live; const uint32_t* n_live;      // pairs that have a chunk table (every other pair has no candidate chain)
     uint32_t* big_list; uint32_t* big_count;           // pairs with more than CMAX candidates, for select_big_kernel
+    int tiny_done;                                     // pairs of at most TINY_ROWS chunks and TINY_CANDS candidates were selected by select_tiny_kernel
 };
+constexpr uint32_t TINY_ROWS = 4, TINY_CANDS = 8;
 
 __device__ __forceinline__ void sel_commit(const SelArgs& S, uint32_t row, uint32_t q0, uint32_t q1, uint32_t n) {
     ChunkOut* o = &S.out[row];
@@ -2025,6 +2027,7 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
         if (C > (uint32_t)CM && !S.force_serial) break;      // does not fit this tier whatever follows (a Gb-scale pair has 150 000 rows to count otherwise)
     }
     if (C == 0) return;
+    if (S.tiny_done && nrows <= TINY_ROWS && C <= TINY_CANDS) return;      // select_tiny_kernel took it
     if (S.force_serial) {   // cross-check path: O(C^2) by one lane (run by the first tier only)
         if (first_tier && lane == 0) { select_serial(S, row0, nrows); atomicAdd(&S.stats[3], 1u); }
         return;
@@ -2130,6 +2133,22 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
 // one wave per LIVE pair (pairs without a chunk table - every rescued short contig against an unrelated reference - never reach
 // the selection): a fixed grid walks the device-side list, so a batch of 10^6 pairs of which 10^5 are live does not schedule
 // 10^6 workgroups of 51 KB of LDS each to find that out
+// Contig pairs: one to three chunks, a handful of candidate chains. A wave that stages them in LDS and runs a 64-key bitonic sort spends
+// ~40 us on what is a comparison or two: here ONE LANE takes the pair and runs the serial greedy (the definition the parallel selection
+// is checked against) on its few candidates in place (64 -> 23 ms per 10^7 live contig pairs of the metagenome step).
+__global__ __launch_bounds__(256) void select_tiny_kernel(SelArgs S) {
+    const uint32_t n = *S.n_live;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = S.live[k];
+    const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
+    if (nrows == 0 || nrows > TINY_ROWS) return;
+    uint32_t C = 0;
+    for (uint32_t r = 0; r < nrows; r++) C += S.out[row0 + r].n_cand;
+    if (C == 0 || C > TINY_CANDS) return;
+    select_serial(S, row0, nrows);
+}
+
 __global__ __launch_bounds__(64) void select_kernel(SelArgs S, uint32_t* __restrict__ mid_list, uint32_t* __restrict__ mid_count) {
     const uint32_t n = S.live ? *S.n_live : S.n_pairs;      // small launches skip the list: every pair is visited
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
@@ -3061,6 +3080,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tl, ids, L.live, L.misc + 9, (int)n_pairs, IsLivePair{L.nch}, st));
     }
     ctx->t_begin(K_SELECT);
+    {   // batches of pairs with short chunk tables (contigs): one lane per pair first; PSK_SELECT_TINY=0 leaves every pair to the wave kernels
+        static const bool tiny_off = getenv("PSK_SELECT_TINY") && getenv("PSK_SELECT_TINY")[0] == '0';
+        SA.tiny_done = use_live && !force_serial && !tiny_off && n_rows / n_pairs < 16;
+        if (SA.tiny_done) hipLaunchKernelGGL(select_tiny_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, SA);
+    }
     // (the list of the second tier lives in huge_list: select_big_kernel only writes that after select_mid_kernel has read it)
     hipLaunchKernelGGL(select_kernel, dim3(std::min<uint32_t>(n_pairs, 16384u)), dim3(64), 0, st, SA, L.huge_list, L.misc + 14);
     hipLaunchKernelGGL(select_mid_kernel, dim3(std::min<uint32_t>(n_pairs, 768u)), dim3(64), 0, st, SA, (const uint32_t*)L.huge_list, (const uint32_t*)(L.misc + 14));
