@@ -13,6 +13,58 @@ void psk_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- large hit arrays: a registry of the blocks handed out (address -> bytes) and ONE kept block (see HitList in common.h)
+#include <sys/mman.h>
+#include <unordered_map>
+namespace {
+struct HitBlocks {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;
+    void* kept = nullptr; size_t kept_bytes = 0;
+    const bool keep = !(getenv("PSK_HIT_CACHE") && getenv("PSK_HIT_CACHE")[0] == '0');
+};
+HitBlocks& hit_blocks() { static HitBlocks* hb = new HitBlocks(); return *hb; }      // never destroyed: psk_free may run during process exit
+}
+void* hit_block_alloc(size_t bytes) {
+    const size_t al = (size_t)2 << 20, rounded = (bytes + al - 1) / al * al;
+    HitBlocks& hb = hit_blocks();
+    void* q = nullptr; size_t have = 0;
+    {
+        std::lock_guard<std::mutex> lk(hb.mu);
+        if (hb.kept && hb.kept_bytes >= rounded) { q = hb.kept; have = hb.kept_bytes; hb.kept = nullptr; hb.kept_bytes = 0; }
+    }
+    if (!q) {
+        q = aligned_alloc(al, rounded);
+        if (!q) return nullptr;
+        (void)madvise(q, rounded, MADV_HUGEPAGE);
+        have = rounded;
+    }
+    std::lock_guard<std::mutex> lk(hb.mu);
+    hb.live[q] = have;
+    return q;
+}
+bool hit_block_free(void* p) {
+    HitBlocks& hb = hit_blocks();
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(hb.mu);
+        auto it = hb.live.find(p);
+        if (it == hb.live.end()) return false;
+        const size_t bytes = it->second;
+        hb.live.erase(it);
+        if (hb.keep && bytes > hb.kept_bytes) { drop = hb.kept; hb.kept = p; hb.kept_bytes = bytes; }      // the larger of the two stays
+        else drop = p;
+    }
+    free(drop);
+    return true;
+}
+void hit_block_trim() {
+    HitBlocks& hb = hit_blocks();
+    void* drop;
+    { std::lock_guard<std::mutex> lk(hb.mu); drop = hb.kept; hb.kept = nullptr; hb.kept_bytes = 0; }
+    free(drop);
+}
+
 static void ingest_release(psk_ctx* c);   // host-ingest pipeline resources (defined with psk_sketch_many_host)
 static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, const uint8_t* const* contigs, const uint64_t* lens,
                               const uint32_t* genome_first_contig, uint32_t n_genomes, int want_seeds, psk_sketch** out);
@@ -21,7 +73,7 @@ extern "C" {
 
 const char* psk_last_error(void) { return g_err; }
 const char* psk_version(void) { return "pyskani_amd 0.1.0 (gfx950; algorithm: skani 0.3.0 restatement)"; }
-void psk_free(void* p) { free(p); }
+void psk_free(void* p) { if (p && !hit_block_free(p)) free(p); }
 
 psk_status psk_ctx_create(int device, psk_ctx** out) {
     if (!out) { psk_set_error("ctx_create: NULL out"); return PSK_EINVAL; }
@@ -68,6 +120,7 @@ void psk_ctx_destroy(psk_ctx* c) {
     }
     c->pool_drain();
     delete c;
+    hit_block_trim();
 }
 
 psk_status psk_ctx_synchronize(psk_ctx* c) {

@@ -277,10 +277,16 @@ struct IndexStore {
     uint32_t* km32 = nullptr;  // the sorted k-mers alone (low word of key): what the join streams, half the bytes
     uint32_t* bucket = nullptr; // per sketch nb+1 offsets: bucket b = entries whose k-mer >> bshift == b (a lookup is one
                                // table read plus a scan of ~4 keys instead of a 15-level binary search)
+    // an index that was launched WITHOUT waiting for it (ensure_index(..., lazy): the one query sketch of a psk_query call): the stream it
+    // was built on and the event behind the build; a lane on another stream waits for the event before it reads the index
+    hipStream_t built_on = nullptr; hipEvent_t ready = nullptr;
     ~IndexStore();
 };
 
-inline IndexStore::~IndexStore() { if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base); }
+inline IndexStore::~IndexStore() {
+    if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }      // (the block goes back to a pool other lanes allocate from)
+    if (ctx) ctx->pool_release(base, bytes); else if (base) (void)hipFree(base);
+}
 
 // Probe tables of a group of sketches (ensure_probe): the reference side of the join of batches of MANY SMALL pairs (metagenome
 // contigs: a few hundred query seeds against a reference of 10^5; anchor_join_probe_kernel). One 64-byte line holds up to
@@ -466,7 +472,7 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
                              int want_seeds, psk_sketch** out);
 // sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
-psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
+psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n, bool lazy = false);
 // builds the probe table of every indexed sketch of the list that lacks one (sketches of 256 .. 2^20 seeds)
 psk_status ensure_probe(Lane* ctx, const psk_sketch* const* refs, uint32_t n);
 // line of a k-mer: multiplicative hash, then scaled to the table. (NOT the k-mer's own top bits: canonical k-mers are the smaller of a
@@ -478,26 +484,27 @@ psk_status screen_impl(Lane* ctx, psk_db* db, const psk_sketch* query, double sc
 psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_sketch* const* queries, uint32_t n,
                             const psk_query_opts* o, psk_hit* out);
 // growing array of hits in malloc'd memory: what the query entry points hand to the caller (psk_free) without another copy
+// Large hit arrays (>= 8 MB) come from hit_block_alloc and go back through hit_block_free (psk_free routes them there): 2 MB-aligned,
+// advised as huge pages, and the last one released is kept for the next call - a 600 MB result is 150 000 first-touch page faults and
+// a 26 ms munmap otherwise, all of it with the GPU idle (profiles/r3/r3q_meta_tail.txt). PSK_HIT_CACHE=0: no block is kept.
+void* hit_block_alloc(size_t bytes);      // nullptr: out of host memory
+bool hit_block_free(void* p);             // false: not one of these blocks (the caller frees it)
+void hit_block_trim();                    // drop the kept block (psk_ctx_destroy)
 struct HitList {
     psk_hit* p = nullptr; size_t n = 0, cap = 0;
     HitList() = default;
     HitList(const HitList&) = delete; HitList& operator=(const HitList&) = delete;
-    ~HitList() { free(p); }
-    // room for `want` hits in all. Large arrays are 2 MB-aligned and advised as huge pages: a fresh 80 MB result is 20 000 first-touch
-    // page faults otherwise (~10 ms of the caller's time after the last kernel); pages that are never touched cost nothing
+    ~HitList() { drop(p); }
+    static void drop(void* q) { if (q && !hit_block_free(q)) free(q); }
+    // room for `want` hits in all; pages that are never touched cost nothing
     bool reserve(size_t want) {
         if (want <= cap) return true;
         if (n && want < 2 * cap) want = 2 * cap;      // a list that already holds hits moves them when it grows: at least double, so a long result is copied O(1) times
         const size_t bytes = sizeof(psk_hit) * want;
-        psk_hit* q;
-        if (bytes >= ((size_t)8 << 20)) {
-            const size_t al = (size_t)2 << 20, rounded = (bytes + al - 1) / al * al;
-            q = (psk_hit*)aligned_alloc(al, rounded);
-            if (q) (void)madvise(q, rounded, MADV_HUGEPAGE);
-        } else q = (psk_hit*)malloc(bytes);
+        psk_hit* q = (psk_hit*)(bytes >= ((size_t)8 << 20) ? hit_block_alloc(bytes) : malloc(bytes));
         if (!q) return false;
         if (n) memcpy(q, p, sizeof(psk_hit) * n);
-        free(p);
+        drop(p);
         p = q; cap = want;
         return true;
     }

@@ -1812,12 +1812,14 @@ struct ChainWaveLds {
 };
 static_assert(sizeof(uint32_t) * 7 * 64 <= sizeof(uint32_t) * 6 * RING, "candidate staging fits the ring");
 
+__device__ void chain_row_candidates(const ChainArgs& A, uint32_t s, uint32_t e, ChunkOut* op, ChainWaveLds& L, int lane, uint32_t R, bool fast);
+
 __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds& L, int lane) {
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
     ChunkOut* op = &A.out[slot];
     uint32_t (*ring)[RING] = L.ring;
-    unsigned long long* s_best_w = L.best; uint32_t (*s_cand_w)[64] = L.cand;
+    unsigned long long* s_best_w = L.best;
     bool fast = !A.force_serial && n < 16384;
     uint32_t R = 0;
     if (fast) {
@@ -1874,6 +1876,12 @@ __device__ void chain_chunk_row(const ChainArgs& A, uint32_t slot, ChainWaveLds&
             }
         }
     }
+    chain_row_candidates(A, s, e, op, L, lane, R, fast);
+}
+
+// the chunk's candidate chains out of the per-tree bests in L.best[0 .. R) (fast), or the lane-serial path over global scratch (!fast)
+__device__ void chain_row_candidates(const ChainArgs& A, uint32_t s, uint32_t e, ChunkOut* op, ChainWaveLds& L, int lane, uint32_t R, bool fast) {
+    unsigned long long* s_best_w = L.best; uint32_t (*s_cand_w)[64] = L.cand;
     uint32_t C = 0;
     if (fast) {
         // candidates: one per chain tree whose best anchor passes the thresholds, in root order
@@ -1939,6 +1947,110 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_list_kernel(Chai
         chain_chunk_row(A, A.ovf_list[k], s_lds[wave], lane);
         lds_wave_sync();
     }
+}
+
+// ---- wave-per-chunk DP with the look-back window in REGISTERS (launches of few rows) ----------------------------
+// A launch of a few hundred rows (one Database.query of a contig: one or two chunks per shortlisted reference) is as slow as its
+// longest chunk, and per anchor the kernels above are a chain of LDS round trips (ring read -> score -> wave maximum -> tree id read ->
+// ring write -> wait: ~1 400 cycles) or, four lanes per chunk, 21 predecessors one after the other (~2 000 cycles): 220-300 us for the
+// 330 anchors of a 10 kb contig at c = 30. Here the window of 64 * S anchors is spread over the wave's registers - the anchor with
+// chunk-local index a lives in lane a & 63, register set (a >> 6) % S - every lane scores the S predecessors it holds, one wave maximum
+// picks the winner, two lane reads fetch its tree and depth, and the per-tree bests sit in registers too (tree t: lane t & 63, register
+// t >> 6). No LDS and no wait inside the loop. Same keys, same tie-break (nearest predecessor), same tree numbering as chain_chunk_row.
+// six registers take wave-uniform values in ONE lane (v_writelane_b32; this compiler has no builtin for it; on gfx9 the lane select sits in M0 when
+// the value is a scalar register too: one constant-bus operand per instruction)
+__device__ __forceinline__ void write_lane6(uint32_t lane, uint32_t& v0, uint32_t a0, uint32_t& v1, uint32_t a1, uint32_t& v2, uint32_t a2, uint32_t& v3, uint32_t a3,
+                                            uint32_t& v4, uint32_t a4, uint32_t& v5, uint32_t a5) {
+    uint32_t keep;      // (M0 is the compiler's own: handed back as it was)
+    asm volatile("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tv_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\tv_writelane_b32 %2, %10, m0\n\t"
+                 "v_writelane_b32 %3, %11, m0\n\tv_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\ts_mov_b32 m0, %6"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "=&s"(keep)
+                 : "s"(lane), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5));
+}
+struct RegWin { uint32_t q1, u, m; int32_t f1; uint32_t id, dp; };      // one window slot per lane: q + 1, diagonal, ref contig | strand, score - 1 (lane_eval2's form), tree, depth
+template <int S>
+__device__ void chain_chunk_row_reg(const ChainArgs& A, uint32_t slot, ChainWaveLds& L, int lane) {
+    static_assert(S == 1 || S == 2, "one or two window slots per lane");
+    constexpr uint32_t WMASK = 64u * S - 1u;
+    const uint2 se = A.chunks[slot];
+    const uint32_t s = se.x, e = se.y, n = e - s;
+    ChunkOut* op = &A.out[slot];
+    bool fast = !A.force_serial && n < 16384;
+    uint32_t R = 0;
+    RegWin w0{0, 0, 0xFFFFFFFFu, 0, 0, 0}, w1 = w0;      // (m = all ones: a slot nothing was written to matches no anchor)
+    uint32_t* s_root = &L.ring[0][0];                    // chunk-local index of every tree's root (the ring itself is not used here)
+    static_assert(RMAX <= 6 * RING, "root table fits the ring's space");
+    const uint32_t band = (uint32_t)A.band;
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < RMAX / 64; u++) L.best[lane + 64 * u] = 0;
+        lds_wave_sync();
+        for (uint32_t base = s; base < e && fast; base += 64) {
+            const uint32_t idx = base + lane;
+            const uint4 my_a = idx < e ? A.anc[idx] : make_uint4(0, 0, 0, 0);
+            const uint32_t cnt = e - base < 64 ? e - base : 64;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t qx = __builtin_amdgcn_readlane(my_a.x, j), rx = __builtin_amdgcn_readlane(my_a.y, j), mx = __builtin_amdgcn_readlane(my_a.z, j);
+                const uint32_t avail = base + j - s;   // anchors before this one in the chunk = its chunk-local index
+                const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
+                // every lane scores the predecessor(s) it holds: lane_eval2's key, negative when not chainable or outside the band
+                const uint32_t d0 = (avail - (uint32_t)lane) & WMASK;      // 0: the slot this anchor is about to take
+                int32_t key = lane_eval2(qx, ux, mx, LanePred{w0.q1, w0.u, w0.m, w0.f1}, (int)d0) | (int32_t)(((band - d0) | (d0 - 1u)) & 0x80000000u);
+                key = key > 0 ? key : 0;
+                if (S > 1) {
+                    const uint32_t d1 = (d0 - 64u) & WMASK;
+                    const int32_t k1 = lane_eval2(qx, ux, mx, LanePred{w1.q1, w1.u, w1.m, w1.f1}, (int)d1) | (int32_t)(((band - d1) | (d1 - 1u)) & 0x80000000u);
+                    key = k1 > key ? k1 : key;
+                }
+                const uint32_t best = __builtin_amdgcn_readfirstlane(wave_max_u32((uint32_t)key));      // (uniform already: this tells the compiler, and the tree count stays in a scalar register)
+                int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
+                if (best) {
+                    f = (int32_t)(best >> 7);
+                    const uint32_t ps = (avail - (127u - (best & 127u))) & WMASK;
+                    // (a lane read per register set and a scalar choice: picking the register set first turns into an indexed array in scratch)
+                    rid = __builtin_amdgcn_readlane(w0.id, ps & 63u); dep = __builtin_amdgcn_readlane(w0.dp, ps & 63u);
+                    if (S > 1) {
+                        const uint32_t rid1 = __builtin_amdgcn_readlane(w1.id, ps & 63u), dep1 = __builtin_amdgcn_readlane(w1.dp, ps & 63u);
+                        if (ps >> 6) { rid = rid1; dep = dep1; }
+                    }
+                    dep++;
+                } else {
+                    rid = R++; dep = 1;
+                    if (rid >= RMAX) { fast = false; break; }
+                    if (lane == 0) s_root[rid] = avail;
+                }
+                // the anchor takes its slot: everything about it is wave-uniform, six lane writes
+                const uint32_t wl = avail & 63u;
+                if (S == 1 || ((avail >> 6) & 1u) == 0) { uint32_t f1 = (uint32_t)w0.f1; write_lane6(wl, w0.q1, qx + 1u, w0.u, ux, w0.m, mx, f1, (uint32_t)(f - 1), w0.id, rid, w0.dp, dep); w0.f1 = (int32_t)f1; }
+                else { uint32_t f1 = (uint32_t)w1.f1; write_lane6(wl, w1.q1, qx + 1u, w1.u, ux, w1.m, mx, f1, (uint32_t)(f - 1), w1.id, rid, w1.dp, dep); w1.f1 = (int32_t)f1; }
+            }
+            if (!fast) break;
+            // the block's 64 anchors now sit one per lane (lane = index & 63) in one register set: their keys go to their trees' bests together
+            // (the maximum over a tree's anchors of f << 28 | (16383 - index) << 14 | depth, as chain_chunk_row keeps it anchor by anchor)
+            const bool set1 = S > 1 && (((base - s) >> 6) & 1u);
+            const uint32_t bf = (uint32_t)((set1 ? w1.f1 : w0.f1) + 1), bid = set1 ? w1.id : w0.id, bdp = set1 ? w1.dp : w0.dp;
+            if ((uint32_t)lane < cnt)
+                atomicMax(&L.best[bid], ((unsigned long long)bf << 28) | ((unsigned long long)(16383u - (base - s + (uint32_t)lane)) << 14) | bdp);
+        }
+    }
+    if (fast) {
+        lds_wave_sync();
+#pragma unroll
+        for (int u = 0; u < RMAX / 64; u++) if ((uint32_t)lane + 64u * u < R) L.best[lane + 64 * u] |= (unsigned long long)s_root[lane + 64 * u] << 49;      // the root's index rides in the top bits
+        lds_wave_sync();
+    }
+    chain_row_candidates(A, s, e, op, L, lane, R, fast);
+}
+
+template <int S>
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_wave_reg_kernel(ChainArgs A) {
+    __shared__ ChainWaveLds s_lds[CHAIN_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // (told to be uniform: the row's bounds, the loop counters and the tree count live in scalar registers)
+    const uint32_t slot = blockIdx.x * CHAIN_WAVES + wave;   // row of the chunk table
+    const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
+    if (slot >= A.n_rows) return;
+    if (slot - A.cbase[pair] >= A.n_chunks[pair]) return;
+    chain_chunk_row_reg<S>(A, slot, s_lds[wave], lane);
 }
 
 // ------------------------------------------------------------------ chain selection (per pair)
@@ -3053,7 +3165,15 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     // bands beyond the lane kernel's window (c < 105; metagenome mode c = 30: 83): four lanes per chunk with 21-deep windows, its leftovers to
     // the wave-per-chunk kernel's list form; PSK_CHAIN_QUAD_DEEP=0 keeps the wave-per-chunk kernel for every chunk (tests, A/B)
     static const bool qd_off = getenv("PSK_CHAIN_QUAD_DEEP") && getenv("PSK_CHAIN_QUAD_DEEP")[0] == '0';
-    const bool quad_deep = !A.lane_dp && !force_serial && !qd_off && A.band <= 4 * QD && !(getenv("PSK_CHAIN_LANE") && getenv("PSK_CHAIN_LANE")[0] == '0');
+    // a launch of few rows is as slow as its longest chunk: one wave per row with the window in registers (PSK_CHAIN_WAVE_REG=1 / 0 force / forbid: tests, A/B)
+    const char* wr_env = getenv("PSK_CHAIN_WAVE_REG");
+    const bool wave_reg = !A.lane_dp && !force_serial && A.band < 128 && (wr_env ? wr_env[0] == '1' : n_rows <= 8192);
+    if (wave_reg) {
+        const dim3 g((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), b(64 * CHAIN_WAVES);
+        if (A.band < 64) hipLaunchKernelGGL(chain_wave_reg_kernel<1>, g, b, 0, st, A);
+        else hipLaunchKernelGGL(chain_wave_reg_kernel<2>, g, b, 0, st, A);
+    }
+    const bool quad_deep = !wave_reg && !A.lane_dp && !force_serial && !qd_off && A.band <= 4 * QD && !(getenv("PSK_CHAIN_LANE") && getenv("PSK_CHAIN_LANE")[0] == '0');
     if (quad_deep) {
         A.ovf_list = L.ovf; A.ovf_count = L.misc + 8;      // misc was zeroed above
         A.lane_dp = 1;                                     // (chain_chunk_list_kernel walks the list)
@@ -3062,7 +3182,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
         hipLaunchKernelGGL(chain_chunk_list_kernel, dim3(lw), dim3(64 * CHAIN_WAVES), 0, st, A);
     }
-    if (!A.lane_dp)
+    if (!A.lane_dp && !wave_reg)
     hipLaunchKernelGGL(chain_chunk_kernel, dim3((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), dim3(64 * CHAIN_WAVES), 0, st, A);
     ctx->t_end();
     SelArgs SA{};
@@ -3461,6 +3581,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         const size_t o_pass = 0, o_cnt = al256((size_t)m * n), o_flag = al256(o_cnt + 4 * (size_t)m), o_end = o_flag + n;
         PSK_TRY(ctx->q_i.reserve(o_end + 256));
         uint8_t* d_pass = (uint8_t*)ctx->q_i.p + o_pass; uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_i.p + o_cnt); uint8_t* d_flag = (uint8_t*)ctx->q_i.p + o_flag;
+        // a single query (psk_query: one contig against the database) is as slow as its chain of waits: its k-mer index is launched here,
+        // ahead of the screen, and not waited for - one host synchronisation fewer per call
+        if (n_queries == 1 && queries[0]->has_seeds && queries[0]->store && queries[0]->n_seeds && !queries[0]->idx &&
+            queries[0]->params.k == db->params.k && queries[0]->params.c == db->params.c)
+            PSK_TRY(ensure_index(ctx, queries, 1, true));
         ScreenStaging keep;
         PSK_TRY(screen_many_device(ctx, db, queries + b, m, screen_val, !o->faster_small, d_pass, keep));
         if (db->has_dups) hipLaunchKernelGGL(pass_canon_kernel, dim3(m), dim3(256), 0, st, d_pass, n, (const uint32_t*)db->d_canon.p);

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
     const uint32_t* __restrict__ genome_seed_off, uint32_t n_tiles,
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
     uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ tile_mcount,
-    SketchConsts C) {
+    SketchConsts C, uint32_t seed_cap) {
     __shared__ __align__(16) uint32_t s_words_all[EMIT_WAVES][TILE_WORDS + 8];   // packed tile + 4 words either side
     __shared__ uint16_t s_list_all[EMIT_WAVES][EMIT_LIST];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     const uint32_t total = __shfl(incl, 63);
-    if (total == 0) { if (lane == 0) tile_mcount[tile] = 0; return; }
+    // (seed_cap: arrays that were sized before the count was known - the one-synchronisation path; a tile beyond them writes nothing, the host sees the total)
+    if (total == 0 || t_off + total > seed_cap) { if (lane == 0) tile_mcount[tile] = 0; return; }
     const uint32_t excl = incl - cnt;
     uint32_t mrun = 0;   // markers of this tile so far: they go to marker_stage[t_off + 0 ..), no atomics
     const uint32_t pos0 = (tile - ti.x) * TILE_BASES;
@@ -393,18 +394,29 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 constexpr int MB_CAP = 8192;
 constexpr int MB_THREADS = 1024;
 constexpr int MB_TILES = 1024;     // tiles of one genome the LDS tile table holds (16.7 Mb)
+// ONE (the one-synchronisation path of a single small genome): tile_moff holds the tiles' raw marker COUNTS - the workgroup scans them itself -
+// the distinct markers go straight to the sketch's array of out_cap entries, and cnt receives {0, distinct} (the marker offsets).
+template <bool ONE>
 __global__ __launch_bounds__(MB_THREADS) void marker_block_kernel(const uint64_t* __restrict__ stage, const uint32_t* __restrict__ tile_off,
                                                                   const uint32_t* __restrict__ tile_moff, const uint32_t* __restrict__ gft,
-                                                                  uint64_t* __restrict__ uniq, uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+                                                                  uint64_t* __restrict__ uniq, uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow, uint32_t out_cap) {
     __shared__ unsigned long long s_m[MB_CAP];
     __shared__ uint32_t s_cnt[MB_CAP];
     __shared__ uint32_t s_tsrc[MB_TILES], s_tdst[MB_TILES + 1];
     __shared__ uint32_t s_wave[MB_THREADS / 64 + 1];
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
-    const uint32_t t0 = gft[g], nt = gft[g + 1] - t0, m0 = tile_moff[t0], n = tile_moff[t0 + nt] - m0;
-    if (n > (uint32_t)MB_CAP || nt > (uint32_t)MB_TILES) { if (tid == 0) { atomicOr(overflow, 1u); cnt[g] = 0; } return; }
+    const uint32_t t0 = gft[g], nt = gft[g + 1] - t0;
+    if (nt > (uint32_t)MB_TILES) { if (tid == 0) { atomicOr(overflow, 1u); cnt[g] = 0; if (ONE) cnt[1] = 0; } return; }
+    uint32_t m0, n;
+    if (ONE) {
+        const uint32_t c = tid < nt ? tile_moff[t0 + tid] : 0u;
+        const uint32_t ex = block_exclusive_scan<MB_THREADS>(c, s_wave, &n);
+        if (tid < nt) { s_tsrc[tid] = tile_off[t0 + tid]; s_tdst[tid] = ex; }
+        m0 = 0;
+    } else { m0 = tile_moff[t0]; n = tile_moff[t0 + nt] - m0; }
+    if (n > (uint32_t)MB_CAP) { if (tid == 0) { atomicOr(overflow, 1u); cnt[g] = 0; if (ONE) cnt[1] = 0; } return; }
     // tile table into LDS with one round of loads, then the markers with at most MB_CAP / MB_THREADS independent loads
-    for (uint32_t q = tid; q < nt; q += MB_THREADS) { s_tsrc[q] = tile_off[t0 + q]; s_tdst[q] = tile_moff[t0 + q] - m0; }
+    if (!ONE) for (uint32_t q = tid; q < nt; q += MB_THREADS) { s_tsrc[q] = tile_off[t0 + q]; s_tdst[q] = tile_moff[t0 + q] - m0; }
     if (tid == 0) s_tdst[nt] = n;
     __syncthreads();
     constexpr int PER = MB_CAP / MB_THREADS;
@@ -461,9 +473,37 @@ __global__ __launch_bounds__(MB_THREADS) void marker_block_kernel(const uint64_t
     for (int r = 0; r < PER; r++) mine += (i0 + r < n && (i0 + r == 0 || e[r + 1] != e[r])) ? 1u : 0u;
     uint32_t total;
     uint32_t rank = block_exclusive_scan<MB_THREADS>(mine, s_wave, &total);
+    if (ONE && total > out_cap) { if (tid == 0) { atomicOr(overflow, 2u); cnt[0] = 0; cnt[1] = 0; } return; }
 #pragma unroll
     for (int r = 0; r < PER; r++) if (i0 + r < n && (i0 + r == 0 || e[r + 1] != e[r])) uniq[m0 + rank++] = e[r + 1];
-    if (tid == 0) cnt[g] = total;
+    if (tid == 0) { if (ONE) { cnt[0] = 0; cnt[1] = total; } else cnt[g] = total; }
+}
+
+// One workgroup: exclusive scan of the tiles' seed counts (tile offsets), the 64-bit total, the genome's and the contigs' seed offsets (res: {total lo, total hi,
+// goff[0], goff[1]}, coff -> the sketch's contig_seed_start AND the result block), the marker overflow flag cleared. Replaces two device scans, a reduction, two gathers
+// and three memsets of the general path when ONE small genome is sketched.
+__global__ __launch_bounds__(1024) void sketch_small_offsets_kernel(const uint32_t* __restrict__ cnt, uint32_t n_tiles, uint32_t* __restrict__ toff, const uint32_t* __restrict__ cft, uint32_t n_desc,
+                                                                   uint32_t* __restrict__ coff_store, uint32_t* __restrict__ res, uint32_t* __restrict__ res_coff, uint32_t* __restrict__ mflag) {
+    __shared__ uint32_t s_wave[1024 / 64 + 1];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024) {
+        const uint32_t i = i0 + tid, c = i < n_tiles ? cnt[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<1024>(c, s_wave, &tot);
+        const uint32_t carry = s_carry;
+        if (i < n_tiles) toff[i] = carry + ex;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    const uint32_t total = s_carry;
+    if (tid == 0) { toff[n_tiles] = total; res[0] = total; res[1] = 0; res[2] = 0; res[3] = total; *mflag = 0; }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t c = tid; c <= n_desc; c += 1024) { const uint32_t v = c < n_desc ? toff[cft[c]] : total; coff_store[c] = v; res_coff[c] = v; }
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -620,7 +660,7 @@ struct SketchJob {
         d_mstage = (uint64_t*)R->s_mark.p; d_mdense = d_mstage + ns + 1; d_msorted = d_mdense + ns + 1;
         ctx->t_begin(K_SKETCH_EMIT, st);
         hipLaunchKernelGGL(sketch_emit_kernel, dim3((n_tiles + EMIT_WAVES - 1) / EMIT_WAVES), dim3(64 * EMIT_WAVES), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff, n_tiles,
-                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_tmc, C);
+                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_tmc, C, 0xFFFFFFFFu);
         ctx->t_end(st);
         ctx->t_begin(K_SKETCH_SORT, st);
         // marker sets: tile-local lists -> dense per-genome segments -> per-genome sort -> distinct values
@@ -635,7 +675,7 @@ struct SketchJob {
             if (sk[g]->total_len / (uint64_t)p->marker_c > (uint64_t)(MB_CAP * 3 / 4)) marker_block = false;
         if (marker_block) {
             JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t), st));      // overflow flag
-            hipLaunchKernelGGL(marker_block_kernel, dim3(n_genomes), dim3(MB_THREADS), 0, st, d_mstage, d_toff, d_tmoff, d_gft, d_mdense, d_moff, d_mcnt);
+            hipLaunchKernelGGL(marker_block_kernel<false>, dim3(n_genomes), dim3(MB_THREADS), 0, st, d_mstage, d_toff, d_tmoff, d_gft, d_mdense, d_moff, d_mcnt, 0xFFFFFFFFu);
             JHIP(hipMemcpyAsync(h_moff + n_genomes + 1, d_mcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         } else {
             PSK_TRY(marker_segsort());
@@ -694,6 +734,81 @@ struct SketchJob {
         PSK_TRY(ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes));
         store->markers = (uint64_t*)store->mbase;
         hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, marker_block ? d_mdense : d_mstage, d_sbeg, d_moff, store->markers);
+        return PSK_OK;
+    }
+
+    // ONE small genome (a contig about to be queried, a genome sketched on its own): the whole pipeline is enqueued against arrays sized from the
+    // EXPECTED counts and the host synchronises once, at the end, where the general path stops three times to learn a size (seeds, distinct markers,
+    // completion). *done = false: not eligible, or a count did not fit (low-complexity input) - the general path runs instead.
+    psk_status run_small(psk_sketch** out, bool* done) {
+        *done = false;
+        const bool off = getenv("PSK_SKETCH_SMALL") && getenv("PSK_SKETCH_SMALL")[0] == '0';
+        if (off || empty || n_genomes != 1 || n_tiles > (uint32_t)MB_TILES || n_desc > 65536) return PSK_OK;
+        const uint64_t bases = sk[0]->total_len;
+        if (bases / (uint64_t)p->marker_c > (uint64_t)(MB_CAP * 3 / 4)) return PSK_OK;
+        // capacity: the expected count (hash-selected: one k-mer in c), a tenth more, six standard deviations of a binomial and a floor
+        auto cap_of = [](double expect) { return (uint32_t)(expect * 1.1 + 6.0 * sqrt(expect) + 64.0); };
+        const uint32_t ns_cap = cap_of((double)bases / (double)p->c), mk_cap = std::min<uint32_t>((uint32_t)MB_CAP, cap_of((double)bases / (double)p->marker_c));
+        // device: [contig descriptors | contig first tiles | genome first tiles {0, n_tiles}] (one upload), work arrays, [result block] (one download)
+        const size_t i_desc = 0, i_cft = align_up(sizeof(ContigDesc) * (size_t)n_desc, 16), i_gft = i_cft + 4 * (size_t)(n_desc + 1), i_end = align_up(i_gft + 8, 256);
+        const size_t w_cnt = i_end, w_toff = w_cnt + 4 * (size_t)(n_tiles + 1), w_tmc = w_toff + 4 * (size_t)(n_tiles + 1), w_end = align_up(w_tmc + 4 * (size_t)(n_tiles + 1), 256);
+        const size_t r_res = w_end, r_moff = r_res + 16, r_flag = r_moff + 8, r_coff = r_flag + 8, r_end = r_coff + 4 * (size_t)(n_desc + 1);
+        PSK_TRY(R->s_offs.reserve(r_end + 256));
+        PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
+        PSK_TRY(R->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS));
+        PSK_TRY(R->s_counts.reserve(sizeof(uint4) * ((size_t)n_tiles + 1) + sizeof(uint32_t) * ((size_t)n_tiles + 4)));
+        PSK_TRY(R->s_mark.reserve(sizeof(uint64_t) * ((size_t)ns_cap + 1)));
+        char* B = (char*)R->s_offs.p;
+        d_desc = (ContigDesc*)(B + i_desc); d_cft = (uint32_t*)(B + i_cft); d_gft = (uint32_t*)(B + i_gft);
+        d_cnt = (uint32_t*)(B + w_cnt); d_toff = (uint32_t*)(B + w_toff); d_tmc = (uint32_t*)(B + w_tmc);
+        uint32_t* d_res = (uint32_t*)(B + r_res);
+        d_tinfo = (uint4*)R->s_counts.p; d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
+        d_packed = (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p; d_mstage = (uint64_t*)R->s_mark.p;
+        void* hp;
+        PSK_TRY(R->pin(i_end + (r_end - r_res) + 64, &hp));
+        char* H = (char*)hp;
+        memcpy(H + i_desc, descs.data(), sizeof(ContigDesc) * (size_t)n_desc);
+        { uint32_t* h_cft = (uint32_t*)(H + i_cft); for (int i = 0; i < n_desc; i++) h_cft[i] = descs[i].first_tile; h_cft[n_desc] = n_tiles; }
+        { uint32_t* h_gft = (uint32_t*)(H + i_gft); h_gft[0] = 0; h_gft[1] = n_tiles; }
+        const uint32_t* h_res = (const uint32_t*)(H + i_end);
+        // the sketch's arrays, sized by the capacities
+        store = std::make_shared<SketchStore>();
+        const size_t ns = ns_cap;
+        const size_t b_kmer = 0, b_pos = align_up(b_kmer + 4 * ns, 256), b_meta = align_up(b_pos + 4 * ns, 256),
+                     b_pm = align_up(b_meta + 4 * ns, 256), b_cstart = align_up(b_pm + 8 * ns, 256), b_end = align_up(b_cstart + 4 * (size_t)(n_desc + 1), 256);
+        store->ctx = ctx->dev;
+        PSK_TRY(ctx->pool_alloc(b_end, &store->base, &store->bytes));
+        char* sb = (char*)store->base;
+        store->seed_kmer = (uint32_t*)(sb + b_kmer); store->seed_pos = (uint32_t*)(sb + b_pos); store->seed_meta = (uint32_t*)(sb + b_meta);
+        store->seed_pm = (uint64_t*)(sb + b_pm); store->contig_seed_start = (uint32_t*)(sb + b_cstart);
+        PSK_TRY(ctx->pool_alloc(sizeof(uint64_t) * ((size_t)mk_cap + 1), &store->mbase, &store->mbytes));
+        store->markers = (uint64_t*)store->mbase;
+        JHIP(hipMemcpyAsync(B, H, i_end, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(tile_contig_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_desc, n_desc, n_tiles, d_tci, d_tinfo);
+        ctx->t_begin(K_SKETCH_SCAN, st);
+        hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), 0, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
+        ctx->t_end(st);
+        ctx->t_begin(K_SKETCH_EMIT, st);
+        hipLaunchKernelGGL(sketch_small_offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)d_cnt, n_tiles, d_toff, (const uint32_t*)d_cft, (uint32_t)n_desc,
+                           store->contig_seed_start, d_res, (uint32_t*)(B + r_coff), (uint32_t*)(B + r_flag));
+        hipLaunchKernelGGL(sketch_emit_kernel, dim3((n_tiles + EMIT_WAVES - 1) / EMIT_WAVES), dim3(64 * EMIT_WAVES), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_res + 2, n_tiles,
+                           store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_tmc, C, ns_cap);
+        ctx->t_end(st);
+        ctx->t_begin(K_SKETCH_SORT, st);
+        hipLaunchKernelGGL(marker_block_kernel<true>, dim3(1), dim3(MB_THREADS), 0, st, d_mstage, d_toff, d_tmc, d_gft, store->markers, (uint32_t*)(B + r_moff), (uint32_t*)(B + r_flag), mk_cap);
+        ctx->t_end(st);
+        JHIP(hipMemcpyAsync(H + i_end, B + r_res, r_end - r_res, hipMemcpyDeviceToHost, st));
+        JHIP(hipStreamSynchronize(st));
+        const uint32_t total = h_res[0], n_mark = h_res[5], flag = h_res[6];
+        if (total > ns_cap || flag) { store.reset(); return PSK_OK; }      // a count did not fit: the general path sizes the arrays from the counts
+        const uint32_t* h_co = h_res + 8;
+        psk_sketch* s = sk[0];
+        s->store = store;
+        s->seed_off = 0; s->n_seeds = total; s->marker_off = 0; s->n_markers = n_mark; s->contig_off = 0;
+        s->contig_seed_start.assign(h_co, h_co + n_desc + 1);
+        out[0] = s;
+        sk.clear();
+        *done = true;
         return PSK_OK;
     }
 
@@ -761,6 +876,12 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
         rc = jb.prepare(contig_off, contig_len, genome_first_contig + cut[j], cut[j + 1] - cut[j]);
         if (rc != PSK_OK) return abort_all(rc);
     }
+    if (J == 1 && n_genomes == 1) {
+        bool done = false;
+        psk_status rc = jobs[0].run_small(out, &done);
+        if (rc != PSK_OK) return abort_all(rc);
+        if (done) return PSK_OK;
+    }
     hipEvent_t prev = nullptr;
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase1(prev); if (rc != PSK_OK) return abort_all(rc); if (!jobs[j].empty) prev = jobs[j].R->scan_done; }
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase2(); if (rc != PSK_OK) return abort_all(rc); }
@@ -810,7 +931,7 @@ constexpr uint32_t IDXT_MAX_SEEDS = 1u << 12;
 // T threads, 2^LB LDS counters: (1 024, 14) for genomes, (256, 10) for sketches of up to IDXT_MAX_SEEDS seeds (contigs): a workgroup of the
 // former takes half a CU whatever the sketch's size - 10 000 contigs indexed in 3.8 ms - the latter fits sixteen to a CU
 template <int T, int LB>
-__global__ __launch_bounds__(T) void index_block_kernel(const IdxSeg* __restrict__ segs, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(T) void index_block_kernel(const IdxSeg* __restrict__ segs, const IdxSeg one, uint32_t slices, uint64_t* __restrict__ key, uint32_t* __restrict__ perm,
                                                                     uint64_t* __restrict__ pms, uint32_t* __restrict__ bucket, uint32_t* __restrict__ km32) {
     // `slices` workgroups share one sketch: workgroup (seg, sl) owns buckets [B0, B1) = the sl-th part of the bucket
     // space and the index positions its k-mers sort to. Every workgroup streams ALL of the sketch's k-mers (coalesced,
@@ -818,7 +939,7 @@ __global__ __launch_bounds__(T) void index_block_kernel(const IdxSeg* __restrict
     // is spread over `slices` CUs; the number of k-mers below B0 gives its base position without any grid sync.
     __shared__ uint32_t s_cnt[1 << LB];
     __shared__ uint32_t s_part[T / 64 + 1];
-    const IdxSeg sg = segs[blockIdx.x / slices];
+    const IdxSeg sg = segs ? segs[blockIdx.x / slices] : one;      // (a single sketch's descriptor rides in the kernel arguments: no table to upload)
     const uint32_t sl = blockIdx.x % slices;
     const uint32_t tid = threadIdx.x, n = sg.n, nb = sg.nb, sh = sg.bshift;
     const uint32_t B0 = (uint32_t)((uint64_t)nb * sl / slices), B1 = (uint32_t)((uint64_t)nb * (sl + 1) / slices), nbl = B1 - B0;
@@ -927,11 +1048,15 @@ __global__ __launch_bounds__(T) void index_block_kernel(const IdxSeg* __restrict
     }
 }
 
-psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
+// lazy: a single small sketch is indexed without waiting for the kernel (the caller's stream order covers its own use; any other lane finds
+// the build's event in the IndexStore and waits for it on its stream). Everything else is complete when the call returns.
+psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n, bool lazy) {
     std::lock_guard<std::mutex> index_lock(ctx->dev->index_mu);   // index builds mutate the sketches they index
     hipStream_t st = ctx->stream;
     std::vector<const psk_sketch*> todo;
     std::unordered_set<const psk_sketch*> seen;
+    for (uint32_t i = 0; i < n; i++) if (refs[i] && refs[i]->idx && refs[i]->idx->ready && refs[i]->idx->built_on != st)
+        PSK_HIP(hipStreamWaitEvent(st, refs[i]->idx->ready, 0));
     for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store && seen.insert(refs[i]).second)
         todo.push_back(refs[i]);
     const uint64_t GROUP = 1ull << 26;   // seeds per sort
@@ -967,8 +1092,12 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
         ix->key = (uint64_t*)ix->base; ix->pms = (uint64_t*)((char*)ix->base + kb); ix->perm = (uint32_t*)((char*)ix->base + 2 * kb);
         ix->km32 = (uint32_t*)((char*)ix->base + 2 * kb + vb);
         ix->bucket = (uint32_t*)((char*)ix->base + 2 * kb + 2 * vb);
-        PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
-        PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
+        const bool by_value = small && m == 1;
+        if (!by_value) {
+            PSK_TRY(ctx->s_offs.reserve(sizeof(IdxSeg) * m));
+            PSK_HIP(hipMemcpyAsync(ctx->s_offs.p, segs.data(), sizeof(IdxSeg) * m, hipMemcpyHostToDevice, st));
+        }
+        const IdxSeg* d_segs = by_value ? (const IdxSeg*)nullptr : (const IdxSeg*)ctx->s_offs.p;
         if (small) {
             ctx->t_begin(K_SKETCH_SORT);
             // The kernel can split a sketch over several workgroups (slices of the bucket space). Measured on MI355X with
@@ -976,10 +1105,14 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n) {
             // kernel's time is its chain of dependent round trips, not one CU's scattered traffic. PSK_INDEX_SLICES overrides.
             uint32_t slices = 1;
             if (const char* e = getenv("PSK_INDEX_SLICES")) slices = (uint32_t)std::max(1, std::min(8, atoi(e)));
-            if (tiny) hipLaunchKernelGGL((index_block_kernel<256, IDXT_MAX_LB>), dim3(m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, 1u, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
-            else hipLaunchKernelGGL((index_block_kernel<IDXB_THREADS, IDXB_MAX_LB>), dim3(m * slices), dim3(IDXB_THREADS), 0, st, (const IdxSeg*)ctx->s_offs.p, slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
+            if (tiny) hipLaunchKernelGGL((index_block_kernel<256, IDXT_MAX_LB>), dim3(m), dim3(256), 0, st, d_segs, segs[0], 1u, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
+            else hipLaunchKernelGGL((index_block_kernel<IDXB_THREADS, IDXB_MAX_LB>), dim3(m * slices), dim3(IDXB_THREADS), 0, st, d_segs, segs[0], slices, ix->key, ix->perm, ix->pms, ix->bucket, ix->km32);
             ctx->t_end();
-            PSK_HIP(hipStreamSynchronize(st));
+            if (lazy && by_value && todo.size() == 1) {
+                PSK_HIP(hipEventCreateWithFlags(&ix->ready, hipEventDisableTiming));
+                PSK_HIP(hipEventRecord(ix->ready, st));
+                ix->built_on = st;
+            } else PSK_HIP(hipStreamSynchronize(st));
             for (uint32_t j = 0; j < m; j++) {
                 todo[i0 + j]->idx = ix; todo[i0 + j]->idx_off = segs[j].out_off;
                 todo[i0 + j]->idx_boff = segs[j].boff; todo[i0 + j]->idx_bshift = segs[j].bshift;

@@ -52,6 +52,7 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
         monkeypatch.setenv("PSK_CHAIN_LANE", "64")  # (a small launch would take the four-lanes-per-chunk kernel otherwise)
     if seed % 4 == 3:
         monkeypatch.setenv("PSK_JOIN", "wide")      # the fallback join format gets a quarter of the sweep
+        monkeypatch.setenv("PSK_CHAIN_WAVE_REG", "0")   # ... with the throughput DP kernels of wide bands (c < 105) instead of the small launch's register-window one
     if seed % 4 == 1:
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another,
         monkeypatch.setenv("PSK_EMIT_EXPAND", "1")  # with the anchor-major emit of Gb-scale pairs behind it
@@ -60,6 +61,7 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
+        monkeypatch.setenv("PSK_SKETCH_SMALL", "0") # ... behind the count-then-allocate sketch pipeline (a single genome takes the one-synchronisation path otherwise)
     for _ in range(4):
         k, c, mc, ref, qry = _case(rng)
         kw = {"median": True} if rng.random() < 0.2 else ({"robust": True} if rng.random() < 0.2 else {})

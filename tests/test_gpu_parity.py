@@ -115,6 +115,29 @@ def test_sketch_empty_and_short(psk, oracle):
     assert len(gs.export()[0]) == 0
 
 
+def test_sketch_one_sync_path_and_its_fallback(psk, oracle, monkeypatch):
+    """A genome sketched on its own goes through the pipeline with ONE host synchronisation, its arrays sized from the expected seed
+    and marker counts; input whose counts do not fit (low complexity: a short period selects every k-mer or none) must fall back to
+    the count-then-allocate path with the same result. Both against the oracle, and the general path (PSK_SKETCH_SMALL=0) too."""
+    rng = np.random.default_rng(11)
+    period = random_genome(rng, 37)
+    cases = [
+        [random_genome(rng, 12000)],
+        [random_genome(rng, 700), random_genome(rng, 45000), random_genome(rng, 300), random_genome(rng, 20000)],      # short contigs are dropped (lib.rs:156)
+        [period * 2000],                                      # 74 kb of a 37-base period: 37 distinct k-mers, each selected ~2 000 times or never
+        [random_genome(rng, 5000) + b"ACGT" * 8000 + random_genome(rng, 5000)],
+        [b"A" * 40000],
+    ]
+    for c, mc in ((30, 200), (8, 16), (125, 1000)):
+        for contigs in cases:
+            want = oracle.Sketch(contigs, c=c, marker_c=mc)
+            for small in ("1", "0"):
+                monkeypatch.setenv("PSK_SKETCH_SMALL", small)
+                db = psk.Database(compression=c, marker_compression=mc)
+                gs = db._sketch("x", contigs, True)
+                assert_sketch_equal(gs, want)
+
+
 def test_sketch_str_and_buffer_inputs(psk, oracle):
     rng = np.random.default_rng(5)
     seq = random_genome(rng, 30000)
