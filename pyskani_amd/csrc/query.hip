@@ -336,8 +336,10 @@ __device__ __forceinline__ uint32_t find_le(const uint32_t* __restrict__ base, u
 // loads in front of every workgroup of every kernel below — with nothing else to overlap, that latency was their run time.
 __global__ __launch_bounds__(256) void pair_table_kernel(const uint32_t* __restrict__ sbase, const uint32_t* __restrict__ cbase, uint32_t n,
                                                          uint32_t n_tiles, uint32_t n_items, uint32_t n_rows,
-                                                         uint32_t* __restrict__ blk_pair, uint32_t* __restrict__ row_pair) {
+                                                         uint32_t* __restrict__ blk_pair, uint32_t* __restrict__ row_pair, uint32_t* __restrict__ misc, uint2* __restrict__ lb_tail) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 64) misc[t] = 0;                  // the launch sequence's status words and counters start from zero (two memsets less)
+    if (t == 64) *lb_tail = make_uint2(0, 0);
     if (t < n_tiles) {                        // pair of the first item of every 256-item tile
         const uint64_t x = (uint64_t)t * 256u;
         blk_pair[t] = find_le(sbase, n, x < n_items ? (uint32_t)x : n_items - 1);
@@ -2982,7 +2984,8 @@ struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
     psk_hit* hits; psk_hit* hits_sel; uint32_t* misc; uint32_t* ovf; unsigned long long* bsum; uint2* pair_qr; BatchQ* bq;
     uint32_t *blk_pair, *row_pair, *live, *big_list, *huge_list;
-    uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum (the 64-bit total sits at bsum[gi_sum])
+    uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum
+    unsigned long long* total;      // the 64-bit anchor total: misc[16..17], so that status, total and the hits behind them cross in one copy
     uint32_t rows_pair_max = 0xFFFFFFFFu;      // most chunk-table rows any pair of the batch can have (the host knows its queries): which reduce kernels have work
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -2991,8 +2994,8 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
            o_pstart = al256(o_cbase + 4 * (n_pairs + 1)), o_lb = al256(o_pstart + 4 * (n_pairs + 1)),
            o_aoff = al256(o_lb + 8 * (n_items + 1)), o_nch = al256(o_aoff + 4 * (n_items + 1)),
            o_chunks = al256(o_nch + 4 * n_pairs), o_cout = al256(o_chunks + sizeof(uint2) * n_rows),
-           o_hits = al256(o_cout + sizeof(ChunkOut) * n_rows), o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),
-           o_misc = al256(o_sel + sizeof(psk_hit) * n_pairs), o_ovf = al256(o_misc + 256), o_bsum = al256(o_ovf + 4 * n_rows),
+           o_misc = al256(o_cout + sizeof(ChunkOut) * n_rows), o_hits = o_misc + 256, o_sel = al256(o_hits + sizeof(psk_hit) * n_pairs),      // (misc | hits: one copy takes both)
+           o_ovf = al256(o_sel + sizeof(psk_hit) * n_pairs), o_bsum = al256(o_ovf + 4 * n_rows),
            o_qr = al256(o_bsum + 8 * (gi_sum + 1)), o_bq = al256(o_qr + 8 * n_pairs), o_bp = al256(o_bq + sizeof(BatchQ) * (n_bq + 1)),
            o_rp = al256(o_bp + 4 * (gi + 1)), o_live = al256(o_rp + 4 * (n_rows + 1)), o_big = al256(o_live + 4 * (n_pairs + 1)),
            o_huge = al256(o_big + 4 * (n_pairs + 1)), o_end = o_huge + 4 * (n_pairs + 1);
@@ -3004,6 +3007,7 @@ static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t
     L->ovf = (uint32_t*)(B + o_ovf); L->bsum = (unsigned long long*)(B + o_bsum); L->pair_qr = (uint2*)(B + o_qr); L->bq = (BatchQ*)(B + o_bq);
     L->blk_pair = (uint32_t*)(B + o_bp); L->row_pair = (uint32_t*)(B + o_rp); L->live = (uint32_t*)(B + o_live); L->big_list = (uint32_t*)(B + o_big); L->huge_list = (uint32_t*)(B + o_huge);
     L->gi = (uint32_t)gi; L->gi_sum = (uint32_t)gi_sum;
+    L->total = (unsigned long long*)(L->misc + 16);
     return PSK_OK;
 }
 
@@ -3014,10 +3018,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                             const psk_query_opts* o, const SketchDesc* d_qd, const SketchDesc* d_rd, uint64_t cap, bool wide, bool probe_ok = false) {
     hipStream_t st = ctx->stream;
     const int force_serial = getenv("PSK_CHAIN_SERIAL") != nullptr;
-    PSK_HIP(hipMemsetAsync(L.misc, 0, 256, st));     // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[32..47] its group barriers
-    PSK_HIP(hipMemsetAsync(L.lbcnt + n_items, 0, 8, st));
+    // misc[0..15] status / counts, misc[11] pairs for select_huge_kernel, misc[16..17] the 64-bit anchor total, misc[32..47] the group barriers: zeroed by pair_table_kernel
     const uint32_t gi = L.gi;
-    hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair);
+    hipLaunchKernelGGL(pair_table_kernel, dim3((uint32_t)(((size_t)gi + n_rows + 255) / 256)), dim3(256), 0, st, L.sbase, L.cbase, n_pairs, gi, (uint32_t)n_items, (uint32_t)n_rows, L.blk_pair, L.row_pair,
+                       L.misc, L.lbcnt + n_items);
     ctx->t_begin(K_ANCHOR);
     if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
     static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
@@ -3059,7 +3063,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
     hipcub::TransformInputIterator<uint32_t, PackedCount, const uint2*> pcnt_it(L.lbcnt, PackedCount());
     PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
-    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.bsum + L.gi_sum, (int)L.gi_sum, st));
+    PSK_HIP(hipcub::DeviceReduce::Sum(nullptr, tmp2, L.bsum, L.total, (int)L.gi_sum, st));
     size_t tmp3 = 0;
     PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
@@ -3075,10 +3079,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
-    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.bsum + L.gi_sum, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
+    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.total, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
     if (!emit_pairs || small_sum)
         hipLaunchKernelGGL(pair_start_kernel, dim3(emit_pairs ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, emit_pairs ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
-                           L.bsum, small_sum ? n_sum : 0u, L.bsum + L.gi_sum);
+                           L.bsum, small_sum ? n_sum : 0u, L.total);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
@@ -3167,7 +3171,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     static const bool qd_off = getenv("PSK_CHAIN_QUAD_DEEP") && getenv("PSK_CHAIN_QUAD_DEEP")[0] == '0';
     // a launch of few rows is as slow as its longest chunk: one wave per row with the window in registers (PSK_CHAIN_WAVE_REG=1 / 0 force / forbid: tests, A/B)
     const char* wr_env = getenv("PSK_CHAIN_WAVE_REG");
-    const bool wave_reg = !A.lane_dp && !force_serial && A.band < 128 && (wr_env ? wr_env[0] == '1' : n_rows <= 8192);
+    const bool wave_reg = !A.lane_dp && !force_serial && A.band < 128 && (wr_env ? wr_env[0] == '1' : n_rows <= 2048);      // (one wave per SIMD up to 1 024 rows: 0.29 us per anchor of the longest chunk; the four-lanes-per-chunk kernel needs 0.9 us but takes 16 rows per wave)
     if (wave_reg) {
         const dim3 g((uint32_t)((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES)), b(64 * CHAIN_WAVES);
         if (A.band < 64) hipLaunchKernelGGL(chain_wave_reg_kernel<1>, g, b, 0, st, A);
@@ -3348,9 +3352,7 @@ static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, c
     bool wide = join_wide_default();
     for (int attempt = 0;; attempt++) {
         PSK_TRY(chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, hp[0].q->params, o, d_desc, d_desc, cap, wide));
-        PSK_HIP(hipMemcpyAsync(h_hits, L.hits, sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
-        PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * n_pairs, hipMemcpyDeviceToHost, st));      // status words, anchor total and the hits behind them: one copy (ChainTail mirrors misc[0..17])
         PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a launch sequence (also keeps the host staging above alive)
         ctx->huge_release();
         bool retry;
@@ -3809,9 +3811,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                         PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
                         PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
                     }
-                    PSK_HIP(hipMemcpyAsync(T->misc, L.misc, 64, hipMemcpyDeviceToHost, st));
-                    PSK_HIP(hipMemcpyAsync(&T->total64, L.bsum + L.gi_sum, 8, hipMemcpyDeviceToHost, st));
-                    PSK_HIP(hipMemcpyAsync(h_sel, host_filter ? L.hits : L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
+                    if (host_filter) PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));      // status, anchor total, hits: one copy
+                    else {
+                        PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, st));
+                        PSK_HIP(hipMemcpyAsync(h_sel, L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
+                    }
                     PSK_TRY(consume());                     // the previous batch's hits, while this one runs
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     ctx->huge_release();

@@ -7,6 +7,8 @@ keeps the reference's file names and flush semantics with this build's own byte 
 """
 import collections
 import ctypes as C
+import itertools
+import operator
 import os
 import pathlib
 import threading
@@ -73,12 +75,16 @@ def _as_bytes(obj):
         raise TypeError(f"expected str, bytes, bytearray or buffer, found {type(obj).__name__}")
 
 
-class Hit:
-    """A single hit found when querying a `Database` with a genome (hit.rs:18-104)."""
+class Hit(tuple):
+    """A single hit found when querying a `Database` with a genome (hit.rs:18-104).
 
-    __slots__ = ("_identity", "_query_name", "_query_fraction", "_reference_name", "_reference_fraction", "_raw", "_learned")
+    The fields sit in a tuple behind the properties so that a query's hits are built by ONE C-level pass over the library's
+    records (`Hit._from_records`): with a Python-level constructor per hit, 200 hits cost more than the GPU work of the query that
+    found them. Like the reference's class, hits compare and hash by identity, not by value."""
 
-    def __init__(self, identity, query_name, query_fraction, reference_name, reference_fraction):
+    __slots__ = ()
+
+    def __new__(cls, identity, query_name, query_fraction, reference_name, reference_fraction):
         identity = float(np.float32(identity))
         query_fraction = float(np.float32(query_fraction))
         reference_fraction = float(np.float32(reference_fraction))
@@ -88,27 +94,47 @@ class Hit:
             raise ValueError(f"Invalid value for `query_fraction`: {query_fraction}")
         if reference_fraction < 0.0 or reference_fraction > 1.0:  # hit.rs:42-48
             raise ValueError(f"Invalid value for `reference_fraction`: {reference_fraction}")
-        self._identity = identity
-        self._query_name = str(query_name)
-        self._query_fraction = query_fraction
-        self._reference_name = str(reference_name)
-        self._reference_fraction = reference_fraction
-        self._raw = None
-        self._learned = False
+        return tuple.__new__(cls, (identity, str(query_name), query_fraction, str(reference_name), reference_fraction, False, None, 0))
+
+    @classmethod
+    def _from_records(cls, recs, qname, names):
+        """[Hit] from a numpy array of psk_hit records. Values come from the library and are valid by construction, so the range
+        checks of the constructor are skipped; the integer intermediates stay reachable as `hit._raw[field]` (the record, looked up on demand)."""
+        n = len(recs)
+        return list(map(tuple.__new__, itertools.repeat(cls, n),
+                        zip(recs["ani"].tolist(), itertools.repeat(qname), recs["af_query"].tolist(), map(names.__getitem__, recs["ref_index"].tolist()),
+                            recs["af_ref"].tolist(), (recs["learned"] != 0).tolist(), itertools.repeat(recs), range(n))))
 
     def __repr__(self):  # hit.rs:61-74
         return ("Hit(identity={!r}, query_name={!r}, query_fraction={!r}, reference_name={!r}, "
                 "reference_fraction={!r})").format(self.identity, self.query_name, self.query_fraction,
                                                     self.reference_name, self.reference_fraction)
 
-    identity = property(lambda self: self._identity)
-    query_name = property(lambda self: self._query_name)
-    query_fraction = property(lambda self: self._query_fraction)
-    reference_name = property(lambda self: self._reference_name)
-    reference_fraction = property(lambda self: self._reference_fraction)
+    __eq__ = object.__eq__
+    __ne__ = object.__ne__
+    __hash__ = object.__hash__
+
+    def __reduce__(self):
+        return (_hit_restore, (tuple(self[:6]),))
+
+    identity = property(operator.itemgetter(0))
+    query_name = property(operator.itemgetter(1))
+    query_fraction = property(operator.itemgetter(2))
+    reference_name = property(operator.itemgetter(3))
+    reference_fraction = property(operator.itemgetter(4))
     # not in the reference: True when `identity` came out of the learned-ANI regression model, False when it is the raw
     # chain ANI (the reference applies skani's embedded model by default, lib.rs:611-614; this build needs the model file)
-    learned = property(lambda self: self._learned)
+    learned = property(operator.itemgetter(5))
+
+    @property
+    def _raw(self):
+        """the psk_hit record behind the hit (numpy void: chaining integers, raw ANI), None for a hit built by hand"""
+        src = tuple.__getitem__(self, 6)
+        return None if src is None else src[tuple.__getitem__(self, 7)]
+
+
+def _hit_restore(fields):
+    return tuple.__new__(Hit, fields + (None, 0))
 
 
 class Sketch:
@@ -272,6 +298,7 @@ class Database:
         self._writer = False
         self._names = []                # insertion order = markers Vec (lib.rs:501-504)
         self._resident = []             # per ref: True when the full sketch (not only its markers) sits in HBM
+        self._n_lazy = 0                # references that are NOT resident (an `open`ed database): 0 = every query goes through psk_query
         self._cache = collections.OrderedDict()   # lazily loaded sketches of a disk-backed database
         self._h = None
         if path is None:
@@ -392,6 +419,7 @@ class Database:
             _capi.check(db._lib.psk_db_add(db._h, rec.name.encode("utf-8"), sk._h))
             db._names.append(rec.name)
             db._resident.append(False)
+            db._n_lazy += 1
         return db
 
     @classmethod
@@ -580,19 +608,8 @@ class Database:
         return self._hits(np.frombuffer(bytes(r), dtype=self._HIT_DTYPE), qname)[0]
 
     def _hits(self, recs, qname):
-        """A numpy array of psk_hit records -> [Hit]. Values come from the library and are valid by construction, so the range
-        checks of Hit.__init__ are skipped; the integer intermediates stay reachable as `hit._raw[field]` without a dict per hit."""
-        names = self._names
-        out = []
-        new = Hit.__new__
-        for rec, ani, afq, ri, afr, learned in zip(recs, recs["ani"].tolist(), recs["af_query"].tolist(), recs["ref_index"].tolist(),
-                                                   recs["af_ref"].tolist(), recs["learned"].tolist()):
-            h = new(Hit)
-            h._identity = ani; h._query_name = qname; h._query_fraction = afq
-            h._reference_name = names[ri]; h._reference_fraction = afr
-            h._raw = rec; h._learned = bool(learned)
-            out.append(h)
-        return out
+        """A numpy array of psk_hit records -> [Hit] (one C-level pass: Hit._from_records)."""
+        return Hit._from_records(recs, qname, self._names)
 
     def _hits_from_ptr(self, hits_p, lo, hi, qname):
         if hi <= lo:
@@ -623,7 +640,7 @@ class Database:
     # ---- record-level entry points (no Python object per hit): what parallel.ShardedDatabase and bench.py use
     def sketch_handles(self):
         """ctypes array of the psk_sketch* of every reference, in insertion order (borrowed: the database owns them)."""
-        if not all(self._resident):
+        if self._n_lazy:
             raise RuntimeError("sketch_handles needs a memory-resident database")
         n = len(self._names)
         return (C.c_void_p * max(n, 1))(*[self._lib.psk_db_sketch(self._h, i) for i in range(n)])
@@ -653,7 +670,7 @@ class Database:
         return recs
 
     def _query_sketches(self, sketches, opts, n):
-        if not all(self._resident):      # `open`ed database: sketches come from disk per query
+        if self._n_lazy:      # `open`ed database: sketches come from disk per query
             return [self._query_lazy(s.name, s, opts) for s in sketches]
         arr = (C.c_void_p * max(n, 1))(*[s._h for s in sketches])
         hits_p = C.POINTER(_capi.Hit)()
@@ -700,7 +717,7 @@ class Database:
     def _query(self, name, contigs, seed, learned_ani, median, robust, cutoff, faster_small):
         q = self._sketch(name, contigs, seed)
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
-        if not all(self._resident):
+        if self._n_lazy:
             return self._query_lazy(name, q, opts)
         hits_p = C.POINTER(_capi.Hit)()
         n = C.c_uint64(0)
