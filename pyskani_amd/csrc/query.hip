@@ -1293,6 +1293,7 @@ struct ChainArgs {
     const uint4* anc;      // anchors, array of (q pos, r pos, ref contig << 1 | reverse_match, q contig): a lane's chunk is one contiguous run of 16-byte records
     const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs, n_rows;
     const uint32_t* row_pair;   // pair of every row of the chunk table
+    const uint32_t* row_order;  // rows by chunk length, longest first, rows without a chunk last (null: table order) - the DP kernels that put several chunks in a wave
     const PairDesc* pairs;
     ChunkOut* out;
     // serial-path scratch, one entry per anchor
@@ -1683,7 +1684,8 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
     __shared__ uint32_t s_rd[LANE_WAVES][QD_RING][16];     // root index << 14 | depth of the last QD_RING anchors, per quad
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2;
     const int32_t j = lane & 3;
-    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    const uint32_t slot_i = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    const uint32_t slot = A.row_order && slot_i < A.n_rows ? A.row_order[slot_i] : slot_i;
     uint32_t s = 0, e = 0;
     bool mine = false, real = false;
     const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
@@ -1949,6 +1951,20 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_chunk_list_kernel(Chai
         chain_chunk_row(A, A.ovf_list[k], s_lds[wave], lane);
         lds_wave_sync();
     }
+}
+
+// Rows of the chunk table by chunk length. A wave of the lane / quad DP kernels runs until the LONGEST of its chunks is through, and rows without a chunk
+// (a pair has as many rows as its query could have chunks) sit between the others: in table order a metagenome batch spends 2.5 x the lane-instructions
+// its anchors need (profiles/r3/r3q_pmc_sq_meta.txt: 3 530 per anchor at 84 predecessors x 17). key = length (0: no chunk), sorted descending with the row
+// number as the value: equal lengths share waves, the long chunks start first, the empty rows end up in waves that exit at once.
+__global__ __launch_bounds__(256) void row_len_kernel(const uint2* __restrict__ chunks, const uint32_t* __restrict__ n_chunks, const uint32_t* __restrict__ cbase,
+                                                      const uint32_t* __restrict__ row_pair, uint32_t n_rows, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t p = row_pair[r];
+    uint32_t len = 0;
+    if (r - cbase[p] < n_chunks[p]) { const uint2 se = chunks[r]; len = se.y - se.x; len = len < 16383u ? len : 16383u; }
+    key[r] = len; val[r] = r;
 }
 
 // ---- wave-per-chunk DP with the look-back window in REGISTERS (launches of few rows) ----------------------------
@@ -3181,6 +3197,17 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if (quad_deep) {
         A.ovf_list = L.ovf; A.ovf_count = L.misc + 8;      // misc was zeroed above
         A.lane_dp = 1;                                     // (chain_chunk_list_kernel walks the list)
+        static const bool rs_off = getenv("PSK_ROW_SORT") && getenv("PSK_ROW_SORT")[0] == '0';
+        if (!rs_off && n_rows >= 4096) {                   // rows by chunk length (row_len_kernel)
+            size_t ts = 0;
+            PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_rows, 0, 14, st));
+            const size_t ob = al256(4 * n_rows);
+            PSK_TRY(ctx->q_g.reserve(4 * ob + ts + 256));
+            uint32_t* k_in = (uint32_t*)ctx->q_g.p; uint32_t* v_in = (uint32_t*)((char*)ctx->q_g.p + ob); uint32_t* k_out = (uint32_t*)((char*)ctx->q_g.p + 2 * ob); uint32_t* v_out = (uint32_t*)((char*)ctx->q_g.p + 3 * ob);
+            hipLaunchKernelGGL(row_len_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.chunks, L.nch, L.cbase, L.row_pair, (uint32_t)n_rows, k_in, v_in);
+            PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending((char*)ctx->q_g.p + 4 * ob, ts, (const uint32_t*)k_in, k_out, (const uint32_t*)v_in, v_out, (int)n_rows, 0, 14, st));
+            A.row_order = v_out;
+        }
         const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
         hipLaunchKernelGGL(chain_quad_deep_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
         const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);
