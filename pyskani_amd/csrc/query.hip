@@ -1406,11 +1406,12 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
     __shared__ unsigned long long s_xk[LANE_WAVES][XT ? XT : 1][XT ? 64 : 1];     // slots 4 .. 4 + XT - 1: best anchor key
     __shared__ uint32_t s_xr[LANE_WAVES][XT ? XT : 1][XT ? 64 : 1];               // ... and root
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
+    const uint32_t slot_i = (blockIdx.x * LANE_WAVES + wave) * rows_per_wave + lane;
+    const uint32_t slot = A.row_order && (uint32_t)lane < rows_per_wave && slot_i < A.n_rows ? A.row_order[slot_i] : slot_i;      // (rows by chunk length: row_len_kernel)
     uint32_t s = 0, e = 0;
     bool mine = false, real = false;     // real: a row of the chunk table that holds a chunk; mine: this lane chains it
     const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
-    if ((uint32_t)lane < rows_per_wave && slot < A.n_rows) {
+    if ((uint32_t)lane < rows_per_wave && slot_i < A.n_rows) {
         if (slot - A.cbase[pair] < A.n_chunks[pair]) {
             const uint2 se = A.chunks[slot];
             s = se.x; e = se.y;
@@ -1553,7 +1554,8 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
     __shared__ uint32_t s_rd[LANE_WAVES][32][16];     // root index << 14 | depth of the last 32 anchors, per quad
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2;
     const uint32_t j = lane & 3;
-    const uint32_t slot = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    const uint32_t slot_i = (blockIdx.x * LANE_WAVES + wave) * 16 + quad;
+    const uint32_t slot = A.row_order && slot_i < A.n_rows ? A.row_order[slot_i] : slot_i;
     uint32_t s = 0, e = 0;
     bool mine = false, real = false;
     const uint32_t pair = A.row_pair[slot < A.n_rows ? slot : A.n_rows - 1];
@@ -3155,10 +3157,25 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     ctx->t_end();
     ctx->t_begin(K_CHAIN_CHUNK);
+    // rows by chunk length for the DP kernels that put several chunks in one wave (row_len_kernel; PSK_ROW_SORT=0: table order)
+    auto order_rows = [&]() -> psk_status {
+        static const bool rs_off = getenv("PSK_ROW_SORT") && getenv("PSK_ROW_SORT")[0] == '0';
+        if (rs_off || n_rows < 4096) return PSK_OK;
+        size_t ts = 0;
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_rows, 0, 14, st));
+        const size_t ob = al256(4 * n_rows);
+        PSK_TRY(ctx->q_g.reserve(4 * ob + ts + 256));
+        uint32_t* k_in = (uint32_t*)ctx->q_g.p; uint32_t* v_in = (uint32_t*)((char*)ctx->q_g.p + ob); uint32_t* k_out = (uint32_t*)((char*)ctx->q_g.p + 2 * ob); uint32_t* v_out = (uint32_t*)((char*)ctx->q_g.p + 3 * ob);
+        hipLaunchKernelGGL(row_len_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.chunks, L.nch, L.cbase, L.row_pair, (uint32_t)n_rows, k_in, v_in);
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending((char*)ctx->q_g.p + 4 * ob, ts, (const uint32_t*)k_in, k_out, (const uint32_t*)v_in, v_out, (int)n_rows, 0, 14, st));
+        A.row_order = v_out;
+        return PSK_OK;
+    };
     {   // lane-per-chunk DP when the band fits its register window (PSK_CHAIN_LANE=0 keeps the wave-per-chunk DP)
         const char* le = getenv("PSK_CHAIN_LANE");
         A.lane_dp = !force_serial && A.band <= LANE_N && !(le && le[0] == '0');
         if (A.lane_dp) {
+            PSK_TRY(order_rows());
             // few rows: spread them over more waves (idle lanes cost nothing on an under-filled chip)
             uint32_t rpw = 64;
             while (rpw > 16 && n_rows / rpw < 512) rpw >>= 1;
@@ -3197,17 +3214,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if (quad_deep) {
         A.ovf_list = L.ovf; A.ovf_count = L.misc + 8;      // misc was zeroed above
         A.lane_dp = 1;                                     // (chain_chunk_list_kernel walks the list)
-        static const bool rs_off = getenv("PSK_ROW_SORT") && getenv("PSK_ROW_SORT")[0] == '0';
-        if (!rs_off && n_rows >= 4096) {                   // rows by chunk length (row_len_kernel)
-            size_t ts = 0;
-            PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_rows, 0, 14, st));
-            const size_t ob = al256(4 * n_rows);
-            PSK_TRY(ctx->q_g.reserve(4 * ob + ts + 256));
-            uint32_t* k_in = (uint32_t*)ctx->q_g.p; uint32_t* v_in = (uint32_t*)((char*)ctx->q_g.p + ob); uint32_t* k_out = (uint32_t*)((char*)ctx->q_g.p + 2 * ob); uint32_t* v_out = (uint32_t*)((char*)ctx->q_g.p + 3 * ob);
-            hipLaunchKernelGGL(row_len_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.chunks, L.nch, L.cbase, L.row_pair, (uint32_t)n_rows, k_in, v_in);
-            PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending((char*)ctx->q_g.p + 4 * ob, ts, (const uint32_t*)k_in, k_out, (const uint32_t*)v_in, v_out, (int)n_rows, 0, 14, st));
-            A.row_order = v_out;
-        }
+        PSK_TRY(order_rows());
         const uint32_t qw = (uint32_t)((n_rows + 15) / 16);
         hipLaunchKernelGGL(chain_quad_deep_kernel, dim3((qw + LANE_WAVES - 1) / LANE_WAVES), dim3(64 * LANE_WAVES), 0, st, A);
         const uint32_t lw = (uint32_t)std::min<size_t>((n_rows + CHAIN_WAVES - 1) / CHAIN_WAVES, 2048);

@@ -66,7 +66,7 @@ def _run(code, extra):
 def test_all_vs_all_batch_paths_agree():
     base = _run(ALL_VS_ALL, {})
     assert base[0] >= 320 * 40                      # every genome finds its family: >= 1 024 chained pairs in one batch
-    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0"}, {"PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_CHUNK_HOPS": "1"}):
+    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0"}, {"PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_CHUNK_HOPS": "1"}, {"PSK_ROW_SORT": "0"}):
         assert _run(ALL_VS_ALL, extra) == base, extra
 
 
