@@ -3619,7 +3619,8 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         uint8_t* d_pass = (uint8_t*)ctx->q_i.p + o_pass; uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_i.p + o_cnt); uint8_t* d_flag = (uint8_t*)ctx->q_i.p + o_flag;
         // a single query (psk_query: one contig against the database) is as slow as its chain of waits: its k-mer index is launched here,
         // ahead of the screen, and not waited for - one host synchronisation fewer per call
-        if (n_queries == 1 && queries[0]->has_seeds && queries[0]->store && queries[0]->n_seeds && !queries[0]->idx &&
+        // (a database that has not been queried yet indexes its references and the query in ONE launch further down: the headline step)
+        if (n_queries == 1 && !db->desc_dirty && db->desc_n == n && queries[0]->has_seeds && queries[0]->store && queries[0]->n_seeds && !queries[0]->idx &&
             queries[0]->params.k == db->params.k && queries[0]->params.c == db->params.c)
             PSK_TRY(ensure_index(ctx, queries, 1, true));
         ScreenStaging keep;
