@@ -2815,6 +2815,16 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
     for (uint32_t k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
         const uint32_t p = R.live ? R.live[k] : k;
         const uint32_t nc = R.n_chunks[p];
+        if (nc == 0 && !R.live) {                         // a launch without the live list (few pairs): the empty record here, as pair_empty_kernel writes it
+            if (lane == 0) {
+                psk_hit h{};
+                h.ani = -1.0f; h.ani_raw = -1.0f;
+                h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+                h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+                R.hits[p] = h;
+            }
+            continue;
+        }
         if (nc == 0 || nc > 64) continue;                 // empty records / larger tables: the other kernels
         const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
         ChunkOut c{};
@@ -3121,7 +3131,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
-    const bool use_hops = hops_env ? hops_env[0] != '0' : (n_pairs < 1024 || n_items / n_pairs > (1u << 20));
+    const bool use_hops = hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
@@ -3311,7 +3321,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     // many pairs with short chunk tables (contigs): one wave per pair first; the workgroup-per-pair kernel then only sees the long tables
     const char* rs_env = getenv("PSK_REDUCE_SMALL");
     const bool no_small = rs_env && rs_env[0] == '0';
-    R.small_done = use_live && !no_small && n_rows / n_pairs < 16;
+    R.small_done = !no_small && n_rows / n_pairs < 16;      // (also without the live list: the few pairs of one contig's query)
     if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
     // (the one-wave kernel takes every table of <= 64 rows: when no pair of the batch can have more - contigs have 1-3 chunks - the two
     // workgroup-per-pair kernels would only walk the live list to find that out: 24 ms per 17 M contig pairs)
