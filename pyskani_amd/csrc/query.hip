@@ -1988,10 +1988,72 @@ __device__ __forceinline__ void write_lane6(uint32_t lane, uint32_t& v0, uint32_
                  : "s"(lane), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5));
 }
 struct RegWin { uint32_t q1, u, m; int32_t f1; uint32_t id, dp; };      // one window slot per lane: q + 1, diagonal, ref contig | strand, score - 1 (lane_eval2's form), tree, depth
+// maximum over the wave as a scalar: the four row steps of wave_max_u32, then the rows are folded into the last one (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3) and lane 63 is read - 6 DPP steps + 1 lane read where four lane reads and their scalar maxima cost 13 instructions
+__device__ __forceinline__ uint32_t wave_max_scalar(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;      // quad_perm [1,0,3,2]
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;               // quad_perm [2,3,0,1]
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true); v = o > v ? o : v;              // row_ror:4
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true); v = o > v ? o : v;              // row_ror:8
+    // (written out: from the builtin the compiler makes a copy, a v_mov_dpp and a v_max for each of the two steps; the no-ops are the DPP read-after-write wait states)
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// one block of up to 64 anchors (chunk-local indices base - s ...): its anchors take register set T (compile time: no branch per anchor)
+template <int S, int T>
+__device__ __forceinline__ void chain_reg_block(const ChainArgs& A, ChainWaveLds& L, uint32_t* s_root, const int lane, const uint32_t s, const uint32_t e, const uint32_t base,
+                                                const uint32_t band, RegWin& w0, RegWin& w1, uint32_t& R, bool& over) {
+    constexpr uint32_t WMASK = 64u * S - 1u;
+    RegWin& wt = T ? w1 : w0;
+    const uint32_t idx = base + lane;
+    const uint4 my_a = idx < e ? A.anc[idx] : make_uint4(0, 0, 0, 0);
+    const uint32_t cnt = e - base < 64 ? e - base : 64;
+    for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t qx = __builtin_amdgcn_readlane(my_a.x, j), rx = __builtin_amdgcn_readlane(my_a.y, j), mx = __builtin_amdgcn_readlane(my_a.z, j);
+        const uint32_t avail = base + j - s;   // anchors before this one in the chunk = its chunk-local index
+        const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
+        // every lane scores the predecessor(s) it holds: lane_eval2's key, negative when not chainable or outside the band
+        const uint32_t d0 = (avail - (uint32_t)lane) & WMASK;      // 0: the slot this anchor is about to take
+        int32_t key = lane_eval2(qx, ux, mx, LanePred{w0.q1, w0.u, w0.m, w0.f1}, (int)d0) | (int32_t)(((band - d0) | (d0 - 1u)) & 0x80000000u);
+        key = key > 0 ? key : 0;
+        if (S > 1) {
+            const uint32_t d1 = (d0 - 64u) & WMASK;
+            const int32_t k1 = lane_eval2(qx, ux, mx, LanePred{w1.q1, w1.u, w1.m, w1.f1}, (int)d1) | (int32_t)(((band - d1) | (d1 - 1u)) & 0x80000000u);
+            key = k1 > key ? k1 : key;
+        }
+        const uint32_t best = wave_max_scalar((uint32_t)key);
+        int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
+        if (best) {
+            f = (int32_t)(best >> 7);
+            const uint32_t ps = (avail - (127u - (best & 127u))) & WMASK;
+            // (a lane read per register set and a scalar choice: picking the register set first turns into an indexed array in scratch)
+            rid = __builtin_amdgcn_readlane(w0.id, ps & 63u); dep = __builtin_amdgcn_readlane(w0.dp, ps & 63u);
+            if (S > 1) {
+                const uint32_t rid1 = __builtin_amdgcn_readlane(w1.id, ps & 63u), dep1 = __builtin_amdgcn_readlane(w1.dp, ps & 63u);
+                if (ps >> 6) { rid = rid1; dep = dep1; }
+            }
+            dep++;
+        } else {
+            rid = R++; dep = 1;
+            if (rid >= RMAX) { over = true; rid = 0; }      // more trees than the LDS tables hold: the block runs to its end (results discarded), the lane-serial path takes the chunk
+            else if (lane == 0) s_root[rid] = avail;
+        }
+        // the anchor takes its slot: everything about it is wave-uniform, six lane writes
+        uint32_t f1 = (uint32_t)wt.f1;
+        write_lane6(j, wt.q1, qx + 1u, wt.u, ux, wt.m, mx, f1, (uint32_t)(f - 1), wt.id, rid, wt.dp, dep);      // (lane = chunk-local index & 63 = j: blocks start at multiples of 64)
+        wt.f1 = (int32_t)f1;
+    }
+    // the block's anchors now sit one per lane in register set T: their keys go to their trees' bests together
+    // (the maximum over a tree's anchors of f << 28 | (16383 - index) << 14 | depth, as chain_chunk_row keeps it anchor by anchor)
+    if (!over && (uint32_t)lane < cnt)
+        atomicMax(&L.best[wt.id], ((unsigned long long)(uint32_t)(wt.f1 + 1) << 28) | ((unsigned long long)(16383u - (base - s + (uint32_t)lane)) << 14) | wt.dp);
+}
+
 template <int S>
 __device__ void chain_chunk_row_reg(const ChainArgs& A, uint32_t slot, ChainWaveLds& L, int lane) {
     static_assert(S == 1 || S == 2, "one or two window slots per lane");
-    constexpr uint32_t WMASK = 64u * S - 1u;
     const uint2 se = A.chunks[slot];
     const uint32_t s = se.x, e = se.y, n = e - s;
     ChunkOut* op = &A.out[slot];
@@ -2005,53 +2067,12 @@ __device__ void chain_chunk_row_reg(const ChainArgs& A, uint32_t slot, ChainWave
 #pragma unroll
         for (int u = 0; u < RMAX / 64; u++) L.best[lane + 64 * u] = 0;
         lds_wave_sync();
-        for (uint32_t base = s; base < e && fast; base += 64) {
-            const uint32_t idx = base + lane;
-            const uint4 my_a = idx < e ? A.anc[idx] : make_uint4(0, 0, 0, 0);
-            const uint32_t cnt = e - base < 64 ? e - base : 64;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t qx = __builtin_amdgcn_readlane(my_a.x, j), rx = __builtin_amdgcn_readlane(my_a.y, j), mx = __builtin_amdgcn_readlane(my_a.z, j);
-                const uint32_t avail = base + j - s;   // anchors before this one in the chunk = its chunk-local index
-                const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
-                // every lane scores the predecessor(s) it holds: lane_eval2's key, negative when not chainable or outside the band
-                const uint32_t d0 = (avail - (uint32_t)lane) & WMASK;      // 0: the slot this anchor is about to take
-                int32_t key = lane_eval2(qx, ux, mx, LanePred{w0.q1, w0.u, w0.m, w0.f1}, (int)d0) | (int32_t)(((band - d0) | (d0 - 1u)) & 0x80000000u);
-                key = key > 0 ? key : 0;
-                if (S > 1) {
-                    const uint32_t d1 = (d0 - 64u) & WMASK;
-                    const int32_t k1 = lane_eval2(qx, ux, mx, LanePred{w1.q1, w1.u, w1.m, w1.f1}, (int)d1) | (int32_t)(((band - d1) | (d1 - 1u)) & 0x80000000u);
-                    key = k1 > key ? k1 : key;
-                }
-                const uint32_t best = __builtin_amdgcn_readfirstlane(wave_max_u32((uint32_t)key));      // (uniform already: this tells the compiler, and the tree count stays in a scalar register)
-                int32_t f = ANCHOR_SCORE2; uint32_t rid, dep;
-                if (best) {
-                    f = (int32_t)(best >> 7);
-                    const uint32_t ps = (avail - (127u - (best & 127u))) & WMASK;
-                    // (a lane read per register set and a scalar choice: picking the register set first turns into an indexed array in scratch)
-                    rid = __builtin_amdgcn_readlane(w0.id, ps & 63u); dep = __builtin_amdgcn_readlane(w0.dp, ps & 63u);
-                    if (S > 1) {
-                        const uint32_t rid1 = __builtin_amdgcn_readlane(w1.id, ps & 63u), dep1 = __builtin_amdgcn_readlane(w1.dp, ps & 63u);
-                        if (ps >> 6) { rid = rid1; dep = dep1; }
-                    }
-                    dep++;
-                } else {
-                    rid = R++; dep = 1;
-                    if (rid >= RMAX) { fast = false; break; }
-                    if (lane == 0) s_root[rid] = avail;
-                }
-                // the anchor takes its slot: everything about it is wave-uniform, six lane writes
-                const uint32_t wl = avail & 63u;
-                if (S == 1 || ((avail >> 6) & 1u) == 0) { uint32_t f1 = (uint32_t)w0.f1; write_lane6(wl, w0.q1, qx + 1u, w0.u, ux, w0.m, mx, f1, (uint32_t)(f - 1), w0.id, rid, w0.dp, dep); w0.f1 = (int32_t)f1; }
-                else { uint32_t f1 = (uint32_t)w1.f1; write_lane6(wl, w1.q1, qx + 1u, w1.u, ux, w1.m, mx, f1, (uint32_t)(f - 1), w1.id, rid, w1.dp, dep); w1.f1 = (int32_t)f1; }
-            }
-            if (!fast) break;
-            // the block's 64 anchors now sit one per lane (lane = index & 63) in one register set: their keys go to their trees' bests together
-            // (the maximum over a tree's anchors of f << 28 | (16383 - index) << 14 | depth, as chain_chunk_row keeps it anchor by anchor)
-            const bool set1 = S > 1 && (((base - s) >> 6) & 1u);
-            const uint32_t bf = (uint32_t)((set1 ? w1.f1 : w0.f1) + 1), bid = set1 ? w1.id : w0.id, bdp = set1 ? w1.dp : w0.dp;
-            if ((uint32_t)lane < cnt)
-                atomicMax(&L.best[bid], ((unsigned long long)bf << 28) | ((unsigned long long)(16383u - (base - s + (uint32_t)lane)) << 14) | bdp);
+        bool over = false;
+        for (uint32_t base = s; base < e && !over; base += 64u * S) {      // anchor a lives in lane a & 63 of register set (a >> 6) % S: blocks alternate between the sets
+            chain_reg_block<S, 0>(A, L, s_root, lane, s, e, base, band, w0, w1, R, over);
+            if (S > 1 && base + 64u < e && !over) chain_reg_block<S, 1>(A, L, s_root, lane, s, e, base + 64u, band, w0, w1, R, over);
         }
+        fast = !over;
     }
     if (fast) {
         lds_wave_sync();
