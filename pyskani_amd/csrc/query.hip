@@ -2149,11 +2149,11 @@ constexpr int CSMALL = 512;
 template <int CM>
 __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __restrict__ over_list, uint32_t* __restrict__ over_count, const bool first_tier) {
     __shared__ uint32_t l_q0[CM], l_q1[CM], l_r0[CM], l_r1[CM], l_rc[CM], l_row[CM], l_n[CM];
-    __shared__ unsigned long long l_key[CM];     // priority keys, then (ref contig, r0) keys
-    __shared__ uint32_t l_pm[CM];                // running max of r1 in reference order; afterwards (first half) the kept list of the greedy
-    __shared__ uint16_t l_ord[CM];               // candidate index by priority rank
+    __shared__ unsigned long long l_key[CM];     // (ref contig, r0) keys of the reference-order sort, then the priority keys of the conflicted candidates
+    __shared__ uint32_t l_sc[CM];                // candidate scores; afterwards (first half) the kept list of the greedy
+    __shared__ uint16_t l_ord[CM];               // conflicted candidates by priority rank
     __shared__ uint16_t l_idx[CM];               // payload of the reference-order sort, then the conflicted list
-    uint16_t* const l_kept = (uint16_t*)l_pm;    // (the running maxima are dead once the conflicts are known)
+    uint16_t* const l_kept = (uint16_t*)l_sc;    // (the scores are dead once the conflicted candidates are in priority order)
     __shared__ uint8_t l_conf[CM];
     const int lane = threadIdx.x;
     const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
@@ -2170,7 +2170,7 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
         if (!S.force_serial && C + tot <= (uint32_t)CM && cnt) {
             uint32_t s = S.chunks[row0 + r].x;
             for (uint32_t i = 0; i < cnt; i++) {
-                l_key[off + i] = ((unsigned long long)(uint32_t)S.c_score[s + i] << 32) | (0xFFFFFFFFu - (off + i));      // priority key: (score desc, generation order asc)
+                l_sc[off + i] = (uint32_t)S.c_score[s + i];
                 l_q0[off + i] = S.c_q0[s + i]; l_q1[off + i] = S.c_q1[s + i];
                 l_r0[off + i] = S.c_r0[s + i]; l_r1[off + i] = S.c_r1[s + i]; l_rc[off + i] = S.c_rc[s + i];
                 l_row[off + i] = r; l_n[off + i] = S.c_n[s + i];
@@ -2187,24 +2187,10 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
     }
     if (C > (uint32_t)CM) { if (lane == 0) over_list[atomicAdd(over_count, 1u)] = p; return; }   // the next tier takes the pairs that do not fit in this one's LDS (an append per such pair)
     uint32_t P = 64; while (P < C) P <<= 1;
-    // ---- priority order: (score desc, generation order asc) ----
-    for (uint32_t i = C + lane; i < P; i += 64) l_key[i] = 0ull;      // padding (the keys of the candidates were written as they were gathered)
     lds_wave_sync();
-    for (uint32_t kk = 2; kk <= P; kk <<= 1)
-        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t t = lane; t < P; t += 64) {
-                uint32_t ixj = t ^ jj;
-                if (ixj > t) {
-                    unsigned long long a = l_key[t], b = l_key[ixj];
-                    bool desc = (t & kk) == 0;
-                    if ((a < b) == desc) { l_key[t] = b; l_key[ixj] = a; }
-                }
-            }
-            lds_wave_sync();
-        }
-    for (uint32_t t = lane; t < C; t += 64) l_ord[t] = (uint16_t)(0xFFFFFFFFu - (uint32_t)l_key[t]);
-    lds_wave_sync();
-    // ---- which candidates overlap ANY other candidate? Only those need the sequential greedy. ----
+    // ---- which candidates overlap ANY other candidate? Only those need the sequential greedy - and only those need to be in priority
+    // order: a candidate that overlaps nothing is kept whatever its rank (the commits add and take minima / maxima: any order), so the one
+    // full-length sort of a pair is the reference-order one (two of them were 2/3 of this kernel's time at ~300 candidates per 5 Mb pair) ----
     // query side: chunk mates are neighbours in generation order
     for (uint32_t i = lane; i < C; i += 64) {
         const uint32_t row = l_row[i], q0 = l_q0[i], q1 = l_q1[i];
@@ -2230,44 +2216,73 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
             lds_wave_sync();
         }
     {
-        uint32_t carry_rc = 0xFFFFFFFFu, carry_max = 0;      // segmented inclusive max-scan of r1 in reference order
+        uint32_t carry_rc = 0xFFFFFFFFu, carry_max = 0;      // segmented inclusive max-scan of r1 in reference order; the running maximum BEFORE u decides the backward overlap
         for (uint32_t u0 = 0; u0 < C; u0 += 64) {
             const uint32_t u = u0 + lane;
             const bool in = u < C;
-            const uint32_t rc = in ? (uint32_t)(l_key[u] >> 32) : 0xFFFFFFFEu;
-            uint32_t v = in ? l_r1[l_idx[u]] : 0;
+            const unsigned long long ku = in ? l_key[u] : 0ull;
+            const uint32_t rc = in ? (uint32_t)(ku >> 32) : 0xFFFFFFFEu, r0 = (uint32_t)ku;
+            const uint32_t i = in ? l_idx[u] : 0;
+            const uint32_t r1 = in ? l_r1[i] : 0;
+            uint32_t v = r1;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { uint32_t pv = __shfl_up(v, o), prc = __shfl_up(rc, o); if (lane >= o && prc == rc) v = pv > v ? pv : v; }
             if (rc == carry_rc) v = carry_max > v ? carry_max : v;
-            if (in) l_pm[u] = v;
+            // the inclusive maximum of the element before u (lane 0: the carry), if it is of the same ref contig
+            uint32_t pv = __shfl_up(v, 1), prc = __shfl_up(rc, 1);
+            if (lane == 0) { pv = carry_max; prc = carry_rc; }
+            bool cf = false;
+            if (in && u > 0 && prc == rc && pv >= r0) cf = true;
+            if (in && u + 1 < C) { const unsigned long long kn = l_key[u + 1]; if ((uint32_t)(kn >> 32) == rc && (uint32_t)kn <= r1) cf = true; }
+            if (cf) l_conf[i] = 1;
             carry_rc = __shfl(rc, 63); carry_max = __shfl(v, 63);
         }
     }
     lds_wave_sync();
-    for (uint32_t u = lane; u < C; u += 64) {
-        const uint32_t i = l_idx[u];
-        const uint32_t rc = (uint32_t)(l_key[u] >> 32), r0 = (uint32_t)l_key[u], r1 = l_r1[i];
-        bool cf = false;
-        if (u > 0 && (uint32_t)(l_key[u - 1] >> 32) == rc && l_pm[u - 1] >= r0) cf = true;
-        if (u + 1 < C && (uint32_t)(l_key[u + 1] >> 32) == rc && (uint32_t)l_key[u + 1] <= r1) cf = true;
-        if (cf) l_conf[i] = 1;
-    }
-    lds_wave_sync();
-    // ---- candidates that overlap nothing are kept outright; the others go through the greedy in priority order ----
+    // ---- candidates that overlap nothing are kept outright; the others are listed ----
     uint32_t ncf = 0;
     for (uint32_t t0 = 0; t0 < C; t0 += 64) {
-        const uint32_t t = t0 + lane;
-        const uint32_t i = t < C ? l_ord[t] : 0;
-        const bool cf = t < C && l_conf[i];
-        if (t < C && !cf) sel_commit(S, row0 + l_row[i], l_q0[i], l_q1[i], l_n[i]);
+        const uint32_t i = t0 + lane;
+        const bool cf = i < C && l_conf[i];
+        if (i < C && !cf) sel_commit(S, row0 + l_row[i], l_q0[i], l_q1[i], l_n[i]);
         unsigned long long bal = __ballot(cf);
-        if (cf) l_idx[ncf + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)i;   // l_idx is free again: conflicted list by rank
+        if (cf) l_idx[ncf + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)i;   // l_idx is free again: the conflicted list
         ncf += (uint32_t)__popcll(bal);
+    }
+    lds_wave_sync();
+    if (ncf == 0) return;
+    // ---- the conflicted ones in priority order: (score desc, generation order asc), keys distinct ----
+    for (uint32_t t = lane; t < ncf; t += 64) { const uint32_t i = l_idx[t]; l_key[t] = ((unsigned long long)l_sc[i] << 32) | (0xFFFFFFFFu - i); }
+    lds_wave_sync();
+    if (ncf <= 128u) {      // few: every key counts the keys above it (two LDS broadcast reads per comparison round, no exchange steps)
+        for (uint32_t t = lane; t < ncf; t += 64) {
+            const unsigned long long my = l_key[t];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < ncf; j++) rank += l_key[j] > my ? 1u : 0u;
+            l_ord[rank] = l_idx[t];
+        }
+    } else {                // many (repeat-rich pairs): bitonic sort, descending, of the padded list
+        uint32_t P2 = 64; while (P2 < ncf) P2 <<= 1;
+        for (uint32_t t = ncf + lane; t < P2; t += 64) l_key[t] = 0ull;
+        lds_wave_sync();
+        for (uint32_t kk = 2; kk <= P2; kk <<= 1)
+            for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (uint32_t t = lane; t < P2; t += 64) {
+                    uint32_t ixj = t ^ jj;
+                    if (ixj > t) {
+                        unsigned long long a = l_key[t], b = l_key[ixj];
+                        bool desc = (t & kk) == 0;
+                        if ((a < b) == desc) { l_key[t] = b; l_key[ixj] = a; }
+                    }
+                }
+                lds_wave_sync();
+            }
+        for (uint32_t t = lane; t < ncf; t += 64) l_ord[t] = (uint16_t)(0xFFFFFFFFu - (uint32_t)l_key[t]);
     }
     lds_wave_sync();
     uint32_t nk = 0;
     for (uint32_t t = 0; t < ncf; t++) {
-        const uint32_t i = l_idx[t];
+        const uint32_t i = l_ord[t];
         const uint32_t q0 = l_q0[i], q1 = l_q1[i], r0 = l_r0[i], r1 = l_r1[i], rc = l_rc[i], row = l_row[i];
         bool ov = false;
         for (uint32_t j = lane; j < nk; j += 64) {
