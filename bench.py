@@ -235,7 +235,7 @@ class Engine:
         nh = int(offsets[n])
         recs = None
         if keep:
-            recs = (np.frombuffer((self.capi.Hit * nh).from_address(C.addressof(hits_p.contents)), dtype=self.hit_dtype).copy() if nh else np.zeros(0, self.hit_dtype),
+            recs = (self.capi.hit_records(hits_p, 0, nh, self.hit_dtype),
                     np.frombuffer(offsets, dtype=np.uint64).astype(np.int64))
         if hits_p:
             self.lib.psk_free(hits_p)
@@ -246,7 +246,7 @@ class Engine:
         hits_p = C.POINTER(self.capi.Hit)()
         nh = C.c_uint64(0)
         self.capi.check(self.lib.psk_query(db, handle, C.byref(opts), C.byref(hits_p), C.byref(nh)))
-        recs = np.frombuffer((self.capi.Hit * nh.value).from_address(C.addressof(hits_p.contents)), dtype=self.hit_dtype).copy() if nh.value else np.zeros(0, self.hit_dtype)
+        recs = self.capi.hit_records(hits_p, 0, nh.value, self.hit_dtype)
         if hits_p:
             self.lib.psk_free(hits_p)
         return recs

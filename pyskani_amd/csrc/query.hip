@@ -1162,6 +1162,8 @@ __global__ __launch_bounds__(64) void chunk_heads_kernel(const uint32_t* __restr
 // COARSE = 1: the successor of every 64th anchor only, into nxt[a / 64]; COARSE = 2: every anchor, searched between the successors of
 // the two 64th anchors around it (nxt is monotone within a pair: 6-7 probes next to each other instead of 13 across megabytes;
 // 16.6 -> 8.0 + 1.5 ms per launch over the 8 x 3 Gb step's anchors); COARSE = 0: every anchor on its own (few, small pairs).
+// (Staging a workgroup's common range of keys in LDS - one round of coalesced loads, the probes as LDS reads - was measured SLOWER: 13.2 ms per
+// launch, profiles/r3/experiments/mammalian8_anchor_next_lds_window_kernel_stats.md: the probes of neighbouring lanes already share cache lines.)
 template <int COARSE>
 __global__ __launch_bounds__(256) void anchor_next_kernel(const uint4* __restrict__ anc,
                                                           const uint32_t* __restrict__ pstart, uint32_t n_pairs,

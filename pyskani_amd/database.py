@@ -614,8 +614,7 @@ class Database:
     def _hits_from_ptr(self, hits_p, lo, hi, qname):
         if hi <= lo:
             return []
-        buf = (_capi.Hit * (hi - lo)).from_address(C.addressof(hits_p.contents) + lo * C.sizeof(_capi.Hit))
-        return self._hits(np.frombuffer(buf, dtype=self._HIT_DTYPE).copy(), qname)
+        return self._hits(_capi.hit_records(hits_p, lo, hi, self._HIT_DTYPE), qname)
 
     def query_many(self, genomes, *, seed=True, learned_ani=None, median=False, robust=False, cutoff=None,
                    faster_small=False):
@@ -655,8 +654,7 @@ class Database:
             _capi.check(self._lib.psk_query_many(self._h, handles, n, C.byref(opts), C.byref(hits_p), offs))
             try:
                 total = int(offs[n])
-                recs = (np.frombuffer((_capi.Hit * total).from_address(C.addressof(hits_p.contents)), dtype=self._HIT_DTYPE).copy()
-                        if total else np.zeros(0, self._HIT_DTYPE))
+                recs = _capi.hit_records(hits_p, 0, total, self._HIT_DTYPE)
             finally:
                 if hits_p:
                     self._lib.psk_free(hits_p)

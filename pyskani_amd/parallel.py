@@ -220,7 +220,7 @@ class CapiComm:
         _capi.check(self._lib.psk_gather_hits(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), C.byref(out_p), C.byref(n_all), counts))
         try:
             n = n_all.value
-            out = np.frombuffer((_capi.Hit * n).from_address(C.addressof(out_p.contents)), dtype=HIT_DTYPE).copy() if n else np.zeros(0, HIT_DTYPE)
+            out = _capi.hit_records(out_p, 0, n, HIT_DTYPE)
         finally:
             if out_p:
                 self._lib.psk_free(out_p)
