@@ -2205,14 +2205,26 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
     // a later one iff the next r0 is <= r1[u]
     for (uint32_t i = lane; i < P; i += 64) { l_key[i] = i < C ? (((unsigned long long)l_rc[i] << 32) | l_r0[i]) : ~0ull; l_idx[i] = (uint16_t)i; }
     lds_wave_sync();
+    // bitonic network over P keys with their payload: a lane owns compare-exchange pairs q = lane, lane + 64, ... of every stage (pair q: the index with a
+    // zero inserted at the stride's bit, and its partner) and reads ALL of its pairs before it compares and writes - the stage is one LDS round trip
+    // instead of one per pair (the loop over indices t that skipped half of them waited for each pair's reads in turn)
+    constexpr int NPAIR = CM / 128;
     for (uint32_t kk = 2; kk <= P; kk <<= 1)
         for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t t = lane; t < P; t += 64) {
-                uint32_t ixj = t ^ jj;
-                if (ixj > t) {
-                    unsigned long long a = l_key[t], b = l_key[ixj];
-                    bool asc = (t & kk) == 0;
-                    if ((a > b) == asc) { l_key[t] = b; l_key[ixj] = a; uint16_t ia = l_idx[t]; l_idx[t] = l_idx[ixj]; l_idx[ixj] = ia; }
+            unsigned long long ka[NPAIR], kb[NPAIR]; uint16_t ia[NPAIR], ib[NPAIR]; uint32_t ta[NPAIR];
+#pragma unroll
+            for (int u = 0; u < NPAIR; u++) {
+                const uint32_t q = (uint32_t)lane + 64u * u;
+                const uint32_t t = ((q & ~(jj - 1u)) << 1) | (q & (jj - 1u));
+                ta[u] = t;
+                if (q < P / 2) { ka[u] = l_key[t]; kb[u] = l_key[t | jj]; ia[u] = l_idx[t]; ib[u] = l_idx[t | jj]; }
+            }
+#pragma unroll
+            for (int u = 0; u < NPAIR; u++) {
+                const uint32_t q = (uint32_t)lane + 64u * u, t = ta[u];
+                if (q < P / 2) {
+                    const bool asc = (t & kk) == 0;
+                    if ((ka[u] > kb[u]) == asc) { l_key[t] = kb[u]; l_key[t | jj] = ka[u]; l_idx[t] = ib[u]; l_idx[t | jj] = ia[u]; }
                 }
             }
             lds_wave_sync();
