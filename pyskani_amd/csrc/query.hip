@@ -2502,8 +2502,7 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
     }
     uint32_t P = 1024; while (P < C) P <<= 1;
     grp_sync(g);
-    // ---- priority order ----
-    for (uint32_t j = gt; j < P; j += GT) key[j] = j < C ? (((unsigned long long)(uint32_t)S.c_score[slot[j]] << 32) | (0xFFFFFFFFu - j)) : 0ull;
+    // (only the candidates that overlap another one need to be in priority order: the one full-length sort is the reference-order one, as in select_pair)
     // ---- conflicts: chunk mates on the query ----
     for (uint32_t j = gt; j < C; j += GT) {
         const uint32_t row = crow[j], q0 = S.c_q0[slot[j]], q1 = S.c_q1[slot[j]];
@@ -2512,9 +2511,6 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         for (uint32_t v = j + 1; v < C && crow[v] == row; v++) if (!(q1 < S.c_q0[slot[v]] || q0 > S.c_q1[slot[v]])) cf = true;
         conf[j] = cf;
     }
-    grp_sync(g);
-    big_bitonic(key, nullptr, P, true, g, t_key, t_pay);
-    for (uint32_t t = gt; t < C; t += GT) ord[t] = 0xFFFFFFFFu - (uint32_t)key[t];
     grp_sync(g);
     // ---- conflicts on the reference: order by (ref contig, r0), running max of r1 by doubling ----
     for (uint32_t j = gt; j < P; j += GT) { key[j] = j < C ? (((unsigned long long)S.c_rc[slot[j]] << 32) | S.c_r0[slot[j]]) : ~0ull; idx[j] = j; }
@@ -2541,13 +2537,13 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         if (cf) conf[j] = 1;
     }
     grp_sync(g);
-    // ---- unconflicted chains are kept; conflicted ones listed in priority order (spans of ranks, stitched as above) ----
+    // ---- unconflicted chains are kept; conflicted ones listed (spans of candidates, stitched as above), then put in priority order ----
     const uint32_t tspan = (((C + G - 1) / G) + BIG_T - 1) / BIG_T * BIG_T;
     const uint32_t ta = gr * tspan < C ? gr * tspan : C, tb = ta + tspan < C ? ta + tspan : C;
     {
         uint32_t c = 0;
         for (uint32_t t = ta + tid; t < tb; t += BIG_T) {
-            const uint32_t j = ord[t];
+            const uint32_t j = t;
             if (conf[j]) c++;
             else { const uint32_t sl = slot[j]; sel_commit(S, row0 + crow[j], S.c_q0[sl], S.c_q1[sl], S.c_n[sl]); }
         }
@@ -2561,7 +2557,7 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
     __syncthreads();
     for (uint32_t t0 = ta; t0 < tb; t0 += BIG_T) {
         const uint32_t t = t0 + tid;
-        const uint32_t j = t < tb ? ord[t] : 0;
+        const uint32_t j = t < tb ? t : 0;
         const uint32_t cf = (t < tb && conf[j]) ? 1u : 0u;
         const uint32_t incl = big_block_scan(cf, s_scan);
         if (cf) clist[s_carry + incl - 1] = j;
@@ -2570,6 +2566,14 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         __syncthreads();
     }
     grp_sync(g);
+    if (ncf) {      // (score desc, generation order asc) over the conflicted ones only
+        uint32_t P2 = 1024; while (P2 < ncf) P2 <<= 1;
+        for (uint32_t t = gt; t < P2; t += GT) { const uint32_t j = t < ncf ? clist[t] : 0; key[t] = t < ncf ? (((unsigned long long)(uint32_t)S.c_score[slot[j]] << 32) | (0xFFFFFFFFu - j)) : 0ull; }
+        grp_sync(g);
+        big_bitonic(key, nullptr, P2, true, g, t_key, t_pay);
+        for (uint32_t t = gt; t < ncf; t += GT) clist[t] = 0xFFFFFFFFu - (uint32_t)key[t];
+        grp_sync(g);
+    }
     if (gr != 0) return;
     // ---- greedy over the conflicted chains in priority order, by the group's first workgroup: candidates staged 1024 at a time
     // in LDS, kept chains in LDS (the first KL) and in compact global arrays (pm, pm2, idx, ord and the key array are free now) ----
