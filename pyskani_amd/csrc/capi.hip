@@ -407,7 +407,7 @@ void psk_db_destroy(psk_db* db) {
     (void)hipSetDevice(db->ctx->device);
     for (psk_sketch* s : db->refs) delete s;
     db->d_marker_ptr.release(); db->d_marker_n.release();
-    db->inv_key.release(); db->inv_ref.release(); db->inv_tmp.release();
+    db->inv_key.release(); db->inv_ref.release(); db->inv_tmp.release(); db->inv_bucket.release();
     db->d_refdesc.release(); db->d_canon.release();
     delete db;
 }

@@ -405,8 +405,8 @@ struct psk_db {
     PoolScratch d_marker_ptr, d_marker_n;
     // inverted marker index for many-query screens: every (marker, ref) of the db sorted by marker
     bool inv_dirty = true;
-    PoolScratch inv_key, inv_ref, inv_tmp;
-    uint64_t inv_n = 0;
+    PoolScratch inv_key, inv_ref, inv_tmp, inv_bucket;      // inv_bucket: first entry of every bucket of the marker's top inv_bits bits (2^inv_bits + 1 offsets)
+    uint64_t inv_n = 0; int inv_bits = 0;
     // device table of SketchDesc, one per reference (refreshed when references are added or indexed)
     bool desc_dirty = true;
     uint64_t desc_indexed = 0; uint32_t desc_n = 0;

@@ -209,6 +209,56 @@ __global__ __launch_bounds__(512) void inv_screen_lds_kernel(const MarkerSet* __
     }
 }
 
+// bucket[b] = first entry of the sorted inverted index whose marker >> shift is >= b (b = 0 .. nb)
+__global__ __launch_bounds__(256) void inv_bucket_kernel(const uint64_t* __restrict__ key, uint32_t n, int shift, uint32_t nb, uint32_t* __restrict__ bucket) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = (uint32_t)(key[i] >> shift);
+    const uint32_t from = i ? (uint32_t)(key[i - 1] >> shift) + 1u : 0u;
+    for (uint32_t x = from; x <= b; x++) bucket[x] = i;
+    if (i == n - 1) for (uint32_t x = b + 1; x <= nb; x++) bucket[x] = n;
+}
+
+// The inverted screen, one workgroup per query as above, with the lookup done by WAVES: a marker's bucket (its top bits index a table of first entries,
+// ~16 entries per bucket) is read with one coalesced load, the lanes that hold the marker itself add to their reference's counter. Per marker that is
+// three dependent round trips (table, keys, references) shared by 64 lanes, four markers in flight per wave - where one lane per marker walked a 26-step
+// binary search over the whole index and then its ~100 matches one dependent load at a time (59 -> 9 ms per 10 000 x 10 000 screen).
+__global__ __launch_bounds__(512) void inv_screen_wave_kernel(const MarkerSet* __restrict__ refs, const MarkerSet* __restrict__ queries,
+                                                              const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, const uint32_t* __restrict__ bucket, int shift,
+                                                              uint32_t n_refs, double thresh, int rescue_small, uint8_t* __restrict__ pass) {
+    extern __shared__ uint32_t s_count[];
+    const MarkerSet q = queries[blockIdx.x];
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) s_count[r] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    constexpr int U = 4;
+    for (uint32_t i0 = wave * U; i0 < q.n; i0 += n_waves * U) {
+        uint64_t m[U]; uint32_t lo[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { m[u] = i0 + u < q.n ? q.p[i0 + u] : ~0ull; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const uint32_t b = (uint32_t)(m[u] >> shift); lo[u] = 0; hi[u] = 0; if (i0 + u < q.n) { lo[u] = bucket[b]; hi[u] = bucket[b + 1]; } }
+        uint64_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = lo[u] + lane < hi[u] ? key[lo[u] + lane] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (lo[u] + lane < hi[u] && k[u] == m[u]) atomicAdd(&s_count[val[lo[u] + lane]], 1u);
+            for (uint32_t x = lo[u] + 64u + lane; x < hi[u]; x += 64u) if (key[x] == m[u]) atomicAdd(&s_count[val[x]], 1u);      // a bucket of more than 64 entries (rare)
+        }
+    }
+    __syncthreads();
+    uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) {
+        const uint32_t b = refs[r].n, small = q.n < b ? q.n : b;
+        int ok;
+        if (rescue_small && small < SMALL_MARKER_COUNT) ok = 1;
+        else if (small == 0) ok = 0;
+        else ok = ((double)s_count[r] / (double)small) > thresh;
+        row[r] = (uint8_t)ok;
+    }
+}
+
 static psk_status build_inverted(Lane* ctx, psk_db* db) {
     if (!db->inv_dirty) return PSK_OK;
     hipStream_t st = ctx->stream;
@@ -230,6 +280,15 @@ static psk_status build_inverted(Lane* ctx, psk_db* db) {
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, (uint64_t*)db->inv_key.p, v_in, (uint32_t*)db->inv_ref.p, (int)tot, 0, 2 * K_MARKER, st));
         PSK_TRY(ctx->q_c.reserve(tmp));
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_c.p, tmp, k_in, (uint64_t*)db->inv_key.p, v_in, (uint32_t*)db->inv_ref.p, (int)tot, 0, 2 * K_MARKER, st));
+    }
+    {   // bucket table on the markers' top bits: ~16 entries per bucket (markers are 2 K_MARKER-bit canonical k-mers)
+        int bits = 4; while (bits < 24 && (16ull << bits) < tot) bits++;
+        if (bits > 2 * K_MARKER) bits = 2 * K_MARKER;
+        db->inv_bits = bits;
+        const uint32_t nb = 1u << bits;
+        PSK_TRY(db->inv_bucket.reserve(ctx->dev, 4 * ((size_t)nb + 2)));
+        if (tot) hipLaunchKernelGGL(inv_bucket_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, (const uint64_t*)db->inv_key.p, (uint32_t)tot, 2 * K_MARKER - bits, nb, (uint32_t*)db->inv_bucket.p);
+        else PSK_HIP(hipMemsetAsync(db->inv_bucket.p, 0, 4 * ((size_t)nb + 2), st));
     }
     PSK_HIP(hipStreamSynchronize(st));
     db->inv_dirty = false;
@@ -277,7 +336,16 @@ static psk_status screen_many_device(Lane* ctx, psk_db* db, const psk_sketch* co
         ctx->t_begin(K_SCREEN);
         if (use_inv && n <= INV_LDS_REFS && !getenv("PSK_SCREEN_GLOBAL")) {
             static bool lds_attr = false;
-            if (!lds_attr) { PSK_HIP(hipFuncSetAttribute((const void*)inv_screen_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * INV_LDS_REFS))); lds_attr = true; }
+            if (!lds_attr) {
+                PSK_HIP(hipFuncSetAttribute((const void*)inv_screen_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * INV_LDS_REFS)));
+                PSK_HIP(hipFuncSetAttribute((const void*)inv_screen_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * INV_LDS_REFS)));
+                lds_attr = true;
+            }
+            const bool wave_off = getenv("PSK_SCREEN_WAVE") && getenv("PSK_SCREEN_WAVE")[0] == '0';      // "0": one lane per marker, binary search over the whole index (A/B, tests)
+            if (!wave_off && db->inv_n)
+                hipLaunchKernelGGL(inv_screen_wave_kernel, dim3(m), dim3(512), 4 * (size_t)n, st, (const MarkerSet*)db->d_marker_ptr.p, d_q,
+                                   (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (const uint32_t*)db->inv_bucket.p, 2 * K_MARKER - db->inv_bits, n, thresh, rescue_small, pass_b);
+            else
             hipLaunchKernelGGL(inv_screen_lds_kernel, dim3(m), dim3(512), 4 * (size_t)n, st, (const MarkerSet*)db->d_marker_ptr.p, d_q,
                                (const uint64_t*)db->inv_key.p, (const uint32_t*)db->inv_ref.p, (uint32_t)db->inv_n, n, thresh, rescue_small, pass_b);
         } else if (use_inv) {

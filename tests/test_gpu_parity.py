@@ -389,18 +389,20 @@ def test_all_vs_all_query_many_matches_oracle(psk, oracle):
     db = psk.Database()
     for n, contigs in genomes:
         db.sketch(n, *contigs)
-    # the batched screen has three implementations (workgroup per pair / inverted marker index with the count row in LDS /
-    # the same with a count matrix in HBM): all must agree
+    # the batched screen has four implementations (workgroup per pair / inverted marker index with the count row in LDS, looked up by waves
+    # through a bucket table or by one lane per marker / the same with a count matrix in HBM): all must agree
     per_mode = {}
-    for mode in ("brute", "inv", "inv_global"):
+    for mode in ("brute", "inv", "inv_lane", "inv_global"):
         os.environ["PSK_SCREEN"] = mode.split("_")[0]
         if mode == "inv_global":
             os.environ["PSK_SCREEN_GLOBAL"] = "1"
+        if mode == "inv_lane":
+            os.environ["PSK_SCREEN_WAVE"] = "0"
         try:
             per_mode[mode] = db.query_many([(n, *contigs) for n, contigs in genomes], learned_ani=False)
         finally:
-            os.environ.pop("PSK_SCREEN", None); os.environ.pop("PSK_SCREEN_GLOBAL", None)
-    for mode in ("inv", "inv_global"):
+            os.environ.pop("PSK_SCREEN", None); os.environ.pop("PSK_SCREEN_GLOBAL", None); os.environ.pop("PSK_SCREEN_WAVE", None)
+    for mode in ("inv", "inv_lane", "inv_global"):
         assert [[(h.reference_name, h.identity) for h in hs] for hs in per_mode["brute"]] == [[(h.reference_name, h.identity) for h in hs] for hs in per_mode[mode]], mode
     got_all = per_mode["inv"]
     osk = [(n, oracle.Sketch(contigs)) for n, contigs in genomes]
