@@ -134,6 +134,13 @@ struct Lane {
     psk_ctx* dev = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // hits of a large batch cross to the host here while the next batch computes (created on first use)
+    Scratch q_sel;                          // two halves of selected hits: the one being copied is not the one the next batch writes
+    psk_status copy_lane(hipStream_t* out) {
+        if (!copy_stream) PSK_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        *out = copy_stream;
+        return PSK_OK;
+    }
     bool holds_huge = false;       // between the launch of select_huge_kernel and the synchronisation that follows it
     void huge_acquire() { if (!holds_huge) { dev->huge_mu.lock(); holds_huge = true; } }
     void huge_release() { if (holds_huge) { (void)hipStreamSynchronize(stream); dev->huge_mu.unlock(); holds_huge = false; } }
@@ -205,7 +212,8 @@ struct Lane {
         return PSK_OK;
     }
     void release_all() {
-        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i};
+        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel};
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (Scratch* s : all) s->release();
         jobs_release();
         if (h_pinned) (void)hipHostFree(h_pinned);

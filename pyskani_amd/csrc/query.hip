@@ -3919,8 +3919,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         }
         int parity = 0;
         const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
+        bool pend_copy = false;      // the pending hits are still crossing on the copy stream
+        hipStream_t cst = nullptr;
+        const size_t sel_half = al256(sizeof(psk_hit) * half_pairs + 256);
         auto consume = [&]() -> psk_status {
             if (!pend_n) return PSK_OK;
+            if (pend_copy) { PSK_HIP(hipStreamSynchronize(cst)); pend_copy = false; }
             const size_t old = all.n;
             if (!all.append(pend_hits, pend_n)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
             for (uint32_t i = 0; i < pend_n; i++) { psk_hit& h = all.p[old + i]; q_hits[h.reserved]++; h.reserved = 0; }      // pair_reduce left the round-local query index in `reserved`
@@ -3962,7 +3966,16 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL(pair_build_rows_kernel, dim3((uint32_t)bqs.size()), dim3(256), 0, st, L.bq, d_pass, n, d_qd, (const SketchDesc*)db->d_refdesc.p,
                                    L.pairs, L.sbase, L.cbase, L.pair_qr, n_pairs, (uint32_t)items, (uint32_t)rows);
-                const uint32_t spec = std::min<uint32_t>(n_pairs, 1u << 16);      // hits copied back speculatively with the count
+                // a small batch: status and every record in one copy; a large one: the status alone is waited for, the selected hits then cross on the copy
+                // stream WHILE THE NEXT BATCH COMPUTES (600 MB per metagenome step: 15 ms of copies that kept the compute queues idle), out of one of two
+                // device halves so that the next batch's selection does not write what is still being read
+                const bool host_filter = n_pairs <= 4096;
+                psk_hit* d_sel = nullptr;
+                if (!host_filter) {
+                    PSK_TRY(ctx->copy_lane(&cst));
+                    PSK_TRY(ctx->q_sel.reserve(2 * sel_half));
+                    d_sel = (psk_hit*)((char*)ctx->q_sel.p + (parity ? sel_half : 0));
+                }
                 if (sizeof(psk_hit) * (size_t)n_pairs + 512 > half_bytes) { psk_set_error("internal: batch larger than its staging half"); return PSK_EHIP; }
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
@@ -3972,17 +3985,13 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
-                    const bool host_filter = n_pairs <= 4096;      // a small batch: every record crosses (<= 320 kB), the ani > 0.1 filter runs on the host (three launches fewer)
-                    if (!host_filter) {
+                    if (!host_filter) {      // (the ani > 0.1 filter of a small batch runs on the host: three launches fewer)
                         size_t tmp3 = 0;
-                        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
-                        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, L.hits_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
+                        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, d_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
+                        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, d_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
                     }
-                    if (host_filter) PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));      // status, anchor total, hits: one copy
-                    else {
-                        PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, st));
-                        PSK_HIP(hipMemcpyAsync(h_sel, L.hits_sel, sizeof(psk_hit) * (size_t)spec, hipMemcpyDeviceToHost, st));
-                    }
+                    if (host_filter) PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));      // status, anchor total, hits: one copy
+                    else PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, st));
                     PSK_TRY(consume());                     // the previous batch's hits, while this one runs
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
                     ctx->huge_release();
@@ -4000,9 +4009,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     for (uint32_t i = 0; i < n_pairs; i++) if (h_sel[i].ani > 0.1f) h_sel[w++] = h_sel[i];
                     n_sel = w;
                 }
-                if (n_sel > spec) {
-                    PSK_HIP(hipMemcpyAsync(h_sel + spec, L.hits_sel + spec, sizeof(psk_hit) * (size_t)(n_sel - spec), hipMemcpyDeviceToHost, st));
-                    PSK_HIP(hipStreamSynchronize(st));
+                else if (n_sel) {
+                    PSK_HIP(hipMemcpyAsync(h_sel, d_sel, sizeof(psk_hit) * (size_t)n_sel, hipMemcpyDeviceToHost, cst));      // (the batch is complete: its one synchronisation is behind us)
+                    pend_copy = true;
                 }
             }
             // hits arrive in (query, ref) order; they join the result during the next batch (or after the last one)
