@@ -348,6 +348,34 @@ struct SketchDesc {
     const ProbeLine* tab;
 };
 
+// The per-sketch contig tables: a contig of a metagenome is a sketch of ONE contig, and 100 000 of them are made and dropped per step - two heap blocks each
+// (std::vector) were a third of the host time between the last kernel of a step and the first of the next. Up to four entries live in the object itself.
+struct SmallVecU32 {
+    uint32_t inl[4]; uint32_t* p = inl; uint32_t n = 0, cap = 4;
+    SmallVecU32() = default;
+    SmallVecU32(const SmallVecU32&) = delete; SmallVecU32& operator=(const SmallVecU32&) = delete;
+    ~SmallVecU32() { if (p != inl) delete[] p; }
+    void grow(size_t c) {
+        if (c <= cap) return;
+        const size_t nc = c > 2 * (size_t)cap ? c : 2 * (size_t)cap;
+        uint32_t* q = new uint32_t[nc];
+        memcpy(q, p, 4 * (size_t)n);
+        if (p != inl) delete[] p;
+        p = q; cap = (uint32_t)nc;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint32_t& operator[](size_t i) { return p[i]; }
+    const uint32_t& operator[](size_t i) const { return p[i]; }
+    const uint32_t* begin() const { return p; }
+    const uint32_t* end() const { return p + n; }
+    void push_back(uint32_t v) { grow((size_t)n + 1); p[n++] = v; }
+    void resize(size_t c) { grow(c); for (size_t i = n; i < c; i++) p[i] = 0; n = (uint32_t)c; }
+    void assign(size_t c, uint32_t v) { grow(c); for (size_t i = 0; i < c; i++) p[i] = v; n = (uint32_t)c; }
+    template <class It> void assign(It a, It b) { const size_t c = (size_t)(b - a); grow(c); for (size_t i = 0; i < c; i++) p[i] = (uint32_t)a[i]; n = (uint32_t)c; }
+    SmallVecU32& operator=(const std::vector<uint32_t>& v) { assign(v.begin(), v.end()); return *this; }
+};
+
 struct psk_sketch {
     psk_ctx* ctx = nullptr;
     psk_params params{};
@@ -355,8 +383,8 @@ struct psk_sketch {
     uint64_t seed_off = 0, n_seeds = 0;      // slice of store->seed_* / idx_*
     uint64_t marker_off = 0, n_markers = 0;  // slice of store->markers
     uint64_t contig_off = 0;                 // slice of store->contig_seed_start
-    std::vector<uint32_t> contig_len;        // kept contigs
-    std::vector<uint32_t> contig_seed_start; // host copy, LOCAL offsets, n_contigs+1
+    SmallVecU32 contig_len;                  // kept contigs
+    SmallVecU32 contig_seed_start;           // host copy, LOCAL offsets, n_contigs+1
     uint64_t total_len = 0;
     bool has_seeds = true;
     // contig-length quantiles {q90, q50, q10} (features of the learned-ANI regression): sorted lengths at n*9/10, n/2, n/10
@@ -364,7 +392,7 @@ struct psk_sketch {
         out[0] = out[1] = out[2] = 0.f;
         if (contig_len.empty()) return;
         if (contig_len.size() == 1) { out[0] = out[1] = out[2] = (float)contig_len[0]; return; }
-        std::vector<uint32_t> v(contig_len);
+        std::vector<uint32_t> v(contig_len.begin(), contig_len.end());
         std::sort(v.begin(), v.end());
         const size_t n = v.size();
         out[0] = (float)v[std::min(n - 1, n * 9 / 10)]; out[1] = (float)v[std::min(n - 1, n / 2)]; out[2] = (float)v[std::min(n - 1, n / 10)];
