@@ -3724,7 +3724,10 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
     for (uint32_t i = 0; i < n_queries; i++) if (!queries[i]) { psk_set_error("query_many: NULL query %u", i); return PSK_EINVAL; }
     if (n == 0) { for (uint32_t i = 0; i < n_queries; i++) offsets[i + 1] = 0; return PSK_OK; }
     const double screen_val = o->cutoff != 0.0 ? o->cutoff : 0.80;   // lib.rs:603-609
-    const uint32_t QB = std::max<uint32_t>(1, std::min<uint32_t>(16384, (uint32_t)((1ull << 30) / n)));   // queries per round (pass matrix <= 1 GiB)
+    // queries per round (pass matrix <= 1 GiB). A round costs ~3.5 ms of host work with the GPU idle (its screen set-up, the shortlist, the last batch's hits):
+    // 65 536 queries per round instead of 16 384 is 2 rounds instead of 7 for 100 000 contigs (metagenome step 420 -> 384 ms); PSK_ROUND_QUERIES overrides (tests, A/B)
+    static const uint32_t qb_env = getenv("PSK_ROUND_QUERIES") ? (uint32_t)std::max(1, atoi(getenv("PSK_ROUND_QUERIES"))) : 0u;
+    const uint32_t QB = std::max<uint32_t>(1, std::min<uint32_t>(qb_env ? qb_env : 65536u, (uint32_t)((1ull << 30) / n)));
     {
         const char* force = getenv("PSK_SCREEN");
         const bool want_inv = force ? !strcmp(force, "inv") : ((uint64_t)n * std::min(QB, n_queries) >= (1ull << 18));
