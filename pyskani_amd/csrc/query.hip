@@ -3457,9 +3457,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     return PSK_OK;
 }
 
-static uint64_t anchor_cap_for(Lane* ctx, size_t n_items) {
+static uint64_t anchor_cap_for(Lane* ctx, size_t n_items, bool sparse = false) {
     const uint64_t have = ctx->q_d.cap / 64 > 128 ? ctx->q_d.cap / 64 - 128 : 0;     // anchors the per-anchor arrays already hold
-    const uint64_t want = (uint64_t)n_items + n_items / 4 + 65536;                  // non-repetitive genomes: at most ~one anchor per query seed
+    // non-repetitive genomes: at most ~one anchor per query seed; contigs against a whole database (sparse): a third of the (pair, seed) items match
+    // (100 bytes of scratch per anchor: 2^30 items would reserve 136 GB otherwise; a batch that does not fit is rerun with the true total)
+    const uint64_t want = sparse ? (uint64_t)n_items / 2 + 65536 : (uint64_t)n_items + n_items / 4 + 65536;
     return std::min<uint64_t>(std::max(have, want), 0x7FFFFF00ull);
 }
 
@@ -3903,7 +3905,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         static const int items_env = getenv("PSK_BATCH_ITEMS_LOG2") ? std::min(31, std::max(16, atoi(getenv("PSK_BATCH_ITEMS_LOG2")))) : 0;
         int items_log2 = items_env ? items_env : 29;
         if (!items_env) for (uint32_t i = 0; i < m; i++) if (h_qd[i].n > (1u << 20)) { items_log2 = 27; break; }
-        uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << 20, max_rows = 1ull << 26;
+        // Rounds of many small pairs (contigs): 2^21 pairs and 2^30 seeds per batch. The probe join visits a batch's pairs reference by reference, and a line of a
+        // reference's table is probed about once per 2^20 pairs of a 5 000-reference database: with twice the pairs every line is probed twice while it is still
+        // cached (join 142 -> 124 ms per 100 000 contigs). PSK_BATCH_PAIRS_LOG2 overrides (tests, A/B).
+        static const int pairs_env = getenv("PSK_BATCH_PAIRS_LOG2") ? std::min(24, std::max(10, atoi(getenv("PSK_BATCH_PAIRS_LOG2")))) : 0;
+        if (!items_env && items_log2 == 29 && round_probe) items_log2 = 30;
+        uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : 21), max_rows = 1ull << 26;
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
         // The hits of a batch are appended to the result (and counted per query) while the NEXT batch runs on the GPU: two halves of one
@@ -3982,7 +3989,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 if (sizeof(psk_hit) * (size_t)n_pairs + 512 > half_bytes) { psk_set_error("internal: batch larger than its staging half"); return PSK_EHIP; }
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
-                uint64_t cap = anchor_cap_for(ctx, (size_t)items);
+                uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe);
                 bool too_big = false, wide = join_wide_default();
                 for (int attempt = 0;; attempt++) {
                     psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe);
