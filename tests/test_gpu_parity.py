@@ -488,6 +488,55 @@ def test_concurrent_queries_from_threads(psk, oracle):
     assert len(db) == 7
 
 
+def test_threads_share_query_sketches_and_large_batches(psk):
+    """Stress of what round 3 made asynchronous: the k-mer index of a single query sketch is launched without a wait (another lane that
+    meets the same sketch waits for the build's event), and the hits of a batch of more than 4 096 pairs cross on a copy stream while
+    the next batch runs. Eight threads query the SAME `Sketch` objects one at a time in different orders while two more run the whole
+    set as one batch; every result must equal the single-threaded one."""
+    import threading
+    rng = np.random.default_rng(63)
+    anc = random_genome(rng, 150000)
+    db = psk.Database(compression=30, marker_compression=200)
+    db.sketch_many([(f"r{j}", mutate(rng, anc, 0.0005 * j)) for j in range(120)])      # 120 references of one family: every contig chains against all of them
+    contigs = []
+    for i in range(64):
+        L = int(rng.integers(5000, 20000)); st = int(rng.integers(0, len(anc) - L))
+        contigs.append(mutate(rng, anc[st:st + L], 0.01))
+
+    def key(hits):
+        return [(h.reference_name, h.identity, int(h._raw["n_anchors"]), int(h._raw["sum_chain_anchors"])) for h in hits]
+    want = [key(h) for h in db.query_sketches([db.sketch_only(f"c{i}", c) for i, c in enumerate(contigs)], learned_ani=False)]
+    assert sum(len(w) for w in want) > 4096      # more pairs than the host-filtered small batch takes
+    for rep in range(2):
+        sketches = [db.sketch_only(f"c{i}", c) for i, c in enumerate(contigs)]      # fresh: nothing indexed, the threads race on every one of them
+        errors = []
+
+        def one_by_one(t):
+            try:
+                order = np.random.default_rng(100 + t).permutation(len(sketches))
+                for i in order:
+                    got = key(db.query_sketches([sketches[int(i)]], learned_ani=False)[0])
+                    if got != want[int(i)]:
+                        errors.append(("single", t, int(i)))
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+
+        def all_at_once(t):
+            try:
+                for _ in range(3):
+                    got = [key(h) for h in db.query_sketches(sketches, learned_ani=False)]      # 64 x 120 = 7 680 pairs: the large-batch path
+                    if got != want:
+                        errors.append(("batch", t))
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=one_by_one, args=(t,)) for t in range(8)] + [threading.Thread(target=all_at_once, args=(t,)) for t in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+
+
 def test_lanes_overlap_queries(psk):
     """Throughput of per-contig queries from 1 vs 4 host threads against one database (reported, and required not to be
     slower: with one stream per context the threads used to serialise completely)."""
