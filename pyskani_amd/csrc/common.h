@@ -95,6 +95,7 @@ struct psk_ctx {
     std::vector<char> busy;
     int max_lanes = 8;             // per-contig queries from host threads: 1.6 k/s from one thread, 3.6 k from four, 5.0 k from eight, no more from sixteen (profiles/scripts/lanes_scaling.py)
     std::mutex index_mu;           // k-mer index builds mutate sketches: one at a time
+    uint64_t index_visit = 0;      // (under index_mu)
     std::mutex huge_mu;            // select_huge_kernel's workgroups spin at barriers and must all be resident: one such launch in flight per device
     // device block pool: sketch stores are recycled instead of hipMalloc/hipFree'd per batch
     struct PoolBlock { void* p; size_t bytes; };
@@ -397,6 +398,7 @@ struct psk_sketch {
         const size_t n = v.size();
         out[0] = (float)v[std::min(n - 1, n * 9 / 10)]; out[1] = (float)v[std::min(n - 1, n / 2)]; out[2] = (float)v[std::min(n - 1, n / 10)];
     }
+    mutable uint64_t visit = 0;               // ensure_index / ensure_probe: the call that last listed this sketch (under index_mu; replaces a hash set of 10^5 pointers per round)
     mutable std::shared_ptr<IndexStore> idx;  // built on first chaining use
     mutable uint64_t idx_off = 0;
     mutable uint64_t idx_boff = 0;      // first entry of this sketch's bucket table in idx->bucket

@@ -2743,6 +2743,7 @@ struct ReduceArgs {
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
     const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
     int small_done;                                 // chunk tables of <= 64 rows are reduced by pair_reduce_small_kernel
+    int wave_done;                                  // ... and those of 65 .. 256 rows by pair_reduce_wave_kernel
     int k, median, robust; double min_af;
     psk_hit* hits;
     double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
@@ -2772,6 +2773,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     const uint32_t nc = R.n_chunks[p];
     if (CAP == RED_SMALL ? nc > (uint32_t)RED_SMALL : nc <= (uint32_t)RED_SMALL) return;      // the other instantiation's pair
     if (R.small_done && nc != 0 && nc <= 64) return;      // pair_reduce_small_kernel took it
+    if (R.wave_done && nc > 64 && nc <= 64u * 4) return;      // pair_reduce_wave_kernel took it
     if (nc == 0) {      // only reached when the launch visits every pair (no live list): the empty record of pair_empty_kernel
         if (threadIdx.x == 0) {
             psk_hit h{};
@@ -2992,6 +2994,120 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
                 if (m - 2 * (m / 10) > 0) { lo = m / 10; hi = m - m / 10; }
                 double sum = 0; for (uint32_t j = lo; j < hi; j++) sum += sv[j];
                 ani = sum / (double)(hi - lo);
+            }
+        }
+        if (lane == 0) {
+            psk_hit h{};
+            h.ani = -1.0f;
+            h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+            h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
+            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
+            if (m > 0) {
+                double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
+                double afr = (double)t_cq / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;   // one covered-bases count serves both
+                h.af_query = (float)afq; h.af_ref = (float)afr;
+                if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)ani;
+                h.ani_raw = h.ani; h.ani_std = (float)std_all;
+            }
+            R.hits[p] = h;
+        }
+    }
+}
+
+// Pairs whose chunk table has 65 .. 256 rows (a pair of 5 Mb genomes: ~170-250 chunks): ONE WAVE per pair, four rows per lane, four independent pairs per
+// workgroup, no workgroup barrier - the workgroup-per-pair kernel spends its time in a dozen barriers and a one-thread sum over LDS while 255 threads
+// wait (33 ns per pair of a 10^6-pair batch). Same arithmetic in the same order as pair_reduce_pair: the chunk values compacted in chunk order, mean and
+// deviation sums as that kernel's 256 threads form them (one value per thread, a shuffle tree per 64, the four trees added in order), the ANI mean as the
+// sequential sum in chunk order - here over lane reads of registers -, median / trimmed mean over an ascending order.
+constexpr int RW_PER = 4;
+__global__ __launch_bounds__(256) void pair_reduce_wave_kernel(ReduceArgs R, uint32_t n_pairs) {
+    __shared__ double s_val[4][64 * RW_PER];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = R.live ? *R.n_live : n_pairs;
+    double* sv = s_val[wave];
+    for (uint32_t k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
+        const uint32_t p = R.live ? R.live[k] : k;
+        const uint32_t nc = R.n_chunks[p];
+        if (nc <= 64 || nc > 64u * RW_PER) continue;      // the one-wave-one-row kernel / the workgroup kernel
+        const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
+        unsigned long long t_cq = 0, t_a = 0, t_s = 0, t_i = 0;
+        double v[RW_PER]; bool valid[RW_PER];
+#pragma unroll
+        for (int g = 0; g < RW_PER; g++) {
+            const uint32_t r = 64u * g + (uint32_t)lane;
+            ChunkOut c{};
+            if (r < nc) c = co[r];
+            valid[g] = r < nc && c.n_intervals != 0;
+            t_cq += c.cov_q; t_a += c.anchors; t_s += valid[g] ? c.seeds : 0; t_i += c.n_intervals;
+            v[g] = 0.0;
+            if (valid[g]) {
+                double ratio = (double)c.anchors / (double)(c.seeds > 1 ? c.seeds - 1 : 1);   // end seeds are anchors by construction
+                if (ratio > 1.0) ratio = 1.0;
+                v[g] = pow(ratio, 1.0 / (double)R.k);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t_cq += __shfl_xor(t_cq, o); t_a += __shfl_xor(t_a, o); t_s += __shfl_xor(t_s, o); t_i += __shfl_xor(t_i, o); }
+        // the values of the chunks that kept a chain, compacted in chunk order
+        lds_wave_sync();
+        uint32_t m = 0;
+#pragma unroll
+        for (int g = 0; g < RW_PER; g++) {
+            const unsigned long long vm = __ballot(valid[g]);
+            if (valid[g]) sv[m + (uint32_t)__popcll(vm & ((1ull << lane) - 1))] = v[g];
+            m += (uint32_t)__popcll(vm);
+        }
+        lds_wave_sync();
+        double cv[RW_PER];      // compacted value j sits where thread j of the workgroup kernel has it: lane j & 63 of group j >> 6
+#pragma unroll
+        for (int g = 0; g < RW_PER; g++) cv[g] = 64u * g + (uint32_t)lane < m ? sv[64 * g + lane] : 0.0;
+        auto tree4 = [&](const double* x) {      // block_sum of pair_reduce_pair: a shuffle tree per 64 threads, the four results added in order
+            double t[RW_PER];
+#pragma unroll
+            for (int g = 0; g < RW_PER; g++) { double y = 0.0 + x[g]; for (int o = 32; o > 0; o >>= 1) y += __shfl_xor(y, o); t[g] = y; }
+            return t[0] + t[1] + t[2] + t[3];
+        };
+        const double mean_all = m ? tree4(cv) / (double)m : 0.0;
+        double dv[RW_PER];
+#pragma unroll
+        for (int g = 0; g < RW_PER; g++) { const double d = cv[g] - mean_all; dv[g] = 64u * g + (uint32_t)lane < m ? 0.0 + d * d : 0.0; }
+        const double ssq = tree4(dv);
+        const double std_all = m > 1 ? sqrt(ssq / (double)(m - 1)) : 0.0;
+        double ani = 0.0;
+        if (m) {
+            if (R.median || R.robust) {
+                // ascending order: rank = values below + equal values at lower positions
+                uint32_t rank[RW_PER];
+#pragma unroll
+                for (int g = 0; g < RW_PER; g++) rank[g] = 0;
+                for (uint32_t j = 0; j < m; j++) {
+                    const double o = sv[j];
+#pragma unroll
+                    for (int g = 0; g < RW_PER; g++) rank[g] += (o < cv[g]) || (o == cv[g] && j < 64u * g + (uint32_t)lane);
+                }
+                lds_wave_sync();
+#pragma unroll
+                for (int g = 0; g < RW_PER; g++) if (64u * g + (uint32_t)lane < m) sv[rank[g]] = cv[g];
+                lds_wave_sync();
+                if (R.median) ani = sv[m / 2];
+                else {
+                    uint32_t lo = 0, hi = m;
+                    if (m - 2 * (m / 10) > 0) { lo = m / 10; hi = m - m / 10; }
+                    double sum = 0; for (uint32_t j = lo; j < hi; j++) sum += sv[j];
+                    ani = sum / (double)(hi - lo);
+                }
+            } else {
+                // the sequential sum in chunk order, over lane reads (a row without a chain contributes an exact + 0.0)
+                double sum = 0;
+#pragma unroll
+                for (int g = 0; g < RW_PER; g++) {
+                    const uint32_t lo32 = (uint32_t)__double2loint(v[g]), hi32 = (uint32_t)__double2hiint(v[g]);
+                    const uint32_t cnt = nc > 64u * g ? (nc - 64u * g < 64u ? nc - 64u * g : 64u) : 0u;
+                    for (uint32_t l = 0; l < cnt; l++)
+                        sum += __hiloint2double((int)__builtin_amdgcn_readlane(hi32, l), (int)__builtin_amdgcn_readlane(lo32, l));
+                }
+                ani = sum / (double)m;
             }
         }
         if (lane == 0) {
@@ -3443,11 +3559,16 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     // many pairs with short chunk tables (contigs): one wave per pair first; the workgroup-per-pair kernel then only sees the long tables
     const char* rs_env = getenv("PSK_REDUCE_SMALL");
     const bool no_small = rs_env && rs_env[0] == '0';
-    R.small_done = !no_small && n_rows / n_pairs < 16;      // (also without the live list: the few pairs of one contig's query)
+    // tables of 65 .. 256 rows (pairs of ~5 Mb genomes): one wave per pair, four rows per lane; PSK_REDUCE_WAVE=0 leaves them to the workgroup kernel (tests, A/B)
+    const bool no_wave = getenv("PSK_REDUCE_WAVE") && getenv("PSK_REDUCE_WAVE")[0] == '0';
+    R.wave_done = !no_wave && !no_small && L.rows_pair_max > 64u && n_rows / n_pairs <= 256u;
+    // tables of <= 64 rows (contigs; the short pairs beside the others): one wave per pair, a row per lane (also without the live list: the few pairs of one contig's query)
+    R.small_done = !no_small && (n_rows / n_pairs < 16 || R.wave_done);
     if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
-    // (the one-wave kernel takes every table of <= 64 rows: when no pair of the batch can have more - contigs have 1-3 chunks - the two
-    // workgroup-per-pair kernels would only walk the live list to find that out: 24 ms per 17 M contig pairs)
-    if (!(R.small_done && L.rows_pair_max <= 64u))
+    if (R.wave_done) hipLaunchKernelGGL(pair_reduce_wave_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 16384u)), dim3(256), 0, st, R, n_pairs);
+    // (when no pair of the batch can have more rows than the wave kernels take - contigs have 1-3 chunks, 5 Mb genomes ~250 - the two
+    // workgroup-per-pair kernels would only walk the pairs to find that out: 24 ms per 17 M contig pairs)
+    if (!((R.small_done && L.rows_pair_max <= 64u) || (R.small_done && R.wave_done && L.rows_pair_max <= 256u)))
         hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
     if (n_rows > (size_t)RED_SMALL && L.rows_pair_max > (uint32_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
@@ -3923,8 +4044,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             // bring - growing the list round by round copied everything gathered before, 14, 27, 39, ... ms with the GPU idle (a third of the
             // metagenome step: profiles/r3/r3i_metagenome_gaps.txt)
             size_t want = all.n + (size_t)std::min<uint64_t>(round_pairs, 1ull << 26);
-            if (b == 0 && n_queries > m) want = std::max(want, (size_t)std::min<double>((double)round_pairs * ((double)n_queries / (double)m) * 1.05, (double)(1ull << 27)));      // every pair yields at most one hit
-            if (b > 0 && all.n) want = std::max(want, (size_t)((double)all.n * ((double)n_queries / (double)b) * 1.1) + 4096);
+            // (the extrapolations only where the list has to grow anyway: a second round whose own pairs still fit must not move 6 M hits - 50 ms - because
+            // its estimate of the whole call came out 5 % above the first round's)
+            if (want > all.cap) {
+                if (b == 0 && n_queries > m) want = std::max(want, (size_t)std::min<double>((double)round_pairs * ((double)n_queries / (double)m) * 1.05, (double)(1ull << 27)));      // every pair yields at most one hit
+                if (b > 0 && all.n) want = std::max(want, (size_t)((double)all.n * ((double)n_queries / (double)b) * 1.1) + 4096);
+            }
             if (round_pairs > 4096 && !all.reserve(want)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
         }
         int parity = 0;

@@ -1054,11 +1054,13 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n, bo
     std::lock_guard<std::mutex> index_lock(ctx->dev->index_mu);   // index builds mutate the sketches they index
     hipStream_t st = ctx->stream;
     std::vector<const psk_sketch*> todo;
-    std::unordered_set<const psk_sketch*> seen;
+    const uint64_t visit = ++ctx->dev->index_visit;      // a sketch listed twice is taken once
     for (uint32_t i = 0; i < n; i++) if (refs[i] && refs[i]->idx && refs[i]->idx->ready && refs[i]->idx->built_on != st)
         PSK_HIP(hipStreamWaitEvent(st, refs[i]->idx->ready, 0));
-    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store && seen.insert(refs[i]).second)
+    for (uint32_t i = 0; i < n; i++) if (refs[i] && !refs[i]->idx && refs[i]->n_seeds && refs[i]->store && refs[i]->visit != visit) {
+        refs[i]->visit = visit;
         todo.push_back(refs[i]);
+    }
     const uint64_t GROUP = 1ull << 26;   // seeds per sort
     // small sketches first (one workgroup each), large ones after (device radix sort); PSK_INDEX_RADIX=1 forces the latter
     const bool force_radix = getenv("PSK_INDEX_RADIX") != nullptr;
