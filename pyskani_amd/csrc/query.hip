@@ -4026,12 +4026,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         static const int items_env = getenv("PSK_BATCH_ITEMS_LOG2") ? std::min(31, std::max(16, atoi(getenv("PSK_BATCH_ITEMS_LOG2")))) : 0;
         int items_log2 = items_env ? items_env : 29;
         if (!items_env) for (uint32_t i = 0; i < m; i++) if (h_qd[i].n > (1u << 20)) { items_log2 = 27; break; }
-        // Rounds of many small pairs (contigs): 2^21 pairs and 2^30 seeds per batch. The probe join visits a batch's pairs reference by reference, and a line of a
+        // Rounds of many small pairs (contigs): up to 2^22 pairs and 2^30 seeds per batch. The probe join visits a batch's pairs reference by reference, and a line of a
         // reference's table is probed about once per 2^20 pairs of a 5 000-reference database: with twice the pairs every line is probed twice while it is still
         // cached (join 142 -> 124 ms per 100 000 contigs). PSK_BATCH_PAIRS_LOG2 overrides (tests, A/B).
         static const int pairs_env = getenv("PSK_BATCH_PAIRS_LOG2") ? std::min(24, std::max(10, atoi(getenv("PSK_BATCH_PAIRS_LOG2")))) : 0;
         if (!items_env && items_log2 == 29 && round_probe) items_log2 = 30;
-        uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : 21), max_rows = 1ull << 26;
+        uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : (round_probe ? 22 : 21)), max_rows = 1ull << 26;      // (2^22 pairs: 363 -> 353 ms per 100 000 contigs)
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
         // The hits of a batch are appended to the result (and counted per query) while the NEXT batch runs on the GPU: two halves of one
