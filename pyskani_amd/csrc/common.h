@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <sys/mman.h>
 #include <algorithm>
 #include <atomic>
@@ -61,11 +62,16 @@ struct Scratch {
     size_t cap = 0;
     psk_status reserve(size_t bytes) {
         if (bytes <= cap) return PSK_OK;
+        static const bool trace = getenv("PSK_TRACE_ALLOC") != nullptr;      // diagnostics: every growth of a scratch buffer with its cost
+        struct timespec t0{}, t1{};
+        if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
+        const size_t old = cap;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 4 + 256;
         PSK_HIP(hipMalloc(&p, want));
         cap = want;
+        if (trace) { clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "[psk alloc] scratch %.1f MB -> %.1f MB: %.1f ms\n", old / 1e6, want / 1e6, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6); }
         return PSK_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -160,7 +166,7 @@ struct Lane {
     struct JobRes {
         hipStream_t stream = nullptr; bool own_stream = false;
         hipEvent_t scan_done = nullptr;
-        Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark;
+        Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_slices;
         void* pinned = nullptr; size_t pinned_cap = 0;
         psk_status pin(size_t bytes, void** out) {
             if (bytes > pinned_cap) {
@@ -188,7 +194,7 @@ struct Lane {
     }
     void jobs_release() {
         for (JobRes* r : jobs) {
-            Scratch* all[] = {&r->s_desc, &r->s_packed, &r->s_mask, &r->s_counts, &r->s_offs, &r->s_tmp, &r->s_mark};
+            Scratch* all[] = {&r->s_desc, &r->s_packed, &r->s_mask, &r->s_counts, &r->s_offs, &r->s_tmp, &r->s_mark, &r->s_slices};
             for (Scratch* s : all) s->release();
             if (r->pinned) (void)hipHostFree(r->pinned);
             if (r->scan_done) (void)hipEventDestroy(r->scan_done);

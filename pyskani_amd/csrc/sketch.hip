@@ -355,11 +355,54 @@ __global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __re
     }
     if (threadIdx.x == 0) cnt[blockIdx.x] = s_base;
 }
-// moff = exclusive scan of the distinct counts: copy each genome's distinct markers to its dense slot
+template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t* total);      // (defined below)
+// The same for FEW LARGE genomes (3 M markers per 3 Gb genome, one genome per call when the ASCII is streamed): a workgroup per genome walks its segment 256 markers at a
+// time with three barriers per step - 9.8 ms per launch whatever the number of genomes, 0.5 s of a 50-genome pass. Here a genome's segment is cut into gridDim.x slices:
+// pass 0 counts the distinct markers of every slice, marker_slice_scan_kernel turns the counts into offsets, pass 1 writes.
+template <int WRITE>
+__global__ __launch_bounds__(256) void marker_unique_sliced_kernel(const uint64_t* __restrict__ sorted, uint64_t* __restrict__ uniq,
+                                                                    const uint32_t* __restrict__ beg, const uint32_t* __restrict__ end,
+                                                                    uint32_t* __restrict__ slice_cnt) {
+    __shared__ uint32_t s_w[4], s_base;
+    const uint32_t g = blockIdx.y, S = gridDim.x;
+    const uint32_t b = beg[g], e = end[g], len = e - b;
+    const uint32_t per = ((len + S - 1) / S + 255u) & ~255u;
+    const uint32_t sb = b + blockIdx.x * per < e ? b + blockIdx.x * per : e, se = sb + per < e ? sb + per : e;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = WRITE ? slice_cnt[g * S + blockIdx.x] : 0u;      // pass 1: the slice's offset in the genome's distinct list
+    __syncthreads();
+    for (uint32_t i0 = sb; i0 < se; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool f = i < se && (i == b || sorted[i] != sorted[i - 1]);
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (WRITE) {
+            uint32_t off = s_base;
+            for (int w = 0; w < wv; w++) off += s_w[w];
+            if (f) uniq[b + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = sorted[i] & ((1ull << MARKER_BITS) - 1ull);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (!WRITE && threadIdx.x == 0) slice_cnt[g * S + blockIdx.x] = s_base;
+}
+// one workgroup per genome: exclusive scan of its S slice counts in place, the total to cnt[g] (S <= 1024)
+__global__ __launch_bounds__(1024) void marker_slice_scan_kernel(uint32_t* __restrict__ slice_cnt, uint32_t S, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_part[1024 / 64 + 1];
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t c = t < S ? slice_cnt[g * S + t] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<1024>(c, s_part, &total);
+    if (t < S) slice_cnt[g * S + t] = ex;
+    if (t == 0) cnt[g] = total;
+}
+// moff = exclusive scan of the distinct counts: copy each genome's distinct markers to its dense slot (gridDim.y slices per genome)
 __global__ void marker_copy_kernel(const uint64_t* __restrict__ uniq, const uint32_t* __restrict__ beg,
                                    const uint32_t* __restrict__ moff, uint64_t* __restrict__ out) {
     uint32_t b = beg[blockIdx.x], o = moff[blockIdx.x], n = moff[blockIdx.x + 1] - o;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = uniq[b + i];
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) out[o + i] = uniq[b + i];
 }
 
 
@@ -686,6 +729,7 @@ struct SketchJob {
     }
 
     bool marker_block = false;
+    uint32_t marker_slices = 1;      // slices per genome of the distinct-marker pass (few large genomes)
     // tile-local lists -> dense per-genome segments -> segmented radix sort -> distinct values (in d_mstage)
     psk_status marker_segsort() {
         const size_t ns = h_goff[n_genomes];
@@ -706,7 +750,21 @@ struct SketchJob {
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
         }
-        hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_moff);
+        // few large genomes: their segments in slices (marker_unique_sliced_kernel); many smaller ones: a workgroup each
+        uint64_t est = 0;
+        for (uint32_t g = 0; g < n_genomes; g++) est = std::max<uint64_t>(est, sk[g]->total_len / (uint64_t)p->marker_c);
+        marker_slices = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(1, est / 8192));
+        if (const char* e = getenv("PSK_MARKER_SLICES")) marker_slices = (uint32_t)std::max(1, std::min(1024, atoi(e)));      // tests: slices whatever the size
+        if (marker_slices > 1 && (uint64_t)marker_slices * n_genomes <= (1u << 20) && !getenv("PSK_MARKER_UNSLICED")) {
+            PSK_TRY(R->s_slices.reserve(4 * (size_t)marker_slices * n_genomes + 256));
+            uint32_t* d_sc = (uint32_t*)R->s_slices.p;
+            hipLaunchKernelGGL(marker_unique_sliced_kernel<0>, dim3(marker_slices, n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_sc);
+            hipLaunchKernelGGL(marker_slice_scan_kernel, dim3(n_genomes), dim3(1024), 0, st, d_sc, marker_slices, d_moff);
+            hipLaunchKernelGGL(marker_unique_sliced_kernel<1>, dim3(marker_slices, n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_sc);
+        } else {
+            marker_slices = 1;
+            hipLaunchKernelGGL(marker_unique_kernel, dim3(n_genomes), dim3(256), 0, st, d_msorted, d_mstage, d_sbeg, d_sbeg + 1, d_moff);
+        }
         return PSK_OK;
     }
     // distinct counts -> offsets, on their way to the host
@@ -733,7 +791,7 @@ struct SketchJob {
         const uint32_t total_markers = h_moff[n_genomes];
         PSK_TRY(ctx->pool_alloc(sizeof(uint64_t) * ((size_t)total_markers + 1), &store->mbase, &store->mbytes));
         store->markers = (uint64_t*)store->mbase;
-        hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes), dim3(256), 0, st, marker_block ? d_mdense : d_mstage, d_sbeg, d_moff, store->markers);
+        hipLaunchKernelGGL(marker_copy_kernel, dim3(n_genomes, marker_block ? 1u : marker_slices), dim3(256), 0, st, marker_block ? d_mdense : d_mstage, d_sbeg, d_moff, store->markers);
         return PSK_OK;
     }
 

@@ -99,12 +99,14 @@ def test_marker_paths(psk, oracle):
         "print(len(seeds), len(markers), hashlib.sha256(markers.tobytes()).hexdigest())\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     outs = []
-    for force in (False, True):
-        env = dict(os.environ); env.pop("PSK_MARKER_SEGSORT", None)
+    for force in (False, True, "sliced"):      # "sliced": the distinct-marker pass of few LARGE genomes (a segment cut into slices), forced on this one
+        env = dict(os.environ); env.pop("PSK_MARKER_SEGSORT", None); env.pop("PSK_MARKER_SLICES", None)
         if force:
             env["PSK_MARKER_SEGSORT"] = "1"
+        if force == "sliced":
+            env["PSK_MARKER_SLICES"] = "7"
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip())
-    assert outs[0] == outs[1], outs
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 def test_sketch_empty_and_short(psk, oracle):
