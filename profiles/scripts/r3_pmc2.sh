@@ -2,8 +2,8 @@
 # round 3: counter passes again for the kernels that changed after the first collection (all-vs-all emit, metagenome join and DP)
 cd "$GRAFT_REPO_ROOT"
 profiles/scripts/pmc.sh r3_ava "anchor_join4|anchor_emit_pairs|chain_lane20|select_kernel" --workload allvsall --refs 1000 --steps 2 --warmup 1 --cpu-sample 0
-profiles/scripts/pmc.sh r3_meta "anchor_join_probe|chain_quad_deep|chain_chunk_list|chunk_heads|anchor_emit_packed4|pref_count|select_kernel" --workload metagenome --refs 5000 --queries 20000 --steps 2 --warmup 1 --cpu-sample 0 --api-queries 0
-for w in "allvsall --refs 1000" "metagenome --refs 5000 --queries 20000 --api-queries 0"; do
+profiles/scripts/pmc.sh r3_meta "anchor_join_probe|chain_quad_deep|chain_chunk_list|chunk_heads|anchor_emit_packed4|pref_count|select_kernel" --workload metagenome --refs 5000 --queries 100000 --steps 2 --warmup 1 --cpu-sample 0 --api-queries 0
+for w in "allvsall --refs 1000" "metagenome --refs 5000 --queries 100000 --api-queries 0"; do
   tag=$(echo $w | cut -d' ' -f1)
   python bench.py --workload $w --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/pmc/r3_units_$tag.json 2> /dev/null
 done
