@@ -3578,11 +3578,13 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     return PSK_OK;
 }
 
-static uint64_t anchor_cap_for(Lane* ctx, size_t n_items, bool sparse = false) {
+static uint64_t anchor_cap_for(Lane* ctx, size_t n_items, bool sparse = false, bool gb_scale = false) {
     const uint64_t have = ctx->q_d.cap / 64 > 128 ? ctx->q_d.cap / 64 - 128 : 0;     // anchors the per-anchor arrays already hold
     // non-repetitive genomes: at most ~one anchor per query seed; contigs against a whole database (sparse): a third of the (pair, seed) items match
     // (100 bytes of scratch per anchor: 2^30 items would reserve 136 GB otherwise; a batch that does not fit is rerun with the true total)
-    const uint64_t want = sparse ? (uint64_t)n_items / 2 + 65536 : (uint64_t)n_items + n_items / 4 + 65536;
+    // Gb-scale pairs: a seed has ~6.5 matches (chance 15-mer hits in 3 Gb beside the true one) - sized for that at once: the first batch used to overflow, and its
+    // second attempt freed 7 GB to allocate 40 GB, which takes 1.5 s when the driver is still clearing memory a previous process released (profiles/r3/r3y_50x_alloc_trace.txt)
+    const uint64_t want = gb_scale ? (uint64_t)n_items * 7 + 65536 : sparse ? (uint64_t)n_items / 2 + 65536 : (uint64_t)n_items + n_items / 4 + 65536;
     return std::min<uint64_t>(std::max(have, want), 0x7FFFFF00ull);
 }
 
@@ -4114,10 +4116,14 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 if (sizeof(psk_hit) * (size_t)n_pairs + 512 > half_bytes) { psk_set_error("internal: batch larger than its staging half"); return PSK_EHIP; }
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
-                uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe);
+                uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe, items / n_pairs > (1u << 20));
                 bool too_big = false, wide = join_wide_default();
+                static const bool trace_batch = getenv("PSK_TRACE_BATCH") != nullptr;      // diagnostics: host wall clock of every batch (launching, waiting)
                 for (int attempt = 0;; attempt++) {
+                    struct timespec tb0{}, tb1{}, tb2{};
+                    if (trace_batch) clock_gettime(CLOCK_MONOTONIC, &tb0);
                     psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe);
+                    if (trace_batch) clock_gettime(CLOCK_MONOTONIC, &tb1);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);
                     if (!host_filter) {      // (the ani > 0.1 filter of a small batch runs on the host: three launches fewer)
@@ -4129,6 +4135,14 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     else PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, st));
                     PSK_TRY(consume());                     // the previous batch's hits, while this one runs
                     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of a batch
+                    if (trace_batch) {
+                        clock_gettime(CLOCK_MONOTONIC, &tb2);
+                        static struct timespec last{};
+                        const double gap = last.tv_sec ? (tb0.tv_sec - last.tv_sec) * 1e3 + (tb0.tv_nsec - last.tv_nsec) / 1e6 : 0.0;
+                        fprintf(stderr, "[psk batch] pairs %u items %llu attempt %d: since last %.1f ms, launch %.1f ms, wait %.1f ms\n", n_pairs, (unsigned long long)items, attempt, gap,
+                                (tb1.tv_sec - tb0.tv_sec) * 1e3 + (tb1.tv_nsec - tb0.tv_nsec) / 1e6, (tb2.tv_sec - tb1.tv_sec) * 1e3 + (tb2.tv_nsec - tb1.tv_nsec) / 1e6);
+                        last = tb2;
+                    }
                     ctx->huge_release();
                     bool retry;
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
