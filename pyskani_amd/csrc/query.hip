@@ -2744,6 +2744,7 @@ struct ReduceArgs {
     const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
     int small_done;                                 // chunk tables of <= 64 rows are reduced by pair_reduce_small_kernel
     int wave_done;                                  // ... and those of 65 .. 256 rows by pair_reduce_wave_kernel
+    int tiny_done;                                  // ... and those of 1 .. 4 rows (contig pairs, mean ANI) by pair_reduce_tiny_kernel, a lane per pair
     int k, median, robust; double min_af;
     psk_hit* hits;
     double* big_vals;   // 2 * rows(+pad) doubles per launch: sort space for pairs with more than RED_CAP chunk values
@@ -2950,6 +2951,7 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
             continue;
         }
         if (nc == 0 || nc > 64) continue;                 // empty records / larger tables: the other kernels
+        if (R.tiny_done && nc <= 4) continue;             // pair_reduce_tiny_kernel took it
         const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
         ChunkOut c{};
         if ((uint32_t)lane < nc) c = co[lane];
@@ -3013,6 +3015,56 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
             R.hits[p] = h;
         }
     }
+}
+
+// Contig pairs: one to three chunks. A wave per pair leaves 61 lanes idle for 17 M pairs per metagenome step (15 ms); here ONE LANE reduces a pair of up to four chunk
+// rows (mean ANI only: median / trimmed mean stay with the wave kernel). Same values in the same order as pair_reduce_small_kernel: the mean as the sequential sum
+// in chunk order, the squared deviations added the way that kernel's shuffle tree adds lanes 0..3: (d0 + d2) + (d1 + d3).
+__global__ __launch_bounds__(256) void pair_reduce_tiny_kernel(ReduceArgs R, uint32_t n_pairs) {
+    const uint32_t n = R.live ? *R.n_live : n_pairs;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = R.live ? R.live[k] : k;
+    const uint32_t nc = R.n_chunks[p];
+    if (nc == 0 || nc > 4) return;
+    const ChunkOut* co = R.chunks + (size_t)R.cbase[p];
+    unsigned long long t_cq = 0, t_a = 0, t_s = 0, t_i = 0;
+    double v[4] = {0.0, 0.0, 0.0, 0.0}; bool valid[4] = {false, false, false, false};
+    uint32_t m = 0;
+    double sum_all = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) if (r < nc) {
+        const ChunkOut c = co[r];
+        valid[r] = c.n_intervals != 0;
+        t_cq += c.cov_q; t_a += c.anchors; t_s += valid[r] ? c.seeds : 0; t_i += c.n_intervals;
+        if (valid[r]) {
+            double ratio = (double)c.anchors / (double)(c.seeds > 1 ? c.seeds - 1 : 1);   // end seeds are anchors by construction
+            if (ratio > 1.0) ratio = 1.0;
+            v[r] = pow(ratio, 1.0 / (double)R.k);
+            sum_all += v[r];
+            m++;
+        }
+    }
+    const double mean_all = m ? sum_all / (double)m : 0.0;
+    double d[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) d[r] = valid[r] ? (v[r] - mean_all) * (v[r] - mean_all) : 0.0;
+    const double dev = (d[0] + d[2]) + (d[1] + d[3]);
+    const double std_all = m > 1 ? sqrt(dev / (double)(m - 1)) : 0.0;
+    psk_hit h{};
+    h.ani = -1.0f;
+    h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
+    h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
+    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+    h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
+    if (m > 0) {
+        double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
+        double afr = (double)t_cq / (double)R.pairs[p].r_total_len; if (afr > 1) afr = 1;   // one covered-bases count serves both
+        h.af_query = (float)afq; h.af_ref = (float)afr;
+        if (afq >= R.min_af || afr >= R.min_af) h.ani = (float)mean_all;
+        h.ani_raw = h.ani; h.ani_std = (float)std_all;
+    }
+    R.hits[p] = h;
 }
 
 // Pairs whose chunk table has 65 .. 256 rows (a pair of 5 Mb genomes: ~170-250 chunks): ONE WAVE per pair, four rows per lane, four independent pairs per
@@ -3564,6 +3616,10 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     R.wave_done = !no_wave && !no_small && L.rows_pair_max > 64u && n_rows / n_pairs <= 256u;
     // tables of <= 64 rows (contigs; the short pairs beside the others): one wave per pair, a row per lane (also without the live list: the few pairs of one contig's query)
     R.small_done = !no_small && (n_rows / n_pairs < 16 || R.wave_done);
+    // contig batches with the mean ANI: pairs of up to four chunk rows by one lane each first (PSK_REDUCE_TINY=0: by a wave each)
+    static const bool no_tiny = getenv("PSK_REDUCE_TINY") && getenv("PSK_REDUCE_TINY")[0] == '0';
+    R.tiny_done = R.small_done && !no_tiny && !o->median && !o->robust && n_rows / n_pairs < 16;
+    if (R.tiny_done) hipLaunchKernelGGL(pair_reduce_tiny_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, R, n_pairs);
     if (R.small_done) hipLaunchKernelGGL(pair_reduce_small_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 8192u)), dim3(256), 0, st, R, n_pairs);
     if (R.wave_done) hipLaunchKernelGGL(pair_reduce_wave_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 16384u)), dim3(256), 0, st, R, n_pairs);
     // (when no pair of the batch can have more rows than the wave kernels take - contigs have 1-3 chunks, 5 Mb genomes ~250 - the two
