@@ -2175,6 +2175,7 @@ struct SelArgs {
     const int32_t* c_score; const uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_rc; uint32_t* c_state;
     ChunkOut* out; uint32_t two_c; int force_serial; uint32_t* stats;
     const uint32_t* live; const uint32_t* n_live;      // pairs that have a chunk table (every other pair has no candidate chain)
+    uint32_t* rest_list; uint32_t* rest_count;         // select_tiny_kernel: the live pairs it did NOT take (what the wave kernel still has to visit)
     uint32_t* big_list; uint32_t* big_count;           // pairs with more than CMAX candidates, for select_big_kernel
     int tiny_done;                                     // pairs of at most TINY_ROWS chunks and TINY_CANDS candidates were selected by select_tiny_kernel
 };
@@ -2389,20 +2390,34 @@ __device__ void select_pair(const SelArgs& S, const uint32_t p, uint32_t* __rest
 __global__ __launch_bounds__(256) void select_tiny_kernel(SelArgs S) {
     const uint32_t n = *S.n_live;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t p = S.live[k];
-    const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
-    if (nrows == 0 || nrows > TINY_ROWS) return;
-    uint32_t C = 0;
-    for (uint32_t r = 0; r < nrows; r++) C += S.out[row0 + r].n_cand;
-    if (C == 0 || C > TINY_CANDS) return;
-    select_serial(S, row0, nrows);
+    bool rest = false; uint32_t p = 0;
+    if (k < n) {
+        p = S.live[k];
+        const uint32_t row0 = S.cbase[p], nrows = S.n_chunks[p];
+        if (nrows != 0) {
+            uint32_t C = 0;
+            if (nrows <= TINY_ROWS) for (uint32_t r = 0; r < nrows; r++) C += S.out[row0 + r].n_cand;
+            if (nrows > TINY_ROWS || C > TINY_CANDS) rest = true;
+            else if (C != 0) select_serial(S, row0, nrows);
+        }
+    }
+    // the pairs left for the wave kernel, listed (one append per wave): walking all 17 M live pairs of a metagenome step again only to find the
+    // few with more candidates cost that kernel 18 ms
+    const unsigned long long bal = __ballot(rest);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(S.rest_count, (uint32_t)__popcll(bal));
+        base = __shfl(base, __ffsll((long long)bal) - 1);
+        if (rest) S.rest_list[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = p;
+    }
 }
 
 __global__ __launch_bounds__(64) void select_kernel(SelArgs S, uint32_t* __restrict__ mid_list, uint32_t* __restrict__ mid_count) {
-    const uint32_t n = S.live ? *S.n_live : S.n_pairs;      // small launches skip the list: every pair is visited
+    const uint32_t* list = S.tiny_done ? S.rest_list : S.live;      // after select_tiny_kernel: only what it left
+    const uint32_t n = S.tiny_done ? *S.rest_count : (S.live ? *S.n_live : S.n_pairs);      // small launches skip the list: every pair is visited
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        select_pair<CSMALL>(S, S.live ? S.live[k] : k, mid_list, mid_count, true);
+        select_pair<CSMALL>(S, list ? list[k] : k, mid_list, mid_count, true);
         lds_wave_sync();
     }
 }
@@ -3541,6 +3556,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     {   // batches of pairs with short chunk tables (contigs): one lane per pair first; PSK_SELECT_TINY=0 leaves every pair to the wave kernels
         static const bool tiny_off = getenv("PSK_SELECT_TINY") && getenv("PSK_SELECT_TINY")[0] == '0';
         SA.tiny_done = use_live && !force_serial && !tiny_off && n_rows / n_pairs < 16;
+        SA.rest_list = (uint32_t*)L.hits_sel; SA.rest_count = L.misc + 13;      // (hits_sel: free until the hits are selected; misc was zeroed by pair_table_kernel)
         if (SA.tiny_done) hipLaunchKernelGGL(select_tiny_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, SA);
     }
     // (the list of the second tier lives in huge_list: select_big_kernel only writes that after select_mid_kernel has read it)
