@@ -92,6 +92,8 @@ typedef struct { uint32_t kmer, pos, contig, canon; } psk_seed; /* export record
 
 const char* psk_last_error(void);
 const char* psk_version(void);
+/* Releases an array the library returned (hit lists, gathered lists). Never release such an array with free(): large hit arrays are
+ * huge-page blocks the library keeps one of for its next call ($PSK_HIT_CACHE=0: returned to the system at once). */
 void psk_free(void* p);
 
 psk_status psk_ctx_create(int device, psk_ctx** out);
