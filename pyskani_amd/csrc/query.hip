@@ -858,7 +858,9 @@ __device__ __forceinline__ int probe_slot_of(const ProbeLine* __restrict__ tab, 
 __global__ __launch_bounds__(256) void anchor_join_probe_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
                                                                 const uint32_t* __restrict__ order, uint32_t n_pairs,
                                                                 uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
-                                                                uint32_t* __restrict__ need_wide) {
+                                                                uint32_t* __restrict__ need_wide, uint32_t* __restrict__ aoff_local, uint32_t* __restrict__ pair_cnt) {
+    // aoff_local / pair_cnt: the wave walks its pair's seeds in position order anyway - it leaves every item's anchor offset WITHIN the pair (a running count) and
+    // the pair's total, so that the offsets of a batch are one scan over its 2 M pairs instead of one over its 700 M items (19 ms per metagenome step)
     const uint32_t lb = xcd_block_id();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t w = lb * 4 + wave;
@@ -870,6 +872,8 @@ __global__ __launch_bounds__(256) void anchor_join_probe_kernel(const PairDesc* 
         const ProbeLine* __restrict__ tab = P.r_tab;
         const uint32_t* __restrict__ q_kmer = P.q_kmer;
         uint2* __restrict__ out = item_out + sbase[p];
+        uint32_t* __restrict__ loc = aoff_local ? aoff_local + sbase[p] : nullptr;
+        uint32_t run = 0;      // anchors of the pair before the items of this step
         constexpr int U = 4;
         for (uint32_t j0 = 0; j0 < qn; j0 += 64 * U) {
             uint32_t km[U], ln[U];
@@ -897,7 +901,20 @@ __global__ __launch_bounds__(256) void anchor_join_probe_kernel(const PairDesc* 
                 out[j] = rec[u];
                 total += c;
             }
+            if (loc) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    const uint32_t c = j < qn ? rec[u].y >> 24 : 0u;
+                    uint32_t incl = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                    if (j < qn) loc[j] = run + incl - c;
+                    run += __shfl(incl, 63);
+                }
+            }
         }
+        if (pair_cnt && lane == 0) pair_cnt[p] = run;
     }
     block_total(total, lb, block_sum);
 }
@@ -906,7 +923,8 @@ __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc
                                                                   uint32_t n_pairs, uint32_t n_items, uint32_t n_tiles,
                                                                   const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
                                                                   uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
-                                                                  const uint32_t* __restrict__ blk_pair) {
+                                                                  const uint32_t* __restrict__ blk_pair, const uint32_t* __restrict__ pstart_local) {
+    // (pstart_local: aoff holds offsets WITHIN the item's pair - the probe join's own running counts -, the pair's first anchor is added here)
     const uint32_t lb = xcd_block_id();
     uint32_t i[JT], p[JT], c[JT], dst[JT], qp[JT], qm[JT], hint[JT];
     uint2 rec[JT];
@@ -925,7 +943,9 @@ __global__ __launch_bounds__(256) void anchor_emit_packed4_kernel(const PairDesc
         c[t] = rec[t].y >> 24;
         act[t] = act[t] && c[t] != 0;
         p[t] = pair_from_hint(sbase, n_pairs, i[t] < n_items ? i[t] : n_items - 1, hint[t]);
-        if (act[t] && (uint64_t)dst[t] + c[t] > cap) { atomicOr(err, 2u); act[t] = false; }   // beyond the optimistic capacity: the host reruns the batch
+        unsigned long long d64 = dst[t];
+        if (pstart_local && act[t]) { d64 += pstart_local[p[t]]; dst[t] = (uint32_t)d64; }
+        if (act[t] && d64 + c[t] > cap) { atomicOr(err, 2u); act[t] = false; }   // beyond the optimistic capacity: the host reruns the batch
     }
 #pragma unroll
     for (int t = 0; t < JT; t++) {
@@ -3362,6 +3382,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
     const bool join_pairs = !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
+    bool probe_local = false;
     if (join_pairs) {
         // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys
         size_t ts = 0;
@@ -3375,7 +3396,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->q_g.p, ts, keys_in, keys_out, vals_in, order, (int)n_pairs, 0, 32, st));
         const uint32_t nb = (n_pairs + 3) / 4;
         // every reference of the batch carries a probe table (ensure_probe): one line read per lookup instead of the index's chain of reads
-        if (probe_ok) hipLaunchKernelGGL(anchor_join_probe_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
+        // (the probe join leaves offsets within the pair + pair totals: PSK_PROBE_LOCAL=0 keeps the scan over all items; tests, A/B)
+        static const bool pl_off = getenv("PSK_PROBE_LOCAL") && getenv("PSK_PROBE_LOCAL")[0] == '0';
+        probe_local = probe_ok && !pl_off;
+        if (probe_ok) hipLaunchKernelGGL(anchor_join_probe_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5,
+                                         probe_local ? L.aoff : (uint32_t*)nullptr, probe_local ? L.big_list : (uint32_t*)nullptr);      // (big_list: free until select runs)
         else hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
         n_sum = nb;
     }
@@ -3409,12 +3434,23 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
         hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap);
     }
+    else if (probe_local) {      // the pairs' totals (anchor_join_probe_kernel) -> 64-bit prefix -> pstart; the items carry their offsets within the pair
+        hipcub::TransformInputIterator<unsigned long long, Widen, const uint32_t*> pl_it(L.big_list, Widen());
+        size_t tmp5 = 0;
+        PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp5, pl_it, (unsigned long long*)nullptr, (int)(n_pairs + 1), st));
+        const size_t o_poff = al256(tmp5 + 256);
+        PSK_TRY(ctx->q_g.reserve(o_poff + 8 * ((size_t)n_pairs + 2) + 256));
+        unsigned long long* pl_off64 = (unsigned long long*)((char*)ctx->q_g.p + o_poff);
+        PSK_HIP(hipMemsetAsync(L.big_list + n_pairs, 0, 4, st));      // the scan reads n_pairs + 1 counts
+        PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_g.p, tmp5, pl_it, pl_off64, (int)(n_pairs + 1), st));
+        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)pl_off64, n_pairs, L.pstart, (uint32_t)cap);
+    }
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
     const bool small_sum = n_sum <= 16384;
     if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.total, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
-    if (!emit_pairs || small_sum)
-        hipLaunchKernelGGL(pair_start_kernel, dim3(emit_pairs ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, emit_pairs ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
+    if ((!emit_pairs && !probe_local) || small_sum)
+        hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe_local) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe_local) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.total);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
@@ -3449,7 +3485,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         const char* ex_env = getenv("PSK_EMIT_EXPAND");
         const bool expand = ex_env ? ex_env[0] == '1' : n_items / n_pairs > (1u << 20);
         if (expand) hipLaunchKernelGGL(anchor_emit_expand_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
-        else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+        else hipLaunchKernelGGL(anchor_emit_packed4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair,
+                                probe_local ? (const uint32_t*)L.pstart : (const uint32_t*)nullptr);
     }
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
     if (use_hops) {

@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -76,6 +76,7 @@ def test_rescue_prefilter_agrees_at_scale():
     # (the default joins these many small pairs through the references' probe tables; PSK_PROBE=0: through their k-mer indexes)
     for extra in ({"PSK_PREFILTER": "0"}, {"PSK_PREFILTER": "1"}, {"PSK_PREFILTER": "1", "PSK_JOIN_PAIRS": "0"}, {"PSK_PROBE": "0"}, {"PSK_PROBE": "0", "PSK_PREFILTER": "0"},
                   {"PSK_SELECT_TINY": "0"},           # chain selection of pairs with a handful of candidates by one lane each; "0": by a wave each
+                  {"PSK_PROBE_LOCAL": "0"},           # anchor offsets by a scan over all items (default for the probe join: its own running counts + a scan over the pairs)
                   {"PSK_REDUCE_TINY": "0"},           # pairs of up to four chunk rows reduced by a wave each (default: a lane each)
                   {"PSK_ROUND_QUERIES": "700"},       # seven rounds of queries instead of one (screen, shortlist and the trailing copy of the hits per round)
                   {"PSK_ROW_SORT": "0"},              # chunk-table rows in table order for the DP (default: by chunk length, longest first)
