@@ -99,7 +99,7 @@ struct psk_ctx {
     std::condition_variable lanes_cv;
     std::vector<Lane*> lanes;
     std::vector<char> busy;
-    int max_lanes = 8;             // per-contig queries from host threads: 1.6 k/s from one thread, 3.6 k from four, 5.0 k from eight, no more from sixteen (profiles/scripts/lanes_scaling.py)
+    int max_lanes = 8;             // per-contig queries from host threads: 2.9 k/s from one thread, 6.5 k from four, 8.6 k from eight, no more from sixteen (profiles/r3/r3q_query_threads.txt)
     std::mutex index_mu;           // k-mer index builds mutate sketches: one at a time
     uint64_t index_visit = 0;      // (under index_mu)
     std::mutex huge_mu;            // select_huge_kernel's workgroups spin at barriers and must all be resident: one such launch in flight per device
