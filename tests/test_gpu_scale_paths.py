@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -66,22 +66,22 @@ def _run(code, extra):
 def test_all_vs_all_batch_paths_agree():
     base = _run(ALL_VS_ALL, {})
     assert base[0] >= 320 * 40                      # every genome finds its family: >= 1 024 chained pairs in one batch
-    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0"}, {"PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_CHUNK_HOPS": "1"}, {"PSK_ROW_SORT": "0"}):
+    # (switches that act on different stages share a run: every run is a process that loads the library and sketches the genomes again)
+    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0", "PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22", "PSK_ROW_SORT": "0"}, {"PSK_CHUNK_HOPS": "1", "PSK_REDUCE_SMALL": "0"}):
         assert _run(ALL_VS_ALL, extra) == base, extra
 
 
 def test_rescue_prefilter_agrees_at_scale():
     base = _run(RESCUE, {})                         # 3 600 rescued contigs x 300 references: 2^20 pairs and more, the prefilter's default range
     assert base[0] > 4800 * 20
-    # (the default joins these many small pairs through the references' probe tables; PSK_PROBE=0: through their k-mer indexes)
-    for extra in ({"PSK_PREFILTER": "0"}, {"PSK_PREFILTER": "1"}, {"PSK_PREFILTER": "1", "PSK_JOIN_PAIRS": "0"}, {"PSK_PROBE": "0"}, {"PSK_PROBE": "0", "PSK_PREFILTER": "0"},
-                  {"PSK_SELECT_TINY": "0"},           # chain selection of pairs with a handful of candidates by one lane each; "0": by a wave each
-                  {"PSK_PROBE_LOCAL": "0"},           # anchor offsets by a scan over all items (default for the probe join: its own running counts + a scan over the pairs)
-                  {"PSK_REDUCE_TINY": "0"},           # pairs of up to four chunk rows reduced by a wave each (default: a lane each)
-                  {"PSK_ROUND_QUERIES": "700"},       # seven rounds of queries instead of one (screen, shortlist and the trailing copy of the hits per round)
-                  {"PSK_ROW_SORT": "0"},              # chunk-table rows in table order for the DP (default: by chunk length, longest first)
-                  {"PSK_CHAIN_WAVE_REG": "1"},        # the small launch's wave-per-chunk DP (look-back window in registers) forced on the large batch
-                  {"PSK_CHAIN_QUAD_DEEP": "0"}):      # c = 30: band 83, four lanes per chunk with 21-deep windows by default; "0": the wave-per-chunk DP
+    # (the default joins these many small pairs through the references' probe tables, hands the DP its rows by chunk length, selects and reduces the
+    # pairs of a handful of rows by one lane each, takes the anchor offsets from the join's running counts; switches of different stages share a run)
+    for extra in ({"PSK_PREFILTER": "0"},
+                  {"PSK_PREFILTER": "1", "PSK_JOIN_PAIRS": "0"},
+                  {"PSK_PROBE": "0", "PSK_PREFILTER": "0", "PSK_SELECT_TINY": "0", "PSK_REDUCE_TINY": "0"},      # joins through the k-mer indexes, a wave per pair in selection and reduce
+                  {"PSK_ROW_SORT": "0", "PSK_PROBE_LOCAL": "0", "PSK_ROUND_QUERIES": "700"},                  # rows in table order, offsets by a scan over the items, seven rounds of queries
+                  {"PSK_CHAIN_WAVE_REG": "1", "PSK_PREFILTER": "1"},                                        # the small launch's register-window DP forced on the large batch
+                  {"PSK_CHAIN_QUAD_DEEP": "0", "PSK_SELECT_TINY": "0"}):                                     # c = 30 (band 83): the wave-per-chunk LDS-ring DP
         assert _run(RESCUE, extra) == base, extra
 
 
