@@ -1076,6 +1076,10 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long run0 = poff[p], total = poff[p + 1] - run0;
+    if (err[5]) {      // the join asked for the wide format: this attempt is rerun whatever it produces (see pair_start64_kernel) - no anchors, no chunk table
+        if (chunks != nullptr && threadIdx.x == 0) n_chunks[p] = 0;
+        return;
+    }
     const bool heads = chunks != nullptr && total >= MIN_ANCHORS;     // fewer: no chain can form, no chunk table, every later kernel skips the pair
     if (chunks != nullptr && !heads && threadIdx.x == 0) n_chunks[p] = 0;
     if (s0 == s1) return;
@@ -1181,16 +1185,21 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
 }
 
 // pstart from the 64-bit prefix of the pairs' anchor counts (clamped into the optimistically sized anchor arrays)
-__global__ __launch_bounds__(256) void pair_start64_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap) {
+// (need_wide: the join met a count or contig number its packed records cannot hold - the host reruns the batch in the wide format whatever this attempt
+// produces, so every pair is left EMPTY here and the chunk, DP and selection kernels of the attempt have nothing to do: a genome whose k-mers repeat
+// 47 000 times spent minutes chaining 24 M clamped anchors before the rerun refused it)
+__global__ __launch_bounds__(256) void pair_start64_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap,
+                                                           const uint32_t* __restrict__ need_wide) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= n_pairs) { const unsigned long long a = poff[p]; pstart[p] = a < cap ? (uint32_t)a : cap; }
+    if (p <= n_pairs) { const unsigned long long a = poff[p]; pstart[p] = *need_wide ? 0u : (a < cap ? (uint32_t)a : cap); }
 }
 
 // pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
 __global__ __launch_bounds__(256) void pair_start_kernel(const uint32_t* __restrict__ aoff, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart, uint32_t cap,
-                                                         const unsigned long long* __restrict__ bsum, uint32_t n_sum, unsigned long long* __restrict__ total64) {
+                                                         const unsigned long long* __restrict__ bsum, uint32_t n_sum, unsigned long long* __restrict__ total64,
+                                                         const uint32_t* __restrict__ need_wide) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (aoff && p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = a < cap ? a : cap; }   // inside the (optimistically sized) anchor arrays whatever the counts were
+    if (aoff && p <= n_pairs) { const uint32_t a = aoff[sbase[p]]; pstart[p] = *need_wide ? 0u : (a < cap ? a : cap); }   // inside the (optimistically sized) anchor arrays whatever the counts were
     if (n_sum && blockIdx.x == 0) {   // small launches: the 64-bit anchor total here instead of a device-wide reduction (two launches fewer)
         __shared__ unsigned long long s_t[4];
         unsigned long long t = 0;
@@ -3432,7 +3441,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
         PSK_TRY(ctx->q_c.reserve(std::max(tmp4, std::max(tmp, std::max(tmp2, tmp3)))));
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
-        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap);
+        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, poff, n_pairs, L.pstart, (uint32_t)cap, (const uint32_t*)(L.misc + 5));
     }
     else if (probe_local) {      // the pairs' totals (anchor_join_probe_kernel) -> 64-bit prefix -> pstart; the items carry their offsets within the pair
         hipcub::TransformInputIterator<unsigned long long, Widen, const uint32_t*> pl_it(L.big_list, Widen());
@@ -3443,7 +3452,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         unsigned long long* pl_off64 = (unsigned long long*)((char*)ctx->q_g.p + o_poff);
         PSK_HIP(hipMemsetAsync(L.big_list + n_pairs, 0, 4, st));      // the scan reads n_pairs + 1 counts
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_g.p, tmp5, pl_it, pl_off64, (int)(n_pairs + 1), st));
-        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)pl_off64, n_pairs, L.pstart, (uint32_t)cap);
+        hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)pl_off64, n_pairs, L.pstart, (uint32_t)cap, (const uint32_t*)(L.misc + 5));
     }
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
@@ -3451,7 +3460,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.total, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
     if ((!emit_pairs && !probe_local) || small_sum)
         hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe_local) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe_local) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
-                           L.bsum, small_sum ? n_sum : 0u, L.total);
+                           L.bsum, small_sum ? n_sum : 0u, L.total, (const uint32_t*)(L.misc + 5));
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
