@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(EP_T) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     const uint32_t s0 = sbase[p], s1 = sbase[p + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long run0 = poff[p], total = poff[p + 1] - run0;
-    if (err[5]) {      // the join asked for the wide format: this attempt is rerun whatever it produces (see pair_start64_kernel) - no anchors, no chunk table
+    if (err[5] || *(const unsigned long long*)(err + 16) > cap) {      // this attempt is rerun whatever it produces (see pair_guard_kernel; err + 16: the 64-bit anchor total) - no anchors, no chunk table
         if (chunks != nullptr && threadIdx.x == 0) n_chunks[p] = 0;
         return;
     }
@@ -1192,6 +1192,16 @@ __global__ __launch_bounds__(256) void pair_start64_kernel(const unsigned long l
                                                            const uint32_t* __restrict__ need_wide) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p <= n_pairs) { const unsigned long long a = poff[p]; pstart[p] = *need_wide ? 0u : (a < cap ? (uint32_t)a : cap); }
+}
+
+// An attempt that will be rerun whatever it produces - the join asked for the wide format, or the anchor total does not fit the capacity the arrays were sized
+// for (or the 32-bit offsets) - leaves every pair EMPTY: chunk tables, DP and selection then have nothing to do. (A genome whose k-mer repeats 47 000 times, met by
+// a context whose arrays a Gb-scale batch had grown, spent nine minutes in the lane-serial DP of 75 M-anchor chunks before its total was looked at.)
+__global__ __launch_bounds__(256) void pair_guard_kernel(const uint32_t* __restrict__ need_wide, const unsigned long long* __restrict__ total64, unsigned long long cap,
+                                                         uint32_t* __restrict__ pstart, uint32_t n_pairs) {
+    if (!*need_wide && *total64 <= cap) return;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= n_pairs) pstart[p] = 0;
 }
 
 // pstart[p] = first anchor of pair p (pstart[n_pairs] = total)
@@ -3461,6 +3471,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if ((!emit_pairs && !probe_local) || small_sum)
         hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe_local) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe_local) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.total, (const uint32_t*)(L.misc + 5));
+    hipLaunchKernelGGL(pair_guard_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)(L.misc + 5), (const unsigned long long*)L.total, (unsigned long long)cap, L.pstart, n_pairs);
     // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * 16));
