@@ -63,6 +63,169 @@ def cpu_model():
     return "unknown"
 
 
+# ------------------------------------------------------------------ the contract line: compact (< 4 kB) on stdout, everything else on disk
+LINE_BUDGET = 4096      # the driver keeps an 8 kB stdout tail: the LAST line must fit well inside it (round 3's 21 kB line could not be parsed)
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant digits (the full-precision object is in the file named by `full`)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "…"
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if d is not None and k in d}
+
+
+def compact_roofline(r, short=False):
+    if not r:
+        return None
+    keys = ("kernel", "frac", "traffic") if short else ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_bw", "traffic", "traffic_source", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")
+    out = _pick(r, keys)
+    if "traffic_source" in out:
+        out["traffic_source"] = _clip(out["traffic_source"], 72)
+    return out
+
+
+def compact_cpu(c, short=False):
+    if not c:
+        return None
+    if short:
+        out = _pick(c, ("value", "cores"))
+        if "all_cores" in c:
+            out["all_cores"] = _pick(c["all_cores"], ("value", "cores"))
+        return out
+    out = _pick(c, ("value", "unit", "cores", "kind", "cpu"))
+    out["sample"] = _clip(c.get("sample", ""), 160)
+    if "all_cores" in c:
+        out["all_cores"] = _pick(c["all_cores"], ("value", "cores"))
+    return out
+
+
+def compact_workload(e):
+    """one entry of extras.workloads in the compact line: ms_per_step, value, unit, hits, roofline{kernel, frac, traffic}, cpu_baseline{value, cores}"""
+    if not e:
+        return None
+    if "ms_per_step" not in e:      # the API leg: rates only
+        return {k: _sig(v) for k, v in e.items() if isinstance(v, (int, float))}
+    out = _pick(e, ("ms_per_step", "value", "unit", "hits", "hits_digest"))
+    out["roofline"] = compact_roofline(e.get("roofline"), short=True)
+    if e.get("cpu_baseline"):
+        out["cpu_baseline"] = compact_cpu(e["cpu_baseline"], short=True)
+    if "oracle_check" in e:
+        out["oracle_check"] = e["oracle_check"].get("result")
+    return out
+
+
+def compact_line(full, full_path=None):
+    """The contract line the driver parses. Everything bulky (per-kernel tables, prose notes, per-workload detail) stays in `full`
+    (written to `full_path`, and each workload's full entry is its own EARLIER stdout line)."""
+    line = {k: _sig(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(full.get("config", {}))
+    cfg["workload"] = _clip(cfg.get("workload", ""), 240)
+    for k in list(cfg):
+        if isinstance(cfg[k], str) and k != "workload":
+            cfg[k] = _clip(cfg[k], 120)
+    line["config"] = cfg
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    if full.get("roofline") and full["roofline"].get("valu"):
+        line["roofline"]["valu_issue_frac"] = _sig(full["roofline"]["valu"].get("valu_issue_frac_at_probed_clock"))
+    line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    if "clock" in full and full["clock"]:
+        line["clock_mhz"] = _sig(full["clock"].get("shader_clock_mhz"))
+    if "copy_bw" in full:
+        line["copy_bw_GBps"] = _sig(full["copy_bw"].get("GBps"))
+    if "kernel_ms_per_step" in full:
+        line["kernel_ms_per_step"] = {k: _sig(v, 4) for k, v in full["kernel_ms_per_step"].items()}
+    ex_full = full.get("extras", {})
+    ex = {}
+    for k in ("genomes_sketched_per_s", "bases_sketched_per_s", "api_pairs_per_s", "host_ascii_pairs_per_s", "host_packed_pairs_per_s", "queries_per_s", "workloads_wall_s", "hits_digest"):
+        if k in ex_full:
+            ex[k] = _sig(ex_full[k])
+    if "exchange" in ex_full:
+        ex["exchange"] = _pick(ex_full["exchange"], ("rccl_ranks", "bytes_sent_per_rank_last_step", "collective_s_last_step", "psk_s_last_step", "outside_psk_and_collectives_frac"))
+    if "workloads" in ex_full:
+        ex["workloads"] = {k: compact_workload(v) for k, v in ex_full["workloads"].items() if v}
+    line["extras"] = ex
+    if full_path:
+        line["full"] = full_path
+    if len(json.dumps(line)) >= LINE_BUDGET:      # never exceed the budget: drop the least important parts, in this order
+        line.pop("kernel_ms_per_step", None)
+    if len(json.dumps(line)) >= LINE_BUDGET and "workloads" in ex:
+        ex["workloads"] = {k: _pick(v, ("ms_per_step", "value", "unit")) for k, v in ex["workloads"].items()}
+    while len(json.dumps(line)) >= LINE_BUDGET and ex.get("workloads"):
+        ex["workloads"].popitem()
+        ex["workloads_truncated"] = True
+    return line
+
+
+def write_full(full, tag):
+    """the complete object: profiles/r4/ (tracked) and gpurun_out/ (what travels back from the GPU box). Returns the repo-relative path."""
+    name = f"bench_full_{tag}_{time.strftime('%Y%m%d_%H%M%S')}.json"
+    rel = None
+    for d in (os.path.join("gpurun_out"), os.path.join("profiles", "r4")):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, name), "w") as f:
+                json.dump(full, f, indent=1)
+            rel = os.path.join(d, name)
+        except OSError:
+            pass
+    return rel
+
+
+def spawn_decision(gpus, env):
+    """bench.py --gpus N without a launcher starts its own N ranks: True when this process must become the launcher's parent.
+    (The driver's own launch sets WORLD_SIZE; a rank never spawns.)"""
+    return gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def spawn_ranks(gpus, argv):
+    """Start `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD (never exec: this process stays the
+    parent and exits with the child's code), pass its output through, and repeat rank 0's contract line as the LAST stdout line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            if last is not None:
+                print(last, flush=True)
+            last = t
+        else:
+            sys.stdout.write(ln); sys.stdout.flush()
+    rc = proc.wait()
+    if last is not None:
+        print(last, flush=True)
+    return rc
+
+
+def device_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
+    """SURVEY.md §8(d)'s second denominator: the rate of a plain device-to-device copy on this box (bytes read + bytes written per second)"""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device); b = torch.empty_like(a)
+    a.zero_(); b.copy_(a); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return {"GBps": 2.0 * nbytes / (ms * 1e-3) / 1e9, "bytes": nbytes, "ms": ms, "how": "torch copy_ of 1 GiB device to device, read + written bytes over the HIP-event time"}
+
+
 # ------------------------------------------------------------------ synthetic data (built on the GPU)
 def family_layout(seed_shared, n_genomes, n_families):
     """Family model of SURVEY.md §8(d): ancestors of iid ACGT, L ~ U[4.5, 5.5] Mb; genome i belongs to family i // (n / families).
@@ -516,6 +679,8 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
         else:
             comm = parallel.TorchComm(job.dist, None, job.coll_device)
 
+    sent = {"bytes": 0}
+
     def step():
         out = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, n)
         db = eng.make_db(names, out, n - 1)
@@ -525,8 +690,10 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
             eng.lib.psk_sketch_free(out[n - 1])
             eng.lib.psk_db_destroy(db)
         if comm is not None:   # exchange step: all-gather of the per-shard hit records (RCCL over xGMI), global reference indices
+            b0 = comm.bytes_sent
             recs["ref_index"] += rank * n_refs
             recs, _ = comm.gather_hit_records(recs)
+            sent["bytes"] = comm.bytes_sent - b0
         return len(recs)
 
     dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
@@ -552,13 +719,15 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
             "metric": "genome-pairs/sec (sketch+ANI)", "value": n_refs * world * steps / dt, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15",
+            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15; device-resident ASCII in, hit list on host out (from host memory: extras.host_ascii_pairs_per_s)",
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)" + (f", hit lists all-gathered ({job.args.comm})" if world > 1 else "")},
             "roofline": roof, "clock": clock,
             "kernel_ms_per_step": {k: table[k]["ms_per_step"] for k in KERNELS},
             "extras": {"genomes_sketched_per_s": (n_refs + 1) * world * steps / dt, "bases_sketched_per_s": bases * world * steps / dt,
                        "reported_hits_per_step": int(n_hits), "chain_work_per_step": work},
         }
+        if comm is not None:
+            line["extras"]["exchange"] = {"rccl_ranks": int(job.dist.get_world_size()), "backend": job.args.backend, "bytes_sent_per_rank_last_step": int(sent["bytes"])}
         if world == 1 and (cpu_sample > 0 or with_api):
             host = buf.cpu().numpy()
             fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
@@ -624,7 +793,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
         digest = records_digest(recs)
         table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
-                "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}), c=125 marker_c=1000 k=15",
+                "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
                 "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
         if cpu_queries > 0:
@@ -661,10 +830,10 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
             other = st["total_s"] - st["psk_s"] - st["collective_s"]
             table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
             line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
-                    "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15; "
+                    "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15, device-resident ASCII; "
                                 f"query side = all-gather of the shards' packed sketch records, {args.exchange_batch} genomes per rank and round; hit records all-gathered once ({args.comm})",
                     "hits": int(n_hits), "hits_digest": records_digest(state["recs"]), "scaling": "strong",
-                    "exchange": {"bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
+                    "exchange": {"rccl_ranks": int(job.dist.get_world_size()), "backend": args.backend, "bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
                                  "python_s_last_step": other, "all_vs_all_s_last_step": st["total_s"],
                                  "outside_psk_and_collectives_frac": other / st["total_s"] if st["total_s"] > 0 else None,
                                  "note": "rank 0's split of the last step's ShardedDatabase.all_vs_all_records call (sketching the shard and loading the database come before it)"},
@@ -709,7 +878,7 @@ def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs,
         entry = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": n_queries * job.world * steps / dt, "unit": "queries/s",
                  "pairs_per_s": float(n_queries) * n_refs * job.world * steps / dt,
                  "workload": f"metagenome: {n_queries} contigs (2-50 kb, log-uniform, 0-5 % divergence) vs a resident database of {n_refs} synthetic ~5 Mb refs ({n_families} families), "
-                             f"c=30 marker_c=200 k=15, faster_small={faster_small}; a step = sketch every contig + psk_query_many + hits to host",
+                             f"c=30 marker_c=200 k=15, faster_small={faster_small}, device-resident ASCII; a step = sketch every contig + psk_query_many + hits to host",
                  "hits": int(n_hits), "chain_work_per_step": work, "db_build_s": db_build_s,
                  "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock}
         if job.world == 1 and cpu_contigs > 0 and job.rank == 0:
@@ -933,6 +1102,10 @@ def main():
     ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: this process starts the N ranks itself, BEFORE torch is imported or any HIP call is made
+    if spawn_decision(args.gpus, os.environ):
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -956,6 +1129,7 @@ def main():
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     job = Job(torch, device, local_rank, rank, world, dist, coll_device, args)
+    job.copy_bw = device_copy_bandwidth(torch, device)
     cpu_n = args.cpu_sample if world == 1 else 0
 
     def as_line(entry, workload, extra_cfg=None):
@@ -998,7 +1172,17 @@ def main():
              else run_mammalian(job, args.steps, args.warmup, args.refs or 8, args.contig_mb, 2 if cpu_n > 0 else 0))
         line = as_line(e, "mammalian") if rank == 0 else None
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        line["n_gpus"] = world
+        line["copy_bw"] = job.copy_bw
+        for r in [line.get("roofline")] + [w.get("roofline") for w in line.get("extras", {}).get("workloads", {}).values() if w]:
+            if r and r.get("achieved") and job.copy_bw["GBps"] > 0:
+                r["frac_of_copy_bw"] = r["achieved"] / job.copy_bw["GBps"]
+        # every workload's full entry is its own stdout line, the complete object goes to disk, the LAST line is the compact contract line
+        for k, w in line.get("extras", {}).get("workloads", {}).items():
+            if w:
+                print(json.dumps({"workload_entry": k, **w}), flush=True)
+        path = write_full(line, args.workload + (f"_n{world}" if world > 1 else ""))
+        print(json.dumps(compact_line(line, path)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,72 @@
+"""CPU: the bench's contract line stays inside the driver's stdout tail, and `--gpus N` decides to start its own ranks.
+
+Round 3's line was 21 kB; the driver keeps an 8 kB tail and could not parse it (BENCH_r03.json: parsed = null). The mock below is
+that very line (profiles/r3/r3z_bench_default.json): the compact form of it must fit in 4 kB and still carry the contract's keys."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import importlib
+    return importlib.import_module("bench")
+
+
+def _mock_full():
+    return json.load(open(os.path.join(ROOT, "profiles", "r3", "r3z_bench_default.json")))
+
+
+def test_compact_line_fits_the_driver_tail_and_keeps_the_contract(bench):
+    full = _mock_full()
+    assert len(json.dumps(full)) > 16000                      # the mock really is the line that broke the parser
+    full["copy_bw"] = {"GBps": 4321.0}
+    full["roofline"]["frac_of_copy_bw"] = 0.4
+    line = bench.compact_line(full, "profiles/r4/bench_full_search_x.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET == 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-4) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-4)
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "frac_of_copy_bw"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["cpu_baseline"]["all_cores"]["cores"] == full["cpu_baseline"]["all_cores"]["cores"]
+    wl = line["extras"]["workloads"]
+    assert set(wl) == {k for k, v in full["extras"]["workloads"].items() if v}
+    for k, w in wl.items():
+        if "ms_per_step" in full["extras"]["workloads"][k]:
+            assert set(w) >= {"ms_per_step", "value", "unit", "hits", "roofline"}, (k, w)
+            assert set(w["roofline"]) <= {"kernel", "frac", "traffic"}
+    assert "model" not in line["config"] and "workload" in line["config"]
+
+
+def test_compact_line_never_exceeds_the_budget_even_with_many_workloads(bench):
+    full = _mock_full()
+    w = full["extras"]["workloads"]
+    for i in range(40):
+        w[f"copy{i}"] = dict(w["allvsall_10k"])
+    assert len(json.dumps(bench.compact_line(full))) < bench.LINE_BUDGET
+
+
+def test_gpus_n_without_a_launcher_spawns_its_own_ranks(bench):
+    assert bench.spawn_decision(8, {}) is True
+    assert bench.spawn_decision(2, {"PATH": "/bin"}) is True
+    assert bench.spawn_decision(1, {}) is False                          # the default run stays one process
+    assert bench.spawn_decision(8, {"WORLD_SIZE": "8", "RANK": "3"}) is False   # a rank started by the driver's torch.distributed.run never spawns
+    assert bench.spawn_decision(8, {"WORLD_SIZE": "1"}) is False
+
+
+def test_spawn_happens_before_torch_is_imported_or_hip_is_touched():
+    """the launcher parent must not initialise the GPU: the decision sits above `import torch` in main()"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("spawn_decision(") < main.index("import torch")
+    assert "os.exec" not in src and "execv" not in src
