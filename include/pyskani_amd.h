@@ -110,6 +110,9 @@ psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, ui
 /* Work of the chain stage since the last reset: pairs that reached chain_seeds (lib.rs:652-653), (pair, query seed) items joined,
  * anchors emitted. The per-kernel algorithmic bytes of bench.py are counted from these. Any pointer may be NULL. */
 psk_status psk_ctx_work(psk_ctx* ctx, uint64_t* pairs, uint64_t* items, uint64_t* anchors, int reset);
+/* Measurement: psk_query_host calls since the context was created that ran as one launch sequence (`taken`), that exceeded one of its
+ * capacities and were rerun on the general path (`rerun`), and that went to the general path at once (`general`, which includes `rerun`). */
+psk_status psk_ctx_small_query_stats(psk_ctx* ctx, uint64_t* taken, uint64_t* rerun, uint64_t* general);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
 psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
 psk_status psk_device_free(psk_ctx* ctx, void* dptr);
@@ -252,6 +255,14 @@ psk_status psk_chain(psk_ctx* ctx, const psk_sketch* const* refs, uint32_t n_ref
 /* Database.query: screen, chain the shortlist, keep ani > 0.1. hits in ref insertion order. */
 psk_status psk_query(psk_db* db, const psk_sketch* query, const psk_query_opts* o,
                      psk_hit** hits, uint64_t* n_hits);
+
+/* Database.query from the caller's host bytes, as the reference's pymethod runs it (lib.rs:549-660: `_sketch` of the query at
+ * :571 - not stored - then the screen / chain closure): contigs[i] is lens[i] ASCII bytes, borrowed for the call; contigs shorter
+ * than 500 are ignored (lib.rs:156); seed = the `seed` kwarg (lib.rs:553). Same hits as psk_sketch_host + psk_query + psk_sketch_free.
+ * A small genome (one or a few contigs, up to ~90 kb at c = 30 / ~380 kb at c = 125) runs as ONE launch sequence with ONE
+ * synchronisation (csrc/small_query.hip); $PSK_SMALL_QUERY=0 keeps every call on the general path (tests, A/B). */
+psk_status psk_query_host(psk_db* db, const uint8_t* const* contigs, const uint64_t* lens, uint32_t n_contigs, int seed,
+                          const psk_query_opts* o, psk_hit** hits, uint64_t* n_hits);
 
 /* n_queries x Database.query against one database (all-vs-all and metagenome-bin workloads, BASELINE
  * configs[2]/[3]); offsets has n_queries+1 entries, hits of query i are hits[offsets[i]..offsets[i+1]). */

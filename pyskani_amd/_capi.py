@@ -48,10 +48,10 @@ class Seed(C.Structure):
 # every symbol include/pyskani_amd.h declares
 SYMBOLS = [
     "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
-    "psk_ctx_synchronize", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
+    "psk_ctx_synchronize", "psk_ctx_small_query_stats", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_free_many", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
-    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_many",
+    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_host", "psk_query_many",
     "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe", "psk_ctx_work",
     "psk_comm_unique_id", "psk_comm_create", "psk_comm_destroy", "psk_comm_info", "psk_gather_hits", "psk_gather_sketches",
     "psk_model_create", "psk_model_load_json", "psk_model_load_file", "psk_model_free", "psk_model_info", "psk_model_predict",
@@ -78,6 +78,7 @@ def load():
     lib.psk_ctx_destroy.argtypes = [vp]
     lib.psk_ctx_destroy.restype = None
     lib.psk_ctx_synchronize.argtypes = [vp]
+    lib.psk_ctx_small_query_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.psk_ctx_set_timing.argtypes = [vp, C.c_int]
     lib.psk_ctx_timing.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
     lib.psk_db_add_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), u32]
@@ -108,6 +109,7 @@ def load():
     lib.psk_screen.argtypes = [vp, vp, C.c_double, C.c_int, vp, vp]
     lib.psk_chain.argtypes = [vp, C.POINTER(vp), u32, vp, C.POINTER(QueryOpts), C.POINTER(Hit)]
     lib.psk_query.argtypes = [vp, vp, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
+    lib.psk_query_host.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_query_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_sketch_pack_size.argtypes = [vp, C.POINTER(u64)]
     lib.psk_sketch_pack.argtypes = [vp, vp, u64]

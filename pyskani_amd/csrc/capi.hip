@@ -221,6 +221,13 @@ psk_status psk_ctx_work(psk_ctx* c, uint64_t* pairs, uint64_t* items, uint64_t* 
     return PSK_OK;
 }
 
+psk_status psk_ctx_small_query_stats(psk_ctx* c, uint64_t* taken, uint64_t* rerun, uint64_t* general) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    if (taken) *taken = c->sq_taken.load();
+    if (rerun) *rerun = c->sq_rerun.load();
+    if (general) *general = c->sq_general.load();
+    return PSK_OK;
+}
 psk_status psk_device_alloc(psk_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) { psk_set_error("device_alloc: NULL argument"); return PSK_EINVAL; }
     PSK_HIP(hipSetDevice(c->device));
@@ -419,7 +426,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     db->refs.push_back(s);
     db->names.emplace_back(name);
     db->note_added((uint32_t)db->refs.size() - 1);
-    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0;
     return PSK_OK;
 }
 
@@ -433,7 +440,7 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
         db->names.emplace_back(names[i]);
         db->note_added((uint32_t)db->refs.size() - 1);
     }
-    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0;
     return PSK_OK;
 }
 
@@ -471,6 +478,35 @@ psk_status psk_query(psk_db* db, const psk_sketch* q, const psk_query_opts* o, p
     PSK_TRY(hits_out(all, hits));
     *n_hits = nh;
     return PSK_OK;
+}
+
+/* Database.query as the reference runs it (lib.rs:549-660): the query genome arrives as host ASCII contigs, is sketched (lib.rs:571, not stored)
+ * and queried. Same hits as psk_sketch_host + psk_query + psk_sketch_free. A small genome (a contig, a bin of a few hundred kb) takes the
+ * one-launch-sequence path of small_query.hip - one upload, four kernels, one download, one synchronisation; anything else, or a call that
+ * exceeds that path's capacities, runs the two general calls here. */
+psk_status psk_query_host(psk_db* db, const uint8_t* const* contigs, const uint64_t* lens, uint32_t n_contigs, int want_seeds,
+                          const psk_query_opts* o, psk_hit** hits, uint64_t* n_hits) {
+    if (!db || !o || !hits || !n_hits || (n_contigs && (!contigs || !lens))) { psk_set_error("query_host: NULL argument"); return PSK_EINVAL; }
+    *hits = nullptr; *n_hits = 0;
+    HitList all;
+    if (want_seeds) {
+        PSK_LANE(lg, db->ctx);
+        bool done = false;
+        PSK_TRY(query_host_small(lg.lane, db, contigs, lens, n_contigs, o, all, &done));
+        if (!done) db->ctx->sq_general++;
+        if (done) {
+            const uint64_t nh = all.n;
+            PSK_TRY(hits_out(all, hits));
+            *n_hits = nh;
+            return PSK_OK;
+        }
+        all.n = 0;
+    }
+    psk_sketch* q = nullptr;
+    PSK_TRY(psk_sketch_host(db->ctx, &db->params, contigs, lens, n_contigs, want_seeds, &q));
+    const psk_status rc = psk_query(db, q, o, hits, n_hits);
+    delete q;
+    return rc;
 }
 
 /* Many queries against one database. Same result as n_queries x psk_query; hits of query i are

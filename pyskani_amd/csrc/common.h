@@ -94,6 +94,8 @@ struct psk_ctx {
     uint64_t acc_n[K_COUNT] = {0};
     // work done by the chain stage since the last reset (psk_ctx_work): what the algorithmic bytes of its kernels are counted from
     std::atomic<uint64_t> w_pairs{0}, w_items{0}, w_anchors{0};
+    // psk_query_host calls that ran as one launch sequence / were rerun on the general path because a capacity was exceeded / never qualified (psk_ctx_small_query_stats)
+    std::atomic<uint64_t> sq_taken{0}, sq_rerun{0}, sq_general{0};
     // lanes: created on demand, at most max_lanes; a call takes a free one (LaneGuard) and gives it back
     std::mutex lanes_mu;
     std::condition_variable lanes_cv;
@@ -205,6 +207,7 @@ struct Lane {
     }
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
+    Scratch q_small;                                                                       // the one-launch-sequence query's workspace (small_query.hip)
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
     size_t h_pinned_cap = 0;
     psk_status pinned(size_t bytes, void** out) {
@@ -219,7 +222,7 @@ struct Lane {
         return PSK_OK;
     }
     void release_all() {
-        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel};
+        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small};
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (Scratch* s : all) s->release();
         jobs_release();
@@ -456,6 +459,8 @@ struct psk_db {
     uint64_t desc_indexed = 0; uint32_t desc_n = 0;
     PoolScratch d_refdesc, d_canon;
     std::vector<SketchDesc> h_refdesc;
+    // the one-launch-sequence query (small_query.hip): 1 = every device table it reads is up to date, 2 = this database cannot take it; reset when references are added
+    std::atomic<int> small_state{0};
 };
 
 // learned-ANI regression model: flattened trees in HBM
@@ -473,6 +478,51 @@ struct psk_model {
 // pair_qr[p] = (index into qd, index into rd) of pair p.
 void learned_apply_launch(const psk_model* m, psk_hit* d_hits, const uint2* pair_qr, const SketchDesc* qd, const SketchDesc* rd,
                           uint32_t n_pairs, hipStream_t st);
+
+// ---- sketch kernel descriptors (sketch.hip; the host side of small_query.hip fills them too) ----
+struct ContigDesc {
+    uint64_t byte_off;     // offset of the contig in the ASCII buffer (16-byte aligned)
+    uint32_t len;
+    uint32_t first_tile;   // tiles of one contig are consecutive
+    uint32_t genome;       // genome index inside the batch
+    uint32_t contig_index; // index among the genome's kept contigs
+    uint32_t pad0, pad1;
+};
+
+struct SketchConsts {
+    uint64_t thr, thr_marker;
+    uint32_t kmask;     // (1 << 2k) - 1
+    int k, d, rshift;   // d = distance from window end to the seed's last base; rshift = 2k-2
+    int delta;          // 16 - (21-k)/2: delay (bases) that puts every seed's FIRST base at a fixed index in sketch_scan
+};
+
+
+// ---- the one-launch-sequence query of a small genome from host bytes (psk_query_host; small_query.hip) -------------------------
+// Fixed capacities: a call whose genome does not fit them takes the general path (psk_sketch_host + psk_query).
+constexpr uint32_t SQ_MAX_TILES = 64, SQ_MAX_DESC = 64;     // tiles of 16 384 bases / kept contigs of the query
+constexpr uint32_t SQ_SEEDS = 3072;        // query seeds, and anchors of one (query, reference) pair, the fused chain kernel holds in LDS
+constexpr uint32_t SQ_MARKERS = 2048;      // raw query markers the screen workgroup sorts in LDS
+constexpr uint32_t SQ_ROWS = 64;           // chunk-table rows of a pair
+constexpr uint32_t SQ_CANDS = 256;         // candidate chains of a pair
+constexpr uint32_t SQ_HITS_FIRST = 256;    // hit records that cross with the status words in the one download
+constexpr uint32_t SQ_F_SEEDS = 1u, SQ_F_MARKERS = 2u, SQ_F_PAIR = 4u;      // flags: a capacity was exceeded -> the general path reruns the call
+struct SmallQHead {
+    uint32_t n_seeds, n_markers_raw, n_markers, n_short;      // seeds of the query, raw / distinct markers, shortlisted references
+    uint32_t flags, pad0;
+    unsigned long long n_anchors;                              // anchors over all pairs (psk_ctx_work)
+    uint32_t coff[SQ_MAX_DESC + 1];                            // first seed of every kept contig
+    uint32_t pad1[128 - 8 - (SQ_MAX_DESC + 1)];
+};
+static_assert(sizeof(SmallQHead) == 512, "the status block is 512 bytes, the hits follow it");
+struct SmallQSketch {      // device arrays of the query's sketch (lane-owned, reused from call to call)
+    const uint8_t* d_bases; const ContigDesc* d_desc; const uint32_t* d_tci; const uint4* d_tinfo; const uint32_t* d_cft;
+    uint32_t n_desc, n_tiles;
+    uint32_t *d_packed; uint64_t* d_mask; uint32_t *d_cnt, *d_toff, *d_tmc;
+    uint32_t *seed_kmer, *seed_pos, *seed_meta; uint64_t* seed_pm; uint64_t* mstage;
+    SmallQHead* head;
+};
+// sketch_scan + sketch_emit (tile offsets computed by the emit waves themselves) on `st`; no synchronisation (sketch.hip)
+psk_status small_query_sketch_enqueue(Lane* ctx, const psk_params* p, const SmallQSketch& A, hipStream_t st);
 
 // ---- shared device helpers ----
 __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
@@ -565,3 +615,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                            HitList& all, uint64_t* offsets);
 psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);
+// Database.query from host bytes (lib.rs:549-660 with the _sketch call inside it): the one-launch-sequence path for a small genome
+// (small_query.hip; *done = false: not eligible or a capacity was exceeded - the caller takes psk_sketch_host + query_many_impl)
+constexpr uint32_t SQ_MAX_REFS = 24 * 1024;      // the screen workgroup keeps one shared-marker counter per reference in LDS
+psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs, const uint64_t* lens, uint32_t n_contigs, const psk_query_opts* o,
+                            HitList& all, bool* done);
+// what that path reads on the device (query.hip): marker table, inverted marker index, canon table, every reference indexed and described.
+// Called with the database locked SHARED through `sh`; *ok = false: this database cannot take the path (a reference without seeds, other parameters)
+psk_status small_query_prepare(Lane* ctx, psk_db* db, std::shared_lock<std::shared_mutex>& sh, bool* ok);

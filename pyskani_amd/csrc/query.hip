@@ -5,6 +5,7 @@
 //                                                                        chain_chunk / pair_reduce
 // Semantics are normative in oracle/skani_oracle.c (orc_screen / orc_chain).
 #include "common.h"
+#include "chain_dev.h"
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <algorithm>
@@ -13,7 +14,7 @@
 
 // ------------------------------------------------------------------ screen
 static inline size_t al256s(size_t x) { return (x + 255) & ~(size_t)255; }
-struct MarkerSet { const uint64_t* p; uint32_t n; uint32_t pad; };
+
 
 __global__ __launch_bounds__(256) void screen_kernel(const MarkerSet* __restrict__ refs, const uint64_t* __restrict__ qm,
                                                      uint32_t nq, double thresh, int rescue_small,
@@ -367,13 +368,6 @@ static psk_status screen_many_device(Lane* ctx, psk_db* db, const psk_sketch* co
         ctx->t_end();
     }
     return PSK_OK;
-}
-
-// LDS hand-off between lanes of ONE wave: order the ds ops, no workgroup barrier
-__device__ __forceinline__ void lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // ------------------------------------------------------------------ anchors
@@ -1478,32 +1472,6 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
 constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4)
 constexpr int LANE_WAVES = 2;
 constexpr int LANE_TREES = 4;        // qualifying chain trees per chunk kept in registers
-
-// u = q - r', r' the strand-signed reference position (-r on the reverse strand): the anchor's diagonal. With it the gap of a
-// pair is |ux - uy| and dr = dq - (ux - uy): three instructions fewer per (anchor, predecessor) pair than from q and r.
-struct LaneAnchor { uint32_t q, u, m; int32_t f; };
-__device__ __forceinline__ uint32_t lane_diag(uint32_t qx, uint32_t rx, uint32_t sg) { return qx - ((rx ^ sg) - sg); }
-
-// key of predecessor y for anchor x at distance d, NEGATIVE when y is not chainable; same rule as the wave kernel and the oracle.
-// The DP kernel's time is its VALU instruction count (profiles/r3/r3a_chain_lane20_counters.md: 65 % of all issue cycles at three
-// waves per SIMD, the rest waits), so the step is written for it: a predecessor is kept as (q + 1, diagonal, contig | strand,
-// score - 1) - the two "- 1" of the range tests are paid once per anchor instead of once per pair -, every requirement is a sign
-// bit, and the verdict is the key's own sign (one v_and_or) so that the running maximum, taken signed, skips what is not chainable.
-// ISA per (anchor, predecessor) pair: 8 v_sub, 3 v_or3, v_xor, v_lshl_add, v_and_or, 2 v_max = 17 instructions / 46 issue cycles;
-// the first version had 20 / 70 (its mask came out as v_cmp + v_cndmask, the slowest VALU instruction there is: 32.8 -> 29.3 ms).
-struct LanePred { uint32_t q1, u, m; int32_t f1; };
-__device__ __forceinline__ int32_t lane_eval2(uint32_t qx, uint32_t ux, uint32_t mx, const LanePred& y, int d) {
-    const int32_t a = (int32_t)(qx - y.q1);                               // dq - 1
-    const int32_t t = (int32_t)(ux - y.u), nt = (int32_t)(y.u - ux);      // dq - dr (strand -: dr = ry - rx)
-    const int32_t gap = t > nt ? t : nt;
-    const int32_t b = a - t;                                              // dr - 1
-    const int32_t s1 = y.f1 - gap;                                        // score - ANCHOR_SCORE2 - 1
-    const uint32_t z = y.m ^ mx;
-    // 1 <= dq <= 2500, dr >= 1, gap <= 300, score > 40, same ref contig and strand
-    const uint32_t bad = (uint32_t)a | (uint32_t)(BP_CHAIN_BAND - 1 - a) | (uint32_t)b | (uint32_t)(MAX_GAP_LENGTH - gap) | (uint32_t)s1 | z | (0u - z);
-    const uint32_t key = ((uint32_t)s1 << 7) + ((((uint32_t)ANCHOR_SCORE2 + 1u) << 7) | (127u - (uint32_t)d));      // scores stay below 2^20 (a chunk holds < 16 384 anchors): the key's sign bit is free
-    return (int32_t)(key | (bad & 0x80000000u));
-}
 
 // XT: further tree slots per lane in LDS (0, or LANE_XTREES for Gb-scale pairs: there a seed has ~6 chance 15-mer matches beside the
 // true one, the band of 20 ANCHORS reaches back only ~3 seeds, a true chain breaks wherever three seeds in a row do not match and a
@@ -4299,5 +4267,45 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         PSK_TRY(consume());
         for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i] + q_hits[i];
     }
+    return PSK_OK;
+}
+
+
+// ------------------------------------------------------------------ what the one-launch-sequence query (small_query.hip) reads on the device
+psk_status small_query_prepare(Lane* ctx, psk_db* db, std::shared_lock<std::shared_mutex>& sh, bool* ok) {
+    *ok = false;
+    const int state = db->small_state.load(std::memory_order_acquire);
+    if (state == 1) { *ok = true; return PSK_OK; }
+    if (state == 2) return PSK_OK;
+    const uint32_t n = (uint32_t)db->refs.size();
+    if (n == 0 || n > SQ_MAX_REFS) return PSK_OK;      // (not recorded: the database may grow into / out of the range)
+    for (const psk_sketch* r : db->refs)
+        if (!r->has_seeds || !r->store || r->params.k != db->params.k || r->params.c != db->params.c) { db->small_state = 2; return PSK_OK; }
+    sh.unlock();
+    psk_status rc = PSK_OK;
+    {
+        std::unique_lock<std::shared_mutex> ex(db->rw);
+        if (db->refs.size() == n && db->small_state.load() == 0) {
+            auto build = [&]() -> psk_status {
+                PSK_TRY(upload_marker_table(ctx, db));
+                PSK_TRY(build_inverted(ctx, db));
+                if (db->has_dups && db->canon_dirty) {
+                    PSK_TRY(db->d_canon.reserve(ctx->dev, 4 * (size_t)n));
+                    PSK_HIP(hipMemcpyAsync(db->d_canon.p, db->canon.data(), 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+                    db->canon_dirty = false;
+                }
+                std::vector<const psk_sketch*> all_refs(db->refs.begin(), db->refs.end());
+                PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
+                PSK_TRY(refresh_ref_descs(ctx, db));
+                PSK_HIP(hipStreamSynchronize(ctx->stream));
+                return PSK_OK;
+            };
+            rc = build();
+            if (rc == PSK_OK) db->small_state.store(1, std::memory_order_release);
+        }
+    }
+    sh.lock();
+    PSK_TRY(rc);
+    *ok = db->small_state.load(std::memory_order_acquire) == 1 && db->refs.size() == n;
     return PSK_OK;
 }

@@ -14,22 +14,6 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 
-struct ContigDesc {
-    uint64_t byte_off;     // offset of the contig in the ASCII buffer (16-byte aligned)
-    uint32_t len;
-    uint32_t first_tile;   // tiles of one contig are consecutive
-    uint32_t genome;       // genome index inside the batch
-    uint32_t contig_index; // index among the genome's kept contigs
-    uint32_t pad0, pad1;
-};
-
-struct SketchConsts {
-    uint64_t thr, thr_marker;
-    uint32_t kmask;     // (1 << 2k) - 1
-    int k, d, rshift;   // d = distance from window end to the seed's last base; rshift = 2k-2
-    int delta;          // 16 - (21-k)/2: delay (bases) that puts every seed's FIRST base at a fixed index in sketch_scan
-};
-
 // ---- ASCII -> 2-bit, four bytes at a time; every byte that is not ACGT/acgt maps to 0 ----
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {  // 0x80 in each byte of v that is 0
     uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
@@ -215,18 +199,37 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int n) {
 constexpr int EMIT_WAVES = 4;      // tiles per workgroup (independent waves)
 constexpr int EMIT_LIST = 1024;    // seed positions listed per pass
 
-__global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
+// SELF: the tiles' seed offsets are not given - every wave forms them from the tiles' counts (n_tiles <= 64: one count per lane, a shuffle scan), and
+// the wave of tile 0 leaves them, the total and the contigs' first seeds for the kernels that follow (the one-launch-sequence query of a small genome)
+template <bool SELF>
+__device__ __forceinline__ void sketch_emit_body(
     const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed,
-    const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
-    const uint32_t* __restrict__ genome_seed_off, uint32_t n_tiles,
+    const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off, uint32_t n_tiles,
     uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
     uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ tile_mcount,
-    SketchConsts C, uint32_t seed_cap) {
+    const SketchConsts& C, uint32_t seed_cap,
+    const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ toff_out, const uint32_t* __restrict__ cft, uint32_t n_desc, SmallQHead* __restrict__ head) {
     __shared__ __align__(16) uint32_t s_words_all[EMIT_WAVES][TILE_WORDS + 8];   // packed tile + 4 words either side
     __shared__ uint16_t s_list_all[EMIT_WAVES][EMIT_LIST];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * EMIT_WAVES + wv;
     if (tile >= n_tiles) return;
+    uint32_t self_off = 0;
+    if (SELF) {
+        const uint32_t c = (uint32_t)lane < n_tiles ? tile_cnt[lane] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        const uint32_t all = __shfl(inc, 63);
+        self_off = __shfl(inc - c, (int)tile);
+        if (tile == 0) {
+            if ((uint32_t)lane < n_tiles) toff_out[lane] = inc - c;
+            if (lane == 0) { toff_out[n_tiles] = all; head->n_seeds = all; head->flags = all > seed_cap ? SQ_F_SEEDS : 0u; head->n_anchors = 0ull; head->n_short = 0u; }      // (the status block starts from here: no memset)
+            const uint32_t ft = (uint32_t)lane <= n_desc ? cft[lane] : 0u;
+            const uint32_t ex_at = __shfl(inc - c, (int)(ft < 64u ? ft : 0u));      // (every lane takes part in the shuffle: a lane outside a branch has nothing to give)
+            if ((uint32_t)lane <= n_desc) head->coff[lane] = ft < n_tiles ? ex_at : all;
+        }
+    }
     uint32_t* s_words = s_words_all[wv];
     uint16_t* s_list = s_list_all[wv];
     // four consecutive 64-base stripes per lane
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
     const ulonglong2 ma = mp[0], mb = mp[1];
     const unsigned long long m[4] = {ma.x, ma.y, mb.x, mb.y};
     const uint4 ti = tile_info[tile];          // {first_tile, genome, contig_index, contig id}
-    const uint32_t t_off = tile_off[tile];
+    const uint32_t t_off = SELF ? self_off : tile_off[tile];
     const uint32_t cnt = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
     uint32_t incl = cnt;
 #pragma unroll
@@ -303,6 +306,26 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (lane == 0) tile_mcount[tile] = mrun;
+}
+
+__global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_kernel(
+    const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed,
+    const uint64_t* __restrict__ seedmask, const uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ genome_seed_off, uint32_t n_tiles,
+    uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
+    uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ tile_mcount,
+    SketchConsts C, uint32_t seed_cap) {
+    sketch_emit_body<false>(tile_info, packed, seedmask, tile_off, n_tiles, seed_kmer, seed_pos, seed_meta, seed_pm, marker_stage, tile_mcount, C, seed_cap,
+                            nullptr, nullptr, nullptr, 0u, nullptr);
+}
+__global__ __launch_bounds__(64 * EMIT_WAVES) void sketch_emit_self_kernel(
+    const uint4* __restrict__ tile_info, const uint32_t* __restrict__ packed, const uint64_t* __restrict__ seedmask, uint32_t n_tiles,
+    uint32_t* __restrict__ seed_kmer, uint32_t* __restrict__ seed_pos, uint32_t* __restrict__ seed_meta,
+    uint64_t* __restrict__ seed_pm, uint64_t* __restrict__ marker_stage, uint32_t* __restrict__ tile_mcount,
+    SketchConsts C, uint32_t seed_cap, const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ toff_out, const uint32_t* __restrict__ cft, uint32_t n_desc,
+    SmallQHead* __restrict__ head) {
+    sketch_emit_body<true>(tile_info, packed, seedmask, nullptr, n_tiles, seed_kmer, seed_pos, seed_meta, seed_pm, marker_stage, tile_mcount, C, seed_cap,
+                           tile_cnt, toff_out, cft, n_desc, head);
 }
 
 // dense per-genome marker staging: tile t's markers move from marker_stage[tile_off[t] ..) to dense[tile_moff[t] ..)
@@ -550,6 +573,31 @@ __global__ __launch_bounds__(1024) void sketch_small_offsets_kernel(const uint32
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static SketchConsts make_sketch_consts(const psk_params* p) {
+    SketchConsts C{};
+    C.k = p->k; C.thr = UINT64_MAX / (uint64_t)p->c; C.thr_marker = UINT64_MAX / (uint64_t)p->marker_c;
+    C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
+    C.rshift = 2 * p->k - 2;
+    C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
+    C.delta = 16 - (K_MARKER - p->k) / 2;
+    return C;
+}
+
+// The sketch kernels of the one-launch-sequence query (small_query.hip): the tile -> contig tables come from the host with the bases (ONE upload),
+// sketch_scan runs as ever, the emit waves form their own offsets. Seeds land in (contig, position) order in A.seed_*, the tiles' raw markers in
+// A.mstage at their tiles' seed offsets with the counts in A.d_tmc (the screen workgroup gathers and sorts them), totals in A.head. Nothing is waited for.
+psk_status small_query_sketch_enqueue(Lane* ctx, const psk_params* p, const SmallQSketch& A, hipStream_t st) {
+    if (A.n_tiles == 0 || A.n_tiles > SQ_MAX_TILES || A.n_desc == 0 || A.n_desc > SQ_MAX_DESC) { psk_set_error("internal: small query beyond its capacities"); return PSK_EINVAL; }
+    const SketchConsts C = make_sketch_consts(p);
+    ctx->t_begin(K_SKETCH_SCAN, st);
+    hipLaunchKernelGGL(sketch_scan_kernel, dim3(A.n_tiles), dim3(TILE_THREADS), 0, st, A.d_bases, A.d_desc, A.d_tci, A.d_packed, A.d_mask, A.d_cnt, C);
+    ctx->t_end(st);
+    ctx->t_begin(K_SKETCH_EMIT, st);
+    hipLaunchKernelGGL(sketch_emit_self_kernel, dim3((A.n_tiles + EMIT_WAVES - 1) / EMIT_WAVES), dim3(64 * EMIT_WAVES), 0, st, A.d_tinfo, (const uint32_t*)A.d_packed, (const uint64_t*)A.d_mask, A.n_tiles,
+                       A.seed_kmer, A.seed_pos, A.seed_meta, A.seed_pm, A.mstage, A.d_tmc, C, SQ_SEEDS, (const uint32_t*)A.d_cnt, A.d_toff, A.d_cft, A.n_desc, A.head);
+    ctx->t_end(st);
+    return PSK_OK;
+}
 struct ToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 
 // One sub-batch of genomes moving through the sketch pipeline on its own stream. The phases are split
@@ -606,11 +654,7 @@ struct SketchJob {
         if (n_tiles64 >= (1ull << 31)) { psk_set_error("batch of %llu bases exceeds the per-launch tile limit; split it", (unsigned long long)total_bases); return PSK_ELIMIT; }
         n_tiles = (uint32_t)n_tiles64; n_desc = (int)descs.size();
         empty = n_tiles == 0;
-        C.k = p->k; C.thr = UINT64_MAX / (uint64_t)p->c; C.thr_marker = UINT64_MAX / (uint64_t)p->marker_c;
-        C.kmask = p->k == 16 ? 0xFFFFFFFFu : ((1u << (2 * p->k)) - 1u);
-        C.rshift = 2 * p->k - 2;
-        C.d = K_MARKER - p->k - (K_MARKER - p->k) / 2;
-        C.delta = 16 - (K_MARKER - p->k) / 2;
+        C = make_sketch_consts(p);
         return PSK_OK;
     }
 

@@ -662,10 +662,27 @@ class Database:
 
     def query_records(self, name, *contigs, seed=True, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False):
         """Database.query returning the psk_hit records (numpy structured array, ref_index = insertion index) instead of `Hit`s."""
+        opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         with Database._Borrow(self, False):
-            q = self._sketch(name, contigs, seed)
-        recs, _ = self.query_handles((C.c_void_p * 1)(q._h), 1, learned_ani=learned_ani, median=median, robust=robust, cutoff=cutoff, faster_small=faster_small)
-        return recs
+            if self._n_lazy:
+                raise RuntimeError("query_records needs a memory-resident database")
+            return self._query_host(contigs, seed, opts)
+
+    def _query_host(self, contigs, seed, opts):
+        """lib.rs:571 + 569-659 in ONE library call (psk_query_host): the query is sketched from the caller's bytes (not stored) and
+        queried; a contig-sized query runs as one launch sequence with one synchronisation. Returns the psk_hit records."""
+        views = [_as_bytes(c) for c in contigs]
+        nc = len(views)
+        arr = (C.c_char_p * max(nc, 1))(*views)
+        lens = (C.c_uint64 * max(nc, 1))(*map(len, views))
+        hits_p = C.POINTER(_capi.Hit)()
+        n = C.c_uint64(0)
+        _capi.check(self._lib.psk_query_host(self._h, arr, lens, nc, int(bool(seed)), C.byref(opts), C.byref(hits_p), C.byref(n)))
+        try:
+            return _capi.hit_records(hits_p, 0, n.value, self._HIT_DTYPE)
+        finally:
+            if hits_p:
+                self._lib.psk_free(hits_p)
 
     def _query_sketches(self, sketches, opts, n):
         if self._n_lazy:      # `open`ed database: sketches come from disk per query
@@ -713,15 +730,8 @@ class Database:
             return self._query(name, contigs, seed, learned_ani, median, robust, cutoff, faster_small)
 
     def _query(self, name, contigs, seed, learned_ani, median, robust, cutoff, faster_small):
-        q = self._sketch(name, contigs, seed)
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         if self._n_lazy:
-            return self._query_lazy(name, q, opts)
-        hits_p = C.POINTER(_capi.Hit)()
-        n = C.c_uint64(0)
-        _capi.check(self._lib.psk_query(self._h, q._h, C.byref(opts), C.byref(hits_p), C.byref(n)))
-        try:
-            return self._hits_from_ptr(hits_p, 0, n.value, name)
-        finally:
-            if hits_p:
-                self._lib.psk_free(hits_p)
+            return self._query_lazy(name, self._sketch(name, contigs, seed), opts)
+        recs = self._query_host(contigs, seed, opts)
+        return self._hits(recs, name) if len(recs) else []

@@ -97,6 +97,7 @@ extern "C" {
     pub fn psk_model_info(m: *const PskModel, n_trees: *mut u32, n_nodes: *mut u64, n_features: *mut u32) -> c_int;
     pub fn psk_model_predict(m: *const PskModel, rows: *const f32, n_rows: u32, out: *mut f32) -> c_int;
     // database: markers.push + sketches.store (lib.rs:501-508)
+    pub fn psk_ctx_small_query_stats(ctx: *mut PskCtx, taken: *mut u64, rerun: *mut u64, general: *mut u64) -> c_int;
     pub fn psk_db_create(ctx: *mut PskCtx, p: *const PskParams, out: *mut *mut PskDb) -> c_int;
     pub fn psk_db_destroy(db: *mut PskDb);
     pub fn psk_db_add(db: *mut PskDb, name: *const c_char, s: *mut PskSketch) -> c_int;
@@ -107,6 +108,10 @@ extern "C" {
     // query: the allow_threads closure of lib.rs:569-659
     pub fn psk_query(db: *mut PskDb, q: *const PskSketch, o: *const PskQueryOpts,
                      hits: *mut *mut PskHit, n_hits: *mut u64) -> c_int;
+    // the same from the caller's host bytes: the query is sketched (lib.rs:571, not stored) and queried in one call - a contig-sized
+    // query runs as one launch sequence with one synchronisation
+    pub fn psk_query_host(db: *mut PskDb, contigs: *const *const u8, lens: *const u64, n_contigs: u32, seed: c_int, o: *const PskQueryOpts,
+                          hits: *mut *mut PskHit, n_hits: *mut u64) -> c_int;
     // many queries in one call (all-vs-all, bins of a metagenome): hits of query i are hits[offsets[i]..offsets[i+1]]
     pub fn psk_query_many(db: *mut PskDb, qs: *const *const PskSketch, n: u32, o: *const PskQueryOpts,
                           hits: *mut *mut PskHit, offsets: *mut u64) -> c_int;

@@ -76,7 +76,10 @@ impl GpuState {
     pub fn query<'c, C>(&self, name: String, contigs: C, seed: bool, learned_ani: Option<bool>, median: bool, robust: bool,
                         cutoff: Option<f64>, faster_small: bool) -> PyResult<Vec<skani::types::AniEstResult>>
     where C: IntoIterator<Item = &'c [u8]> {
-        let q = self.sketch(name.clone(), contigs, seed)?;            // lib.rs:571: the query sketch is not stored
+        // lib.rs:571: the query sketch is not stored - psk_query_host sketches and queries in one call
+        let views: Vec<&[u8]> = contigs.into_iter().collect();
+        let ptrs: Vec<*const u8> = views.iter().map(|v| v.as_ptr()).collect();
+        let lens: Vec<u64> = views.iter().map(|v| v.len() as u64).collect();
         let learned = learned_ani.unwrap_or_else(|| skani::regression::use_learned_ani(self.params.c as usize, false, false, median));
         let model = self.model_for(learned)?;                         // null when get_model returns None
         let opts = PskQueryOpts {
@@ -87,7 +90,7 @@ impl GpuState {
             model,
         };
         let (mut hits, mut n): (*mut PskHit, u64) = (std::ptr::null_mut(), 0);
-        unsafe { ffi::check(ffi::psk_query(self.db, q.handle, &opts, &mut hits, &mut n))?; }
+        unsafe { ffi::check(ffi::psk_query_host(self.db, ptrs.as_ptr(), lens.as_ptr(), ptrs.len() as u32, seed as i32, &opts, &mut hits, &mut n))?; }
         let mut out = Vec::with_capacity(n as usize);
         for i in 0..n as usize {
             let h = unsafe { *hits.add(i) };

@@ -26,7 +26,7 @@ def test_rust_binding_lists_every_symbol_and_handover_files_use_them():
     bound = set(re.findall(r"pub fn (psk_[a-z0-9_]+)\s*\(", text))
     assert bound == declared, bound ^ declared
     patch = open(os.path.join(ROOT, "rust", "lib_patch.rs")).read()
-    for sym in ("psk_ctx_create", "psk_db_create", "psk_sketch_host", "psk_db_add", "psk_query", "psk_db_name", "psk_free", "psk_sketch_free"):
+    for sym in ("psk_ctx_create", "psk_db_create", "psk_sketch_host", "psk_db_add", "psk_query_host", "psk_db_name", "psk_free", "psk_sketch_free"):
         assert f"ffi::{sym}(" in patch, sym
     model = open(os.path.join(ROOT, "rust", "model.rs")).read()
     assert "fn to_psk_model(g: &gbdt::gradient_boost::GBDT)" in model and "ffi::psk_model_create(" in model and "ffi::psk_model_load_json(" in model
