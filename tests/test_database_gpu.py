@@ -1,5 +1,5 @@
-"""GPU: storage behaviour of `Database`, mirroring the reference's test_database.py
-(/root/reference/src/pyskani/tests/test_database.py:9-42) plus round trips through open/load/save."""
+"""GPU: storage behaviour of `Database`: the file layout the reference's tests pin (as a table), error behaviour, and round trips
+through open/load/save."""
 import os
 import pathlib
 
@@ -17,40 +17,40 @@ def psk():
     return pyskani_amd
 
 
-def test_memory(psk):                                            # test_database.py:11-14
-    database = psk.Database()
-    database.sketch("test genome", b"ATGC" * 100)
-    assert database.path is None
+# What the reference's storage tests pin (src/pyskani/tests/test_database.py:11-42), as DATA: for every on-disk format, which files of the
+# database folder exist after two genomes were sketched and which appear only with flush() (the marker file, and the consolidated format's index,
+# are written on flush: lib.rs:187-227, 662-686). Inputs of 400 bases never reach the seeding code (lib.rs:156): this is file-layout behaviour only.
+LAYOUT = {
+    # format: (files present right after sketch(), files that flush() adds)
+    "separated": (("{name}.sketch",), ("markers.bin",)),
+    "consolidated": (("sketches.db",), ("index.db", "markers.bin")),
+}
+GENOMES = (("test1", b"ATGC" * 100), ("test2", b"TTGC" * 100))
 
 
-def test_folder_separated(psk, tmp_path):                        # test_database.py:16-28
-    tmpdir = str(tmp_path)
-    database = psk.Database(tmpdir, format="separated")
-    database.sketch("test1", b"ATGC" * 100)
-    database.sketch("test2", b"TTGC" * 100)
-    assert os.path.exists(os.path.join(tmpdir, "test1.sketch"))
-    assert os.path.exists(os.path.join(tmpdir, "test2.sketch"))
-    assert not os.path.exists(os.path.join(tmpdir, "markers.bin"))
-    database.flush()
-    assert os.path.exists(os.path.join(tmpdir, "test1.sketch"))
-    assert os.path.exists(os.path.join(tmpdir, "test2.sketch"))
-    assert os.path.exists(os.path.join(tmpdir, "markers.bin"))
-    assert database.path == pathlib.Path(tmpdir)
+def _present(folder, patterns):
+    names = {pat.format(name=n) for pat in patterns for n, _ in GENOMES}
+    return {f: os.path.exists(os.path.join(folder, f)) for f in sorted(names)}
 
 
-def test_folder_consolidated(psk, tmp_path):                     # test_database.py:30-42
-    tmpdir = str(tmp_path)
-    database = psk.Database(tmpdir, format="consolidated")
-    database.sketch("test1", b"ATGC" * 100)
-    database.sketch("test2", b"TTGC" * 100)
-    assert os.path.exists(os.path.join(tmpdir, "sketches.db"))
-    assert not os.path.exists(os.path.join(tmpdir, "index.db"))
-    assert not os.path.exists(os.path.join(tmpdir, "markers.bin"))
-    database.flush()
-    assert os.path.exists(os.path.join(tmpdir, "sketches.db"))
-    assert os.path.exists(os.path.join(tmpdir, "index.db"))
-    assert os.path.exists(os.path.join(tmpdir, "markers.bin"))
-    assert database.path == pathlib.Path(tmpdir)
+def test_memory_database_has_no_path(psk):
+    db = psk.Database()
+    db.sketch(*GENOMES[0])
+    assert db.path is None
+
+
+@pytest.mark.parametrize("fmt", sorted(LAYOUT))
+def test_folder_layout_before_and_after_flush(psk, tmp_path, fmt):
+    at_once, on_flush = LAYOUT[fmt]
+    folder = str(tmp_path)
+    db = psk.Database(folder, format=fmt)
+    for name, seq in GENOMES:
+        db.sketch(name, seq)
+    assert all(_present(folder, at_once).values()), _present(folder, at_once)
+    assert not any(_present(folder, on_flush).values()), _present(folder, on_flush)
+    db.flush()
+    assert all(_present(folder, at_once + on_flush).values()), _present(folder, at_once + on_flush)
+    assert db.path == pathlib.Path(folder)
 
 
 def test_errors_like_the_reference(psk, tmp_path):
