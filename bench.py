@@ -618,10 +618,16 @@ def cpu_baseline_metagenome(fetch_ref, n_cpu_refs, n_refs, contigs, threads, fas
 
 def api_rates(psk, genomes, query):
     """The drop-in path a pyskani user calls, from ASCII in HOST memory (SURVEY.md §8d 'Metric'):
-    (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query."""
+    (a) n x Database.sketch(name, bytes) + one Database.query(name, bytes); (b) Database.sketch_many + query with the bytes crossing PCIe
+    as ASCII (PSK_INGEST_PACKED=0); (c) the same with the ingest worker threads packing 2 bits per base (the default: L / 4 bytes over PCIe)."""
     out = {}
     n = len(genomes)
-    for label, bulk in (("api", False), ("host_ascii", True), ("api", False), ("host_ascii", True)):   # second pass = warm
+    modes = (("api", False, None), ("host_ascii", True, "0"), ("host_packed", True, "1"))
+    for label, bulk, packed in modes + modes:   # second pass = warm
+        if packed is None:
+            os.environ.pop("PSK_INGEST_PACKED", None)
+        else:
+            os.environ["PSK_INGEST_PACKED"] = packed
         db = psk.Database()
         t0 = time.perf_counter()
         if bulk:
@@ -635,6 +641,7 @@ def api_rates(psk, genomes, query):
         out[label] = {"pairs_per_s": n / (t2 - t0), "sketch_s": t1 - t0, "query_ms": (t2 - t1) * 1e3, "hits": len(hits),
                       "host_GBps": sum(len(g) for g in genomes) / (t1 - t0) / 1e9}
         del db
+    os.environ.pop("PSK_INGEST_PACKED", None)
     return out
 
 
@@ -719,7 +726,7 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
             "metric": "genome-pairs/sec (sketch+ANI)", "value": n_refs * world * steps / dt, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15; device-resident ASCII in, hit list on host out (from host memory: extras.host_ascii_pairs_per_s)",
+            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15; device-resident ASCII in, hit list on host out (from host memory, packed ingest: extras.host_packed_pairs_per_s)",
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)" + (f", hit lists all-gathered ({job.args.comm})" if world > 1 else "")},
             "roofline": roof, "clock": clock,
             "kernel_ms_per_step": {k: table[k]["ms_per_step"] for k in KERNELS},
@@ -735,10 +742,11 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
                 import pyskani_amd as psk
                 r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
                 psk.database.release_default_context(job.local_rank)
-                line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"],
-                                      api_detail=r["api"], host_ascii_detail=r["host_ascii"],
+                line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"], host_packed_pairs_per_s=r["host_packed"]["pairs_per_s"],
+                                      api_detail=r["api"], host_ascii_detail=r["host_ascii"], host_packed_detail=r["host_packed"],
                                       api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
-                                               "api = n x sketch() + query(); host_ascii = sketch_many() (pinned, double-buffered H2D pipeline) + query()")
+                                               "api = n x sketch() + query(); host_ascii = sketch_many() (pinned, double-buffered H2D pipeline, ASCII over PCIe) + query(); "
+                                               "host_packed = the same with the ingest threads packing 2 bits per base (the library's default for genomes of long contigs)")
             if cpu_sample > 0:
                 line["cpu_baseline"] = cpu_baseline_search(fetch, min(cpu_sample, n_refs), os.cpu_count() or 1)
             del host

@@ -113,6 +113,10 @@ psk_status psk_ctx_work(psk_ctx* ctx, uint64_t* pairs, uint64_t* items, uint64_t
 /* Measurement: psk_query_host calls since the context was created that ran as one launch sequence (`taken`), that exceeded one of its
  * capacities and were rerun on the general path (`rerun`), and that went to the general path at once (`general`, which includes `rerun`). */
 psk_status psk_ctx_small_query_stats(psk_ctx* ctx, uint64_t* taken, uint64_t* rerun, uint64_t* general);
+/* Host-side 2-bit packing of the ingest pipeline (csrc/pack_host.cpp), exposed for tests: n ASCII bases -> ceil(n / 16) words, the first base in a
+ * word's highest two bits; A 0, C 1, G 2, T 3, case-insensitive, every other byte 0 (the codes of the sketch kernels). mode 0: the best
+ * implementation the CPU has (AVX-512BW), 1: the scalar one. */
+void psk_pack2bit_host(const uint8_t* src, uint64_t n, uint32_t* dst, int mode);
 /* device bump allocator for callers that stage genomes in HBM themselves (bench, multi-GPU) */
 psk_status psk_device_alloc(psk_ctx* ctx, size_t bytes, void** dptr);
 psk_status psk_device_free(psk_ctx* ctx, void* dptr);

@@ -48,7 +48,7 @@ class Seed(C.Structure):
 # every symbol include/pyskani_amd.h declares
 SYMBOLS = [
     "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
-    "psk_ctx_synchronize", "psk_ctx_small_query_stats", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
+    "psk_ctx_synchronize", "psk_pack2bit_host", "psk_ctx_small_query_stats", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_free_many", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
     "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_host", "psk_query_many",
@@ -79,6 +79,8 @@ def load():
     lib.psk_ctx_destroy.restype = None
     lib.psk_ctx_synchronize.argtypes = [vp]
     lib.psk_ctx_small_query_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    lib.psk_pack2bit_host.argtypes = [vp, u64, vp, C.c_int]
+    lib.psk_pack2bit_host.restype = None
     lib.psk_ctx_set_timing.argtypes = [vp, C.c_int]
     lib.psk_ctx_timing.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
     lib.psk_db_add_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), u32]

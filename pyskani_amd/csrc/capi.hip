@@ -631,7 +631,10 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
                 return irc;
             }
             const char* env = getenv("PSK_INGEST_THREADS");
-            int nt = env ? atoi(env) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+            // (measured on the 256-thread MI355X hosts, 1 000 x 5 Mb genomes: packed ingest 33.2 k genomes/s with 8 workers, 28.1 k with 16, 26.8 k with 32, 21.0 k with 64 -
+            // more workers only contend for the memory controllers; the plain ASCII copy is PCIe-bound at 8.4-8.9 k whatever the count: profiles/r4/r4d_ingest_threads.txt)
+            const unsigned hw = std::thread::hardware_concurrency();
+            int nt = env ? atoi(env) : (int)std::min(8u, std::max(1u, hw / 2));
             fresh->pool.reset(new ParallelFor(std::max(0, nt - 1)));
             slot = fresh;
         }
@@ -639,19 +642,36 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
     }
     std::lock_guard<std::mutex> ingest_lock(R->mu);     // one pipelined ingest per context at a time (its staging slots are shared)
     const uint32_t n_contigs = genome_first_contig[n_genomes];
-    // sub-batches of ~192 MB of ASCII (whole genomes); device offsets of the kept contigs, 16-byte aligned
-    const uint64_t SUB = 192ull << 20;
+    // PACKED ingest: the worker threads turn ASCII into 2-bit words (pack_host.cpp) while they fill the pinned slots, so a genome crosses PCIe as
+    // L / 4 bytes and sketch_scan reads the words (its phase 1 becomes a copy). Every kept contig starts a 4 KB tile in the packed layout, so the mode
+    // is taken where that is at most half of the ASCII (genomes of long contigs: always; bins of thousands of 500-base contigs: never).
+    // PSK_INGEST_PACKED=0 / 1 forbid / force it (tests, A/B).
+    auto tiles_of = [&](uint32_t c) -> uint64_t { return lens[c] >= MIN_LENGTH_CONTIG ? (lens[c] + TILE_BASES - 1) / TILE_BASES : 0; };
+    bool packed;
+    {
+        uint64_t ascii_total = 0, tiles_total = 0;
+        for (uint32_t c = 0; c < n_contigs; c++) if (lens[c] >= MIN_LENGTH_CONTIG) { ascii_total += lens[c]; tiles_total += tiles_of(c); }
+        const char* pe = getenv("PSK_INGEST_PACKED");
+        packed = pe ? pe[0] == '1' : tiles_total * (uint64_t)(4 * TILE_WORDS) * 2 <= ascii_total;
+    }
+    constexpr uint64_t TILE_BYTES = 4ull * TILE_WORDS;
+    // sub-batches of ~192 MB of ASCII (whole genomes; packed: ~96 MB of words = 384 MB of ASCII); device offsets of the kept contigs, 16-byte aligned
+    // (packed: off[] stays zero - the tile tables of sketch_batch_impl place the contigs - and tile0[c] is the contig's first tile in its sub-batch)
+    const uint64_t SUB = packed ? (96ull << 20) : (192ull << 20);
     struct Sub { uint32_t g0, g1; uint64_t bytes; };
     std::vector<Sub> subs;
-    std::vector<uint64_t> off(n_contigs, 0), len64(lens, lens + n_contigs);
+    std::vector<uint64_t> off(n_contigs, 0), len64(lens, lens + n_contigs), tile0(packed ? n_contigs : 0, 0);
     for (uint32_t g = 0; g < n_genomes;) {
         Sub s{g, g, 0};
         while (s.g1 < n_genomes) {
             uint64_t gb = 0;
-            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) if (lens[c] >= MIN_LENGTH_CONTIG) gb += (lens[c] + 15) & ~15ull;
+            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) if (lens[c] >= MIN_LENGTH_CONTIG) gb += packed ? tiles_of(c) * TILE_BYTES : ((lens[c] + 15) & ~15ull);
             if (s.g1 > s.g0 && s.bytes + gb > SUB) break;
             uint64_t o = s.bytes;
-            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) { off[c] = o; if (lens[c] >= MIN_LENGTH_CONTIG) o += (lens[c] + 15) & ~15ull; }
+            for (uint32_t c = genome_first_contig[s.g1]; c < genome_first_contig[s.g1 + 1]; c++) {
+                if (packed) { tile0[c] = o / TILE_BYTES; o += tiles_of(c) * TILE_BYTES; }
+                else { off[c] = o; if (lens[c] >= MIN_LENGTH_CONTIG) o += (lens[c] + 15) & ~15ull; }
+            }
             s.bytes += gb; s.g1++;
         }
         subs.push_back(s);
@@ -677,6 +697,24 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
                 e = hipEventSynchronize(R->slot_free[slot_i]);      // its previous DMA has drained
                 if (e != hipSuccess) break;
                 const int parts = (int)std::min<uint64_t>(64, (hi - lo + (1u << 20) - 1) >> 20);
+                if (packed) R->pool->run(parts, [&](int t) {      // tiles [ta, tz) of the sub-batch: 16 384 bases -> 1 024 words each, zeros behind a contig's end
+                    const uint64_t ta = (lo + (hi - lo) * (uint64_t)t / parts) / TILE_BYTES, tz = t + 1 == parts ? hi / TILE_BYTES : (lo + (hi - lo) * (uint64_t)(t + 1) / parts) / TILE_BYTES;
+                    uint32_t l = c0, r = c1;      // first contig whose tiles end after ta
+                    while (l < r) { const uint32_t mid = (l + r) >> 1; if (tile0[mid] + tiles_of(mid) <= ta) l = mid + 1; else r = mid; }
+                    uint32_t c = l;
+                    for (uint64_t tl = ta; tl < tz; tl++) {
+                        while (c < c1 && tile0[c] + tiles_of(c) <= tl) c++;
+                        uint32_t* dst = (uint32_t*)(pin + (tl * TILE_BYTES - lo));
+                        uint32_t words = 0;
+                        if (c < c1) {
+                            const uint64_t pos0 = (tl - tile0[c]) * TILE_BASES, nb = std::min<uint64_t>(TILE_BASES, lens[c] - pos0);
+                            psk_pack2bit_host(contigs[c] + pos0, nb, dst, 0);
+                            words = (uint32_t)((nb + 15) / 16);
+                        }
+                        if (words < (uint32_t)TILE_WORDS) memset(dst + words, 0, 4 * (size_t)(TILE_WORDS - words));
+                    }
+                });
+                else
                 R->pool->run(parts, [&](int t) {
                     const uint64_t a = lo + (hi - lo) * (uint64_t)t / parts, z = lo + (hi - lo) * (uint64_t)(t + 1) / parts;
                     // first contig whose device range ends after a
@@ -705,7 +743,8 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
         const Sub& s = subs[b];
         hipError_t e = hipStreamWaitEvent(lane->stream, R->ready[b & 1], 0);
         if (e != hipSuccess) { psk_set_error("hipStreamWaitEvent: %s", hipGetErrorString(e)); rc = PSK_EHIP; break; }
-        rc = sketch_batch_impl(lane, p, (const uint8_t*)R->dev[b & 1].p, off.data(), len64.data(), genome_first_contig + s.g0, s.g1 - s.g0, want_seeds, out + s.g0);
+        rc = sketch_batch_impl(lane, p, (const uint8_t*)R->dev[b & 1].p, off.data(), len64.data(), genome_first_contig + s.g0, s.g1 - s.g0, want_seeds, out + s.g0,
+                               packed ? (const uint32_t*)R->dev[b & 1].p : nullptr);
         { std::lock_guard<std::mutex> l(m); consumed = (int)b + 1; }
         cv.notify_all();
     }

@@ -564,7 +564,10 @@ __device__ __forceinline__ uint64_t mm_hash64_u32(uint32_t key) {
 psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
-                             int want_seeds, psk_sketch** out);
+                             int want_seeds, psk_sketch** out, const uint32_t* d_packed_in = nullptr);
+// d_packed_in: the bases 2-bit packed (pack_host.cpp), TILE_WORDS words per tile, tiles numbered over the kept contigs (length >= 500) in
+// the order given, every contig starting a tile, 8 words of slack behind the last; d_bases and contig_off are then not read
+extern "C" void psk_pack2bit_host(const uint8_t* src, uint64_t n, uint32_t* dst, int mode);
 // sorts the seeds of every not-yet-indexed sketch by k-mer (stable) into its idx_* slice
 psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n, bool lazy = false);
 // builds the probe table of every indexed sketch of the list that lacks one (sketches of 256 .. 2^20 seeds)

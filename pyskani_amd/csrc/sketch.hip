@@ -76,10 +76,13 @@ __device__ __forceinline__ uint32_t rc_word(uint32_t w) {
     return ~y;
 }
 
-__global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
+// PACKED: the bases arrive 2-bit packed, tile by tile, in `packed` (the host ingest packs on its worker threads: a genome crosses PCIe as L / 4 bytes):
+// phase 1 is a copy into LDS and `ascii` is not read
+template <bool PACKED>
+__device__ __forceinline__ void sketch_scan_body(
     const uint8_t* __restrict__ ascii, const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci,
     uint32_t* __restrict__ packed, uint64_t* __restrict__ seedmask, uint32_t* __restrict__ tile_count,
-    SketchConsts C) {
+    const SketchConsts& C) {
     __shared__ __align__(16) uint32_t s_w[4 + TILE_WORDS];
     __shared__ uint32_t s_cnt[TILE_THREADS / 64];
     const uint32_t tile = blockIdx.x;
@@ -90,6 +93,12 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     const uint8_t* src = ascii + cd.byte_off + pos0;
 
     // phase 1: pack 16 bases per lane per round, coalesced 16-byte loads
+    if (PACKED) {      // four words per thread: one 16-byte load, two 8-byte LDS stores (the tile's words sit two words into s_w, behind the halo)
+        const uint4 v = *reinterpret_cast<const uint4*>(packed + (size_t)tile * TILE_WORDS + 4 * tid);
+        *reinterpret_cast<uint2*>(&s_w[2 + 4 * tid]) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(&s_w[4 + 4 * tid]) = make_uint2(v.z, v.w);
+    }
+    else
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / TILE_THREADS; r++) {
         int w = tid + r * TILE_THREADS;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     }
     if (tid < 2) {
         uint32_t word = 0;
-        if (pos0 > 0) word = pack16(*reinterpret_cast<const uint4*>(src - 32 + tid * 16));
+        if (pos0 > 0) word = PACKED ? packed[(size_t)tile * TILE_WORDS - 2 + tid] : pack16(*reinterpret_cast<const uint4*>(src - 32 + tid * 16));
         s_w[tid] = word;
     }
     __syncthreads();
@@ -177,6 +186,17 @@ __global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
     if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
     __syncthreads();
     if (tid == 0) tile_count[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void sketch_scan_kernel(
+    const uint8_t* __restrict__ ascii, const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci,
+    uint32_t* __restrict__ packed, uint64_t* __restrict__ seedmask, uint32_t* __restrict__ tile_count, SketchConsts C) {
+    sketch_scan_body<false>(ascii, contigs, tile_ci, packed, seedmask, tile_count, C);
+}
+__global__ __launch_bounds__(TILE_THREADS) void sketch_scan_packed_kernel(
+    const ContigDesc* __restrict__ contigs, const uint32_t* __restrict__ tile_ci,
+    uint32_t* __restrict__ packed, uint64_t* __restrict__ seedmask, uint32_t* __restrict__ tile_count, SketchConsts C) {
+    sketch_scan_body<true>(nullptr, contigs, tile_ci, packed, seedmask, tile_count, C);
 }
 
 // n (<= 32) bases starting at contig-relative base `start` of a packed stream, first base highest
@@ -605,6 +625,7 @@ struct ToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) con
 struct SketchJob {
     Lane* ctx; Lane::JobRes* R; hipStream_t st;
     const psk_params* p; const uint8_t* d_bases; int want_seeds;
+    const uint32_t* packed_in = nullptr;      // the bases arrive 2-bit packed, tile by tile in this job's tile order (host ingest): d_bases is not read
     uint32_t n_genomes = 0, n_tiles = 0; int n_desc = 0;
     std::vector<ContigDesc> descs;
     std::vector<uint32_t> g_first_desc, g_first_tile;
@@ -638,7 +659,7 @@ struct SketchJob {
                 uint64_t len = contig_len[ci];
                 if (len < MIN_LENGTH_CONTIG) continue;
                 if (len > 0xFFFFFFFFull) { psk_set_error("contig longer than 2^32-1 bases"); return PSK_ELIMIT; }
-                if (contig_off[ci] & 15) { psk_set_error("contig offset not 16-byte aligned"); return PSK_EINVAL; }
+                if (!packed_in && (contig_off[ci] & 15)) { psk_set_error("contig offset not 16-byte aligned"); return PSK_EINVAL; }
                 ContigDesc d{};
                 d.byte_off = contig_off[ci]; d.len = (uint32_t)len; d.first_tile = (uint32_t)n_tiles64;
                 d.genome = g; d.contig_index = (uint32_t)s->contig_len.size();
@@ -666,7 +687,7 @@ struct SketchJob {
                o_sbeg = o_mcnt + n_genomes, o_send = o_sbeg + n_genomes + 1, o_moff = o_send + n_genomes, o_tmc = o_moff + n_genomes + 1,
                o_tmoff = o_tmc + n_tiles + 1, o_end = o_tmoff + n_tiles + 1;
         PSK_TRY(R->s_desc.reserve(sizeof(ContigDesc) * n_desc));
-        PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
+        if (!packed_in) PSK_TRY(R->s_packed.reserve(sizeof(uint32_t) * ((size_t)n_tiles * TILE_WORDS + 8)));
         PSK_TRY(R->s_mask.reserve(sizeof(uint64_t) * (size_t)n_tiles * TILE_MASKS));
         size_t red_tmp = 0;
         hipcub::TransformInputIterator<unsigned long long, ToU64, const uint32_t*> it64_probe((const uint32_t*)nullptr, ToU64());
@@ -680,7 +701,7 @@ struct SketchJob {
         d_goff = d_offs + o_goff; d_coff = d_offs + o_coff; d_mcnt = d_offs + o_mcnt; d_sbeg = d_offs + o_sbeg;
         d_send = d_offs + o_send; d_moff = d_offs + o_moff; d_tmc = d_offs + o_tmc; d_tmoff = d_offs + o_tmoff;
         d_tinfo = (uint4*)R->s_counts.p; d_tci = (uint32_t*)(d_tinfo + n_tiles + 1);
-        d_desc = (ContigDesc*)R->s_desc.p; d_packed = (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p;
+        d_desc = (ContigDesc*)R->s_desc.p; d_packed = packed_in ? const_cast<uint32_t*>(packed_in) : (uint32_t*)R->s_packed.p; d_mask = (uint64_t*)R->s_mask.p;
         size_t hbytes = sizeof(ContigDesc) * n_desc + sizeof(uint32_t) * (n_genomes + 1 + n_desc + 1);
         void* hp;
         PSK_TRY(R->pin(hbytes + sizeof(uint32_t) * (2 * (n_genomes + 1) + n_desc + 1 + 4) + 16, &hp));
@@ -705,7 +726,8 @@ struct SketchJob {
         // optional dynamic-LDS ballast caps the scan's residency so that the latency-bound emit/sort kernels of the
         // previous sub-batch find free wave slots beside it (the scan is issue-bound well below 8 waves/SIMD)
         static const int scan_lds = getenv("PSK_SCAN_LDS") ? atoi(getenv("PSK_SCAN_LDS")) : 0;
-        hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), scan_lds, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
+        if (packed_in) hipLaunchKernelGGL(sketch_scan_packed_kernel, dim3(n_tiles), dim3(TILE_THREADS), scan_lds, st, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
+        else hipLaunchKernelGGL(sketch_scan_kernel, dim3(n_tiles), dim3(TILE_THREADS), scan_lds, st, d_bases, d_desc, d_tci, d_packed, d_mask, d_cnt, C);
         ctx->t_end(st);
         JHIP(hipEventRecord(R->scan_done, st));
         size_t tmp_bytes = 0;
@@ -941,7 +963,7 @@ struct SketchJob {
 psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_bases,
                              const uint64_t* contig_off, const uint64_t* contig_len,
                              const uint32_t* genome_first_contig, uint32_t n_genomes,
-                             int want_seeds, psk_sketch** out) {
+                             int want_seeds, psk_sketch** out, const uint32_t* d_packed_in) {
     if (!ctx || !p || !out || (!genome_first_contig && n_genomes)) { psk_set_error("sketch: NULL argument"); return PSK_EINVAL; }
     if (p->k < 1 || p->k > 16) { psk_set_error("Value of k > 16 for DNA; not allowed (k=%d)", p->k); return PSK_EINVAL; }
     if (p->c < 1 || p->marker_c < 1) { psk_set_error("compression factors must be >= 1"); return PSK_EINVAL; }
@@ -957,7 +979,7 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
         gb[g] = b; total += b;
     }
     const char* env = getenv("PSK_SKETCH_JOBS");
-    uint32_t J = env ? (uint32_t)atoi(env) : 1u;
+    uint32_t J = env && !d_packed_in ? (uint32_t)atoi(env) : 1u;      // (packed input is laid out in ONE job's tile order)
     J = std::max(1u, std::min(J, std::min(8u, n_genomes ? n_genomes : 1u)));
     std::vector<uint32_t> cut(J + 1, n_genomes);
     cut[0] = 0;
@@ -971,14 +993,14 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
     };
     for (uint32_t j = 0; j < J; j++) {
         SketchJob& jb = jobs[j];
-        jb.ctx = ctx; jb.p = p; jb.d_bases = d_bases; jb.want_seeds = want_seeds;
+        jb.ctx = ctx; jb.p = p; jb.d_bases = d_bases; jb.want_seeds = want_seeds; jb.packed_in = d_packed_in;
         psk_status rc = ctx->job(j, &jb.R);
         if (rc != PSK_OK) return abort_all(rc);
         jb.st = jb.R->stream;
         rc = jb.prepare(contig_off, contig_len, genome_first_contig + cut[j], cut[j + 1] - cut[j]);
         if (rc != PSK_OK) return abort_all(rc);
     }
-    if (J == 1 && n_genomes == 1) {
+    if (J == 1 && n_genomes == 1 && !d_packed_in) {
         bool done = false;
         psk_status rc = jobs[0].run_small(out, &done);
         if (rc != PSK_OK) return abort_all(rc);

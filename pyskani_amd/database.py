@@ -19,6 +19,11 @@ import numpy as np
 from . import _capi
 from . import storage as _storage
 
+try:      # C-level construction of a query's Hit list (csrc/hitlist.c, built beside the library); host logic only - the Python construction below is its twin
+    from . import _hitlist
+except ImportError:
+    _hitlist = None
+
 _ctx_lock = threading.Lock()
 _ctxs = {}
 
@@ -101,6 +106,8 @@ class Hit(tuple):
         """[Hit] from a numpy array of psk_hit records. Values come from the library and are valid by construction, so the range
         checks of the constructor are skipped; the integer intermediates stay reachable as `hit._raw[field]` (the record, looked up on demand)."""
         n = len(recs)
+        if _hitlist is not None and isinstance(names, list):      # the same objects, built in C (csrc/hitlist.c)
+            return _hitlist.build(cls, recs, n, qname, names, recs)
         return list(map(tuple.__new__, itertools.repeat(cls, n),
                         zip(recs["ani"].tolist(), itertools.repeat(qname), recs["af_query"].tolist(), map(names.__getitem__, recs["ref_index"].tolist()),
                             recs["af_ref"].tolist(), (recs["learned"] != 0).tolist(), itertools.repeat(recs), range(n))))
@@ -678,8 +685,8 @@ class Database:
         hits_p = C.POINTER(_capi.Hit)()
         n = C.c_uint64(0)
         _capi.check(self._lib.psk_query_host(self._h, arr, lens, nc, int(bool(seed)), C.byref(opts), C.byref(hits_p), C.byref(n)))
-        try:
-            return _capi.hit_records(hits_p, 0, n.value, self._HIT_DTYPE)
+        try:      # (one C-level copy into an immutable bytes object; a structured np.empty + memmove costs five times as much for a hundred hits)
+            return np.frombuffer(C.string_at(hits_p, n.value * self._HIT_DTYPE.itemsize), dtype=self._HIT_DTYPE) if n.value else np.empty(0, self._HIT_DTYPE)
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)

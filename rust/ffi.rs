@@ -98,6 +98,7 @@ extern "C" {
     pub fn psk_model_predict(m: *const PskModel, rows: *const f32, n_rows: u32, out: *mut f32) -> c_int;
     // database: markers.push + sketches.store (lib.rs:501-508)
     pub fn psk_ctx_small_query_stats(ctx: *mut PskCtx, taken: *mut u64, rerun: *mut u64, general: *mut u64) -> c_int;
+    pub fn psk_pack2bit_host(src: *const u8, n: u64, dst: *mut u32, mode: c_int);
     pub fn psk_db_create(ctx: *mut PskCtx, p: *const PskParams, out: *mut *mut PskDb) -> c_int;
     pub fn psk_db_destroy(db: *mut PskDb);
     pub fn psk_db_add(db: *mut PskDb, name: *const c_char, s: *mut PskSketch) -> c_int;

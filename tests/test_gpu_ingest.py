@@ -19,8 +19,11 @@ def export_bytes(sk):
     return s.tobytes(), m.tobytes(), sk._info()[1:]
 
 
-def test_sketch_many_equals_per_genome_sketch(psk, oracle):
-    """Ragged genomes (empty, all-short, multi-contig, odd lengths) through the pipeline = psk_sketch_host one by one."""
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_sketch_many_equals_per_genome_sketch(psk, oracle, monkeypatch, packed):
+    """Ragged genomes (empty, all-short, multi-contig, odd lengths) through the pipeline = psk_sketch_host one by one; as ASCII
+    over PCIe and 2-bit packed on the host's worker threads (every byte that is not ACGT/acgt packs to 0, like the kernels' own table)."""
+    monkeypatch.setenv("PSK_INGEST_PACKED", packed)
     rng = np.random.default_rng(31)
     genomes = [("g0", random_genome(rng, 300_001)),
                ("g1", random_genome(rng, 40_000), random_genome(rng, 499), random_genome(rng, 77_777), b""),
@@ -38,15 +41,17 @@ def test_sketch_many_equals_per_genome_sketch(psk, oracle):
     assert np.array_equal(s["kmer"], o.seeds["kmer"]) and np.array_equal(s["pos"], o.seeds["pos"]) and np.array_equal(m, o.markers)
 
 
-def test_sketch_many_spans_sub_batches_and_slots(psk, monkeypatch):
-    """More ASCII than one 192 MB sub-batch and genomes straddling the 32 MB staging slots; 3 worker threads."""
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_sketch_many_spans_sub_batches_and_slots(psk, monkeypatch, packed):
+    """More ASCII than one sub-batch (192 MB of ASCII / 96 MB of packed words) and genomes straddling the 32 MB staging slots; 3 worker threads."""
     monkeypatch.setenv("PSK_INGEST_THREADS", "3")
+    monkeypatch.setenv("PSK_INGEST_PACKED", packed)
     rng = np.random.default_rng(32)
     base = random_genome(rng, 9_000_000)
-    genomes = [(f"g{i}", base[i * 1000: i * 1000 + 7_000_000 + 1013 * i], base[:600 + i]) for i in range(45)]   # ~320 MB
+    genomes = [(f"g{i}", base[i * 1000: i * 1000 + 7_000_000 + 1013 * i], base[:600 + i]) for i in range(62)]   # ~440 MB
     db = psk.Database()
     many = db._sketch_many(genomes, True)
-    for i in (0, 4, 5, 26, 27, 44):
+    for i in (0, 4, 5, 26, 27, 44, 54, 55, 61):
         assert export_bytes(many[i]) == export_bytes(db._sketch("x", genomes[i][1:], True)), i
 
 
