@@ -508,10 +508,11 @@ constexpr uint32_t SQ_HITS_FIRST = 256;    // hit records that cross with the st
 constexpr uint32_t SQ_F_SEEDS = 1u, SQ_F_MARKERS = 2u, SQ_F_PAIR = 4u;      // flags: a capacity was exceeded -> the general path reruns the call
 struct SmallQHead {
     uint32_t n_seeds, n_markers_raw, n_markers, n_short;      // seeds of the query, raw / distinct markers, shortlisted references
-    uint32_t flags, pad0;
+    uint32_t flags, n_hits;                                    // n_hits: records with ani > 0.1 (lib.rs:654), appended by the chain workgroups (the host orders them by reference)
     unsigned long long n_anchors;                              // anchors over all pairs (psk_ctx_work)
     uint32_t coff[SQ_MAX_DESC + 1];                            // first seed of every kept contig
-    uint32_t pad1[128 - 8 - (SQ_MAX_DESC + 1)];
+    uint32_t done;                                             // chain workgroups that have finished: the last one hands the status block and the hits to the host
+    uint32_t pad1[128 - 9 - (SQ_MAX_DESC + 1)];
 };
 static_assert(sizeof(SmallQHead) == 512, "the status block is 512 bytes, the hits follow it");
 struct SmallQSketch {      // device arrays of the query's sketch (lane-owned, reused from call to call)

@@ -244,7 +244,7 @@ __device__ __forceinline__ void sketch_emit_body(
         self_off = __shfl(inc - c, (int)tile);
         if (tile == 0) {
             if ((uint32_t)lane < n_tiles) toff_out[lane] = inc - c;
-            if (lane == 0) { toff_out[n_tiles] = all; head->n_seeds = all; head->flags = all > seed_cap ? SQ_F_SEEDS : 0u; head->n_anchors = 0ull; head->n_short = 0u; }      // (the status block starts from here: no memset)
+            if (lane == 0) { toff_out[n_tiles] = all; head->n_seeds = all; head->flags = all > seed_cap ? SQ_F_SEEDS : 0u; head->n_anchors = 0ull; head->n_short = 0u; head->n_hits = 0u; head->done = 0u; }      // (the status block starts from here: no memset)
             const uint32_t ft = (uint32_t)lane <= n_desc ? cft[lane] : 0u;
             const uint32_t ex_at = __shfl(inc - c, (int)(ft < 64u ? ft : 0u));      // (every lane takes part in the shuffle: a lane outside a branch has nothing to give)
             if ((uint32_t)lane <= n_desc) head->coff[lane] = ft < n_tiles ? ex_at : all;

@@ -19,6 +19,8 @@
 #include "common.h"
 #include "chain_dev.h"
 #include <cmath>
+#include <cstddef>
+#include <algorithm>
 
 namespace {
 
@@ -155,6 +157,9 @@ struct SqChainArgs {
     psk_hit* hits;
     unsigned long long q_total_len; uint32_t n_desc;
     uint32_t band, two_c; int k, median, robust; double min_af;
+    unsigned long long* prof;      // diagnostics ($PSK_SQ_PROFILE): 100 MHz timestamps of the first pair's phases
+    int no_team;                   // $PSK_SQ_TEAM=0: every chunk by one wave (tests, A/B)
+    uint4* host_out;               // pinned host block [status | hits]: written by the LAST workgroup to finish (no download command); null: the host copies
 };
 
 constexpr int SQ_CHAIN_T = 256;
@@ -182,7 +187,13 @@ __device__ void sq_chain_chunk(const uint4* __restrict__ s_anc, const uint32_t s
         int32_t key = 0;
         const uint32_t avail = __builtin_amdgcn_readfirstlane(B - s);                     // anchors before the block (a multiple of 64)
         const uint32_t nst = avail < band ? avail : band;
-        const uint32_t n0 = nst < 64u ? nst : 64u;
+        // predecessors more than BP_CHAIN_BAND bases before the block's FIRST anchor serve no lane of it: positions ascend with the index, so the
+        // ones in reach are the last lanes of the previous blocks - counted once per block, not tested per step
+        const uint32_t q_first = sq_rl(qx, 0);
+        const uint32_t reach0 = (uint32_t)__popcll(__ballot((int32_t)(q_first - w0.q1) < BP_CHAIN_BAND && w0.m != 0xFFFFFFFFu));
+        const uint32_t reach1 = (uint32_t)__popcll(__ballot((int32_t)(q_first - w1.q1) < BP_CHAIN_BAND && w1.m != 0xFFFFFFFFu));
+        const uint32_t n0 = __builtin_amdgcn_readfirstlane(nst < 64u ? (nst < reach0 ? nst : reach0) : reach0);
+        const uint32_t n1 = __builtin_amdgcn_readfirstlane(reach0 < 64u || nst <= 64u ? 64u : (nst < 64u + reach1 ? nst : 64u + reach1));
         for (uint32_t t = 0; t < n0; t++) {                                                // (1) the block before this one: its lane 63 - t is at distance lane + 1 + t
             const uint32_t pl = 63u - t;
             const LanePred y{sq_rl(w0.q1, pl), sq_rl(w0.u, pl), sq_rl(w0.m, pl), (int32_t)sq_rl((uint32_t)w0.f1, pl)};
@@ -190,7 +201,7 @@ __device__ void sq_chain_chunk(const uint4* __restrict__ s_anc, const uint32_t s
             const int32_t kx = lane_eval2(qx, ux, mx, y, (int)(d & 127u)) | (int32_t)((band - d) & 0x80000000u);
             key = kx > key ? kx : key;
         }
-        for (uint32_t t = 64; t < nst; t++) {                                              //     and the one before that (bands beyond 64 anchors)
+        for (uint32_t t = 64; t < n1; t++) {                                               //     and the one before that (bands beyond 64 anchors)
             const uint32_t pl = 127u - t;
             const LanePred y{sq_rl(w1.q1, pl), sq_rl(w1.u, pl), sq_rl(w1.m, pl), (int32_t)sq_rl((uint32_t)w1.f1, pl)};
             const uint32_t d = (uint32_t)lane + 1u + t;
@@ -230,23 +241,92 @@ __device__ void sq_chain_chunk(const uint4* __restrict__ s_anc, const uint32_t s
     R_out = R;
 }
 
-// number of query seeds of contig qc with pos in [lo, hi] (positions in LDS)
-__device__ __forceinline__ uint32_t sq_seeds_between(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ coff, uint32_t qc, uint32_t lo, uint32_t hi) {
-    const uint32_t a = coff[qc], b = coff[qc + 1];
-    uint32_t l = a, r = b;
-    while (l < r) { const uint32_t m = (l + r) >> 1; if (pos[m] < lo) l = m + 1; else r = m; }
-    const uint32_t first = l; r = b;
-    while (l < r) { const uint32_t m = (l + r) >> 1; if (pos[m] <= hi) l = m + 1; else r = m; }
-    return l - first;
+
+// The same DP by a TEAM of T = 2 or 4 waves of the workgroup (pairs of one or two chunks leave three or two of its waves - and of the CU's SIMDs - idle).
+// Part (1) is what a team can share: its steps are independent, so wave tw takes steps tw, tw + T, ... and leaves its partial keys in LDS; the team's
+// first wave merges them and runs (2) and (3) alone. The state of the last 128 anchors (what (1) reads and what an anchor's tree follows from) lives in an
+// LDS ring, one 16-byte broadcast read per step where the single-wave version reads four lanes. Every wave of the WORKGROUP calls this for the same number
+// of blocks (`n_blocks`: the longest chunk of the round; a team without a block left only keeps the barriers company).
+struct SqRing { uint4 p[128]; uint32_t id[128], dp[128]; };      // (q + 1, diagonal, ref contig | strand, score - 1), tree, depth by chunk-local index & 127
+__device__ void sq_chain_team(const uint4* __restrict__ s_anc, const uint32_t s, const uint32_t e, const bool active, const uint32_t n_blocks, const uint32_t band,
+                              SqRing& ring, int32_t (*__restrict__ pk)[64], const uint32_t T, const uint32_t tw, unsigned long long* __restrict__ best,
+                              uint32_t* __restrict__ root, const int lane, uint32_t& R_out, bool& over) {
+    uint32_t R = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const uint32_t B = s + 64u * b;
+        const bool act = active && !over && B < e;
+        uint32_t cnt = 0, qx = 0, mx = 0xFFFFFFFEu, ux = 0, q1 = 0;
+        const uint32_t avail = 64u * b;
+        bool have = false;
+        if (act) {
+            cnt = __builtin_amdgcn_readfirstlane(e - B < 64u ? e - B : 64u);
+            have = (uint32_t)lane < cnt;
+            const uint4 a = have ? s_anc[B + lane] : make_uint4(0u, 0u, 0xFFFFFFFEu, 0u);
+            qx = a.x; mx = a.z; ux = lane_diag(qx, a.y, 0u - (mx & 1u)); q1 = qx + 1u;
+            const uint32_t nst = avail < band ? avail : band;
+            // steps in reach of the block's first anchor (positions ascend with the index: the predecessors in reach are the nearest ones)
+            const uint32_t q_first = sq_rl(qx, 0);
+            const uint32_t t0 = (uint32_t)lane, t1 = (uint32_t)lane + 64u;
+            const bool in0 = t0 < nst && (int32_t)(q_first - ring.p[(avail - 1u - t0) & 127u].x) < BP_CHAIN_BAND;
+            const bool in1 = t1 < nst && (int32_t)(q_first - ring.p[(avail - 1u - t1) & 127u].x) < BP_CHAIN_BAND;
+            const uint32_t n_steps = (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1));
+            int32_t key = 0;
+            for (uint32_t t = tw; t < n_steps; t += T) {                                       // (1) this wave's share of the earlier blocks' anchors
+                const uint4 yp = ring.p[(avail - 1u - t) & 127u];
+                const LanePred y{yp.x, yp.y, yp.z, (int32_t)yp.w};
+                const uint32_t d = (uint32_t)lane + 1u + t;
+                const int32_t kx = lane_eval2(qx, ux, mx, y, (int)(d & 127u)) | (int32_t)((band - d) & 0x80000000u);
+                key = kx > key ? kx : key;
+            }
+            pk[tw][lane] = key;
+        }
+        __syncthreads();
+        if (act && tw == 0) {
+            int32_t key = pk[0][lane];
+            for (uint32_t w = 1; w < T; w++) { const int32_t o = pk[w][lane]; key = o > key ? o : key; }
+            for (uint32_t j = 0; j + 1 < cnt; j++) {                                           // (2) the sweep
+                const int32_t kj = (int32_t)sq_rl((uint32_t)key, j);
+                const int32_t fj1 = (kj > 0 ? (kj >> 7) : ANCHOR_SCORE2) - 1;
+                const LanePred y{sq_rl(q1, j), sq_rl(ux, j), sq_rl(mx, j), fj1};
+                const uint32_t d = (uint32_t)lane - j;
+                const int32_t kx = lane_eval2(qx, ux, mx, y, (int)(d & 127u)) | (int32_t)(((band - d) | (d - 1u)) & 0x80000000u);
+                key = kx > key ? kx : key;
+            }
+            const bool isroot = key <= 0;                                                     // (3) score, tree and depth
+            const int32_t f = isroot ? ANCHOR_SCORE2 : (key >> 7);
+            const uint32_t dd = 127u - ((uint32_t)key & 127u);
+            const unsigned long long rb = __ballot(have && isroot);
+            const bool outside = !isroot && dd > (uint32_t)lane;
+            const uint32_t pidx = (avail + (uint32_t)lane - dd) & 127u;
+            const uint32_t o_id = ring.id[pidx], o_dp = ring.dp[pidx];
+            uint32_t t_id = 0, t_dp = 0, ptr = (uint32_t)lane, dist = 0;
+            if (isroot) { t_id = R + (uint32_t)__popcll(rb & ((1ull << lane) - 1)); t_dp = 1; }
+            else if (outside) { t_id = o_id; t_dp = o_dp + 1u; }
+            else { ptr = (uint32_t)lane - dd; dist = 1; }
+#pragma unroll
+            for (int r = 0; r < 6; r++) { const uint32_t np = __shfl(ptr, (int)ptr), nd = __shfl(dist, (int)ptr); dist += nd; ptr = np; }
+            const uint32_t id = __shfl(t_id, (int)ptr), dp = __shfl(t_dp, (int)ptr) + dist;
+            R += (uint32_t)__popcll(rb);
+            if (R > SQ_TREES) over = true;
+            else {
+                if (have && isroot) root[t_id] = avail + (uint32_t)lane;
+                if (have) {
+                    atomicMax(&best[id], ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (avail + (uint32_t)lane)) << 14) | dp);
+                    const uint32_t me = (avail + (uint32_t)lane) & 127u;
+                    ring.p[me] = make_uint4(q1, ux, mx, (uint32_t)(f - 1)); ring.id[me] = id; ring.dp[me] = dp;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    R_out = R;
 }
 
 __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
-    __shared__ uint4 s_anc[SQ_SEEDS];                       // anchors of the pair: (q pos, r pos, ref contig << 1 | reverse_match, q contig)
-    __shared__ uint32_t s_qpos[SQ_SEEDS];
-    __shared__ uint32_t s_coff[SQ_MAX_DESC + 1];
+    __shared__ uint4 s_anc[SQ_SEEDS];                       // anchors of the pair: (q pos, r pos, ref contig << 1 | reverse_match, q contig << 16 | index of the query seed)
     __shared__ unsigned long long s_best[SQ_CHAIN_T / 64][SQ_TREES];
     __shared__ uint32_t s_root[SQ_CHAIN_T / 64][SQ_TREES];
-    __shared__ uint32_t c_sc[SQ_CANDS], c_q0[SQ_CANDS], c_q1[SQ_CANDS], c_r0[SQ_CANDS], c_r1[SQ_CANDS], c_rc[SQ_CANDS], c_row[SQ_CANDS], c_n[SQ_CANDS], c_ord[SQ_CANDS];
+    __shared__ uint32_t c_sc[SQ_CANDS], c_q0[SQ_CANDS], c_q1[SQ_CANDS], c_r0[SQ_CANDS], c_r1[SQ_CANDS], c_rc[SQ_CANDS], c_row[SQ_CANDS], c_n[SQ_CANDS], c_ord[SQ_CANDS], c_i0[SQ_CANDS], c_i1[SQ_CANDS];
     __shared__ uint16_t s_prio[SQ_CANDS], s_kept[SQ_CANDS];
     __shared__ uint2 s_chunk[SQ_ROWS];
     __shared__ uint32_t r_anch[SQ_ROWS], r_nint[SQ_ROWS], r_left[SQ_ROWS], r_right[SQ_ROWS];
@@ -254,27 +334,28 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
     __shared__ double s_val[64];
     __shared__ uint32_t s_wt[4][4];
     __shared__ uint32_t s_nrows, s_ncand, s_over;
+    __shared__ SqRing s_ring[2];
+    __shared__ int32_t s_pk[SQ_CHAIN_T / 64][64];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SmallQHead* H = A.head;
-    const uint32_t n_short = H->n_short, nq = H->n_seeds;
-    if (blockIdx.x >= n_short || (H->flags & (SQ_F_SEEDS | SQ_F_MARKERS))) return;
-    for (uint32_t i = tid; i <= A.n_desc; i += SQ_CHAIN_T) s_coff[i] = H->coff[i];
-    for (uint32_t i = tid; i < nq; i += SQ_CHAIN_T) s_qpos[i] = A.q_pos[i];
+    const uint32_t nq = H->n_seeds;
+    const uint32_t n_short = (H->flags & (SQ_F_SEEDS | SQ_F_MARKERS)) ? 0u : H->n_short;
     for (uint32_t pi = blockIdx.x; pi < n_short; pi += gridDim.x) {
         const uint32_t ref = A.shortlist[pi];
         const SketchDesc R = A.rd[ref];
         if (tid == 0) { s_ncand = 0; s_over = 0; s_nrows = 0; }
         __syncthreads();
+        if (A.prof && pi == 0 && tid == 0) A.prof[0] = wall_clock64();
         // ---- A. join: every query seed looked up in the reference's k-mer index, anchors written in seed order (already (q contig, q pos, r contig, r pos) order) ----
         uint32_t run = 0;
         bool a_over = false;
         constexpr int U = 4;
         for (uint32_t base = 0; base < nq; base += SQ_CHAIN_T * U) {
-            uint32_t iq[U], km[U], lo[U], hi[U], cnt[U];
+            uint32_t iq[U], km[U], lo[U], hi[U], cnt[U], qpos[U], qmeta[U];
             bool ok[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { iq[u] = base + u * SQ_CHAIN_T + tid; ok[u] = iq[u] < nq && R.n != 0; km[u] = ok[u] ? A.q_kmer[iq[u]] : 0u; }
+            for (int u = 0; u < U; u++) { iq[u] = base + u * SQ_CHAIN_T + tid; ok[u] = iq[u] < nq && R.n != 0; km[u] = ok[u] ? A.q_kmer[iq[u]] : 0u; qpos[u] = ok[u] ? A.q_pos[iq[u]] : 0u; qmeta[u] = ok[u] ? A.q_meta[iq[u]] : 0u; }
 #pragma unroll
             for (int u = 0; u < U; u++) { lo[u] = 0; hi[u] = 0; if (ok[u]) { const uint32_t bk = km[u] >> R.bshift; lo[u] = R.bucket[bk]; hi[u] = R.bucket[bk + 1]; } }
             for (;;) {      // lower bound of km in [lo, hi), the four seeds of a thread in lockstep
@@ -329,11 +410,11 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
                 if (cnt[u]) {
                     if (off + cnt[u] > SQ_SEEDS) a_over = true;
                     else {
-                        const uint32_t qp = s_qpos[iq[u]], qm = A.q_meta[iq[u]];
+                        const uint32_t qp = qpos[u], qm = qmeta[u];
                         for (uint32_t j = 0; j < cnt[u]; j++) {
                             const unsigned long long p2 = j ? R.pms[lo[u] + j] : pm[u];
                             const uint32_t rmeta = (uint32_t)p2;
-                            s_anc[off + j] = make_uint4(qp, (uint32_t)(p2 >> 32), (rmeta & ~1u) | ((rmeta ^ qm) & 1u), qm >> 1);
+                            s_anc[off + j] = make_uint4(qp, (uint32_t)(p2 >> 32), (rmeta & ~1u) | ((rmeta ^ qm) & 1u), ((qm >> 1) << 16) | iq[u]);
                         }
                     }
                 }
@@ -345,17 +426,18 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
         const uint32_t na = run;      // (the same in every thread)
         __syncthreads();
         bool skip = s_over != 0 || na < MIN_ANCHORS;
+        if (A.prof && pi == 0 && tid == 0) A.prof[1] = wall_clock64();
         // ---- B. chunk table (wave 0): a chunk = the anchors of one query contig within FRAGMENT_LENGTH of its first anchor ----
         if (!skip && wave == 0) {
             uint32_t h = 0, n = 0;
             while (h < na) {
                 const uint4 ah = s_anc[h];
-                const unsigned long long limit = (((unsigned long long)ah.w << 32) | ah.x) + FRAGMENT_LENGTH;
+                const unsigned long long limit = (((unsigned long long)(ah.w >> 16) << 32) | ah.x) + FRAGMENT_LENGTH;
                 uint32_t sp = h + 1, b = na;
                 while (sp < na) {
                     const uint32_t idx = sp + (uint32_t)lane;
                     bool past = false;
-                    if (idx < na) { const uint4 ai = s_anc[idx]; past = ((((unsigned long long)ai.w << 32) | ai.x) > limit); }
+                    if (idx < na) { const uint4 ai = s_anc[idx]; past = ((((unsigned long long)(ai.w >> 16) << 32) | ai.x) > limit); }
                     const unsigned long long bal = __ballot(past);
                     if (bal) { b = sp + (uint32_t)__ffsll((long long)bal) - 1u; break; }
                     sp += 64;
@@ -368,8 +450,51 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
         __syncthreads();
         const uint32_t nrows = s_nrows;
         skip = skip || s_over != 0;
-        // ---- C. the chunks' DP, a wave per chunk; candidate chains of the pair in LDS ----
-        if (!skip) {
+        if (A.prof && pi == 0 && tid == 0) A.prof[2] = wall_clock64();
+        // ---- C. the chunks' DP; candidate chains of the pair in LDS. Three chunks or more: a wave per chunk. One or two (most contigs): a team of four or two waves per chunk ----
+        auto emit_candidates = [&](const uint32_t row, const uint2 se, const unsigned long long* best, const uint32_t* root, const uint32_t Rn) {
+            uint32_t crow = 0;
+            for (uint32_t r0 = 0; r0 < Rn; r0 += 64) {      // one candidate per chain tree whose best anchor passes the thresholds, in root order
+                const uint32_t r = r0 + (uint32_t)lane;
+                bool qual = false; uint32_t f = 0, lx = 0, dep = 0;
+                if (r < Rn) {
+                    const unsigned long long bk = best[r];
+                    f = (uint32_t)(bk >> 28); lx = 16383u - (uint32_t)((bk >> 14) & 16383u); dep = (uint32_t)(bk & 16383u);
+                    qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE2;
+                }
+                const unsigned long long bal = __ballot(qual);
+                if (!bal) continue;
+                uint32_t slot0 = 0;
+                if (lane == 0) slot0 = atomicAdd(&s_ncand, (uint32_t)__popcll(bal));
+                slot0 = __shfl(slot0, 0);
+                const uint32_t rk = (uint32_t)__popcll(bal & ((1ull << lane) - 1));
+                if (slot0 + (uint32_t)__popcll(bal) > SQ_CANDS) { if (lane == 0) s_over = 1; break; }
+                if (qual) {
+                    const uint32_t ci = slot0 + rk;
+                    const uint4 ar = s_anc[se.x + root[r]], ab = s_anc[se.x + lx];
+                    c_sc[ci] = f; c_q0[ci] = ar.x; c_q1[ci] = ab.x; c_r0[ci] = ar.y < ab.y ? ar.y : ab.y; c_r1[ci] = ar.y < ab.y ? ab.y : ar.y;
+                    c_n[ci] = dep; c_rc[ci] = ar.z >> 1; c_i0[ci] = ar.w & 0xFFFFu; c_i1[ci] = ab.w & 0xFFFFu; c_row[ci] = row; c_ord[ci] = (row << 16) | (crow + rk);      // generation order: rows, then trees
+                }
+                crow += (uint32_t)__popcll(bal);
+            }
+        };
+        if (!skip && nrows <= 2 && !A.no_team) {
+            const uint32_t T = nrows == 1 ? 4u : 2u, team = (uint32_t)wave / T, tw = (uint32_t)wave % T;
+            const bool active = team < nrows;
+            const uint2 se = active ? s_chunk[team] : make_uint2(0u, 0u);
+            uint32_t n_blocks = 0;
+            for (uint32_t r = 0; r < nrows; r++) { const uint2 x = s_chunk[r]; const uint32_t nb = (x.y - x.x + 63u) / 64u; n_blocks = nb > n_blocks ? nb : n_blocks; }
+            unsigned long long* best = s_best[wave]; uint32_t* root = s_root[wave];      // (the team's first wave's tables)
+            if (tw == 0) for (uint32_t i = lane; i < SQ_TREES; i += 64) best[i] = 0ull;
+            uint32_t Rn = 0; bool over = false;
+            sq_chain_team(s_anc, se.x, se.y, active, n_blocks, A.band, s_ring[team & 1u], &s_pk[team * T], T, tw, best, root, lane, Rn, over);
+            if (tw == 0 && active) {
+                lds_wave_sync();
+                if (over) { if (lane == 0) s_over = 1; }
+                else emit_candidates(team, se, best, root, Rn);
+            }
+        }
+        else if (!skip) {
             for (uint32_t row = (uint32_t)wave; row < nrows; row += SQ_CHAIN_T / 64) {
                 const uint2 se = s_chunk[row];
                 unsigned long long* best = s_best[wave]; uint32_t* root = s_root[wave];
@@ -379,35 +504,13 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
                 sq_chain_chunk(s_anc, se.x, se.y, A.band, best, root, lane, Rn, over);
                 lds_wave_sync();
                 if (over) { if (lane == 0) s_over = 1; continue; }
-                uint32_t crow = 0;
-                for (uint32_t r0 = 0; r0 < Rn; r0 += 64) {      // one candidate per chain tree whose best anchor passes the thresholds, in root order
-                    const uint32_t r = r0 + (uint32_t)lane;
-                    bool qual = false; uint32_t f = 0, lx = 0, dep = 0;
-                    if (r < Rn) {
-                        const unsigned long long bk = best[r];
-                        f = (uint32_t)(bk >> 28); lx = 16383u - (uint32_t)((bk >> 14) & 16383u); dep = (uint32_t)(bk & 16383u);
-                        qual = dep >= MIN_ANCHORS && (int32_t)f >= MIN_SCORE2;
-                    }
-                    const unsigned long long bal = __ballot(qual);
-                    if (!bal) continue;
-                    uint32_t slot0 = 0;
-                    if (lane == 0) slot0 = atomicAdd(&s_ncand, (uint32_t)__popcll(bal));
-                    slot0 = __shfl(slot0, 0);
-                    const uint32_t rk = (uint32_t)__popcll(bal & ((1ull << lane) - 1));
-                    if (slot0 + (uint32_t)__popcll(bal) > SQ_CANDS) { if (lane == 0) s_over = 1; break; }
-                    if (qual) {
-                        const uint32_t ci = slot0 + rk;
-                        const uint4 ar = s_anc[se.x + root[r]], ab = s_anc[se.x + lx];
-                        c_sc[ci] = f; c_q0[ci] = ar.x; c_q1[ci] = ab.x; c_r0[ci] = ar.y < ab.y ? ar.y : ab.y; c_r1[ci] = ar.y < ab.y ? ab.y : ar.y;
-                        c_n[ci] = dep; c_rc[ci] = ar.z >> 1; c_row[ci] = row; c_ord[ci] = (row << 16) | (crow + rk);      // generation order: rows, then trees
-                    }
-                    crow += (uint32_t)__popcll(bal);
-                }
+                emit_candidates(row, se, best, root, Rn);
             }
         }
         __syncthreads();
         skip = skip || s_over != 0;
         const uint32_t C = skip ? 0u : (s_ncand < SQ_CANDS ? s_ncand : SQ_CANDS);
+        if (A.prof && pi == 0 && tid == 0) A.prof[3] = wall_clock64();
         // ---- D. greedy selection over ALL candidates of the pair by (score desc, generation order): kept unless it overlaps a kept chain on the
         //         query (same chunk) or on the reference (same ref contig) ----
         if (tid < C) {
@@ -432,7 +535,8 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
                     if (lane == 0) {
                         s_kept[nk] = (uint16_t)i;
                         r_anch[row] += c_n[i]; r_nint[row] += 1u;
-                        r_left[row] = q0 < r_left[row] ? q0 : r_left[row]; r_right[row] = q1 > r_right[row] ? q1 : r_right[row];
+                        const uint32_t i0 = c_i0[i], i1 = c_i1[i];      // the chains' end SEEDS: the query seeds between the leftmost and the rightmost kept anchor are an index difference
+                        r_left[row] = i0 < r_left[row] ? i0 : r_left[row]; r_right[row] = i1 > r_right[row] ? i1 : r_right[row];
                         r_cov[row] += (unsigned long long)(q1 - q0) + 1ull + A.two_c;
                     }
                     nk++;
@@ -452,7 +556,7 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
                 const uint32_t ni = inrow ? r_nint[lane] : 0u, an = inrow ? r_anch[lane] : 0u;
                 const bool valid = inrow && ni != 0;
                 uint32_t seeds = 0;
-                if (valid) seeds = sq_seeds_between(s_qpos, s_coff, s_anc[s_chunk[lane].x].w, r_left[lane], r_right[lane]);
+                if (valid) seeds = r_right[lane] - r_left[lane] + 1u;      // seeds of the chunk's contig with position in [leftmost, rightmost kept anchor] (orc_chain's seeds_between)
                 unsigned long long t_cq = inrow ? r_cov[lane] : 0ull, t_a = an, t_s = valid ? seeds : 0, t_i = ni;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { t_cq += __shfl_xor(t_cq, o); t_a += __shfl_xor(t_a, o); t_s += __shfl_xor(t_s, o); t_i += __shfl_xor(t_i, o); }
@@ -502,12 +606,27 @@ __global__ __launch_bounds__(SQ_CHAIN_T) void sq_chain_kernel(SqChainArgs A) {
                 }
             }
             if (lane == 0) {
-                A.hits[pi] = h;
+                if (h.ani > 0.1f) A.hits[atomicAdd(&A.head_w->n_hits, 1u)] = h;      // lib.rs:654: only these cross to the host (in arrival order; the host sorts the few of them by reference)
                 atomicAdd(&A.head_w->n_anchors, (unsigned long long)na);
                 if (s_over) atomicOr(&A.head_w->flags, SQ_F_PAIR);
             }
+            if (A.prof && pi == 0 && tid == 0) { A.prof[4] = wall_clock64(); A.prof[5] = na; A.prof[6] = nrows; }
         }
         __syncthreads();
+    }
+    // ---- the last workgroup to finish hands the status block and the hits to the host: plain stores into pinned memory, no download command in the stream ----
+    if (A.host_out) {
+        __shared__ uint32_t s_last;
+        __syncthreads();
+        if (tid == 0) { __threadfence(); s_last = atomicAdd(&A.head_w->done, 1u) == gridDim.x - 1u; }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const uint32_t nh = __hip_atomic_load(&A.head_w->n_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint4* src = (const uint4*)A.head_w;
+            const uint32_t n16 = (uint32_t)((sizeof(SmallQHead) + sizeof(psk_hit) * (size_t)nh) / 16);
+            for (uint32_t i = tid; i < n16; i += SQ_CHAIN_T) A.host_out[i] = src[i];
+        }
     }
 }
 
@@ -578,12 +697,16 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
         }
         h_cft[n_desc] = n_tiles;
     }
-    PSK_HIP(hipMemcpyAsync(D, Hin, in_bytes, hipMemcpyHostToDevice, st));
+    // PSK_SQ_ZEROCOPY=0: the input crosses with an upload command and the results with a download command (A/B); default: the kernels read the pinned
+    // input block in place (a contig is tens of kilobytes) and the chain kernel's last workgroup writes the results into pinned memory - two commands fewer in the stream
+    static const bool zc = !(getenv("PSK_SQ_ZEROCOPY") && getenv("PSK_SQ_ZEROCOPY")[0] == '0');
+    char* In = zc ? Hin : D;
+    if (!zc) PSK_HIP(hipMemcpyAsync(D, Hin, in_bytes, hipMemcpyHostToDevice, st));
     SmallQHead* d_head = (SmallQHead*)(D + w_out);
     psk_hit* d_hits = (psk_hit*)(D + w_out + sizeof(SmallQHead));
     SmallQSketch S{};
-    S.d_bases = (const uint8_t*)(D + i_ascii); S.d_desc = (const ContigDesc*)(D + i_desc); S.d_tci = (const uint32_t*)(D + i_tci); S.d_tinfo = (const uint4*)(D + i_tinfo);
-    S.d_cft = (const uint32_t*)(D + i_cft); S.n_desc = n_desc; S.n_tiles = n_tiles;
+    S.d_bases = (const uint8_t*)(In + i_ascii); S.d_desc = (const ContigDesc*)(In + i_desc); S.d_tci = (const uint32_t*)(In + i_tci); S.d_tinfo = (const uint4*)(In + i_tinfo);
+    S.d_cft = (const uint32_t*)(In + i_cft); S.n_desc = n_desc; S.n_tiles = n_tiles;
     S.d_packed = (uint32_t*)(D + w_packed); S.d_mask = (uint64_t*)(D + w_mask); S.d_cnt = (uint32_t*)(D + w_cnt); S.d_toff = (uint32_t*)(D + w_toff); S.d_tmc = (uint32_t*)(D + w_tmc);
     S.seed_kmer = (uint32_t*)(D + w_kmer); S.seed_pos = (uint32_t*)(D + w_pos); S.seed_meta = (uint32_t*)(D + w_meta); S.seed_pm = (uint64_t*)(D + w_pm); S.mstage = (uint64_t*)(D + w_mstage);
     S.head = d_head;
@@ -607,24 +730,35 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
     CA.rd = (const SketchDesc*)db->d_refdesc.p; CA.hits = d_hits; CA.q_total_len = total_len; CA.n_desc = n_desc;
     CA.band = (uint32_t)std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c)); CA.two_c = 2u * (uint32_t)prm.c;
     CA.k = prm.k; CA.median = o->median; CA.robust = o->robust; CA.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15;
+    static const bool prof_on = getenv("PSK_SQ_PROFILE") != nullptr;
+    const size_t prof_off = (offsetof(SmallQHead, pad1) + 7) & ~(size_t)7;      // (seven 8-byte words inside the status block's padding)
+    CA.prof = prof_on ? (unsigned long long*)((char*)d_head + prof_off) : nullptr;
+    CA.host_out = zc ? (uint4*)Hout : nullptr;
+    static const bool no_team = getenv("PSK_SQ_TEAM") && getenv("PSK_SQ_TEAM")[0] == '0';
+    CA.no_team = no_team;
     ctx->t_begin(K_CHAIN_CHUNK);
     hipLaunchKernelGGL(sq_chain_kernel, dim3(std::min<uint32_t>(n_refs, 1024u)), dim3(SQ_CHAIN_T), 0, st, CA);
     ctx->t_end();
-    PSK_HIP(hipMemcpyAsync(Hout, d_head, out_first, hipMemcpyDeviceToHost, st));
+    if (!zc) PSK_HIP(hipMemcpyAsync(Hout, d_head, out_first, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of the call
     const SmallQHead* hh = (const SmallQHead*)Hout;
     if (hh->flags) { ctx->dev->sq_rerun++; return PSK_OK; }            // a capacity was exceeded: the general path sizes everything from the counts
-    const uint32_t n_short = hh->n_short;
-    if (n_short > n_refs) { psk_set_error("internal: shortlist longer than the database"); return PSK_EHIP; }
-    if (n_short > SQ_HITS_FIRST) {          // a long shortlist (a rescued short contig passes every reference): the rest of the records
-        PSK_HIP(hipMemcpyAsync(Hout + out_first, (const char*)d_head + out_first, sizeof(psk_hit) * (size_t)(n_short - SQ_HITS_FIRST), hipMemcpyDeviceToHost, st));
+    const uint32_t n_short = hh->n_short, nh = hh->n_hits;
+    if (n_short > n_refs || nh > n_short) { psk_set_error("internal: shortlist longer than the database"); return PSK_EHIP; }
+    if (!zc && nh > SQ_HITS_FIRST) {          // more hits than cross with the status block: the rest of the records
+        PSK_HIP(hipMemcpyAsync(Hout + out_first, (const char*)d_head + out_first, sizeof(psk_hit) * (size_t)(nh - SQ_HITS_FIRST), hipMemcpyDeviceToHost, st));
         PSK_HIP(hipStreamSynchronize(st));
     }
-    const psk_hit* hits = (const psk_hit*)(Hout + sizeof(SmallQHead));
-    uint32_t nh = 0;
-    for (uint32_t i = 0; i < n_short; i++) nh += hits[i].ani > 0.1f;      // lib.rs:654
+    psk_hit* hits = (psk_hit*)(Hout + sizeof(SmallQHead));
+    std::sort(hits, hits + nh, [](const psk_hit& a, const psk_hit& b) { return a.ref_index < b.ref_index; });      // ascending insertion index, like the general path
     if (!all.reserve(all.n + std::max<uint32_t>(nh, 1u))) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
-    for (uint32_t i = 0; i < n_short; i++) if (hits[i].ani > 0.1f) all.p[all.n++] = hits[i];
+    memcpy(all.p + all.n, hits, sizeof(psk_hit) * (size_t)nh);
+    all.n += nh;
+    if (prof_on) {
+        const unsigned long long* P = (const unsigned long long*)(Hout + prof_off);
+        fprintf(stderr, "[psk small query] seeds %u markers %u shortlist %u hits %u | first pair: anchors %llu rows %llu, join %.2f us, chunk table %.2f, DP %.2f, select+reduce %.2f\n",
+                hh->n_seeds, hh->n_markers, n_short, nh, P[5], P[6], (P[1] - P[0]) / 100.0, (P[2] - P[1]) / 100.0, (P[3] - P[2]) / 100.0, (P[4] - P[3]) / 100.0);
+    }
     ctx->dev->w_pairs += n_short; ctx->dev->w_items += (uint64_t)n_short * hh->n_seeds; ctx->dev->w_anchors += hh->n_anchors;
     ctx->dev->sq_taken++;
     *done = true;
