@@ -208,6 +208,7 @@ struct Lane {
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
     Scratch q_small;                                                                       // the one-launch-sequence query's workspace (small_query.hip)
+    uint32_t sq_last_short = 192;                                                          // ... and the shortlist length of its last call on this lane: sizes the next chain launch
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
     size_t h_pinned_cap = 0;
     psk_status pinned(size_t bytes, void** out) {
@@ -459,6 +460,13 @@ struct psk_db {
     uint64_t desc_indexed = 0; uint32_t desc_n = 0;
     PoolScratch d_refdesc, d_canon;
     std::vector<SketchDesc> h_refdesc;
+    // database-wide seed index (query.hip build_gsi): EVERY reference's seeds sorted by k-mer (stable: within a k-mer by reference, contig, position).
+    // One lookup per query seed finds its matches in all references at once: the seed prefilter of a rescued contig in the one-launch-sequence
+    // query, the join of batches of many small pairs (metagenome). gsi_val = ref << 48 | contig << 33 | pos << 1 | (fwd < rc); built once per
+    // database state for databases of <= 65 536 references with <= 32 768 contigs each and < 2^31 seeds in all, dropped when references are added.
+    int gsi_state = 0;      // 0 = not built, 1 = built, 2 = this database cannot have one (limits, memory)
+    PoolScratch gsi_key, gsi_val, gsi_bucket;
+    uint64_t gsi_n = 0; int gsi_shift = 0;
     // the one-launch-sequence query (small_query.hip): 1 = every device table it reads is up to date, 2 = this database cannot take it; reset when references are added
     std::atomic<int> small_state{0};
 };

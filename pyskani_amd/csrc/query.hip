@@ -4271,6 +4271,71 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
 }
 
 
+// ------------------------------------------------------------------ database-wide seed index (psk_db::gsi_*)
+struct GsiSeg { const uint32_t* kmer; const uint64_t* pm; uint32_t n, off; };
+__global__ __launch_bounds__(256) void gsi_gather_kernel(const GsiSeg* __restrict__ segs, uint32_t* __restrict__ key, unsigned long long* __restrict__ val) {
+    const GsiSeg sg = segs[blockIdx.y];
+    const unsigned long long ref = (unsigned long long)blockIdx.y << 48;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) {
+        const unsigned long long pm = sg.pm[i];
+        const uint32_t meta = (uint32_t)pm;      // contig << 1 | (fwd < rc)
+        key[sg.off + i] = sg.kmer[i];
+        val[sg.off + i] = ref | ((unsigned long long)(meta >> 1) << 33) | ((pm >> 32) << 1) | (meta & 1u);
+    }
+}
+// bucket[b] = first entry whose k-mer >> shift is >= b (b = 0 .. nb)
+__global__ __launch_bounds__(256) void gsi_bucket_kernel(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nb, uint32_t* __restrict__ bucket) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = key[i] >> shift;
+    const uint32_t from = i ? (key[i - 1] >> shift) + 1u : 0u;
+    for (uint32_t x = from; x <= b; x++) bucket[x] = i;
+    if (i == n - 1) for (uint32_t x = b + 1; x <= nb; x++) bucket[x] = n;
+}
+// called with the database locked exclusively; leaves gsi_state 1 (built) or 2 (this database cannot have one)
+static psk_status build_gsi(Lane* ctx, psk_db* db) {
+    if (db->gsi_state) return PSK_OK;
+    static const bool off = getenv("PSK_GSI") && getenv("PSK_GSI")[0] == '0';
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)db->refs.size();
+    db->gsi_state = 2;
+    if (off || n == 0 || n > 65536u || db->params.k > 16) return PSK_OK;
+    std::vector<GsiSeg> segs(n);
+    uint64_t N = 0; uint32_t maxn = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const psk_sketch* r = db->refs[i];
+        if (!r->has_seeds || r->contig_len.size() > 32768u || r->params.k != db->params.k || r->params.c != db->params.c) return PSK_OK;
+        const uint32_t ns = r->store ? (uint32_t)r->n_seeds : 0u;
+        segs[i] = GsiSeg{ns ? r->store->seed_kmer + r->seed_off : nullptr, ns ? r->store->seed_pm + r->seed_off : nullptr, ns, (uint32_t)N};
+        N += ns; maxn = std::max(maxn, ns);
+        if (N >= 0x7FFFFF00ull) return PSK_OK;
+    }
+    if (N == 0) return PSK_OK;
+    const int kbits = 2 * db->params.k;
+    int bits = 4; while (bits < 26 && (8ull << bits) < N) bits++;      // ~8 entries per bucket
+    if (bits > kbits) bits = kbits;
+    const uint32_t nb = 1u << bits;
+    size_t ts = 0;
+    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)N, 0, kbits, st));
+    PoolScratch tmp;      // unsorted copies + sort scratch + segment table: back to the pool when the build is done
+    const size_t o_k = 0, o_v = al256(4 * (size_t)N), o_t = al256(o_v + 8 * (size_t)N), o_s = al256(o_t + ts), o_end = o_s + sizeof(GsiSeg) * (size_t)n;
+    psk_status rc = tmp.reserve(ctx->dev, o_end + 256);
+    if (rc == PSK_OK) rc = db->gsi_key.reserve(ctx->dev, 4 * (size_t)N + 256);
+    if (rc == PSK_OK) rc = db->gsi_val.reserve(ctx->dev, 8 * (size_t)N + 256);
+    if (rc == PSK_OK) rc = db->gsi_bucket.reserve(ctx->dev, 4 * ((size_t)nb + 2));
+    if (rc == PSK_ENOMEM) { db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); return PSK_OK; }      // no room: the paths that would use it take their other route
+    PSK_TRY(rc);
+    char* T = (char*)tmp.p;
+    PSK_HIP(hipMemcpyAsync(T + o_s, segs.data(), sizeof(GsiSeg) * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gsi_gather_kernel, dim3(std::max(1u, std::min(64u, (maxn + 4095u) / 4096u)), n), dim3(256), 0, st, (const GsiSeg*)(T + o_s), (uint32_t*)(T + o_k), (unsigned long long*)(T + o_v));
+    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(T + o_t, ts, (const uint32_t*)(T + o_k), (uint32_t*)db->gsi_key.p, (const unsigned long long*)(T + o_v), (unsigned long long*)db->gsi_val.p, (int)N, 0, kbits, st));
+    hipLaunchKernelGGL(gsi_bucket_kernel, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, (const uint32_t*)db->gsi_key.p, (uint32_t)N, kbits - bits, nb, (uint32_t*)db->gsi_bucket.p);
+    PSK_HIP(hipStreamSynchronize(st));      // (segs and tmp die with this frame)
+    db->gsi_n = N; db->gsi_shift = kbits - bits;
+    db->gsi_state = 1;
+    return PSK_OK;
+}
+
 // ------------------------------------------------------------------ what the one-launch-sequence query (small_query.hip) reads on the device
 psk_status small_query_prepare(Lane* ctx, psk_db* db, std::shared_lock<std::shared_mutex>& sh, bool* ok) {
     *ok = false;
@@ -4298,6 +4363,7 @@ psk_status small_query_prepare(Lane* ctx, psk_db* db, std::shared_lock<std::shar
                 PSK_TRY(ensure_index(ctx, all_refs.data(), (uint32_t)all_refs.size()));
                 PSK_TRY(refresh_ref_descs(ctx, db));
                 PSK_HIP(hipStreamSynchronize(ctx->stream));
+                PSK_TRY(build_gsi(ctx, db));      // (optional: without it a rescued contig is chained against every reference)
                 return PSK_OK;
             };
             rc = build();

@@ -33,6 +33,8 @@ struct SqScreenArgs {
     const MarkerSet* refs; const uint64_t* inv_key; const uint32_t* inv_val; const uint32_t* inv_bucket; int inv_shift; uint32_t inv_n;
     uint32_t n_refs; double thresh; int rescue_small; const uint32_t* canon;
     uint32_t* shortlist;
+    // database-wide seed index (null: none) and the query's seed k-mers: the seed prefilter of a rescued contig
+    const uint32_t* gsi_key; const unsigned long long* gsi_val; const uint32_t* gsi_bucket; int gsi_shift; const uint32_t* q_kmer;
 };
 
 // exclusive scan over the workgroup's threads (blockDim = SQ_SCREEN_T), total to every thread
@@ -135,6 +137,26 @@ __global__ __launch_bounds__(SQ_SCREEN_T) void sq_screen_kernel(SqScreenArgs A) 
     __syncthreads();
     if (A.canon) {
         for (uint32_t r = tid; r < A.n_refs; r += SQ_SCREEN_T) { const uint32_t cr = A.canon[r]; if (s_count[r] && cr != r) { s_count[cr] = 1; s_count[r] = 0; } }      // canon[r] > r, canon[canon[r]] == canon[r]
+        __syncthreads();
+    }
+    // ---- a RESCUED contig (fewer than 20 markers, lib.rs:538-541) has passed against every reference, yet a pair with fewer than MIN_ANCHORS shared
+    // seeds cannot chain and never yields a hit: the exact anchor count of every reference, one lookup per query seed in the database-wide seed index
+    // (an anchor = a (query seed, reference seed) pair of equal k-mer), takes those pairs off the shortlist - 5 000 chain workgroups become ~100 ----
+    if (A.gsi_key && A.rescue_small && n_mark < SMALL_MARKER_COUNT) {
+        const uint32_t nq = H->n_seeds;
+        constexpr int U = 4;
+        for (uint32_t i0 = wave * U; i0 < nq; i0 += (SQ_SCREEN_T / 64) * U) {
+            uint32_t km[U], lo[U], hi[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) km[u] = i0 + u < nq ? A.q_kmer[i0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++) { lo[u] = 0; hi[u] = 0; if (i0 + u < nq) { const uint32_t b = km[u] >> A.gsi_shift; lo[u] = A.gsi_bucket[b]; hi[u] = A.gsi_bucket[b + 1]; } }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                for (uint32_t x = lo[u] + lane; x < hi[u]; x += 64u) if (A.gsi_key[x] == km[u]) atomicAdd(&s_count[(uint32_t)(A.gsi_val[x] >> 48)], 2u);      // (bit 0: the pass flag)
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r < A.n_refs; r += SQ_SCREEN_T) { const uint32_t v = s_count[r]; s_count[r] = (v & 1u) && (v >> 1) >= MIN_ANCHORS ? 1u : 0u; }
         __syncthreads();
     }
     uint32_t run = 0;
@@ -718,6 +740,9 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
     SA.thresh = pow(o->cutoff != 0.0 ? o->cutoff : 0.80, (double)K_MARKER); SA.rescue_small = !o->faster_small;      // lib.rs:597, 603-609
     SA.canon = db->has_dups ? (const uint32_t*)db->d_canon.p : nullptr;
     SA.shortlist = (uint32_t*)(D + w_short);
+    static const bool pf_off = getenv("PSK_SQ_PREFILTER") && getenv("PSK_SQ_PREFILTER")[0] == '0';      // tests, A/B
+    if (db->gsi_state == 1 && !pf_off) { SA.gsi_key = (const uint32_t*)db->gsi_key.p; SA.gsi_val = (const unsigned long long*)db->gsi_val.p; SA.gsi_bucket = (const uint32_t*)db->gsi_bucket.p; SA.gsi_shift = db->gsi_shift; }
+    SA.q_kmer = S.seed_kmer;
     static std::once_flag lds_once;
     static hipError_t lds_rc = hipSuccess;
     std::call_once(lds_once, [] { lds_rc = hipFuncSetAttribute((const void*)sq_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SQ_MAX_REFS)); });
@@ -737,13 +762,20 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
     static const bool no_team = getenv("PSK_SQ_TEAM") && getenv("PSK_SQ_TEAM")[0] == '0';
     CA.no_team = no_team;
     ctx->t_begin(K_CHAIN_CHUNK);
-    hipLaunchKernelGGL(sq_chain_kernel, dim3(std::min<uint32_t>(n_refs, 1024u)), dim3(SQ_CHAIN_T), 0, st, CA);
+    // The shortlist's length is known on the device only, and a workgroup of this kernel holds 77 KB of LDS: a grid sized for the worst case (every
+    // reference) is a thousand workgroups that queue for LDS only to find nothing to do - from eight host threads they held the rate at 20 k queries/s
+    // where 128-256 workgroups give 31 k (profiles/r4/r4i_grid.txt). The grid follows the LAST call's shortlist on this lane (neighbouring queries of a
+    // workload have similar shortlists); a longer one is walked in several rounds by the same workgroups. PSK_SQ_GRID fixes it (A/B).
+    static const uint32_t grid_env = getenv("PSK_SQ_GRID") ? (uint32_t)std::max(1, atoi(getenv("PSK_SQ_GRID"))) : 0u;
+    const uint32_t grid = grid_env ? grid_env : std::max(64u, std::min(1024u, ctx->sq_last_short + ctx->sq_last_short / 4 + 16u));
+    hipLaunchKernelGGL(sq_chain_kernel, dim3(std::min<uint32_t>(n_refs, grid)), dim3(SQ_CHAIN_T), 0, st, CA);
     ctx->t_end();
     if (!zc) PSK_HIP(hipMemcpyAsync(Hout, d_head, out_first, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of the call
     const SmallQHead* hh = (const SmallQHead*)Hout;
     if (hh->flags) { ctx->dev->sq_rerun++; return PSK_OK; }            // a capacity was exceeded: the general path sizes everything from the counts
     const uint32_t n_short = hh->n_short, nh = hh->n_hits;
+    ctx->sq_last_short = n_short;
     if (n_short > n_refs || nh > n_short) { psk_set_error("internal: shortlist longer than the database"); return PSK_EHIP; }
     if (!zc && nh > SQ_HITS_FIRST) {          // more hits than cross with the status block: the rest of the records
         PSK_HIP(hipMemcpyAsync(Hout + out_first, (const char*)d_head + out_first, sizeof(psk_hit) * (size_t)(nh - SQ_HITS_FIRST), hipMemcpyDeviceToHost, st));

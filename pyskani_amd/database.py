@@ -293,6 +293,7 @@ class Database:
         self._ctx = default_context(device)
         self._model = None
         self._warned_no_model = False
+        self._opts_cache = {}
         self._cache_lock = threading.Lock()
         self._device = device
         self._lib = self._ctx._lib
@@ -342,6 +343,7 @@ class Database:
         if model is not None and not isinstance(model, Model):
             model = Model.from_file(model, device=self._device)
         self._model = model
+        self._opts_cache = {}
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -603,9 +605,14 @@ class Database:
                               "(Database(model=...), Database.load_model(), $PSK_MODEL_PATH)", RuntimeWarning, stacklevel=3)
                 self._warned_no_model = True
             learned = False
-        o = _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
-                            float(cutoff) if cutoff else 0.0, 0.0, self._model._h if (learned and self._model is not None) else None)
-        o._keep = self._model
+        key = (learned, bool(median), bool(robust), bool(faster_small), float(cutoff) if cutoff else 0.0, id(self._model) if learned else 0)
+        o = self._opts_cache.get(key)
+        if o is None:      # (a ctypes structure per distinct flag set, not per call: per-contig queries are microseconds apart)
+            o = _capi.QueryOpts(1 if learned else 0, int(bool(median)), int(bool(robust)), int(bool(faster_small)),
+                                float(cutoff) if cutoff else 0.0, 0.0, self._model._h if (learned and self._model is not None) else None)
+            o._keep = self._model
+            if len(self._opts_cache) < 64:
+                self._opts_cache[key] = o
         return o
 
     _HIT_DTYPE = np.dtype(_capi.Hit)
