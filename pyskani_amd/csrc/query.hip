@@ -3228,12 +3228,14 @@ struct IsLivePair { const uint32_t* nch; __host__ __device__ bool operator()(con
 // ------------------------------------------------------------------ host orchestration
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static SketchDesc make_desc(const psk_sketch* s) {
+// unindexed_ok: the sketch is described with its seed count and chunk-table rows although it has no k-mer index (rounds that join through the
+// database-wide seed index: no kernel of theirs reads a per-sketch index)
+static SketchDesc make_desc(const psk_sketch* s, bool unindexed_ok = false) {
     SketchDesc d{};
     const bool ix = s->idx != nullptr;
     d.key = ix ? s->idx->km32 + s->idx_off : nullptr; d.pms = ix ? s->idx->pms + s->idx_off : nullptr;
     d.perm = ix ? s->idx->perm + s->idx_off : nullptr; d.bucket = ix ? s->idx->bucket + s->idx_boff : nullptr;
-    d.bshift = ix ? s->idx_bshift : 0; d.n = ix ? (uint32_t)s->n_seeds : 0;
+    d.bshift = ix ? s->idx_bshift : 0; d.n = (ix || (unindexed_ok && s->store)) ? (uint32_t)s->n_seeds : 0;
     d.pos = s->store ? s->store->seed_pos + s->seed_off : nullptr; d.meta = s->store ? s->store->seed_meta + s->seed_off : nullptr;
     d.kmer = s->store ? s->store->seed_kmer + s->seed_off : nullptr;
     d.seed_pos_base = s->store ? s->store->seed_pos : nullptr;
@@ -3317,6 +3319,138 @@ __global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restri
     if (threadIdx.x == 0) row_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 
+// ------------------------------------------------------------------ join of MANY SMALL pairs through the database-wide seed index (psk_db::gsi_*)
+// The probe join visits one 64-byte table line per (pair, query seed): 5.7 G lines for 100 000 contigs against 5 000 references, 68 bytes of HBM traffic per
+// 16 algorithmic ones, although the batch holds only 33 M distinct query seeds. Here ONE lookup per query seed returns the seed's matches in EVERY reference
+// (a contiguous run of the index, sorted by reference, contig, position), and the wave that owns the query deals them to the query's pairs:
+//   * one wave per batch entry (a query and a rank range of at most GSI_PMAX of its passing references);
+//   * the query's row of the pass matrix becomes a bitset + per-word prefix counts in LDS: reference -> rank -> pair of the entry, two LDS reads;
+//   * seeds are taken in (contig, position) order, a run's entries in index order, and every pair has a cursor in LDS: the anchors of a pair come out in
+//     (q contig, q pos, r contig, r pos) order with no sort. A reference that holds the k-mer several times sits in consecutive lanes: ballot arithmetic gives
+//     every lane its place in the group, the group's last lane moves the cursor.
+// COUNT pass: the cursors' final values are the pairs' anchor counts (-> scan -> pstart). EMIT pass: the same walk writes the 16-byte anchors.
+// The item records, their scan and the per-item emit of the other joins do not exist here.
+constexpr uint32_t GSI_PMAX = 256;      // (an entry's LDS: 4 B (count) / 20 B (emit) per pair; a query with more passing references is walked by several entries - cheap for the short contigs that have them)
+struct GsiJoinArgs {
+    const BatchQ* bq; const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
+    const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;
+    uint32_t* pair_cnt; const uint32_t* pstart; uint4* anc; uint32_t cap; uint32_t* err;
+    uint32_t p_cap;      // most pairs any entry of the batch holds, rounded up: what the cursor arrays in LDS are sized for (<= GSI_PMAX)
+    uint2* chunks; uint32_t* n_chunks;      // EMIT: the pairs' chunk tables, written by the same walk (rows at entry.row_off + slot * query rows)
+};
+template <bool EMIT>
+__global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
+    extern __shared__ unsigned long long s_gsi[];
+    const uint32_t nw = (A.n_refs + 63u) / 64u;
+    unsigned long long* s_bits = s_gsi;
+    uint32_t* s_pref = (uint32_t*)(s_bits + nw);
+    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);
+    uint32_t* s_ps = s_cur + A.p_cap;       // EMIT: first anchor of every pair of the entry (GSI_DEAD: fewer than MIN_ANCHORS anchors - it cannot chain: no anchors, no chunk table),
+    uint32_t* s_hq = s_ps + A.p_cap;        //       query position, anchor index and (q contig << 16 | rows so far) of the chunk being filled
+    uint32_t* s_hi = s_hq + A.p_cap;
+    uint32_t* s_hc = s_hi + A.p_cap;
+    constexpr uint32_t GSI_DEAD = 0xFFFFFFFFu;
+    const int lane = threadIdx.x;
+    const BatchQ B = A.bq[blockIdx.x];
+    const uint32_t P = B.rank_hi - B.rank_lo;
+    {   // pass row -> bitset + prefix counts
+        const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 4) {
+            uint8_t f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t r = (w0 + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(f[u] != 0);
+                if (w0 + u < nw && lane == 0) { s_bits[w0 + u] = m; s_pref[w0 + u] = run; }
+                run += (uint32_t)__popcll(m);
+            }
+        }
+        for (uint32_t j = lane; j < P; j += 64) { s_cur[j] = 0; if (EMIT) { const uint32_t a = A.pstart[B.pair_off + j], z = A.pstart[B.pair_off + j + 1]; s_ps[j] = z - a < MIN_ANCHORS ? GSI_DEAD : a; s_hc[j] = 0; } }
+    }
+    lds_wave_sync();
+    const SketchDesc Q = A.qd[B.q];
+    const uint32_t nq = Q.n;
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64) {
+        const uint32_t i = c0 + (uint32_t)lane;
+        const uint32_t km = i < nq ? Q.kmer[i] : 0u;
+        uint32_t lo = 0, hi = 0, qp = 0, qm = 0;
+        if (i < nq) { const uint32_t b = km >> A.g_shift; lo = A.g_bucket[b]; hi = A.g_bucket[b + 1]; if (EMIT) { qp = Q.pos[i]; qm = Q.meta[i]; } }
+        const uint32_t cnt = nq - c0 < 64u ? nq - c0 : 64u;
+        // the first 64 index entries of seed 0's bucket; those of seed s + 1 are requested before seed s is dealt out (the walk is a chain of dependent
+        // round trips otherwise: bucket bounds -> entries -> LDS), key and value together
+        uint32_t nlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0), nhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 0);
+        uint32_t nk = nlo + (uint32_t)lane < nhi ? A.g_key[nlo + lane] : 0xFFFFFFFFu;
+        unsigned long long nv = nlo + (uint32_t)lane < nhi ? A.g_val[nlo + lane] : 0ull;
+        for (uint32_t s = 0; s < cnt; s++) {
+            const uint32_t slo = nlo, shi = nhi, skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)s);
+            const uint32_t sqp = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s) : 0u, sqm = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s) : 0u;
+            uint32_t k = nk; unsigned long long v = nv;
+            if (s + 1 < cnt) {
+                nlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)(s + 1)); nhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(s + 1));
+                nk = nlo + (uint32_t)lane < nhi ? A.g_key[nlo + lane] : 0xFFFFFFFFu;
+                nv = nlo + (uint32_t)lane < nhi ? A.g_val[nlo + lane] : 0ull;
+            }
+            for (uint32_t x0 = slo; x0 < shi; x0 += 64) {
+                const uint32_t x = x0 + (uint32_t)lane;
+                if (x0 != slo) { k = x < shi ? A.g_key[x] : 0xFFFFFFFFu; v = x < shi ? A.g_val[x] : 0ull; }      // (a bucket of more than 64 entries)
+                const bool match = x < shi && k == skm;
+                if (!__any(match)) continue;
+                const uint32_t ref = (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;
+                uint32_t slot = 0xFFFFFFFFu;
+                if (match) {
+                    const unsigned long long bits = s_bits[w];
+                    const uint32_t rk = s_pref[w] + (uint32_t)__popcll(bits & ((1ull << bpos) - 1ull));
+                    if (((bits >> bpos) & 1ull) && rk >= B.rank_lo && rk < B.rank_hi) slot = rk - B.rank_lo;
+                    if (EMIT && slot != 0xFFFFFFFFu && s_ps[slot] == GSI_DEAD) slot = 0xFFFFFFFFu;
+                }
+                const bool valid = slot != 0xFFFFFFFFu;
+                if (!__any(valid)) continue;
+                const uint32_t prev = __shfl_up(slot, 1), next = __shfl_down(slot, 1);
+                const bool same = valid && lane > 0 && prev == slot;                       // not the first lane of its (seed, reference) group
+                const bool last = valid && !(lane < 63 && next == slot);
+                const unsigned long long starts = __ballot(valid && !same);
+                const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                const uint32_t j = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
+                const uint32_t base = valid ? s_cur[slot] : 0u;
+                if (EMIT && valid) {
+                    const unsigned long long dst = (unsigned long long)s_ps[slot] + base + j;
+                    if (dst < A.cap) {
+                        const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
+                        A.anc[dst] = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
+                    } else atomicOr(A.err, 2u);
+                    // chunk table: a chunk = the pair's anchors of one query contig within FRAGMENT_LENGTH of its first anchor (chunk_heads_kernel's rule), decided
+                    // by the first lane of the (seed, reference) group - one group per pair and step
+                    if (!same) {
+                        const uint32_t idx = s_ps[slot] + base, qc = sqm >> 1, hc = s_hc[slot];
+                        if (base == 0) { s_hq[slot] = sqp; s_hi[slot] = idx; s_hc[slot] = qc << 16; }
+                        else if ((hc >> 16) != qc || (unsigned long long)sqp > (unsigned long long)s_hq[slot] + FRAGMENT_LENGTH) {
+                            const uint32_t rows = hc & 0xFFFFu;
+                            if (rows < Q.rows && rows < 0xFFFFu) A.chunks[(size_t)B.row_off + (size_t)slot * Q.rows + rows] = make_uint2(s_hi[slot], idx < A.cap ? idx : A.cap); else atomicOr(A.err, 1u);
+                            s_hq[slot] = sqp; s_hi[slot] = idx; s_hc[slot] = (qc << 16) | (rows + 1u);
+                        }
+                    }
+                }
+                lds_wave_sync();
+                if (last) s_cur[slot] = base + j + 1u;
+                lds_wave_sync();
+            }
+        }
+    }
+    if (!EMIT) for (uint32_t j = lane; j < P; j += 64) A.pair_cnt[B.pair_off + j] = s_cur[j];
+    else for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
+        uint32_t rows = 0;
+        if (s_ps[j] != GSI_DEAD && s_cur[j]) {
+            rows = s_hc[j] & 0xFFFFu;
+            const unsigned long long e = (unsigned long long)s_ps[j] + s_cur[j];
+            if (rows < Q.rows) { A.chunks[(size_t)B.row_off + (size_t)j * Q.rows + rows] = make_uint2(s_hi[j], e < A.cap ? (uint32_t)e : A.cap); rows++; } else atomicOr(A.err, 1u);
+        }
+        A.n_chunks[B.pair_off + j] = rows;
+    }
+}
+__global__ void gsi_total_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, unsigned long long* __restrict__ total64) { *total64 = poff[n_pairs]; }
+
 struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const { return h.ani > 0.1f; } };   // lib.rs:654
 
 // device arrays of one chain launch sequence, carved from ctx->q_b
@@ -3327,6 +3461,9 @@ struct ChainBufs {
     uint32_t gi, gi_sum;      // 256-item tiles; entries of bsum
     unsigned long long* total;      // the 64-bit anchor total: misc[16..17], so that status, total and the hits behind them cross in one copy
     uint32_t rows_pair_max = 0xFFFFFFFFu;      // most chunk-table rows any pair of the batch can have (the host knows its queries): which reduce kernels have work
+    // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
+    const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
+    const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
     const size_t gi = (n_items + 255) / 256, gi_sum = std::max(gi, (n_pairs + 3) / 4);
@@ -3368,9 +3505,19 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
-    const bool join_pairs = !wide && (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048));
+    static const bool gsi_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // tests, A/B: the probe-table join instead
+    const bool gsi_join = !wide && !gsi_off && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
+    const bool join_pairs = !wide && (gsi_join || (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048)));
     bool probe_local = false;
-    if (join_pairs) {
+    GsiJoinArgs GA{};
+    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
+    if (gsi_join) {
+        GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
+        GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
+        hipLaunchKernelGGL(gsi_join_kernel<false>, dim3(L.n_bq), dim3(64), gsi_lds_count, st, GA);
+        probe_local = true;      // (the scan over the pairs' counts below is the probe join's)
+    }
+    else if (join_pairs) {
         // pair ids sorted by reference index (a pair's reference = pair_qr[p].y): one radix sort of n_pairs small keys
         size_t ts = 0;
         uint32_t* keys_in = L.big_list;                     // free until select runs
@@ -3431,11 +3578,12 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_HIP(hipMemsetAsync(L.big_list + n_pairs, 0, 4, st));      // the scan reads n_pairs + 1 counts
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_g.p, tmp5, pl_it, pl_off64, (int)(n_pairs + 1), st));
         hipLaunchKernelGGL(pair_start64_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)pl_off64, n_pairs, L.pstart, (uint32_t)cap, (const uint32_t*)(L.misc + 5));
+        if (gsi_join) hipLaunchKernelGGL(gsi_total_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)pl_off64, n_pairs, L.total);
     }
     else if (wide) PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, cnt_it, L.aoff, (int)(n_items + 1), st));
     else PSK_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->q_c.p, tmp, pcnt_it, L.aoff, (int)(n_items + 1), st));
-    const bool small_sum = n_sum <= 16384;
-    if (!small_sum) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.total, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
+    const bool small_sum = !gsi_join && n_sum <= 16384;
+    if (!small_sum && !gsi_join) PSK_HIP(hipcub::DeviceReduce::Sum(ctx->q_c.p, tmp2, L.bsum, L.total, (int)n_sum, st));      // 64-bit total, beside the 32-bit offsets
     if ((!emit_pairs && !probe_local) || small_sum)
         hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe_local) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe_local) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.total, (const uint32_t*)(L.misc + 5));
@@ -3460,11 +3608,12 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
-    const bool use_hops = hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
+    const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
-    if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
+    if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit, st, GA); }
+    else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
@@ -3493,7 +3642,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                 hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, pass, scratch_rows, L.chunks, L.nch, L.misc);
         } else
         hipLaunchKernelGGL(chunk_hops_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, a_nxt, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
-    } else if (!emit_heads)
+    } else if (!emit_heads && !gsi_join)
         hipLaunchKernelGGL(chunk_heads_kernel, dim3(n_pairs), dim3(64), 0, st, L.pstart, anc, L.cbase, n_pairs, L.chunks, L.nch, L.misc);
     ctx->t_end();
     ctx->t_begin(K_CHAIN_CHUNK);
@@ -3902,6 +4051,39 @@ __global__ __launch_bounds__(256) void pref_apply_kernel(const uint32_t* __restr
 }
 
 // how many references carry a k-mer index (low word) / a probe table (high word): the descriptor table is stale when this moves
+// Seed prefilter of rescued queries through the database-wide seed index: the exact anchor count of (query, every reference) is one lookup per query seed
+// (pref_count_kernel streams every reference's own k-mer index past LDS tables of the queries' k-mers: it needs those indexes, a gather and a radix sort).
+// One workgroup per rescued query, a 16-bit counter per reference in LDS (saturating at MIN_ANCHORS); pairs below MIN_ANCHORS leave the pass matrix.
+__global__ __launch_bounds__(256) void gsi_prefilter_kernel(const SketchDesc* __restrict__ qd, const uint32_t* __restrict__ rq, uint32_t n_refs,
+                                                            const uint32_t* __restrict__ g_key, const unsigned long long* __restrict__ g_val, const uint32_t* __restrict__ g_bucket, int g_shift,
+                                                            uint8_t* __restrict__ pass) {
+    extern __shared__ uint32_t s_pc[];      // two 16-bit counters per word
+    const uint32_t q = rq[blockIdx.x];
+    const SketchDesc Q = qd[q];
+    const uint32_t nwd = (n_refs + 1u) / 2u;
+    for (uint32_t i = threadIdx.x; i < nwd; i += blockDim.x) s_pc[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr int U = 2;
+    for (uint32_t i0 = wave * U; i0 < Q.n; i0 += 4 * U) {
+        uint32_t km[U], lo[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) km[u] = i0 + u < Q.n ? Q.kmer[i0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) { lo[u] = 0; hi[u] = 0; if (i0 + u < Q.n) { const uint32_t b = km[u] >> g_shift; lo[u] = g_bucket[b]; hi[u] = g_bucket[b + 1]; } }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            for (uint32_t x = lo[u] + lane; x < hi[u]; x += 64u)
+                if (g_key[x] == km[u]) {
+                    const uint32_t ref = (uint32_t)(g_val[x] >> 48), sh = (ref & 1u) * 16u;
+                    if (((s_pc[ref >> 1] >> sh) & 0xFFFFu) < MIN_ANCHORS) atomicAdd(&s_pc[ref >> 1], 1u << sh);      // (at most MIN_ANCHORS - 1 + 256 concurrent adds: no carry into the neighbour)
+                }
+    }
+    __syncthreads();
+    uint8_t* row = pass + (size_t)q * n_refs;
+    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (((s_pc[r >> 1] >> ((r & 1u) * 16u)) & 0xFFFFu) < MIN_ANCHORS) row[r] = 0;
+}
+
 static uint64_t index_stamp(const psk_db* db) {
     uint64_t v = 0;
     for (const psk_sketch* r : db->refs) v += (uint64_t)(r->idx != nullptr) + ((uint64_t)(r->ptab != nullptr) << 32);
@@ -3920,6 +4102,7 @@ static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
     return PSK_OK;
 }
 
+static psk_status build_gsi(Lane* ctx, psk_db* db);
 psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                            HitList& all, uint64_t* offsets) {
     hipStream_t st = ctx->stream;
@@ -4000,6 +4183,27 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 }
             bool refs_ok = !rq.empty() && ((uint64_t)rq.size() * n >= (pf_force ? 1ull : (1ull << 20))) && (uint64_t)rq.size() * n * 4 <= (1ull << 31);
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
+            // through the database-wide seed index where the database can have one (no per-reference index, no gather, no sort); PSK_GSI_JOIN=0: the per-reference path
+            static const bool gsi_pf_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';
+            if (refs_ok && !gsi_pf_off && n <= 65536u && !join_wide_default()) {
+                if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
+                if (db->gsi_state == 1) {
+                    const uint32_t nr = (uint32_t)rq.size();
+                    h_qd.resize(m);
+                    for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], true);
+                    const size_t o_qd = al256(4 * (size_t)nr), o_endp = o_qd + sizeof(SketchDesc) * (size_t)m;
+                    PSK_TRY(pf_buf.reserve(ctx->dev, o_endp + 256));
+                    char* Bp = (char*)pf_buf.p;
+                    PSK_HIP(hipMemcpyAsync(Bp, rq.data(), 4 * (size_t)nr, hipMemcpyHostToDevice, st));
+                    PSK_HIP(hipMemcpyAsync(Bp + o_qd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
+                    static std::once_flag pf_once; static hipError_t pf_rc = hipSuccess;
+                    std::call_once(pf_once, [] { pf_rc = hipFuncSetAttribute((const void*)gsi_prefilter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 16); });
+                    PSK_HIP(pf_rc);
+                    hipLaunchKernelGGL(gsi_prefilter_kernel, dim3(nr), dim3(256), 4 * (size_t)((n + 1) / 2), st, (const SketchDesc*)(Bp + o_qd), (const uint32_t*)Bp, n,
+                                       (const uint32_t*)db->gsi_key.p, (const unsigned long long*)db->gsi_val.p, (const uint32_t*)db->gsi_bucket.p, db->gsi_shift, d_pass);
+                    refs_ok = false;      // (done)
+                }
+            }
             if (refs_ok) {
                 bool all_idx = !db->desc_dirty && db->desc_n == n;
                 for (const psk_sketch* rs : db->refs) if (!rs->idx && rs->n_seeds && rs->store) all_idx = false;
@@ -4079,6 +4283,27 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         }
         for (const psk_sketch* rs : need) if (rs->params.k != db->params.k || rs->params.c != db->params.c) { psk_set_error("a reference and the database were sketched with different parameters"); return PSK_EINVAL; }
         if (round_pairs == 0) { for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i]; continue; }
+        // Rounds of many SMALL pairs (metagenome contigs) do not merge-join through the sketches' own k-mer indexes: they go through the database-wide seed
+        // index (one lookup per query SEED finds its matches in every reference: gsi_join_kernel; no per-sketch index is read, so none is built for such a
+        // round - neither for the references nor for the round's 65 536 contigs) or, where the database cannot have one, through per-reference probe tables
+        // (one 64-byte line per (pair, seed)). PSK_PROBE=0 never, =1 whatever the round's shape; PSK_GSI_JOIN=0: the probe tables (tests, A/B)
+        bool round_probe = false, round_gsi = false, want_small = false;
+        {
+            const char* pb_env = getenv("PSK_PROBE");
+            const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
+            uint64_t round_items = 0;
+            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
+            want_small = !pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048));
+            static const bool gsi_join_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';
+            if (want_small && !gsi_join_off && n <= 65536u && !join_wide_default()) {
+                if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
+                round_gsi = db->gsi_state == 1;
+            }
+        }
+        if (round_gsi) {
+            round_probe = true;      // (the round's batches are sized for small pairs)
+            if (db->desc_dirty || db->desc_n != n) PSK_TRY(exclusive([&]() -> psk_status { return refresh_ref_descs(ctx, db); }));
+        } else {
         {   // references first (shared state: exclusive), then this call's own query sketches
             bool refs_stale = db->desc_dirty || db->desc_n != n;
             refs_stale = refs_stale || index_stamp(db) != db->desc_indexed;
@@ -4090,30 +4315,22 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 }));
             else if (need.size() > n_need_refs) PSK_TRY(ensure_index(ctx, need.data() + n_need_refs, (uint32_t)(need.size() - n_need_refs)));
         }
-        // rounds of many SMALL pairs (metagenome contigs) join through the references' probe tables: built once per reference, like the
-        // k-mer index, for the references about to be chained (PSK_PROBE=0 never, =1 whatever the round's shape: tests)
-        bool round_probe = false;
-        {
-            const char* pb_env = getenv("PSK_PROBE");
-            const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
-            uint64_t round_items = 0;
-            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
-            if (!pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048))) {
-                round_probe = true;
-                bool missing = false;
-                for (size_t i = 0; i < n_need_refs; i++) {
-                    if (need[i]->n_seeds < 64 || need[i]->n_seeds > (1u << 22)) { round_probe = false; break; }
-                    missing = missing || !need[i]->ptab;
-                }
-                if (round_probe && missing)
-                    PSK_TRY(exclusive([&]() -> psk_status {
-                        PSK_TRY(ensure_probe(ctx, need.data(), (uint32_t)n_need_refs));
-                        return refresh_ref_descs(ctx, db);
-                    }));
+        if (want_small) {      // probe tables: built once per reference, like the k-mer index, for the references about to be chained
+            round_probe = true;
+            bool missing = false;
+            for (size_t i = 0; i < n_need_refs; i++) {
+                if (need[i]->n_seeds < 64 || need[i]->n_seeds > (1u << 22)) { round_probe = false; break; }
+                missing = missing || !need[i]->ptab;
             }
+            if (round_probe && missing)
+                PSK_TRY(exclusive([&]() -> psk_status {
+                    PSK_TRY(ensure_probe(ctx, need.data(), (uint32_t)n_need_refs));
+                    return refresh_ref_descs(ctx, db);
+                }));
+        }
         }
         h_qd.resize(m);
-        for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
+        for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], round_gsi);
         PSK_TRY(ctx->q_h.reserve(sizeof(SketchDesc) * (size_t)m + 256));
         SketchDesc* d_qd = (SketchDesc*)ctx->q_h.p;
         PSK_HIP(hipMemcpyAsync(d_qd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
@@ -4176,6 +4393,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 if (left == 0) { pq++; pr = 0; continue; }
                 const uint64_t qn = h_qd[pq].n, qrows = h_qd[pq].rows;
                 uint64_t take = std::min<uint64_t>(left, max_pairs - pairs);
+                if (round_gsi) take = std::min<uint64_t>(take, GSI_PMAX);      // (an entry = one wave of the index join: its pairs' cursors sit in LDS)
                 if (qn) take = std::min<uint64_t>(take, (max_items - items) / qn);
                 if (qrows) take = std::min<uint64_t>(take, (max_rows - rows) / qrows);
                 if (take == 0) { if (pairs == 0) take = 1; else break; }      // a single pair always goes through (chain_check refuses what cannot fit)
@@ -4195,6 +4413,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 ChainBufs L;
                 psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
                 L.rows_pair_max = (uint32_t)std::min<uint64_t>(rows_pair_max, 0xFFFFFFFFu);
+                if (round_gsi) {
+                    L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift;
+                    L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
+                    uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
+                    L.p_cap = (pm + 63u) & ~63u;
+                }
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
                 PSK_TRY(lrc);
                 PSK_HIP(hipMemcpyAsync(L.bq, bqs.data(), sizeof(BatchQ) * bqs.size(), hipMemcpyHostToDevice, st));
@@ -4219,7 +4443,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 for (int attempt = 0;; attempt++) {
                     struct timespec tb0{}, tb1{}, tb2{};
                     if (trace_batch) clock_gettime(CLOCK_MONOTONIC, &tb0);
-                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe);
+                    psk_status rrc = chain_run(ctx, L, n_pairs, (size_t)items, (size_t)rows, db->params, o, d_qd, (const SketchDesc*)db->d_refdesc.p, cap, wide, round_probe && !round_gsi);
                     if (trace_batch) clock_gettime(CLOCK_MONOTONIC, &tb1);
                     if (rrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { (void)hipStreamSynchronize(st); ctx->huge_release(); too_big = true; break; }
                     PSK_TRY(rrc);

@@ -57,7 +57,9 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another,
         monkeypatch.setenv("PSK_EMIT_EXPAND", "1")  # with the anchor-major emit of Gb-scale pairs behind it
         if seed % 8 == 1:
-            monkeypatch.setenv("PSK_PROBE", "1")    # ... through the references' probe tables (the metagenome join)
+            monkeypatch.setenv("PSK_PROBE", "1")    # ... through the database-wide seed index (the metagenome join) or, every other time, the references' probe tables
+            if seed % 16 == 1:
+                monkeypatch.setenv("PSK_GSI_JOIN", "0")
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
@@ -73,7 +75,10 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
         seeds, markers = gs.export()
         assert np.array_equal(seeds["kmer"], q.seeds["kmer"]) and np.array_equal(seeds["pos"], q.seeds["pos"]), (seed, k, c)
         assert np.array_equal(markers, q.markers), (seed, k, c, mc)
-        got = db.query("q", *qry, learned_ani=False, **kw)
+        got = db.query_sketches([gs], learned_ani=False, **kw)[0]      # the general path, under this seed's forced kernel variants
+        one = db.query("q", *qry, learned_ani=False, **kw)             # ... and Database.query (a small query: the one-launch-sequence path): the same records
+        assert [(h.reference_name, h.identity, h._raw["n_anchors"], h._raw["covered_query"], h._raw["sum_chunk_seeds"]) for h in one] == \
+               [(h.reference_name, h.identity, h._raw["n_anchors"], h._raw["covered_query"], h._raw["sum_chunk_seeds"]) for h in got], (seed, k, c, mc, kw)
         assert len(got) == len(want), (seed, k, c, mc, kw)
         if want:
             for f in INT_FIELDS:
@@ -90,8 +95,10 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
     if seed % 2:
         monkeypatch.setenv("PSK_PREFILTER", "1")      # seed prefilter of rescued queries whatever the batch size
     else:
-        monkeypatch.setenv("PSK_JOIN_PAIRS", "1")     # the reference-major join of many small pairs, through the references' probe tables,
-        monkeypatch.setenv("PSK_PROBE", "1")          # whatever the batch size
+        monkeypatch.setenv("PSK_JOIN_PAIRS", "1")     # the join of many small pairs whatever the batch size: through the database-wide seed index,
+        monkeypatch.setenv("PSK_PROBE", "1")          # or (every other seed) through the references' probe tables
+        if seed % 4 == 2:
+            monkeypatch.setenv("PSK_GSI_JOIN", "0")
     k = int(rng.integers(11, 17)); c = int(rng.choice([30, 60, 125, 200])); mc = int(c * rng.choice([4, 8]))
     fams = [random_genome(rng, int(rng.integers(60000, 250000))) for _ in range(int(rng.integers(1, 4)))]
     refs = []
