@@ -457,11 +457,15 @@ def load_pmc():
         ss = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": "profiles/r2/r2n_pmc_sketch_scan.json", "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
         for wl in ("search", "allvsall", "metagenome", "mammalian"):
             out.setdefault(wl, {})["sketch_scan"] = ss
-    p = os.path.join(ROOT, "profiles", "r3", "pmc_kernels.json")
-    if os.path.exists(p):
-        for wl, timers in json.load(open(p)).items():
-            for k, v in timers.items():
-                out.setdefault(wl, {})[k] = dict(v, source="profiles/r3/pmc_kernels.json")
+    # (round 4: scale factors calibrated per access shape, profiles/r4/r4k_pmc_calibration.md; the round-3 file for whatever the newer one lacks)
+    for rel in (("profiles", "r3", "pmc_kernels.json"), ("profiles", "r4", "pmc_kernels.json")):
+        p = os.path.join(ROOT, *rel)
+        if os.path.exists(p):
+            for wl, timers in json.load(open(p)).items():
+                if wl.startswith("_"):
+                    continue
+                for k, v in timers.items():
+                    out.setdefault(wl, {})[k] = dict(v, source="/".join(rel))
     return out
 
 

@@ -209,7 +209,7 @@ psk_status psk_model_predict(const psk_model* m, const float* rows, uint32_t n_r
  * passes through host memory except the 64-byte headers and the contig tables. */
 psk_status psk_sketch_pack_size(const psk_sketch* s, uint64_t* bytes);
 psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity);
-psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out);
+psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, uint64_t capacity, const uint64_t* offsets, uint32_t n, psk_sketch** out);
 /* n sketches (of one context) -> n records at d_dst + offsets[i] (16-byte aligned, inside `capacity` bytes): one header upload,
  * one copy launch and one synchronisation for the whole batch */
 psk_status psk_sketch_pack_many(const psk_sketch* const* sketches, uint32_t n, void* d_dst, const uint64_t* offsets, uint64_t capacity);

@@ -115,7 +115,7 @@ def load():
     lib.psk_query_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_sketch_pack_size.argtypes = [vp, C.POINTER(u64)]
     lib.psk_sketch_pack.argtypes = [vp, vp, u64]
-    lib.psk_sketch_unpack.argtypes = [vp, vp, C.POINTER(u64), u32, C.POINTER(vp)]
+    lib.psk_sketch_unpack.argtypes = [vp, vp, u64, C.POINTER(u64), u32, C.POINTER(vp)]
     lib.psk_sketch_pack_many.argtypes = [C.POINTER(vp), u32, vp, C.POINTER(u64), u64]
     lib.psk_ctx_clock_probe.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.psk_ctx_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_int]

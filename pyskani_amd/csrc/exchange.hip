@@ -101,10 +101,13 @@ psk_status pack_many_impl(Lane* lane, const psk_sketch* const* sk, uint32_t n, v
 
 // n records at d_src + offsets[i] -> n device-resident sketches sharing one store. Three synchronisations per BATCH (headers,
 // contig tables, done), three copy launches; nothing is per record except host bookkeeping.
-psk_status unpack_impl(Lane* lane, psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out) {
+// capacity: bytes readable at d_src (0: unknown - the caller vouches for the records); sizes: what the sender announced for every record (may be NULL).
+// A record header is only believed when it fits both (a truncated or corrupt record from another rank must not steer reads past the buffer).
+psk_status unpack_impl(Lane* lane, psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out, uint64_t capacity, const uint64_t* sizes) {
     hipStream_t st = lane->stream;
     const char* src = (const char*)d_src;
     for (uint32_t i = 0; i < n; i++) if (offsets[i] & 15) { psk_set_error("unpack: record %u is not 16-byte aligned", i); return PSK_EINVAL; }
+    if (capacity) for (uint32_t i = 0; i < n; i++) if (offsets[i] > capacity || capacity - offsets[i] < sizeof(PackHeader)) { psk_set_error("unpack: record %u starts beyond the buffer (%llu bytes)", i, (unsigned long long)capacity); return PSK_EINVAL; }
     // headers: gathered into one staging block, one D2H
     PSK_TRY(lane->s_misc.reserve(sizeof(PackHeader) * (size_t)n));
     std::vector<Seg> segs(n);
@@ -118,6 +121,8 @@ psk_status unpack_impl(Lane* lane, psk_ctx* ctx, const void* d_src, const uint64
         const PackHeader& h = H[i];
         if (h.magic != PACK_MAGIC || h.version != 1 || h.k < 1 || h.k > 16 || h.c < 1 || h.marker_c < 1 ||
             h.bytes != pack_layout(h.n_contigs, h.n_seeds, h.n_markers).end) { psk_set_error("unpack: record %u is not a packed sketch", i); return PSK_EINVAL; }
+        if (sizes && h.bytes != sizes[i]) { psk_set_error("unpack: record %u says %llu bytes, its sender announced %llu", i, (unsigned long long)h.bytes, (unsigned long long)sizes[i]); return PSK_EINVAL; }
+        if (capacity && h.bytes > capacity - offsets[i]) { psk_set_error("unpack: record %u (%llu bytes at %llu) runs past the buffer (%llu bytes)", i, (unsigned long long)h.bytes, (unsigned long long)offsets[i], (unsigned long long)capacity); return PSK_EINVAL; }
         tot_c += h.n_contigs; tot_s += h.n_seeds; tot_m += h.n_markers;
     }
     if (tot_s >= 0x7FFFFFF0ull || tot_m >= 0x7FFFFFF0ull) { psk_set_error("unpack: batch too large for one store; split it"); return PSK_ELIMIT; }
@@ -189,6 +194,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclId*) = nullptr;
     int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string why;
@@ -203,6 +209,7 @@ Rccl* rccl() {
         R.GetUniqueId = (int (*)(NcclId*))dlsym(R.h, "ncclGetUniqueId");
         R.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(R.h, "ncclCommInitRank");
         R.CommDestroy = (int (*)(void*))dlsym(R.h, "ncclCommDestroy");
+        R.CommAbort = (int (*)(void*))dlsym(R.h, "ncclCommAbort");
         R.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(R.h, "ncclAllGather");
         R.GetErrorString = (const char* (*)(int))dlsym(R.h, "ncclGetErrorString");
         if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) { R.why = "librccl.so lacks an expected symbol"; dlclose(R.h); R.h = nullptr; }
@@ -218,7 +225,16 @@ struct psk_comm {
     void* comm = nullptr;
     std::mutex mu;                 // one collective of this communicator at a time
     uint64_t bytes_sent = 0, bytes_received = 0, collectives = 0;
+    // control words of the exchange steps (counts, byte totals, status): device and pinned host scratch made with the communicator, so that
+    // entering a collective never depends on an allocation that may fail on ONE rank (its peers would wait in the collective for ever)
+    uint64_t* d_ctl = nullptr; uint64_t* h_ctl = nullptr;      // 4 words per rank + 4 to send
+    bool dead = false;             // a collective failed or was abandoned on this rank: the communicator was aborted, every later call fails at once
 };
+static void comm_abort(psk_comm* cm) {
+    if (cm->dead) return;
+    cm->dead = true;
+    if (cm->comm && rccl()->CommAbort) { (void)rccl()->CommAbort(cm->comm); cm->comm = nullptr; }
+}
 
 #define PSK_NCCL(expr)                                                                                              \
     do {                                                                                                            \
@@ -233,8 +249,36 @@ static psk_status need_rccl() {
 
 // all-gather of `bytes` bytes per rank, device to device, on the lane's stream
 static psk_status all_gather_dev(psk_comm* cm, Lane* lane, const void* send, void* recv, size_t bytes) {
-    PSK_NCCL(rccl()->AllGather(send, recv, bytes, NCCL_UINT8, cm->comm, lane->stream));
+    if (cm->dead) { psk_set_error("the communicator was aborted by an earlier failure"); return PSK_ERCCL; }
+    {
+        const int r = rccl()->AllGather(send, recv, bytes, NCCL_UINT8, cm->comm, lane->stream);
+        if (r != 0) { psk_set_error("ncclAllGather failed: %s (communicator aborted)", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "?"); comm_abort(cm); return PSK_ERCCL; }
+    }
     cm->bytes_sent += bytes * (size_t)(cm->world - 1); cm->bytes_received += bytes * (size_t)(cm->world - 1); cm->collectives++;
+    return PSK_OK;
+}
+
+// Every rank contributes 4 control words (the last one its local status) and reads everybody's: a rank whose local work failed still ENTERS the
+// collective, and all ranks leave the exchange step together with the same verdict (a rank that returned on its own left its peers
+// waiting in ncclAllGather for ever). words[3] = local status; on return *bad = the first failing rank's status (PSK_OK if none).
+static psk_status control_gather(psk_comm* cm, Lane* lane, uint64_t w0, uint64_t w1, uint64_t w2, psk_status local, std::vector<uint64_t>& all, psk_status* bad) {
+    const size_t W = (size_t)cm->world;
+    hipStream_t st = lane->stream;
+    uint64_t* mine = cm->h_ctl + 4 * W;
+    mine[0] = w0; mine[1] = w1; mine[2] = w2; mine[3] = (uint64_t)local;
+    hipError_t e = hipMemcpyAsync(cm->d_ctl + 4 * W, mine, 32, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { psk_set_error("exchange control words: %s", hipGetErrorString(e)); comm_abort(cm); return PSK_EHIP; }
+    PSK_TRY(all_gather_dev(cm, lane, cm->d_ctl + 4 * W, cm->d_ctl, 32));
+    e = hipMemcpyAsync(cm->h_ctl, cm->d_ctl, 32 * W, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { psk_set_error("exchange control words: %s", hipGetErrorString(e)); comm_abort(cm); return PSK_EHIP; }
+    all.assign(cm->h_ctl, cm->h_ctl + 4 * W);
+    *bad = PSK_OK;
+    for (size_t r = 0; r < W; r++) if (all[4 * r + 3] != 0) {
+        *bad = (psk_status)all[4 * r + 3];
+        if ((int)r != cm->rank || local == PSK_OK) psk_set_error("exchange step abandoned: rank %zu reported status %d", r, (int)*bad);      // (the failing rank keeps its own message)
+        break;
+    }
     return PSK_OK;
 }
 
@@ -261,12 +305,12 @@ psk_status psk_sketch_pack(const psk_sketch* s, void* d_dst, uint64_t capacity) 
     return psk_sketch_pack_many(&s, 1, d_dst, &zero, capacity);
 }
 
-psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, const uint64_t* offsets, uint32_t n, psk_sketch** out) {
+psk_status psk_sketch_unpack(psk_ctx* ctx, const void* d_src, uint64_t capacity, const uint64_t* offsets, uint32_t n, psk_sketch** out) {
     if (!ctx || (n && (!d_src || !offsets || !out))) { psk_set_error("unpack: NULL argument"); return PSK_EINVAL; }
     for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
     if (!n) return PSK_OK;
     PSK_LANE(lg, ctx);
-    return unpack_impl(lg.lane, ctx, d_src, offsets, n, out);
+    return unpack_impl(lg.lane, ctx, d_src, offsets, n, out, capacity, nullptr);
 }
 
 psk_status psk_comm_unique_id(void* id) {
@@ -286,14 +330,19 @@ psk_status psk_comm_create(psk_ctx* ctx, int rank, int world, const void* id, ps
     cm->ctx = ctx; cm->rank = rank; cm->world = world;
     NcclId nid;
     memcpy(&nid, id, sizeof nid);
-    PSK_NCCL(rccl()->CommInitRank(&cm->comm, world, nid, rank));
+    PSK_HIP(hipMalloc((void**)&cm->d_ctl, 32 * ((size_t)world + 1)));
+    { const hipError_t e = hipHostMalloc((void**)&cm->h_ctl, 32 * ((size_t)world + 1), hipHostMallocDefault); if (e != hipSuccess) { (void)hipFree(cm->d_ctl); psk_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return PSK_ENOMEM; } }
+    { const int r = rccl()->CommInitRank(&cm->comm, world, nid, rank); if (r != 0) { (void)hipFree(cm->d_ctl); (void)hipHostFree(cm->h_ctl); psk_set_error("ncclCommInitRank failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "?"); return PSK_ERCCL; } }
     *out = cm.release();
     return PSK_OK;
 }
 
 void psk_comm_destroy(psk_comm* cm) {
     if (!cm) return;
-    if (cm->comm && rccl()->h) { (void)hipSetDevice(cm->ctx->device); (void)rccl()->CommDestroy(cm->comm); }
+    (void)hipSetDevice(cm->ctx->device);
+    if (cm->comm && rccl()->h) (void)rccl()->CommDestroy(cm->comm);
+    if (cm->d_ctl) (void)hipFree(cm->d_ctl);
+    if (cm->h_ctl) (void)hipHostFree(cm->h_ctl);
     delete cm;
 }
 
@@ -310,44 +359,48 @@ psk_status psk_comm_info(const psk_comm* cm, int* rank, int* world, uint64_t* by
 // ref_index and the global query index in `reserved`. Two collectives: the counts (8 bytes per rank), then the lists padded to the
 // largest count. *all (psk_free) holds the ranks' lists in rank order; counts[r] (world entries, may be NULL) their lengths.
 psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local, psk_hit** all, uint64_t* n_all, uint64_t* counts) {
-    if (!cm || !all || !n_all || (n_local && !local)) { psk_set_error("gather_hits: NULL argument"); return PSK_EINVAL; }
+    if (!cm || !all || !n_all) { psk_set_error("gather_hits: NULL argument"); return PSK_EINVAL; }
     *all = nullptr; *n_all = 0;
     std::lock_guard<std::mutex> lk(cm->mu);
     PSK_LANE(lg, cm->ctx);
     Lane* lane = lg.lane;
     hipStream_t st = lane->stream;
     const size_t W = (size_t)cm->world;
-    void* hp;
-    PSK_TRY(lane->pinned(8 * (W + 1) + 64, &hp));
-    uint64_t* h_cnt = (uint64_t*)hp;
-    h_cnt[W] = n_local;
-    PSK_TRY(lane->s_counts.reserve(8 * (W + 1) + 64));
-    uint64_t* d_cnt = (uint64_t*)lane->s_counts.p;
-    PSK_HIP(hipMemcpyAsync(d_cnt + W, h_cnt + W, 8, hipMemcpyHostToDevice, st));
-    PSK_TRY(all_gather_dev(cm, lane, d_cnt + W, d_cnt, 8));
-    PSK_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8 * W, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipStreamSynchronize(st));
-    std::vector<uint64_t> cnt(h_cnt, h_cnt + W);
+    // collective 1: every rank's count - and its verdict on its own arguments (a rank with bad arguments still takes part)
+    psk_status mine = PSK_OK;
+    if (n_local && !local) { psk_set_error("gather_hits: NULL argument"); mine = PSK_EINVAL; }
+    std::vector<uint64_t> ctl; psk_status bad;
+    PSK_TRY(control_gather(cm, lane, mine == PSK_OK ? n_local : 0, 0, 0, mine, ctl, &bad));
+    if (bad != PSK_OK) return bad;
+    std::vector<uint64_t> cnt(W);
     uint64_t maxc = 0, total = 0;
-    for (uint64_t c : cnt) { maxc = std::max(maxc, c); total += c; }
+    for (size_t r = 0; r < W; r++) { cnt[r] = ctl[4 * r]; maxc = std::max(maxc, cnt[r]); total += cnt[r]; }
     if (counts) for (size_t r = 0; r < W; r++) counts[r] = cnt[r];
+    // local work that can fail (host and device memory, the upload), then ONE more exchange of status words: all ranks enter the payload collective or none
+    const size_t row = sizeof(psk_hit) * (size_t)maxc;
     psk_hit* res = (psk_hit*)malloc(sizeof(psk_hit) * std::max<uint64_t>(total, 1));
-    if (!res) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+    PoolScratch buf;
+    if (!res) { psk_set_error("out of host memory"); mine = PSK_ENOMEM; }
+    if (mine == PSK_OK && maxc) mine = buf.reserve(cm->ctx, row * (W + 1) + 256);
+    char* d_send = buf.p ? (char*)buf.p + row * W : nullptr;
+    if (mine == PSK_OK && maxc && n_local) {
+        const hipError_t e = hipMemcpyAsync(d_send, local, sizeof(psk_hit) * (size_t)n_local, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { psk_set_error("gather_hits: %s", hipGetErrorString(e)); mine = PSK_EHIP; }
+    }
+    {
+        const psk_status rc = control_gather(cm, lane, 0, 0, 0, mine, ctl, &bad);
+        if (rc != PSK_OK || bad != PSK_OK) { free(res); return rc != PSK_OK ? rc : bad; }
+    }
     if (maxc) {
-        const size_t row = sizeof(psk_hit) * (size_t)maxc;
-        PoolScratch buf;
-        psk_status rc = buf.reserve(cm->ctx, row * (W + 1) + 256);
-        if (rc != PSK_OK) { free(res); return rc; }
-        char* d_send = (char*)buf.p + row * W;
-        hipError_t e = n_local ? hipMemcpyAsync(d_send, local, sizeof(psk_hit) * (size_t)n_local, hipMemcpyHostToDevice, st) : hipSuccess;
-        if (e == hipSuccess) rc = all_gather_dev(cm, lane, d_send, buf.p, row);
+        psk_status rc = all_gather_dev(cm, lane, d_send, buf.p, row);
+        hipError_t e = hipSuccess;
         uint64_t w = 0;
         for (size_t r = 0; r < W && e == hipSuccess && rc == PSK_OK; r++) {
             if (cnt[r]) e = hipMemcpyAsync(res + w, (char*)buf.p + row * r, sizeof(psk_hit) * (size_t)cnt[r], hipMemcpyDeviceToHost, st);
             w += cnt[r];
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st); else (void)hipStreamSynchronize(st);
-        if (e != hipSuccess || rc != PSK_OK) { free(res); if (rc == PSK_OK) { psk_set_error("gather_hits: %s", hipGetErrorString(e)); rc = PSK_EHIP; } return rc; }
+        if (e != hipSuccess || rc != PSK_OK) { free(res); if (rc == PSK_OK) { psk_set_error("gather_hits: %s", hipGetErrorString(e)); rc = PSK_EHIP; } return rc; }      // (after the last collective: a local matter)
     }
     *all = res; *n_all = total;
     return PSK_OK;
@@ -358,42 +411,43 @@ psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local,
 // then one buffer per rank = [u64 sizes[n]] pad16 [records], padded to the widest. *all (psk_free; every entry psk_sketch_free)
 // holds the ranks' sketches in rank order, counts[r] their numbers (world entries).
 psk_status psk_gather_sketches(psk_comm* cm, const psk_sketch* const* mine, uint32_t n, psk_sketch*** all, uint32_t* counts) {
-    if (!cm || !all || !counts || (n && !mine)) { psk_set_error("gather_sketches: NULL argument"); return PSK_EINVAL; }
+    if (!cm || !all || !counts) { psk_set_error("gather_sketches: NULL argument"); return PSK_EINVAL; }
     *all = nullptr;
     std::lock_guard<std::mutex> lk(cm->mu);
     PSK_LANE(lg, cm->ctx);
     Lane* lane = lg.lane;
     hipStream_t st = lane->stream;
     const size_t W = (size_t)cm->world;
+    // this rank's verdict on its own arguments travels with its (count, bytes): a rank with a NULL sketch still takes part in collective 1
+    psk_status local = PSK_OK;
+    if (n && !mine) { psk_set_error("gather_sketches: NULL argument"); local = PSK_EINVAL; }
     std::vector<uint64_t> sizes(n), offs(n);
     const uint64_t table = al16(8 * (uint64_t)n);
     uint64_t mybytes = table;
-    for (uint32_t i = 0; i < n; i++) {
-        if (!mine[i]) { psk_set_error("gather_sketches: NULL sketch %u", i); return PSK_EINVAL; }
+    for (uint32_t i = 0; i < n && local == PSK_OK; i++) {
+        if (!mine[i]) { psk_set_error("gather_sketches: NULL sketch %u", i); local = PSK_EINVAL; break; }
         sizes[i] = pack_layout(mine[i]->contig_len.size(), mine[i]->n_seeds, mine[i]->n_markers).end;
         offs[i] = mybytes; mybytes += sizes[i];
     }
-    // collective 1: (count, bytes) of every rank
-    void* hp;
-    PSK_TRY(lane->pinned(16 * (W + 1) + 64, &hp));
-    uint64_t* h_nb = (uint64_t*)hp;
-    h_nb[2 * W] = n; h_nb[2 * W + 1] = mybytes;
-    PSK_TRY(lane->s_counts.reserve(16 * (W + 1) + 64));
-    uint64_t* d_nb = (uint64_t*)lane->s_counts.p;
-    PSK_HIP(hipMemcpyAsync(d_nb + 2 * W, h_nb + 2 * W, 16, hipMemcpyHostToDevice, st));
-    PSK_TRY(all_gather_dev(cm, lane, d_nb + 2 * W, d_nb, 16));
-    PSK_HIP(hipMemcpyAsync(h_nb, d_nb, 16 * W, hipMemcpyDeviceToHost, st));
-    PSK_HIP(hipStreamSynchronize(st));
-    std::vector<uint64_t> nb(h_nb, h_nb + 2 * W);
+    // collective 1: (count, bytes, status) of every rank
+    std::vector<uint64_t> ctl; psk_status bad;
+    PSK_TRY(control_gather(cm, lane, local == PSK_OK ? n : 0, local == PSK_OK ? mybytes : 16, 0, local, ctl, &bad));
+    if (bad != PSK_OK) return bad;
     uint64_t width = 16, n_total = 0;
-    for (size_t r = 0; r < W; r++) { counts[r] = (uint32_t)nb[2 * r]; n_total += nb[2 * r]; width = std::max(width, al16(nb[2 * r + 1])); }
-    // collective 2: the records
+    for (size_t r = 0; r < W; r++) { counts[r] = (uint32_t)ctl[4 * r]; n_total += ctl[4 * r]; width = std::max(width, al16(ctl[4 * r + 1])); }
+    // local work that can fail (the gather buffer, packing), one exchange of status words, then collective 2: the records
     PoolScratch buf;
-    PSK_TRY(buf.reserve(cm->ctx, (size_t)width * (W + 1) + 256));
-    char* d_send = (char*)buf.p + (size_t)width * W;
-    if (n) {
-        PSK_HIP(hipMemcpyAsync(d_send, sizes.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
-        PSK_TRY(pack_many_impl(lane, mine, n, d_send, offs.data(), mybytes));      // synchronises: sizes[] has been read
+    local = buf.reserve(cm->ctx, (size_t)width * (W + 1) + 256);
+    char* d_send = buf.p ? (char*)buf.p + (size_t)width * W : nullptr;
+    if (local == PSK_OK && n) {
+        const hipError_t e = hipMemcpyAsync(d_send, sizes.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { psk_set_error("gather_sketches: %s", hipGetErrorString(e)); local = PSK_EHIP; }
+        else local = pack_many_impl(lane, mine, n, d_send, offs.data(), mybytes);      // synchronises: sizes[] has been read
+    }
+    {
+        const psk_status rc = control_gather(cm, lane, 0, 0, 0, local, ctl, &bad);
+        if (rc != PSK_OK) return rc;
+        if (bad != PSK_OK) return bad;
     }
     PSK_TRY(all_gather_dev(cm, lane, d_send, buf.p, (size_t)width));
     // size tables of every rank -> record offsets inside the gathered buffer -> one unpack over all of them
@@ -421,7 +475,7 @@ psk_status psk_gather_sketches(psk_comm* cm, const psk_sketch* const* mine, uint
     for (uint64_t b = 0; b < n_total && rc == PSK_OK;) {
         uint64_t e = b, bytes = 0;
         while (e < n_total && (e == b || bytes + all_sizes[e] < (8ull << 30))) { bytes += all_sizes[e]; e++; }
-        rc = unpack_impl(lane, cm->ctx, buf.p, roffs.data() + b, (uint32_t)(e - b), res + b);
+        rc = unpack_impl(lane, cm->ctx, buf.p, roffs.data() + b, (uint32_t)(e - b), res + b, (uint64_t)width * W, all_sizes.data() + b);
         if (rc != PSK_OK) for (uint64_t i = 0; i < b; i++) { delete res[i]; }
         b = e;
     }

@@ -207,12 +207,13 @@ class Sketch:
         _capi.check(self._ctx._lib.psk_sketch_pack(self._h, C.c_void_p(device_ptr), capacity))
 
     @classmethod
-    def unpack(cls, ctx, device_ptr, offsets, names):
-        """Packed records at device_ptr + offsets[i] -> device-resident sketches (psk_sketch_unpack)."""
+    def unpack(cls, ctx, device_ptr, offsets, names, capacity=0):
+        """Packed records at device_ptr + offsets[i] -> device-resident sketches (psk_sketch_unpack). `capacity`: the bytes readable at
+        device_ptr - a record whose header points beyond them is refused (0: unchecked, the caller vouches for the records)."""
         n = len(offsets)
         offs = (C.c_uint64 * max(n, 1))(*[int(o) for o in offsets])
         out = (C.c_void_p * max(n, 1))()
-        _capi.check(ctx._lib.psk_sketch_unpack(ctx._h, C.c_void_p(device_ptr), offs, n, out))
+        _capi.check(ctx._lib.psk_sketch_unpack(ctx._h, C.c_void_p(device_ptr), int(capacity), offs, n, out))
         return [cls(ctx, C.c_void_p(out[i]), names[i]) for i in range(n)]
 
     def export(self):

@@ -175,7 +175,7 @@ class TorchComm:
         out = (C.c_void_p * max(total, 1))()
         if total:
             c_roffs = (C.c_uint64 * total)(*roffs)
-            _capi.check(lib.psk_sketch_unpack(ctx._h, C.c_void_p(big.data_ptr()), c_roffs, total, out))
+            _capi.check(lib.psk_sketch_unpack(ctx._h, C.c_void_p(big.data_ptr()), int(big.numel()), c_roffs, total, out))      # (a record that points beyond the gathered buffer is refused)
         return out, counts
 
 

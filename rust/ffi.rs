@@ -77,7 +77,7 @@ extern "C" {
     // device-side records for the multi-GPU exchange (an RCCL all-gather moves them as they are)
     pub fn psk_sketch_pack_size(s: *const PskSketch, bytes: *mut u64) -> c_int;
     pub fn psk_sketch_pack(s: *const PskSketch, d_dst: *mut c_void, capacity: u64) -> c_int;
-    pub fn psk_sketch_unpack(ctx: *mut PskCtx, d_src: *const c_void, offsets: *const u64, n: u32,
+    pub fn psk_sketch_unpack(ctx: *mut PskCtx, d_src: *const c_void, capacity: u64, offsets: *const u64, n: u32,
                              out: *mut *mut PskSketch) -> c_int;
     pub fn psk_sketch_pack_many(sketches: *const *const PskSketch, n: u32, d_dst: *mut c_void, offsets: *const u64, capacity: u64) -> c_int;
     // multi-GPU exchange over RCCL (one process per GPU; the id travels over whatever channel the host program has)

@@ -225,6 +225,14 @@ def test_pack_unpack_device_records(psk, oracle):
     torch.cuda.synchronize()
     with pytest.raises(ValueError):
         psk.Sketch.unpack(db._ctx, bad.data_ptr(), offs[:-1], [s.name for s in sketches])
+    # with the buffer's extent given, a record that would run past it is refused before anything is read through its header
+    total = int(offs[-1])
+    ok = psk.Sketch.unpack(db._ctx, moved.data_ptr(), offs[:-1], [s.name for s in sketches], capacity=total)
+    assert len(ok) == len(sketches)
+    with pytest.raises(ValueError, match="past the buffer|beyond the buffer"):
+        psk.Sketch.unpack(db._ctx, moved.data_ptr(), offs[:-1], [s.name for s in sketches], capacity=total - 16)      # the last record is truncated
+    with pytest.raises(ValueError, match="beyond the buffer"):
+        psk.Sketch.unpack(db._ctx, moved.data_ptr(), offs[:-1], [s.name for s in sketches], capacity=int(offs[-2]) + 8)   # not even its header fits
 
 
 def test_query_edge_cases(psk):
