@@ -236,11 +236,14 @@ def family_layout(seed_shared, n_genomes, n_families):
     return lens, [min(i // per_fam, n_families - 1) for i in range(n_genomes)]
 
 
-def make_genomes(torch, device, seed_shared, seed_members, ids, fam_of, anc_lens, query_family=None):
+def make_genomes(torch, device, seed_shared, seed_members, ids, fam_of, anc_lens, query_family=None, variant="plain"):
     """Members `ids` (GLOBAL genome indices) of the family model: each carries independent substitutions at the cycled rates on its
     family's ancestor, drawn from a generator seeded by (seed_members, global index) — so a rank that builds only its shard gets
     the same genomes as a rank that builds them all. With `query_family` set, one more genome follows: the query (d = 0.02).
-    Returns one uint8 ASCII tensor plus per-genome (offset, length), every offset 16-byte aligned."""
+    Returns one uint8 ASCII tensor plus per-genome (offset, length), every offset 16-byte aligned.
+    variant: "sv" = on top of the substitutions, 20 block rearrangements per member (5-50 kb each: inverted in place - reverse
+    complement - or moved elsewhere), drawn from a numpy generator seeded by the genome's global index; "contigs" = the genome cut into 1-80
+    contigs at random 16-byte aligned points: then the return value is (buf, contig offsets, contig lengths, genome_first_contig)."""
     gs = torch.Generator(device=device)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     fams = sorted({fam_of[i] for i in ids} | ({query_family} if query_family is not None else set()))
@@ -261,8 +264,31 @@ def make_genomes(torch, device, seed_shared, seed_members, ids, fam_of, anc_lens
         gm.manual_seed((seed_members if i >= 0 else seed_shared) * 1_000_003 + (i if i >= 0 else 999_983))
         mut = torch.rand(a.shape, generator=gm, device=device) < d
         shift = torch.randint(1, 4, a.shape, generator=gm, device=device, dtype=torch.uint8)
-        buf[offs[j]:offs[j] + glen[j]] = lut[torch.where(mut, (a + shift) & 3, a).long()]
-        del mut, shift
+        codes = torch.where(mut, (a + shift) & 3, a)
+        if variant == "sv":
+            r = np.random.default_rng((seed_members, 77, i if i >= 0 else 999_983))
+            for _ in range(20):
+                L = int(r.integers(5_000, 50_001)); s0 = int(r.integers(0, codes.numel() - L))
+                if r.random() < 0.5:      # inversion: the block's reverse complement in place
+                    codes[s0:s0 + L] = 3 - torch.flip(codes[s0:s0 + L], (0,))
+                else:                     # translocation: the block cut out and put back elsewhere
+                    block = codes[s0:s0 + L].clone(); rest = torch.cat((codes[:s0], codes[s0 + L:]))
+                    t0 = int(r.integers(0, rest.numel() + 1))
+                    codes = torch.cat((rest[:t0], block, rest[t0:]))
+        buf[offs[j]:offs[j] + glen[j]] = lut[codes.long()]
+        del mut, shift, codes
+    if variant == "contigs":
+        c_off, c_len, gfc = [], [], [0]
+        for j, (i, _, _) in enumerate(todo):
+            r = np.random.default_rng((seed_members, 78, i if i >= 0 else 999_983))
+            n = int(r.integers(1, 81))
+            cuts = sorted({int(x) & ~15 for x in r.integers(16, glen[j] - 16, n - 1)}) if n > 1 else []
+            edges = [0] + cuts + [glen[j]]
+            for a0, a1 in zip(edges[:-1], edges[1:]):
+                if a1 > a0:
+                    c_off.append(offs[j] + a0); c_len.append(a1 - a0)
+            gfc.append(len(c_off))
+        return buf, c_off, c_len, gfc
     return buf, offs, glen
 
 
@@ -495,9 +521,10 @@ def kernel_rooflines(kern, steps, units, pmc):
             b = alg[k][0]
             row.update(algorithmic_bytes_per_step=b, bytes=alg[k][1], achieved_GBps=b / (ms_step * 1e-3) / 1e9, frac_of_hbm_peak=b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS)
             pm = pmc.get(k)
-            if pm and pm.get("unit") == unit_of[k][0]:
-                row["traffic_bytes_per_step"] = pm["bytes_per_unit"] * unit_of[k][1]
-                row["traffic_source"] = f"offline rocprofv3 --pmc pass ({pm['source']}), scaled by {unit_of[k][0]}s"
+            per = {"base": bases, "item": items, "anchor": anchors}
+            if pm and per.get(pm.get("unit"), 0) > 0:      # (the counter pass states its own unit: the Gb-scale emit bracket is counted per anchor, the others per item)
+                row["traffic_bytes_per_step"] = pm["bytes_per_unit"] * per[pm["unit"]]
+                row["traffic_source"] = f"offline rocprofv3 --pmc pass ({pm['source']}), scaled by {pm['unit']}s"
         table[k] = row
     return table
 
@@ -770,7 +797,7 @@ def records_digest(recs):
     return h.hexdigest()[:16]
 
 
-def run_allvsall(job, steps, warmup, n_total, cpu_queries):
+def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", verify_hits=0):
     """BASELINE configs[2] shape: every genome against a database of all of them (families of 100). N=1: one psk_query_many. N>1: the
     FIXED job of n_total genomes is sharded over the ranks (strong scaling) and run through parallel.ShardedDatabase.all_vs_all_records."""
     torch, rank, world, args = job.torch, job.rank, job.world, job.args
@@ -779,15 +806,21 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
     from pyskani_amd.parallel import shard_bounds
     lo, hi = shard_bounds(n_total, rank, world)
     n_local = hi - lo
-    buf, offs, lens = make_genomes(torch, job.device, 3, 31, list(range(lo, hi)), fam_of, anc_lens)
+    gfc_list = None
+    if variant == "contigs":
+        buf, offs, lens, gfc_list = make_genomes(torch, job.device, 3, 31, list(range(lo, hi)), fam_of, anc_lens, variant=variant)
+    else:
+        buf, offs, lens = make_genomes(torch, job.device, 3, 31, list(range(lo, hi)), fam_of, anc_lens, variant=variant)
     torch.cuda.synchronize()
     all_names = [f"g{i}" for i in range(n_total)]
     bases_local = float(sum(lens))
     line = None
+    if variant != "plain" and world != 1:
+        raise SystemExit("the generator variants run at N=1")
     if world == 1:
         eng = Engine(job.local_rank)
         names = (C.c_char_p * n_total)(*[s.encode() for s in all_names])
-        c_off, c_len, gfc, n = eng.layout(offs, lens)
+        c_off, c_len, gfc, n = eng.layout(offs, lens, gfc_list)
         last = {}
 
         def step():
@@ -804,14 +837,18 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
         recs["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(last["offs"]))
         digest = records_digest(recs)
         table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
+        shape = {"plain": "single-contig genomes, substitutions only", "contigs": "every genome cut into 1-80 contigs",
+                 "sv": "20 block inversions / translocations of 5-50 kb per genome on top of the substitutions"}[variant]
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
-                "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}), c=125 marker_c=1000 k=15; device-resident ASCII",
+                "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}; {shape}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
                 "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
-        if cpu_queries > 0:
+        if cpu_queries > 0 and variant == "plain":
             host = buf.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline_allvsall(lambda i: host[offs[i]:offs[i] + lens[i]].tobytes(), n_total, min(cpu_queries, n_total), os.cpu_count() or 1)
             del host
+        if verify_hits > 0 and len(recs):      # outside the timed region: random hits of the last step recomputed by the CPU oracle, every chain integer compared
+            line["oracle_check"] = allvsall_verify(buf, offs, lens, gfc_list, recs, verify_hits)
         eng.close()
     else:
         import pyskani_amd as psk
@@ -855,6 +892,27 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries):
     del buf
     torch.cuda.empty_cache()
     return line
+
+
+def allvsall_verify(buf, offs, lens, gfc, recs, k):
+    """k random hits of an all-vs-all step -> both genomes to the host -> oracle sketches -> oracle.chain: the GPU record must carry the same integers"""
+    from oracle import oracle as O
+    O.build()
+    pick = np.random.default_rng(5).choice(len(recs), size=min(k, len(recs)), replace=False)
+    def contigs_of(g):
+        rng_c = range(gfc[g], gfc[g + 1]) if gfc is not None else (g,)
+        return [buf[offs[c]:offs[c] + lens[c]].cpu().numpy().tobytes() for c in rng_c]
+    fields = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+    checked = []
+    for i in pick:
+        h = recs[int(i)]
+        q, r = int(h["reserved"]), int(h["ref_index"])
+        want = O.chain(O.Sketch(contigs_of(r)), O.Sketch(contigs_of(q)))
+        for f in fields:
+            assert int(h[f]) == int(getattr(want, f)), (q, r, f, int(h[f]), int(getattr(want, f)))
+        assert abs(float(h["ani"]) - want.ani) < 1e-6 and abs(float(h["af_query"]) - want.af_query) < 1e-6 and abs(float(h["af_ref"]) - want.af_ref) < 1e-6
+        checked.append({"query": q, "ref": r, "ani": float(h["ani"]), "n_anchors": int(h["n_anchors"])})
+    return {"pairs": checked, "fields": list(fields) + ["ani (1e-6)", "af_query (1e-6)", "af_ref (1e-6)"], "result": f"{len(checked)} random hits bit-exact"}
 
 
 def run_metagenome(job, steps, warmup, n_refs, n_queries, settings, cpu_contigs, api_queries):
@@ -1111,6 +1169,7 @@ def main():
     ap.add_argument("--exchange-batch", type=int, default=256, help="allvsall N>1: genomes per rank and round of the sketch all-gather")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
     ap.add_argument("--cpu-sample", type=int, default=1000, help="CPU-baseline sample size (0 = skip): search: references (1000 = the whole workload, ~10-20 s); allvsall: queries (capped at 128); metagenome: contigs (capped at 512)")
+    ap.add_argument("--variant", choices=["plain", "contigs", "sv"], default="plain", help="allvsall at N=1: the generator variant of SURVEY.md 8(d) - genomes cut into 1-80 contigs / 20 block rearrangements per genome")
     ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
     args = ap.parse_args()
 
@@ -1163,13 +1222,16 @@ def main():
             t0 = time.perf_counter()
             wl = {}
             wl["allvsall_10k"] = run_allvsall(job, 2, 1, 10000, min(cpu_n, 128))
+            # SURVEY.md §8d's harder shapes (every measured pair above is the easiest chaining case: one contig, substitutions only)
+            wl["allvsall_1k_contigs"] = run_allvsall(job, 2, 1, 1000, 0, variant="contigs", verify_hits=8 if cpu_n > 0 else 0)
+            wl["allvsall_1k_sv"] = run_allvsall(job, 2, 1, 1000, 0, variant="sv", verify_hits=8 if cpu_n > 0 else 0)
             meta = run_metagenome(job, 2, 1, 5000, 100000, (False, True), min(cpu_n, 512), 2000)
             wl["metagenome_100k"], wl["metagenome_100k_faster_small"], wl["metagenome_api"] = meta["rescue"], meta["faster_small"], meta.get("api")
             wl["mammalian_8x3Gb"] = run_mammalian(job, 2, 1, 8, 125, 2 if cpu_n > 0 else 0)
             line["extras"]["workloads"] = wl
             line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
     elif args.workload == "allvsall":
-        e = run_allvsall(job, args.steps, args.warmup, args.refs or 1000, min(cpu_n, 128))
+        e = run_allvsall(job, args.steps, args.warmup, args.refs or 1000, min(cpu_n, 128), variant=args.variant, verify_hits=8 if (cpu_n > 0 and args.variant != "plain") else 0)
         line = as_line(e, "allvsall") if e else None
     elif args.workload == "metagenome":
         m = run_metagenome(job, args.steps, args.warmup, args.refs or 5000, args.queries, (args.faster_small,), min(cpu_n, 512), args.api_queries)
