@@ -4372,6 +4372,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
         bool pend_copy = false;      // the pending hits are still crossing on the copy stream
         hipStream_t cst = nullptr;
+        // every way out of the round (an error return between two batches included) waits for a copy that is still crossing: the lane's pinned staging and the
+        // selection halves it reads go back to the next caller with the lane
+        struct CopyDrain { bool& pend; hipStream_t& s; ~CopyDrain() { if (pend && s) (void)hipStreamSynchronize(s); } } copy_drain{pend_copy, cst};
         const size_t sel_half = al256(sizeof(psk_hit) * half_pairs + 256);
         auto consume = [&]() -> psk_status {
             if (!pend_n) return PSK_OK;

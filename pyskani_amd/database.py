@@ -121,17 +121,30 @@ class Hit(tuple):
     __ne__ = object.__ne__
     __hash__ = object.__hash__
 
-    def __reduce__(self):
-        return (_hit_restore, (tuple(self[:6]),))
+    # The tuple behind a Hit is storage, not interface: the reference's pyclass (hit.rs) is no sequence. Length, iteration, indexing, ordering,
+    # concatenation and repetition raise TypeError like they do for any plain object (`sorted(hits)` used to fall back to tuple
+    # comparison and could end up comparing record arrays; unpacking exposed the internal fields).
+    def _not_a_sequence(self, *args, **kwargs):
+        raise TypeError("'Hit' object is not a sequence")
 
-    identity = property(operator.itemgetter(0))
-    query_name = property(operator.itemgetter(1))
-    query_fraction = property(operator.itemgetter(2))
-    reference_name = property(operator.itemgetter(3))
-    reference_fraction = property(operator.itemgetter(4))
+    __len__ = __iter__ = __getitem__ = __contains__ = __add__ = __radd__ = __mul__ = __rmul__ = _not_a_sequence
+
+    def _not_orderable(self, other):
+        return NotImplemented
+
+    __lt__ = __le__ = __gt__ = __ge__ = _not_orderable
+
+    def __reduce__(self):
+        return (_hit_restore, (tuple(tuple.__getitem__(self, slice(0, 6))),))
+
+    identity = property(lambda self: tuple.__getitem__(self, 0))
+    query_name = property(lambda self: tuple.__getitem__(self, 1))
+    query_fraction = property(lambda self: tuple.__getitem__(self, 2))
+    reference_name = property(lambda self: tuple.__getitem__(self, 3))
+    reference_fraction = property(lambda self: tuple.__getitem__(self, 4))
     # not in the reference: True when `identity` came out of the learned-ANI regression model, False when it is the raw
     # chain ANI (the reference applies skani's embedded model by default, lib.rs:611-614; this build needs the model file)
-    learned = property(operator.itemgetter(5))
+    learned = property(lambda self: tuple.__getitem__(self, 5))
 
     @property
     def _raw(self):

@@ -96,10 +96,13 @@ def all_gather_hits(idx, vals, dist, device="cpu", group=None, state=None):
 
     idx:  int64 [n_local, 2] = (global query index, global ref index), both below 2^32; vals: float32 [n_local, 3] =
     (ani, af_query, af_ref). Returns (idx, vals) concatenated over ranks in rank order, identical on every rank. A thin front
-    of all_gather_hit_records: integers travel as integers (exact for any database size)."""
+    of all_gather_hit_records: the indices travel in the records' 32-bit fields - exact below 2^32, OverflowError beyond (they are
+    never truncated silently)."""
     idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1, 2)
     vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1, HIT_VALS)
     assert len(idx) == len(vals)
+    if len(idx) and (int(idx.min()) < 0 or int(idx.max()) >= 1 << 32):
+        raise OverflowError("hit indices must lie in [0, 2^32): the exchange records carry them in 32-bit fields")
     recs = np.zeros(len(idx), HIT_DTYPE)
     recs["reserved"] = idx[:, 0]; recs["ref_index"] = idx[:, 1]
     recs["ani"] = vals[:, 0]; recs["af_query"] = vals[:, 1]; recs["af_ref"] = vals[:, 2]
@@ -367,6 +370,8 @@ class ShardedDatabase:
                     # global query index of every hit: the batch's queries are rank-major, rank r contributes counts[r]
                     qglob = np.concatenate([self._shard(r)[0] + b * batch + np.arange(counts[r], dtype=np.int64) for r in range(self.world)])
                     per_q = np.diff(offs)
+                    if len(self.names) >= 1 << 32:      # (the records' index fields are 32-bit: refuse rather than wrap)
+                        raise OverflowError("a sharded job of 2^32 genomes or more does not fit the hit records' 32-bit index fields")
                     recs["reserved"] = np.repeat(qglob, per_q).astype(np.uint32)
                     recs["ref_index"] += self._lo
                     chunks.append(recs)

@@ -86,3 +86,18 @@ def test_text_marshalling():
     assert _as_bytes(memoryview(b"GG")) == b"GG" and _as_bytes(array.array("B", b"TT")) == b"TT"
     with pytest.raises(TypeError):
         _as_bytes(12)
+
+
+def test_hit_is_not_a_sequence():
+    """the tuple behind `Hit` is storage - like the reference's pyclass (hit.rs) a Hit has no length, cannot be iterated, indexed,
+    concatenated or ordered; equality and hashing are by identity."""
+    import pickle
+    from pyskani_amd.database import Hit
+    h = Hit(0.9, "q", 0.5, "r", 0.4)
+    for op in (lambda: len(h), lambda: list(h), lambda: h[0], lambda: h + (), lambda: h * 2, lambda: sorted([h, h]), lambda: h < h, lambda: 0.5 in h):
+        with pytest.raises(TypeError):
+            op()
+    a, b = h, pickle.loads(pickle.dumps(h))
+    assert a == a and a != b and hash(a) != hash(b) and (b.identity, b.query_name, b.reference_name) == (a.identity, "q", "r")
+    with pytest.raises(ValueError):
+        Hit(1.5, "q", 0.5, "r", 0.4)
