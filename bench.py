@@ -88,7 +88,7 @@ def compact_roofline(r, short=False):
     keys = ("kernel", "frac", "traffic") if short else ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_bw", "traffic", "traffic_source", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")
     out = _pick(r, keys)
     if "traffic_source" in out:
-        out["traffic_source"] = _clip(out["traffic_source"], 72)
+        out["traffic_source"] = _clip(out["traffic_source"], 56)
     return out
 
 
@@ -127,7 +127,7 @@ def compact_line(full, full_path=None):
     (written to `full_path`, and each workload's full entry is its own EARLIER stdout line)."""
     line = {k: _sig(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
     cfg = dict(full.get("config", {}))
-    cfg["workload"] = _clip(cfg.get("workload", ""), 240)
+    cfg["workload"] = _clip(cfg.get("workload", ""), 200)
     for k in list(cfg):
         if isinstance(cfg[k], str) and k != "workload":
             cfg[k] = _clip(cfg[k], 120)

@@ -19,6 +19,8 @@ import numpy as np
 from . import _capi
 from . import storage as _storage
 
+_CHARP1, _U64_1, _HITP = C.c_char_p * 1, C.c_uint64 * 1, C.POINTER(_capi.Hit)
+
 try:      # C-level construction of a query's Hit list (csrc/hitlist.c, built beside the library); host logic only - the Python construction below is its twin
     from . import _hitlist
 except ImportError:
@@ -701,11 +703,14 @@ class Database:
         queried; a contig-sized query runs as one launch sequence with one synchronisation. Returns the psk_hit records."""
         views = [_as_bytes(c) for c in contigs]
         nc = len(views)
-        arr = (C.c_char_p * max(nc, 1))(*views)
-        lens = (C.c_uint64 * max(nc, 1))(*map(len, views))
-        hits_p = C.POINTER(_capi.Hit)()
+        if nc == 1:      # (the per-contig call: array types made once, not per call)
+            arr = _CHARP1(views[0]); lens = _U64_1(len(views[0]))
+        else:
+            arr = (C.c_char_p * max(nc, 1))(*views)
+            lens = (C.c_uint64 * max(nc, 1))(*map(len, views))
+        hits_p = _HITP()
         n = C.c_uint64(0)
-        _capi.check(self._lib.psk_query_host(self._h, arr, lens, nc, int(bool(seed)), C.byref(opts), C.byref(hits_p), C.byref(n)))
+        _capi.check(self._lib.psk_query_host(self._h, arr, lens, nc, 1 if seed else 0, C.byref(opts), C.byref(hits_p), C.byref(n)))
         try:      # (one C-level copy into an immutable bytes object; a structured np.empty + memmove costs five times as much for a hundred hits)
             return np.frombuffer(C.string_at(hits_p, n.value * self._HIT_DTYPE.itemsize), dtype=self._HIT_DTYPE) if n.value else np.empty(0, self._HIT_DTYPE)
         finally:
