@@ -1389,6 +1389,73 @@ __global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* _
     if (lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
 }
 
+// ---- the chunk table of Gb-scale pairs in ITEM space ---------------------------------------------------------------------------------------------
+// anchor_next_kernel finds, for EVERY anchor, the first anchor past its 20 kb window: 155 M searches of 6-7 probes per 3 Gb pair into 16-byte records at
+// random (58 GB of 64-byte lines per 8-genome step, profiles/r4/pmc_kernels.json) - for a table of 150 000 heads. But a chunk boundary is a property of the
+// QUERY's seed positions, and an anchor-bearing (pair, query seed) item already knows where its anchors start (the scan's offsets): the successor is searched
+// per ITEM (24 M per pair, 6.5 x fewer, in a 4-byte position array where FRAGMENT_LENGTH bases are ~160 entries away: a short gallop), and the walk from head
+// to head hops over items; a chunk's row is (offset of the head item, offset of the successor item) - items without anchors have the offset of the next one.
+// nxtp[i] = first item of the pair whose (contig, position) lies more than FRAGMENT_LENGTH past item i's | 0x80000000 if item i has anchors.
+__global__ __launch_bounds__(256) void item_next_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t n_items,
+                                                        const uint2* __restrict__ item, int wide, const uint32_t* __restrict__ blk_pair, uint32_t* __restrict__ nxtp) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[blockIdx.x]);
+    const PairDesc& P = pairs[p];
+    const uint32_t j = i - sbase[p], n = P.q_n;
+    const uint64_t target = (((uint64_t)(P.q_meta[j] >> 1)) << 32) + (uint64_t)P.q_pos[j] + FRAGMENT_LENGTH;
+    auto key = [&](uint32_t x) { return (((uint64_t)(P.q_meta[x] >> 1)) << 32) | P.q_pos[x]; };
+    uint32_t lo = j + 1, hi = n, step = 64;      // first x in (j, n) with key(x) > target; a gallop: the answer is ~FRAGMENT_LENGTH / c seeds away
+    while (lo + step < hi) { if (key(lo + step) > target) { hi = lo + step; break; } lo += step + 1; step <<= 1; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key(mid) <= target) lo = mid + 1; else hi = mid; }
+    const uint32_t cnt = wide ? item[i].y : item[i].y >> 24;
+    nxtp[i] = (sbase[p] + lo) | (cnt ? 0x80000000u : 0u);
+}
+// pass 0 of chunk_hops_sliced_kernel over items (pass 1 - the copy of the slices' rows to their dense places - is that kernel's own)
+__global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxtp, const uint32_t* __restrict__ aoff,
+                                                               const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, const uint32_t* __restrict__ cbase,
+                                                               uint32_t n_pairs, uint32_t* __restrict__ slice_cnt, uint2* __restrict__ scratch, uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_nx[HOP_WIN], s_ao[HOP_WIN + 1];
+    __shared__ uint32_t s_h, s_n;
+    const uint32_t p = blockIdx.x, w = blockIdx.y;
+    const int lane = threadIdx.x;
+    const PairDesc& P = pairs[p];
+    const uint32_t nc = P.q_nc;
+    const uint32_t c_lo = (uint32_t)((uint64_t)nc * w / HOP_SLICES), c_hi = (uint32_t)((uint64_t)nc * (w + 1) / HOP_SLICES);
+    if (pstart[p + 1] - pstart[p] < MIN_ANCHORS || c_lo == c_hi) { if (lane == 0) slice_cnt[p * HOP_SLICES + w] = 0; return; }
+    const uint32_t row0 = cbase[p], max_chunks = cbase[p + 1] - row0;
+    uint32_t ub = 0;      // rows the contigs before this slice can hold at most: where the slice's scratch rows start
+    for (uint32_t c = lane; c < c_lo; c += 64) ub += contig_row_bound(P, c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ub += __shfl_xor(ub, o);
+    const uint32_t seed0 = (uint32_t)(P.q_pos - P.q_seed_pos_base);      // the query's first seed in its store: q_contig_start holds store offsets
+    const uint32_t base = sbase[p];
+    uint32_t h = base + (P.q_contig_start[c_lo] - seed0);
+    const uint32_t hend = base + (P.q_contig_start[c_hi] - seed0);
+    uint32_t n = 0;
+    while (h < hend) {
+        const uint32_t w0 = h, wn = hend - w0 < (uint32_t)HOP_WIN ? hend - w0 : (uint32_t)HOP_WIN;
+        for (uint32_t i = lane; i < wn; i += 64) { s_nx[i] = nxtp[w0 + i]; s_ao[i] = aoff[w0 + i]; }
+        if (lane == 0) s_ao[wn] = aoff[w0 + wn];
+        lds_wave_sync();
+        if (lane == 0) {
+            while (h < hend && h - w0 < wn) {
+                const uint32_t v = s_nx[h - w0];
+                if (!(v & 0x80000000u)) { h++; continue; }      // no anchor: not a head
+                const uint32_t e = v & 0x7FFFFFFFu;             // first item past the window (<= the first item of the next contig)
+                const uint32_t ee = e < hend ? e : hend;
+                const uint32_t a0 = s_ao[h - w0], a1 = ee - w0 <= wn ? s_ao[ee - w0] : aoff[ee];
+                if (ub + n < max_chunks) scratch[(size_t)row0 + ub + n] = make_uint2(a0, a1); else atomicOr(err, 1u);
+                n++; h = ee;
+            }
+            s_h = h; s_n = n;
+        }
+        lds_wave_sync();
+        h = s_h; n = s_n;
+    }
+    if (lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
+}
+
 // ------------------------------------------------------------------ chaining
 struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, right; uint64_t cov_q; };
 
@@ -3626,7 +3693,20 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                                 probe_local ? (const uint32_t*)L.pstart : (const uint32_t*)nullptr);
     }
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    if (use_hops) {
+    // Gb-scale pairs: successors and the walk in ITEM space where the join left per-item counts and offsets (item_next_kernel); PSK_HOPS_ITEMS=1 / 0 force / forbid (tests, A/B)
+    const char* hi_env = getenv("PSK_HOPS_ITEMS");
+    const bool hops_items = use_hops && !emit_pairs && !join_pairs && !getenv("PSK_HOPS_UNSLICED") && n_items <= 0x7FFFFFFFull &&
+                            (hi_env ? hi_env[0] == '1' : n_items / n_pairs > (1u << 20));
+    if (hops_items) {
+        const size_t o_scr = al256(4 * (size_t)n_pairs * HOP_SLICES + 256);
+        PSK_TRY(ctx->q_g.reserve(o_scr + sizeof(uint2) * n_rows + 256));
+        uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
+        uint2* scratch_rows = (uint2*)((char*)ctx->q_g.p + o_scr);
+        hipLaunchKernelGGL(item_next_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, wide ? 1 : 0, L.blk_pair, a_nxt);      // (a_nxt: one u32 per anchor - at least as many as items)
+        hipLaunchKernelGGL(chunk_hops_items_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, (const uint32_t*)a_nxt, (const uint32_t*)L.aoff, L.pairs, L.sbase, L.cbase, n_pairs, slice_cnt, scratch_rows, L.misc);
+        hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, 1, scratch_rows, L.chunks, L.nch, L.misc);
+    }
+    else if (use_hops) {
         if (n_items / n_pairs > (1u << 20)) {      // Gb-scale: every 64th anchor first (into the spare per-anchor array after a_nxt), then all of them between those
             uint32_t* coarse = D + 5 * na;          // sc_f's space: the serial path is not running yet
             hipLaunchKernelGGL(anchor_next_kernel<1>, dim3((uint32_t)((cap / 64 + 1 + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)nullptr, coarse);
