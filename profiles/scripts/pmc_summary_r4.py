@@ -23,7 +23,8 @@ PLAN = {
     "metagenome": ("r4_meta", {"anchor": ([("gsi_join_kernel<false>", "runs")], "item"), "anchor_emit": ([("gsi_join_kernel<true>", "runs")], "item"),
                                "chain_chunk": ([("chain_quad_deep_kernel", "stream"), ("chain_chunk_list_kernel", "stream")], "anchor")}),
     "mammalian": ("r4_mammal", {"anchor": ([("anchor_join4_kernel", "stream")], "item"),
-                                "anchor_emit": ([("anchor_emit_expand_kernel", "stream"), ("anchor_next_kernel<1>", "gather"), ("anchor_next_kernel<2>", "gather"), ("chunk_hops_sliced_kernel", "gather")], "anchor"),
+                                "anchor_emit": ([("anchor_emit_expand_kernel", "stream"), ("anchor_next_kernel<1>", "gather"), ("anchor_next_kernel<2>", "gather"), ("chunk_hops_sliced_kernel", "gather"),
+                                                 ("item_next_kernel", "gather"), ("chunk_hops_items_kernel", "stream")], "anchor"),
                                 "chain_chunk": ([("chain_lane20x_kernel", "stream"), ("chain_chunk_list_kernel", "stream")], "anchor")}),
 }
 

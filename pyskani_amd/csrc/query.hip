@@ -3474,12 +3474,23 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 }
                 const bool valid = slot != 0xFFFFFFFFu;
                 if (!__any(valid)) continue;
-                const uint32_t prev = __shfl_up(slot, 1), next = __shfl_down(slot, 1);
+                if (!EMIT) {      // the count pass needs no order: one LDS atomic per anchor
+                    if (valid) atomicAdd(&s_cur[slot], 1u);
+                    continue;
+                }
+                const uint32_t prev = __shfl_up(slot, 1);
                 const bool same = valid && lane > 0 && prev == slot;                       // not the first lane of its (seed, reference) group
-                const bool last = valid && !(lane < 63 && next == slot);
-                const unsigned long long starts = __ballot(valid && !same);
-                const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-                const uint32_t j = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
+                // a reference that holds the k-mer ONCE (nearly always) is a group of one lane: every valid lane of the step then has a slot of its own, reads and moves
+                // its cursor itself, and nothing has to be ordered between lanes (the LDS takes a wave's operations in issue order, step after step)
+                const bool dup = __ballot(same) != 0;
+                bool last = valid; uint32_t j = 0;
+                if (dup) {
+                    const uint32_t next = __shfl_down(slot, 1);
+                    last = valid && !(lane < 63 && next == slot);
+                    const unsigned long long starts = __ballot(valid && !same);
+                    const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                    j = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
+                }
                 const uint32_t base = valid ? s_cur[slot] : 0u;
                 if (EMIT && valid) {
                     const unsigned long long dst = (unsigned long long)s_ps[slot] + base + j;
@@ -3499,12 +3510,13 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                         }
                     }
                 }
-                lds_wave_sync();
+                if (dup) lds_wave_sync();
                 if (last) s_cur[slot] = base + j + 1u;
-                lds_wave_sync();
+                if (dup) lds_wave_sync();
             }
         }
     }
+    lds_wave_sync();
     if (!EMIT) for (uint32_t j = lane; j < P; j += 64) A.pair_cnt[B.pair_off + j] = s_cur[j];
     else for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
         uint32_t rows = 0;
