@@ -3439,29 +3439,52 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     lds_wave_sync();
     const SketchDesc Q = A.qd[B.q];
     const uint32_t nq = Q.n;
+    // The walk is a chain of dependent round trips (k-mers -> bucket bounds -> index entries -> LDS) and a launch holds only a few waves per SIMD (one per entry):
+    // everything is requested ahead. A batch of 64 seeds has its k-mers loaded two batches ahead and its bucket bounds one batch ahead; its runs are cut into
+    // STEPS of 64 index entries, numbered through the batch (a prefix sum over the lanes' step counts), and the entries of step t + GSI_AHEAD are requested
+    // before step t is dealt out - the second and third step of a long run (a k-mer that a whole family of references holds) included.
+    constexpr uint32_t GSI_AHEAD = 4;
+    uint32_t km1 = (uint32_t)lane < nq ? Q.kmer[lane] : 0u, km2 = 64u + (uint32_t)lane < nq ? Q.kmer[64 + lane] : 0u;
+    uint32_t lo1 = 0, hi1 = 0;
+    if ((uint32_t)lane < nq) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
     for (uint32_t c0 = 0; c0 < nq; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
-        const uint32_t km = i < nq ? Q.kmer[i] : 0u;
-        uint32_t lo = 0, hi = 0, qp = 0, qm = 0;
-        if (i < nq) { const uint32_t b = km >> A.g_shift; lo = A.g_bucket[b]; hi = A.g_bucket[b + 1]; if (EMIT) { qp = Q.pos[i]; qm = Q.meta[i]; } }
-        const uint32_t cnt = nq - c0 < 64u ? nq - c0 : 64u;
-        // the first 64 index entries of seed 0's bucket; those of seed s + 1 are requested before seed s is dealt out (the walk is a chain of dependent
-        // round trips otherwise: bucket bounds -> entries -> LDS), key and value together
-        uint32_t nlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0), nhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 0);
-        uint32_t nk = nlo + (uint32_t)lane < nhi ? A.g_key[nlo + lane] : 0xFFFFFFFFu;
-        unsigned long long nv = nlo + (uint32_t)lane < nhi ? A.g_val[nlo + lane] : 0ull;
-        for (uint32_t s = 0; s < cnt; s++) {
-            const uint32_t slo = nlo, shi = nhi, skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)s);
-            const uint32_t sqp = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s) : 0u, sqm = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s) : 0u;
-            uint32_t k = nk; unsigned long long v = nv;
-            if (s + 1 < cnt) {
-                nlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)(s + 1)); nhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(s + 1));
-                nk = nlo + (uint32_t)lane < nhi ? A.g_key[nlo + lane] : 0xFFFFFFFFu;
-                nv = nlo + (uint32_t)lane < nhi ? A.g_val[nlo + lane] : 0ull;
-            }
-            for (uint32_t x0 = slo; x0 < shi; x0 += 64) {
-                const uint32_t x = x0 + (uint32_t)lane;
-                if (x0 != slo) { k = x < shi ? A.g_key[x] : 0xFFFFFFFFu; v = x < shi ? A.g_val[x] : 0ull; }      // (a bucket of more than 64 entries)
+        const uint32_t km = km1, lo = lo1, hi = hi1;
+        km1 = km2; lo1 = 0; hi1 = 0;
+        if (i + 64u < nq) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+        km2 = i + 128u < nq ? Q.kmer[i + 128u] : 0u;
+        uint32_t qp = 0, qm = 0;
+        if (EMIT && i < nq) { qp = Q.pos[i]; qm = Q.meta[i]; }
+        const uint32_t nst = (hi - lo + 63u) >> 6;
+        uint32_t pre = nst;      // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (lane >= o) pre += y; }
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+        pre -= nst;
+        uint32_t ns[GSI_AHEAD], nx[GSI_AHEAD], nh[GSI_AHEAD], nk[GSI_AHEAD]; unsigned long long nv[GSI_AHEAD];
+#define GSI_FETCH(t, u) do { \
+            ns[u] = 0; nx[u] = 0; nh[u] = 0; nk[u] = 0xFFFFFFFFu; nv[u] = 0ull; \
+            if ((t) < T) { \
+                const unsigned long long own = __ballot(nst != 0 && pre <= (t)); \
+                ns[u] = 63u - (uint32_t)__clzll((long long)own); \
+                nx[u] = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)ns[u]) + 64u * ((t) - (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)ns[u])); \
+                nh[u] = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)ns[u]); \
+                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = A.g_key[nx[u] + lane]; nv[u] = A.g_val[nx[u] + lane]; } \
+            } } while (0)
+#pragma unroll
+        for (uint32_t u = 0; u < GSI_AHEAD; u++) GSI_FETCH(u, u);
+        for (uint32_t t0 = 0; t0 < T; t0 += GSI_AHEAD) {
+            uint32_t cs[GSI_AHEAD], cx[GSI_AHEAD], ch[GSI_AHEAD], ck[GSI_AHEAD]; unsigned long long cv[GSI_AHEAD];
+#pragma unroll
+            for (uint32_t u = 0; u < GSI_AHEAD; u++) { cs[u] = ns[u]; cx[u] = nx[u]; ch[u] = nh[u]; ck[u] = nk[u]; cv[u] = nv[u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < GSI_AHEAD; u++) GSI_FETCH(t0 + GSI_AHEAD + u, u);
+#pragma unroll
+            for (uint32_t u = 0; u < GSI_AHEAD; u++) {
+                if (t0 + u >= T) break;
+                const uint32_t s = cs[u], shi = ch[u], x = cx[u] + (uint32_t)lane, k = ck[u]; const unsigned long long v = cv[u];
+                const uint32_t skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)s);
+                const uint32_t sqp = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s) : 0u, sqm = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s) : 0u;
                 const bool match = x < shi && k == skm;
                 if (!__any(match)) continue;
                 const uint32_t ref = (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;
@@ -3515,6 +3538,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 if (dup) lds_wave_sync();
             }
         }
+#undef GSI_FETCH
     }
     lds_wave_sync();
     if (!EMIT) for (uint32_t j = lane; j < P; j += 64) A.pair_cnt[B.pair_off + j] = s_cur[j];
