@@ -82,12 +82,42 @@ def _as_bytes(obj):
         raise TypeError(f"expected str, bytes, bytearray or buffer, found {type(obj).__name__}")
 
 
-class Hit(tuple):
-    """A single hit found when querying a `Database` with a genome (hit.rs:18-104).
+class _PyHitBase:
+    """Pure-Python twin of csrc/hitlist.c's HitBase (used when the C module is not built): the same constructor, the same read-only fields."""
 
-    The fields sit in a tuple behind the properties so that a query's hits are built by ONE C-level pass over the library's
-    records (`Hit._from_records`): with a Python-level constructor per hit, 200 hits cost more than the GPU work of the query that
-    found them. Like the reference's class, hits compare and hash by identity, not by value."""
+    __slots__ = ("_f",)
+
+    def __new__(cls, identity, query_name, query_fraction, reference_name, reference_fraction, learned=False, keep=None, idx=0):
+        self = object.__new__(cls)
+        f32 = lambda x: float(np.float32(x))
+        object.__setattr__(self, "_f", (f32(identity), query_name, f32(query_fraction), reference_name, f32(reference_fraction), bool(learned), keep, int(idx)))
+        return self
+
+    def __setattr__(self, name, value):
+        raise AttributeError(f"attribute '{name}' of 'Hit' objects is not writable")
+
+    identity = property(lambda self: self._f[0])
+    query_name = property(lambda self: self._f[1])
+    query_fraction = property(lambda self: self._f[2])
+    reference_name = property(lambda self: self._f[3])
+    reference_fraction = property(lambda self: self._f[4])
+    learned = property(lambda self: self._f[5])
+    _keep = property(lambda self: self._f[6])
+    _idx = property(lambda self: self._f[7])
+
+
+_HIT_BASE = _hitlist.HitBase if _hitlist is not None else _PyHitBase      # (fixed at import: what Hit is made of)
+
+
+class Hit(_HIT_BASE):
+    """A single hit found when querying a `Database` with a genome (hit.rs:18-104): `identity`, `query_name`, `query_fraction`,
+    `reference_name`, `reference_fraction`, read-only like the reference's getters (hit.rs:77-104).
+
+    The fields sit in a C structure (csrc/hitlist.c: HitBase - one allocation per hit) so that a query's hits are built by ONE C-level pass
+    over the library's records (`Hit._from_records`): with a Python-level constructor per hit, 200 hits cost more than the GPU work of the
+    query that found them. Like the reference's class, hits compare and hash by identity, not by value, and are no sequences.
+    `learned` is not in the reference: True when `identity` came out of the learned-ANI regression model, False when it is the raw chain ANI
+    (the reference applies skani's embedded model by default, lib.rs:611-614; this build needs the model file)."""
 
     __slots__ = ()
 
@@ -101,7 +131,7 @@ class Hit(tuple):
             raise ValueError(f"Invalid value for `query_fraction`: {query_fraction}")
         if reference_fraction < 0.0 or reference_fraction > 1.0:  # hit.rs:42-48
             raise ValueError(f"Invalid value for `reference_fraction`: {reference_fraction}")
-        return tuple.__new__(cls, (identity, str(query_name), query_fraction, str(reference_name), reference_fraction, False, None, 0))
+        return super().__new__(cls, identity, str(query_name), query_fraction, str(reference_name), reference_fraction)
 
     @classmethod
     def _from_records(cls, recs, qname, names):
@@ -110,53 +140,28 @@ class Hit(tuple):
         n = len(recs)
         if _hitlist is not None and isinstance(names, list):      # the same objects, built in C (csrc/hitlist.c)
             return _hitlist.build(cls, recs, n, qname, names, recs)
-        return list(map(tuple.__new__, itertools.repeat(cls, n),
-                        zip(recs["ani"].tolist(), itertools.repeat(qname), recs["af_query"].tolist(), map(names.__getitem__, recs["ref_index"].tolist()),
-                            recs["af_ref"].tolist(), (recs["learned"] != 0).tolist(), itertools.repeat(recs), range(n))))
+        return list(map(_HIT_BASE.__new__, itertools.repeat(cls, n), recs["ani"].tolist(), itertools.repeat(qname), recs["af_query"].tolist(),
+                        map(names.__getitem__, recs["ref_index"].tolist()), recs["af_ref"].tolist(), (recs["learned"] != 0).tolist(), itertools.repeat(recs), range(n)))
 
     def __repr__(self):  # hit.rs:61-74
         return ("Hit(identity={!r}, query_name={!r}, query_fraction={!r}, reference_name={!r}, "
                 "reference_fraction={!r})").format(self.identity, self.query_name, self.query_fraction,
                                                     self.reference_name, self.reference_fraction)
 
-    __eq__ = object.__eq__
-    __ne__ = object.__ne__
-    __hash__ = object.__hash__
-
-    # The tuple behind a Hit is storage, not interface: the reference's pyclass (hit.rs) is no sequence. Length, iteration, indexing, ordering,
-    # concatenation and repetition raise TypeError like they do for any plain object (`sorted(hits)` used to fall back to tuple
-    # comparison and could end up comparing record arrays; unpacking exposed the internal fields).
-    def _not_a_sequence(self, *args, **kwargs):
-        raise TypeError("'Hit' object is not a sequence")
-
-    __len__ = __iter__ = __getitem__ = __contains__ = __add__ = __radd__ = __mul__ = __rmul__ = _not_a_sequence
-
-    def _not_orderable(self, other):
-        return NotImplemented
-
-    __lt__ = __le__ = __gt__ = __ge__ = _not_orderable
-
     def __reduce__(self):
-        return (_hit_restore, (tuple(tuple.__getitem__(self, slice(0, 6))),))
-
-    identity = property(lambda self: tuple.__getitem__(self, 0))
-    query_name = property(lambda self: tuple.__getitem__(self, 1))
-    query_fraction = property(lambda self: tuple.__getitem__(self, 2))
-    reference_name = property(lambda self: tuple.__getitem__(self, 3))
-    reference_fraction = property(lambda self: tuple.__getitem__(self, 4))
-    # not in the reference: True when `identity` came out of the learned-ANI regression model, False when it is the raw
-    # chain ANI (the reference applies skani's embedded model by default, lib.rs:611-614; this build needs the model file)
-    learned = property(lambda self: tuple.__getitem__(self, 5))
+        return (_hit_restore, ((self.identity, self.query_name, self.query_fraction, self.reference_name, self.reference_fraction, self.learned),))
 
     @property
     def _raw(self):
         """the psk_hit record behind the hit (numpy void: chaining integers, raw ANI), None for a hit built by hand"""
-        src = tuple.__getitem__(self, 6)
-        return None if src is None else src[tuple.__getitem__(self, 7)]
+        src = self._keep
+        if type(src) is bytes:      # the records of a per-contig query, kept as the bytes the library returned (_hitlist.query_host)
+            src = np.frombuffer(src, dtype=Database._HIT_DTYPE)
+        return None if src is None else src[self._idx]
 
 
 def _hit_restore(fields):
-    return tuple.__new__(Hit, fields + (None, 0))
+    return _HIT_BASE.__new__(Hit, *fields)
 
 
 class Sketch:
@@ -348,6 +353,10 @@ class Database:
         h = C.c_void_p()
         _capi.check(self._lib.psk_db_create(self._ctx._h, C.byref(self._params), C.byref(h)))
         self._h = h
+        # addresses the C-level query call needs (csrc/hitlist.c does not link against the library); $PSK_PY_FASTCALL=0: the ctypes route (tests, A/B)
+        self._fast = None
+        if os.environ.get("PSK_PY_FASTCALL", "1") != "0":
+            self._fast = (C.cast(self._lib.psk_query_host, C.c_void_p).value, C.cast(self._lib.psk_free, C.c_void_p).value)
         if model is None and os.environ.get("PSK_MODEL_PATH"):
             model = os.environ["PSK_MODEL_PATH"]
         if model is not None:
@@ -766,5 +775,13 @@ class Database:
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         if self._n_lazy:
             return self._query_lazy(name, self._sketch(name, contigs, seed), opts)
+        if _hitlist is not None and self._fast is not None:
+            # the whole call in C (csrc/hitlist.c: arguments, psk_query_host with the interpreter lock released, the Hit list): what a query costs under the
+            # lock decides how far concurrent per-contig queries scale (lib.rs:569)
+            views = contigs if all(type(c) is bytes for c in contigs) else tuple(_as_bytes(c) for c in contigs)
+            r = _hitlist.query_host(self._fast[0], self._fast[1], self._h.value, views, 1 if seed else 0, C.addressof(opts), Hit, name, self._names)
+            if type(r) is int:
+                _capi.check(r)
+            return r
         recs = self._query_host(contigs, seed, opts)
         return self._hits(recs, name) if len(recs) else []

@@ -88,16 +88,54 @@ def test_text_marshalling():
         _as_bytes(12)
 
 
-def test_hit_is_not_a_sequence():
-    """the tuple behind `Hit` is storage - like the reference's pyclass (hit.rs) a Hit has no length, cannot be iterated, indexed,
-    concatenated or ordered; equality and hashing are by identity."""
-    import pickle
-    from pyskani_amd.database import Hit
-    h = Hit(0.9, "q", 0.5, "r", 0.4)
-    for op in (lambda: len(h), lambda: list(h), lambda: h[0], lambda: h + (), lambda: h * 2, lambda: sorted([h, h]), lambda: h < h, lambda: 0.5 in h):
-        with pytest.raises(TypeError):
-            op()
-    a, b = h, pickle.loads(pickle.dumps(h))
-    assert a == a and a != b and hash(a) != hash(b) and (b.identity, b.query_name, b.reference_name) == (a.identity, "q", "r")
-    with pytest.raises(ValueError):
-        Hit(1.5, "q", 0.5, "r", 0.4)
+HIT_SEMANTICS = """
+import pickle, sys
+if FALLBACK:
+    sys.modules["pyskani_amd._hitlist"] = None      # the import of the C module fails: database.py takes its pure-Python twin
+from pyskani_amd import database
+from pyskani_amd.database import Hit
+assert (database._hitlist is None) == FALLBACK
+h = Hit(0.9, "q", 0.5, "r", 0.4)
+for op in (lambda: len(h), lambda: list(h), lambda: h[0], lambda: h + (), lambda: h * 2, lambda: sorted([h, h]), lambda: h < h, lambda: 0.5 in h):
+    try:
+        op()
+    except TypeError:
+        continue
+    raise AssertionError("a Hit behaved like a sequence")
+a, b = h, pickle.loads(pickle.dumps(h))
+assert a == a and a != b and hash(a) != hash(b) and (b.identity, b.query_name, b.reference_name, b.learned, b._raw) == (a.identity, "q", "r", False, None)
+assert h.identity == float(__import__("numpy").float32(0.9)) and h.query_fraction == 0.5 and h.reference_fraction == float(__import__("numpy").float32(0.4))
+assert repr(h).startswith("Hit(identity=0.8999999") and repr(h).endswith("reference_name='r', reference_fraction=0.4000000059604645)")
+for bad in ((1.5, "q", 0.5, "r", 0.4), (0.5, "q", -0.1, "r", 0.4), (0.5, "q", 0.1, "r", 1.4)):
+    try:
+        Hit(*bad)
+    except ValueError:
+        continue
+    raise AssertionError("range check missing (hit.rs:34-48)")
+for name in ("identity", "query_name", "query_fraction", "reference_name", "reference_fraction"):      # getters only: hit.rs:77-104
+    try:
+        setattr(h, name, 0.5)
+    except AttributeError:
+        continue
+    raise AssertionError(name + " is writable")
+import numpy as np
+from pyskani_amd import _capi
+recs = np.zeros(3, np.dtype(_capi.Hit)); recs["ani"] = [0.5, 0.25, 0.125]; recs["ref_index"] = [2, 0, 1]; recs["learned"] = [0, 1, 0]; recs["n_anchors"] = [7, 8, 9]
+hs = Hit._from_records(recs, "query", ["a", "b", "c"])
+assert [(x.identity, x.query_name, x.reference_name, x.learned, int(x._raw["n_anchors"])) for x in hs] == [(0.5, "query", "c", False, 7), (0.25, "query", "a", True, 8), (0.125, "query", "b", False, 9)]
+assert all(type(x) is Hit for x in hs)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("fallback", [False, True])
+def test_hit_is_not_a_sequence(fallback):
+    """like the reference's pyclass (hit.rs) a Hit has no length, cannot be iterated, indexed, concatenated or ordered; equality and
+    hashing are by identity; the five fields are read-only getters (hit.rs:77-104) and the constructor checks their ranges (hit.rs:34-48).
+    Held for the C-level storage (csrc/hitlist.c: HitBase) and for the pure-Python twin database.py takes when that module is not built."""
+    import subprocess, sys
+    from pyskani_amd import database
+    if not fallback and database._hitlist is None:
+        pytest.skip("pyskani_amd/_hitlist is not built (make -C pyskani_amd/csrc)")
+    r = subprocess.run([sys.executable, "-c", f"FALLBACK = {fallback}\n" + HIT_SEMANTICS], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]

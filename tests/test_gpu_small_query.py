@@ -202,3 +202,29 @@ def test_concurrent_fused_queries_from_threads(psk, oracle):
     th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
     [t.start() for t in th]; [t.join() for t in th]
     assert out == serial
+
+
+def test_c_level_call_and_ctypes_route_return_the_same_hits(psk):
+    """Database.query goes to the library through ONE C-level call (csrc/hitlist.c: query_host); the ctypes route it replaces
+    ($PSK_PY_FASTCALL=0) gives the same hits, field for field, and errors surface the same way"""
+    rng = np.random.default_rng(31)
+    a = random_genome(rng, 150000)
+    db = psk.Database(compression=30, marker_compression=200)
+    for j, d in enumerate((0.0, 0.01, 0.04)):
+        db.sketch(f"r{j}", mutate(rng, a, d))
+    assert db._fast is not None
+    qs = [(mutate(rng, a[1000:30000], 0.02),), (a[5000:9000], a[60000:90000]), (bytearray(a[100000:120000]),), (a[:2000].decode(),), (b"ACGT" * 100,)]
+    for contigs in qs:
+        fast = db.query("q", *contigs, learned_ani=False)
+        keep, db._fast = db._fast, None
+        try:
+            slow = db.query("q", *contigs, learned_ani=False)
+        finally:
+            db._fast = keep
+        assert len(fast) == len(slow)
+        for x, y in zip(fast, slow):
+            assert (x.identity, x.query_name, x.query_fraction, x.reference_name, x.reference_fraction, x.learned) == \
+                   (y.identity, y.query_name, y.query_fraction, y.reference_name, y.reference_fraction, y.learned)
+            assert all(x._raw[f] == y._raw[f] or x._raw[f] != x._raw[f] for f in REC_FIELDS)
+    with pytest.raises(TypeError):
+        db.query("q", 5)

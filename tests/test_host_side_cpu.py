@@ -68,3 +68,62 @@ def test_hit_lists_built_in_c_equal_the_python_construction():
     with pytest.raises(IndexError):
         database.Hit._from_records(recs, "query", names[:10])
     assert database.Hit._from_records(recs[:0], "q", names) == []
+
+
+def test_c_level_query_call_passes_bytes_and_builds_hits_without_a_gpu():
+    """_hitlist.query_host is the per-contig Database.query as one call from the interpreter (lib.rs:549-660): it hands the contigs' bytes to the
+    function it was given, with the interpreter lock released, and turns the records into Hit objects. Here the function is a stand-in made with
+    ctypes (no GPU, no library compute): what arrives and what comes back is checked, a failing status comes back as an int."""
+    import ctypes as C
+    from pyskani_amd import _capi, database
+    if database._hitlist is None:
+        pytest.skip("pyskani_amd/_hitlist is not built (make -C pyskani_amd/csrc)")
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    seen = {}
+    PROTO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
+
+    def fake(db, contigs, lens, nc, seed, opts, hits, n):
+        seen["db"], seen["seed"], seen["opts"] = db, seed, opts
+        seen["contigs"] = [C.string_at(contigs[i], lens[i]) for i in range(nc)]
+        if seen.get("fail"):
+            return 7
+        k = seen["n_out"]
+        n[0] = k
+        if k:
+            buf = libc.malloc(k * C.sizeof(_capi.Hit))
+            arr = (_capi.Hit * k).from_address(buf)
+            for i in range(k):
+                C.memset(C.addressof(arr[i]), 0, C.sizeof(_capi.Hit))
+                arr[i].ani = 0.5 + 0.001 * i; arr[i].af_query = 0.25; arr[i].af_ref = 0.75; arr[i].ref_index = i % 3; arr[i].learned = i & 1; arr[i].n_anchors = 1000 + i
+            hits[0] = buf
+        else:
+            hits[0] = None
+        return 0
+    cb = PROTO(fake)
+    fn = C.cast(cb, C.c_void_p).value
+    free_fn = C.cast(libc.free, C.c_void_p).value
+    opts = _capi.QueryOpts()
+    names = ["a", "b", "c"]
+    seen["n_out"] = 40
+    contigs = (b"ACGT" * 10, b"", b"TTTT" * 3) + tuple(b"G" * i for i in range(20))      # more than the call's on-stack arrays hold
+    out = database._hitlist.query_host(fn, free_fn, 0x1234, contigs, 1, C.addressof(opts), database.Hit, "q", names)
+    assert seen["db"] == 0x1234 and seen["seed"] == 1 and seen["opts"] == C.addressof(opts) and seen["contigs"] == list(contigs)
+    assert len(out) == 40 and all(type(h) is database.Hit for h in out)
+    for i, h in enumerate(out):
+        assert h.reference_name == names[i % 3] and h.query_name == "q" and h.learned == bool(i & 1)
+        assert h.identity == float(np.float32(0.5 + 0.001 * i)) and h.query_fraction == 0.25 and h.reference_fraction == 0.75
+        assert h._raw["n_anchors"] == 1000 + i and h._raw["ref_index"] == i % 3
+    seen["n_out"] = 0
+    assert database._hitlist.query_host(fn, free_fn, 1, (b"ACGT",), 0, C.addressof(opts), database.Hit, "q", names) == [] and seen["seed"] == 0
+    seen["fail"] = True
+    assert database._hitlist.query_host(fn, free_fn, 1, (), 0, C.addressof(opts), database.Hit, "q", names) == 7
+    with pytest.raises(TypeError):
+        database._hitlist.query_host(fn, free_fn, 1, ("ACGT",), 0, C.addressof(opts), database.Hit, "q", names)
+    with pytest.raises(TypeError):
+        database._hitlist.query_host(fn, free_fn, 1, [b"ACGT"], 0, C.addressof(opts), database.Hit, "q", names)
+    with pytest.raises(ValueError):
+        database._hitlist.query_host(0, free_fn, 1, (b"ACGT",), 0, C.addressof(opts), database.Hit, "q", names)
+    seen["fail"] = False; seen["n_out"] = 5
+    with pytest.raises(IndexError):
+        database._hitlist.query_host(fn, free_fn, 1, (b"ACGT",), 0, C.addressof(opts), database.Hit, "q", names[:1])
