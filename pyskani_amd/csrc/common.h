@@ -614,6 +614,7 @@ struct HitList {
         p = q; cap = want;
         return true;
     }
+    bool reserve_for(size_t k) { return n + k <= cap || reserve(std::max<size_t>(n + k, cap + cap / 2 + 64)); }      // room for k more hits (the caller writes them, then adds k to n)
     bool append(const psk_hit* src, size_t k) {
         if (n + k > cap && !reserve(std::max<size_t>(n + k, cap + cap / 2 + 64))) return false;
         if (k) memcpy(p + n, src, sizeof(psk_hit) * k);
