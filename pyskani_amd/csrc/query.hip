@@ -1471,6 +1471,7 @@ struct ChainArgs {
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
     int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state, *c_rc;   // candidate chains, chunk s writes at [s, s + n_cand)
     uint32_t two_c; int band; int force_serial; int lane_dp;
+    int dp_prune;      // the lane / quad DP kernels score the far part of the band only where it could win ($PSK_DP_PRUNE=0: always)
     uint32_t* ovf_list; uint32_t* ovf_count;   // rows the lane kernel hands to the wave kernel (more than LANE_TREES qualifying chain trees, >= 16 384 anchors)
     uint32_t* stats;   // [1] chunks / [3] pairs that took a serial fallback (rare paths only: a counter every wave bumps
                        // serialises the whole launch on one L2 address)
@@ -1814,6 +1815,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
 // that either joins the candidates (u > j) or not, one select per field (v_cndmask is the slowest VALU instruction: the shifting
 // window of chain_quad_kernel would cost 84 of them per anchor). 16 chunks per wave step: ~66 SIMD cycles per anchor.
 constexpr int QD = 21;            // own anchors per lane: bands up to 4 * QD = 84
+constexpr int QD_NEAR = 5;        // entries per lane that are always scored (the quad's last 20 anchors); the others only when they could win
 constexpr int QD_RING = 128;      // root / depth ring per quad (power of two > 4 * QD + 3)
 __device__ __forceinline__ int32_t quad_eval(uint32_t qx, uint32_t ux, uint32_t mx, uint32_t yq1, uint32_t yu, uint32_t ym, int32_t yf1, int32_t dpj, int32_t bj) {
     // dpj = the distance of the two anchors PLUS j (a compile-time number for the window entries, one select for the extra entry); bj = band + j
@@ -1846,7 +1848,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
     const uint32_t len = mine ? e - s_al : 0;
     uint32_t Wq[QD], Wu[QD], Wm[QD]; int32_t Wf[QD];      // entry i = this lane's anchor 4 (i + 1) - (u - j) ... before x: its (i + 1)-th latest of EARLIER steps
 #pragma unroll
-    for (int i = 0; i < QD; i++) { Wq[i] = 0; Wu[i] = 0; Wm[i] = 0xFFFFFFFFu; Wf[i] = 0; }
+    for (int i = 0; i < QD; i++) { Wq[i] = 0; Wu[i] = 0; Wm[i] = 0xFFFFFFFFu; Wf[i] = -1; }      // (score - 1 of an EMPTY entry: below every real one, see the far bound)
     unsigned long long bk[LANE_TREES];
     uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
 #pragma unroll
@@ -1855,12 +1857,39 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
     bool ovf = false;
     uint32_t (*rd)[16] = s_rd[wave];
     const int32_t bj = A.band + j;
+    const bool prune = A.dp_prune != 0;
+    uint32_t far_diag = 0;
     for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
         const uint32_t x0 = s_al + t0;
         uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
         if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
         const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
-        uint32_t nq = 0, nu = 0, nm = 0xFFFFFFFFu; int32_t nf = 0;      // this lane's own anchor of the step (from u = j on)
+        uint32_t nq = 0, nu = 0, nm = 0xFFFFFFFFu; int32_t nf = -1;      // this lane's own anchor of the step (from u = j on)
+        // The FAR part of the window - a lane's entries QD_NEAR .. QD - 1: the quad's anchors more than 4 QD_NEAR back - can only win with a score above the
+        // best near one: a predecessor y scores f[y] + ANCHOR_SCORE2 - gap <= f[y] + ANCHOR_SCORE2, and on equal scores the NEARER one is taken. far_top =
+        // the largest f - 1 among the far entries of the quad (-1: all empty), one pass per step (the window does not move within a step). Along a chain f
+        // grows by ~ANCHOR_SCORE2 per anchor, so the nearest predecessors nearly always beat that bound and the far three quarters of the band are not scored
+        // at all; the decision is taken per WAVE (an anchor off its chunk's chain - no near predecessor - has all sixteen quads score everything: same
+        // results, nothing skipped). $PSK_DP_PRUNE=0: every entry always (tests, A/B).
+        // ... and only for an anchor whose diagonal is within MAX_GAP_LENGTH of a far entry's. far_diag: one bit per 1024 diagonals (mod 32): an entry on diagonal
+        // d sets the two bits that cover d - MAX_GAP_LENGTH .. d + MAX_GAP_LENGTH; an anchor whose own bit is clear has no predecessor in the far part. That
+        // is the chance match off the chunk's chain (k-mers are seeds by content: ~1 % of a query's seeds also sit somewhere else in a 5 Mb reference): no
+        // near predecessor either, but no reason to score 60 entries that cannot hold one. The bits of the entry that turns far are added every step and
+        // the set is rebuilt every 16 steps (bits of entries that left linger until then: a few more anchors pass the test, none fewer).
+        int32_t far_top = -1;
+        if (prune) {
+            if ((t0 & 63u) == 0) {
+                far_diag = 0;
+#pragma unroll
+                for (int i = QD_NEAR; i < QD; i++) far_diag |= __builtin_amdgcn_alignbit(3u, 3u, 32u - (((Wu[i] - (uint32_t)MAX_GAP_LENGTH) >> 10) & 31u));
+            } else far_diag |= __builtin_amdgcn_alignbit(3u, 3u, 32u - (((Wu[QD_NEAR] - (uint32_t)MAX_GAP_LENGTH) >> 10) & 31u));
+#pragma unroll
+            for (int i = QD_NEAR; i < QD; i++) far_top = Wf[i] > far_top ? Wf[i] : far_top;
+            int32_t o = __builtin_amdgcn_mov_dpp(far_top, 0xB1, 0xF, 0xF, true); far_top = o > far_top ? o : far_top;
+            o = __builtin_amdgcn_mov_dpp(far_top, 0x4E, 0xF, 0xF, true); far_top = o > far_top ? o : far_top;
+        }
+        uint32_t fd = far_diag;      // the quad's
+        fd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)fd, 0xB1, 0xF, 0xF, true); fd |= (uint32_t)__builtin_amdgcn_mov_dpp((int)fd, 0x4E, 0xF, 0xF, true);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t x = x0 + u, t = t0 + u;
@@ -1869,7 +1898,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
             const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
             int32_t best = 0;
 #pragma unroll
-            for (int i = 0; i < QD - 1; i++) {      // own anchors of earlier steps: distance u - j + 4 (i + 1)
+            for (int i = 0; i < QD_NEAR; i++) {      // own anchors of earlier steps: distance u - j + 4 (i + 1)
                 const int32_t k = quad_eval(qx, ux, mx, Wq[i], Wu[i], Wm[i], Wf[i], u + 4 * (i + 1), bj);
                 best = k > best ? k : best;
             }
@@ -1877,6 +1906,20 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
                 const bool late = u > j;
                 const int32_t k = quad_eval(qx, ux, mx, late ? nq : Wq[QD - 1], late ? nu : Wu[QD - 1], late ? nm : Wm[QD - 1], late ? nf : Wf[QD - 1], late ? u : u + 4 * QD, bj);
                 best = k > best ? k : best;
+            }
+            bool far = !prune;
+            if (prune) {      // does any quad of the wave still need its far entries? (best, before the lane's + j: score << 7 | low bits)
+                int32_t nb = best;
+                int32_t o = __builtin_amdgcn_mov_dpp(nb, 0xB1, 0xF, 0xF, true); nb = o > nb ? o : nb;
+                o = __builtin_amdgcn_mov_dpp(nb, 0x4E, 0xF, 0xF, true); nb = o > nb ? o : nb;
+                far = __any(act && far_top >= 0 && (nb >> 7) < far_top + 1 + ANCHOR_SCORE2 && ((fd >> ((ux >> 10) & 31u)) & 1u));      // (a quad past its chunk's end has no say)
+            }
+            if (far) {
+#pragma unroll
+                for (int i = QD_NEAR; i < QD - 1; i++) {
+                    const int32_t k = quad_eval(qx, ux, mx, Wq[i], Wu[i], Wm[i], Wf[i], u + 4 * (i + 1), bj);
+                    best = k > best ? k : best;
+                }
             }
             if (best > 0) best += j;      // the lane-dependent part of 127 - distance
             {   // all four lanes of the quad get the maximum
@@ -1892,7 +1935,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
                 ridx = v >> 14; dep = (v & 16383u) + 1;
             }
             rd[t & (uint32_t)(QD_RING - 1)][quad] = (ridx << 14) | dep;          // four lanes, one value
-            if (j == u) { nq = qx + 1u; nu = ux; nm = act ? mx : 0xFFFFFFFFu; nf = f - 1; }      // x is 4-aligned at u = 0: anchor x belongs to lane u
+            if (j == u) { nq = qx + 1u; nu = ux; nm = act ? mx : 0xFFFFFFFFu; nf = act ? f - 1 : -1; }      // x is 4-aligned at u = 0: anchor x belongs to lane u
             if (act && f >= MIN_SCORE2) {
                 const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
                 bool found = false;
@@ -3710,6 +3753,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
+    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; }
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
