@@ -1541,6 +1541,7 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
 constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4)
 constexpr int LANE_WAVES = 2;
 constexpr int LANE_TREES = 4;        // qualifying chain trees per chunk kept in registers
+constexpr int LANE_NEAR = 6;         // predecessors that are always scored; the rest of the band only where it could win (>= 4: they include the step's own anchors)
 
 // XT: further tree slots per lane in LDS (0, or LANE_XTREES for Gb-scale pairs: there a seed has ~6 chance 15-mer matches beside the
 // true one, the band of 20 ANCHORS reaches back only ~3 seeds, a true chain breaks wherever three seeds in a row do not match and a
@@ -1569,7 +1570,7 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
     const uint32_t len = mine ? e - s_al : 0;          // steps this lane takes part in (the first s - s_al are idle)
     LanePred P[W];
 #pragma unroll
-    for (int i = 0; i < W; i++) { P[i].q1 = 0; P[i].u = 0; P[i].m = 0xFFFFFFFFu; P[i].f1 = 0; }
+    for (int i = 0; i < W; i++) { P[i].q1 = 0; P[i].u = 0; P[i].m = 0xFFFFFFFFu; P[i].f1 = -1; }      // (score - 1 of an EMPTY entry: below every real one, see the far bound)
     // Chain trees that can yield a candidate, at most LANE_TREES per chunk, keyed by the local index of their ROOT
     // anchor. A tree gets a slot when its first anchor with score >= MIN_SCORE2 appears (such an anchor has depth >= 3,
     // and lower-scoring anchors can never be the tree's best once one exists); the many single-anchor trees of
@@ -1582,12 +1583,40 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
     bool ovf = false;
     uint32_t (*rd)[64] = s_rd[wave];      // root index << 14 | depth of the last 32 anchors
     const int band = A.band;
+    // The FAR part of the band - predecessors more than LANE_NEAR anchors back - is scored only where it could win (the rule of chain_quad_deep_kernel): a
+    // predecessor y scores f[y] + ANCHOR_SCORE2 - gap <= f[y] + ANCHOR_SCORE2 and equal scores go to the NEARER one, so an anchor whose best near score
+    // reaches the largest far f + ANCHOR_SCORE2 is done; and an anchor whose diagonal is not within MAX_GAP_LENGTH of any far entry's (far_diag: one bit
+    // per 1024 diagonals mod 32, two bits per entry, rebuilt every 16 steps) has no far predecessor at all - the chance match off the chain. The wave
+    // decides: one lane that needs the far part has all 64 score it (same results). Not for the Gb-scale kernel (XT: most anchors there are chance matches).
+    const bool prune = XT == 0 && A.dp_prune != 0;
+    constexpr int NR = LANE_NEAR;
+    uint32_t far_diag = 0;
     for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
         const uint32_t x0 = s_al + t0;
         uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
         if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
         const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
         LanePred nw[4];
+        int32_t ftop[4] = {-1, -1, -1, -1};      // largest f - 1 among the far entries of the step's anchor u: P[NR - u .. W - 1]
+        if (prune) {
+            if ((t0 & 63u) == 0) {
+                far_diag = 0;
+#pragma unroll
+                for (int i = NR - 3; i < W; i++) far_diag |= __builtin_amdgcn_alignbit(3u, 3u, 32u - (((P[i].u - (uint32_t)MAX_GAP_LENGTH) >> 10) & 31u));
+            } else {
+#pragma unroll
+                for (int i = NR - 3; i <= NR; i++) far_diag |= __builtin_amdgcn_alignbit(3u, 3u, 32u - (((P[i].u - (uint32_t)MAX_GAP_LENGTH) >> 10) & 31u));      // the four that turned far
+            }
+            // (only entries within BP_CHAIN_BAND of the step's FIRST anchor count - the later ones lie further on: where anchors are sparse, pairs 10 % apart,
+            // a chain that broke at a long gap leaves its high scores in the window for twenty anchors, out of reach but above everything the new chain has)
+            const uint32_t q0 = qs[0] + 1u;
+            int32_t m = -1;
+#pragma unroll
+            for (int i = NR; i < W; i++) { const int32_t f = q0 - P[i].q1 <= (uint32_t)BP_CHAIN_BAND ? P[i].f1 : -1; m = f > m ? f : m; }
+            ftop[0] = m;
+#pragma unroll
+            for (int u = 1; u < 4; u++) { const int32_t f = q0 - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND ? P[NR - u].f1 : -1; m = f > m ? f : m; ftop[u] = m; }
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t x = x0 + u, t = t0 + u;
@@ -1596,10 +1625,21 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
             const uint32_t ux = lane_diag(qx, rx, 0u - (mx & 1u));
             int32_t best = 0;
 #pragma unroll
-            for (int d = 1; d <= W; d++) {
+            for (int d = 1; d <= NR; d++) {
                 if (d <= band) {
                     const int32_t k = d <= u ? lane_eval2(qx, ux, mx, nw[u - d], d) : lane_eval2(qx, ux, mx, P[d - 1 - u], d);
                     best = k > best ? k : best;
+                }
+            }
+            // (... and the far entries lie further back on the query than the nearest of them: none is within BP_CHAIN_BAND if that one is not - sparse anchors,
+            // pairs 10 % apart, restart their chains every few anchors and would otherwise ask for the far part each time)
+            if (!prune || __any(act && ftop[u] >= 0 && (best >> 7) < ftop[u] + 1 + ANCHOR_SCORE2 && ((far_diag >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND)) {
+#pragma unroll
+                for (int d = NR + 1; d <= W; d++) {
+                    if (d <= band) {
+                        const int32_t k = lane_eval2(qx, ux, mx, P[d - 1 - u], d);
+                        best = k > best ? k : best;
+                    }
                 }
             }
             int32_t f = ANCHOR_SCORE2; uint32_t ridx = x - s, dep = 1;
@@ -1609,7 +1649,7 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
                 ridx = v >> 14; dep = (v & 16383u) + 1;
             }
             rd[t & 31u][lane] = (ridx << 14) | dep;
-            nw[u].q1 = qx + 1u; nw[u].u = ux; nw[u].m = act ? mx : 0xFFFFFFFFu; nw[u].f1 = f - 1;
+            nw[u].q1 = qx + 1u; nw[u].u = ux; nw[u].m = act ? mx : 0xFFFFFFFFu; nw[u].f1 = act ? f - 1 : -1;
             if (act && f >= MIN_SCORE2) {
                 const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
                 bool found = false;
@@ -1912,7 +1952,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
                 int32_t nb = best;
                 int32_t o = __builtin_amdgcn_mov_dpp(nb, 0xB1, 0xF, 0xF, true); nb = o > nb ? o : nb;
                 o = __builtin_amdgcn_mov_dpp(nb, 0x4E, 0xF, 0xF, true); nb = o > nb ? o : nb;
-                far = __any(act && far_top >= 0 && (nb >> 7) < far_top + 1 + ANCHOR_SCORE2 && ((fd >> ((ux >> 10) & 31u)) & 1u));      // (a quad past its chunk's end has no say)
+                far = __any(act && far_top >= 0 && (nb >> 7) < far_top + 1 + ANCHOR_SCORE2 && ((fd >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - Wq[QD_NEAR] <= (uint32_t)BP_CHAIN_BAND);      // (a quad past its chunk's end has no say; a lane's far entries lie at or behind its nearest one)
             }
             if (far) {
 #pragma unroll
