@@ -1566,7 +1566,11 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
             mine = e > s && e - s < 16384;
         }
     }
-    const uint32_t s_al = s & ~3u;
+    // LD = 2: a lane asks for 128 contiguous bytes - eight anchors, a whole cache line - per load and walks them as two steps of four: with 64 bytes per
+    // load the other half of every line was fetched again a step later (the kernel's counters: 1.8 x its anchors' bytes, and once the far part of the band
+    // is rarely scored that traffic, not the instruction count, is what the kernel waits for)
+    constexpr int LD = XT ? 1 : 2;
+    const uint32_t s_al = s & ~(4u * LD - 1u);
     const uint32_t len = mine ? e - s_al : 0;          // steps this lane takes part in (the first s - s_al are idle)
     LanePred P[W];
 #pragma unroll
@@ -1591,11 +1595,19 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
     const bool prune = XT == 0 && A.dp_prune != 0;
     constexpr int NR = LANE_NEAR;
     uint32_t far_diag = 0;
-    for (uint32_t t0 = 0; __any(t0 < len); t0 += 4) {
-        const uint32_t x0 = s_al + t0;
-        uint4 an0 = make_uint4(0, 0, 0, 0), an1 = an0, an2 = an0, an3 = an0;
-        if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
-        const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
+    for (uint32_t tb = 0; __any(tb < len); tb += 4 * LD) {
+      uint4 an[4 * LD];
+#pragma unroll
+      for (int i = 0; i < 4 * LD; i++) an[i] = make_uint4(0, 0, 0, 0);
+      if (tb < len) {
+#pragma unroll
+          for (int i = 0; i < 4 * LD; i++) an[i] = A.anc[s_al + tb + i];      // (the array ends in 64 spare records)
+      }
+#pragma unroll
+      for (int h = 0; h < LD; h++) {
+        const uint32_t t0 = tb + 4u * h, x0 = s_al + t0;
+        const uint32_t qs[4] = {an[4 * h].x, an[4 * h + 1].x, an[4 * h + 2].x, an[4 * h + 3].x}, rs[4] = {an[4 * h].y, an[4 * h + 1].y, an[4 * h + 2].y, an[4 * h + 3].y},
+                       ms[4] = {an[4 * h].z, an[4 * h + 1].z, an[4 * h + 2].z, an[4 * h + 3].z};
         LanePred nw[4];
         int32_t ftop[4] = {-1, -1, -1, -1};      // largest f - 1 among the far entries of the step's anchor u: P[NR - u .. W - 1]
         if (prune) {
@@ -1633,7 +1645,7 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
             }
             // (... and the far entries lie further back on the query than the nearest of them: none is within BP_CHAIN_BAND if that one is not - sparse anchors,
             // pairs 10 % apart, restart their chains every few anchors and would otherwise ask for the far part each time)
-            if (!prune || __any(act && ftop[u] >= 0 && (best >> 7) < ftop[u] + 1 + ANCHOR_SCORE2 && ((far_diag >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND)) {
+            if (!prune || (A.dp_prune != 2 && __any(act && ftop[u] >= 0 && (best >> 7) < ftop[u] + 1 + ANCHOR_SCORE2 && ((far_diag >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND))) {
 #pragma unroll
                 for (int d = NR + 1; d <= W; d++) {
                     if (d <= band) {
@@ -1677,6 +1689,7 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
 #pragma unroll
         for (int i = W - 1; i >= 4; i--) P[i] = P[i - 4];
         P[0] = nw[3]; P[1] = nw[2]; P[2] = nw[1]; P[3] = nw[0];
+      }
     }
     if ((uint32_t)lane < rows_per_wave && slot < A.n_rows && real) {
         if (mine && !ovf) {
@@ -3793,7 +3806,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
-    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; }
+    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; if (getenv("PSK_DP_PRUNE")) A.dp_prune = atoi(getenv("PSK_DP_PRUNE")); }
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
