@@ -1645,7 +1645,7 @@ __device__ __forceinline__ void chain_lane_body(const ChainArgs& A, const uint32
             }
             // (... and the far entries lie further back on the query than the nearest of them: none is within BP_CHAIN_BAND if that one is not - sparse anchors,
             // pairs 10 % apart, restart their chains every few anchors and would otherwise ask for the far part each time)
-            if (!prune || (A.dp_prune != 2 && __any(act && ftop[u] >= 0 && (best >> 7) < ftop[u] + 1 + ANCHOR_SCORE2 && ((far_diag >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND))) {
+            if (!prune || __any(act && ftop[u] >= 0 && (best >> 7) < ftop[u] + 1 + ANCHOR_SCORE2 && ((far_diag >> ((ux >> 10) & 31u)) & 1u) && qx + 1u - P[NR - u].q1 <= (uint32_t)BP_CHAIN_BAND)) {
 #pragma unroll
                 for (int d = NR + 1; d <= W; d++) {
                     if (d <= band) {
@@ -2926,6 +2926,7 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
 struct ReduceArgs {
     const ChunkOut* chunks; const uint32_t* n_chunks; const uint32_t* cbase;
     const uint32_t* pstart; const PairDesc* pairs;
+    const uint32_t* pcnt;   // anchors per pair where pstart does not say (the one-pass index join: pstart = item offsets); null: pstart[p + 1] - pstart[p]
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
     const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
     int small_done;                                 // chunk tables of <= 64 rows are reduced by pair_reduce_small_kernel
@@ -2945,7 +2946,7 @@ __global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t 
     psk_hit h{};
     h.ani = -1.0f; h.ani_raw = -1.0f;
     h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+    h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
     R.hits[p] = h;
 }
 
@@ -2966,7 +2967,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
             psk_hit h{};
             h.ani = -1.0f; h.ani_raw = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
             R.hits[p] = h;
         }
         return;
@@ -3084,7 +3085,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     if (threadIdx.x == 0) {
         h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
         h.n_chunks = m; h.n_intervals = (uint32_t)s_acc[4];
-        h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+        h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
         h.covered_query = s_acc[0]; h.covered_ref = s_acc[1]; h.sum_chain_anchors = s_acc[2]; h.sum_chunk_seeds = s_acc[3];
         if (m > 0) {
             double ani;
@@ -3131,7 +3132,7 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
                 psk_hit h{};
                 h.ani = -1.0f; h.ani_raw = -1.0f;
                 h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
-                h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+                h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
                 R.hits[p] = h;
             }
             continue;
@@ -3189,7 +3190,7 @@ __global__ __launch_bounds__(256) void pair_reduce_small_kernel(ReduceArgs R, ui
             h.ani = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
             h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
-            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
             h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
             if (m > 0) {
                 double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
@@ -3241,7 +3242,7 @@ __global__ __launch_bounds__(256) void pair_reduce_tiny_kernel(ReduceArgs R, uin
     h.ani = -1.0f;
     h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
     h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
-    h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+    h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
     h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
     if (m > 0) {
         double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
@@ -3353,7 +3354,7 @@ __global__ __launch_bounds__(256) void pair_reduce_wave_kernel(ReduceArgs R, uin
             h.ani = -1.0f;
             h.ref_index = R.pair_qr[p].y; h.reserved = R.pair_qr[p].x;
             h.n_chunks = m; h.n_intervals = (uint32_t)t_i;
-            h.n_anchors = R.pstart[p + 1] - R.pstart[p];
+            h.n_anchors = R.pcnt ? R.pcnt[p] : R.pstart[p + 1] - R.pstart[p];
             h.covered_query = t_cq; h.covered_ref = t_cq; h.sum_chain_anchors = t_a; h.sum_chunk_seeds = t_s;
             if (m > 0) {
                 double afq = (double)t_cq / (double)R.pairs[p].q_total_len; if (afq > 1) afq = 1;
@@ -3501,6 +3502,10 @@ struct GsiJoinArgs {
     uint32_t* pair_cnt; const uint32_t* pstart; uint4* anc; uint32_t cap; uint32_t* err;
     uint32_t p_cap;      // most pairs any entry of the batch holds, rounded up: what the cursor arrays in LDS are sized for (<= GSI_PMAX)
     uint2* chunks; uint32_t* n_chunks;      // EMIT: the pairs' chunk tables, written by the same walk (rows at entry.row_off + slot * query rows)
+    // ONE PASS (no COUNT pass, no scan): pstart holds the pairs' ITEM offsets, stretched (gsi_room_kernel: room for nine anchors per eight query seeds and
+    // eight more), the walk leaves every pair's count in pair_cnt and adds the batch's total to *total; a pair that would need more room (a reference that
+    // holds the query's k-mers several times over) raises err bit 2 and the batch is rerun with the two passes
+    int onepass; unsigned long long* total;
 };
 template <bool EMIT>
 __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
@@ -3531,7 +3536,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 run += (uint32_t)__popcll(m);
             }
         }
-        for (uint32_t j = lane; j < P; j += 64) { s_cur[j] = 0; if (EMIT) { const uint32_t a = A.pstart[B.pair_off + j], z = A.pstart[B.pair_off + j + 1]; s_ps[j] = z - a < MIN_ANCHORS ? GSI_DEAD : a; s_hc[j] = 0; } }
+        for (uint32_t j = lane; j < P; j += 64) { s_cur[j] = 0; if (EMIT) { const uint32_t a = A.pstart[B.pair_off + j], z = A.pstart[B.pair_off + j + 1]; s_ps[j] = !A.onepass && z - a < MIN_ANCHORS ? GSI_DEAD : a; s_hc[j] = 0; } }
     }
     lds_wave_sync();
     const SketchDesc Q = A.qd[B.q];
@@ -3614,7 +3619,8 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 const uint32_t base = valid ? s_cur[slot] : 0u;
                 if (EMIT && valid) {
                     const unsigned long long dst = (unsigned long long)s_ps[slot] + base + j;
-                    if (dst < A.cap) {
+                    if (A.onepass && base + j >= nq + (nq >> 3) + 8u) atomicOr(A.err, 4u);      // the pair's room (gsi_room_kernel) is used up
+                    else if (dst < A.cap) {
                         const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
                         A.anc[dst] = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
                     } else atomicOr(A.err, 2u);
@@ -3639,15 +3645,31 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     }
     lds_wave_sync();
     if (!EMIT) for (uint32_t j = lane; j < P; j += 64) A.pair_cnt[B.pair_off + j] = s_cur[j];
-    else for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
-        uint32_t rows = 0;
-        if (s_ps[j] != GSI_DEAD && s_cur[j]) {
-            rows = s_hc[j] & 0xFFFFu;
-            const unsigned long long e = (unsigned long long)s_ps[j] + s_cur[j];
-            if (rows < Q.rows) { A.chunks[(size_t)B.row_off + (size_t)j * Q.rows + rows] = make_uint2(s_hi[j], e < A.cap ? (uint32_t)e : A.cap); rows++; } else atomicOr(A.err, 1u);
+    else {
+        unsigned long long sum = 0;
+        for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
+            uint32_t rows = 0;
+            const uint32_t n = s_cur[j];
+            if (s_ps[j] != GSI_DEAD && n && !(A.onepass && n < MIN_ANCHORS)) {      // (fewer than MIN_ANCHORS anchors: no chain, no chunk table - the rows written on the way are not counted)
+                rows = s_hc[j] & 0xFFFFu;
+                const unsigned long long e = (unsigned long long)s_ps[j] + n;
+                if (rows < Q.rows) { A.chunks[(size_t)B.row_off + (size_t)j * Q.rows + rows] = make_uint2(s_hi[j], e < A.cap ? (uint32_t)e : A.cap); rows++; } else atomicOr(A.err, 1u);
+            }
+            A.n_chunks[B.pair_off + j] = rows;
+            if (A.onepass) { A.pair_cnt[B.pair_off + j] = n; sum += n; }
         }
-        A.n_chunks[B.pair_off + j] = rows;
+        if (A.onepass) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == 0 && sum) atomicAdd(A.total, sum);
+        }
     }
+}
+// ONE-PASS index join: pair p's anchors start at sbase[p] * 9 / 8 + 8 p - its (pair, query seed) items' offset, stretched: room for one anchor per query seed, an
+// eighth more and eight (a contig that IS part of the reference matches with every seed, and ~1 % of a 5 Mb reference's k-mers sit in it twice)
+__global__ __launch_bounds__(256) void gsi_room_kernel(const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= n_pairs) { const uint32_t a = sbase[p]; pstart[p] = a + (a >> 3) + 8u * p; }
 }
 __global__ void gsi_total_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, unsigned long long* __restrict__ total64) { *total64 = poff[n_pairs]; }
 
@@ -3664,6 +3686,7 @@ struct ChainBufs {
     // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
+    bool gsi_onepass = false;      // the index join without its COUNT pass (GsiJoinArgs::onepass): asked for by the caller, which reruns the batch without it when err bit 2 comes back
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
     const size_t gi = (n_items + 255) / 256, gi_sum = std::max(gi, (n_pairs + 3) / 4);
@@ -3708,13 +3731,14 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     static const bool gsi_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // tests, A/B: the probe-table join instead
     const bool gsi_join = !wide && !gsi_off && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
     const bool join_pairs = !wide && (gsi_join || (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048)));
+    const bool gsi_one = gsi_join && L.gsi_onepass && cap >= n_items + n_items / 8 + 8 * ((size_t)n_pairs + 1);      // (gsi_room_kernel's layout fits)
     bool probe_local = false;
     GsiJoinArgs GA{};
     const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
         GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
-        hipLaunchKernelGGL(gsi_join_kernel<false>, dim3(L.n_bq), dim3(64), gsi_lds_count, st, GA);
+        if (!gsi_one) hipLaunchKernelGGL(gsi_join_kernel<false>, dim3(L.n_bq), dim3(64), gsi_lds_count, st, GA);
         probe_local = true;      // (the scan over the pairs' counts below is the probe join's)
     }
     else if (join_pairs) {
@@ -3761,7 +3785,11 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     PSK_TRY(ctx->q_c.reserve(std::max(tmp, std::max(tmp2, tmp3))));
     unsigned long long* poff = (unsigned long long*)L.aoff;      // emit_pairs: 64-bit prefix of the pairs' counts (the per-item offsets array is not used then)
     hipcub::TransformInputIterator<unsigned long long, Widen, const uint32_t*> pc_it(pair_cnt, Widen());
-    if (emit_pairs) {
+    if (gsi_one) {      // the pairs' anchors start where their items do; the emit walk counts
+        hipLaunchKernelGGL(gsi_room_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)L.sbase, n_pairs, L.pstart);
+        PSK_HIP(hipMemsetAsync(L.total, 0, 8, st));
+    }
+    else if (emit_pairs) {
         size_t tmp4 = 0;
         PSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp4, pc_it, poff, (int)(n_pairs + 1), st));
         PSK_TRY(ctx->q_c.reserve(std::max(tmp4, std::max(tmp, std::max(tmp2, tmp3)))));
@@ -3806,14 +3834,15 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
-    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; if (getenv("PSK_DP_PRUNE")) A.dp_prune = atoi(getenv("PSK_DP_PRUNE")); }
+    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; }
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
-    if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit, st, GA); }
+    if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; GA.onepass = gsi_one ? 1 : 0; GA.total = L.total; if (gsi_one) GA.pair_cnt = L.aoff;      /* (the per-item offsets array: not used by this join) */
+                    hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit, st, GA); }
     else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
@@ -4002,7 +4031,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     ctx->t_end();
     hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
-    R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
+    R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pcnt = gsi_one ? L.aoff : nullptr; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
     R.k = prm.k; R.median = o->median; R.robust = o->robust;
     R.min_af = o->min_aligned_frac > 0 ? o->min_aligned_frac : 0.15; R.hits = L.hits;
     if (o->median || o->robust) {
@@ -4562,6 +4591,11 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         static const int pairs_env = getenv("PSK_BATCH_PAIRS_LOG2") ? std::min(24, std::max(10, atoi(getenv("PSK_BATCH_PAIRS_LOG2")))) : 0;
         if (!items_env && items_log2 == 29 && round_probe) items_log2 = 30;
         uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : (round_probe ? 22 : 21)), max_rows = 1ull << 26;      // (2^22 pairs: 363 -> 353 ms per 100 000 contigs)
+        {   // the one-pass index join lays a batch's anchors out at 9/8 of its items (gsi_room_kernel) where about two thirds of that are used: three quarters of the
+            // items per batch keep the per-anchor arrays (100 bytes per slot) near what the two passes reserved
+            static const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';
+            if (round_gsi && !one_off && !items_env && max_items == (1ull << 30)) max_items = 3ull << 28;
+        }
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
         // The hits of a batch are appended to the result (and counted per query) while the NEXT batch runs on the GPU: two halves of one
@@ -4656,6 +4690,8 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                     L.p_cap = (pm + 63u) & ~63u;
+                    static const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';      // tests, A/B: count pass + scan + emit pass
+                    L.gsi_onepass = !one_off;
                 }
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
                 PSK_TRY(lrc);
@@ -4676,6 +4712,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe, items / n_pairs > (1u << 20));
+                if (L.gsi_onepass) cap = std::min<uint64_t>(std::max<uint64_t>(cap, items + items / 8 + 8 * ((uint64_t)n_pairs + 1) + 64), 0x7FFFFF00ull);      // gsi_room_kernel's layout
                 bool too_big = false, wide = join_wide_default();
                 static const bool trace_batch = getenv("PSK_TRACE_BATCH") != nullptr;      // diagnostics: host wall clock of every batch (launching, waiting)
                 for (int attempt = 0;; attempt++) {
@@ -4707,6 +4744,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
+                    if (!retry && L.gsi_onepass && (T->misc[0] & 4u)) { L.gsi_onepass = false; retry = true; }      // a pair with more anchors than query seeds: with the count pass
                     if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
                     if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }

@@ -60,6 +60,8 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
             monkeypatch.setenv("PSK_PROBE", "1")    # ... through the database-wide seed index (the metagenome join) or, every other time, the references' probe tables
             if seed % 16 == 1:
                 monkeypatch.setenv("PSK_GSI_JOIN", "0")
+            elif seed % 32 == 9:
+                monkeypatch.setenv("PSK_GSI_ONEPASS", "0")      # ... the index join with its count pass (without: anchors placed at the pairs' item offsets, one walk)
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
@@ -99,6 +101,8 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
         monkeypatch.setenv("PSK_PROBE", "1")          # or (every other seed) through the references' probe tables
         if seed % 4 == 2:
             monkeypatch.setenv("PSK_GSI_JOIN", "0")
+        elif seed % 8 == 4:
+            monkeypatch.setenv("PSK_GSI_ONEPASS", "0")
     k = int(rng.integers(11, 17)); c = int(rng.choice([30, 60, 125, 200])); mc = int(c * rng.choice([4, 8]))
     fams = [random_genome(rng, int(rng.integers(60000, 250000))) for _ in range(int(rng.integers(1, 4)))]
     refs = []
@@ -128,3 +132,31 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
             assert abs(g[n].identity - w.ani) < 1e-6 and abs(g[n].query_fraction - w.af_query) < 1e-6
         single = db.query(qn, qs, learned_ani=False, faster_small=fs, cutoff=cutoff)
         assert [(h.reference_name, h.identity) for h in single] == [(h.reference_name, h.identity) for h in got]
+
+
+@pytest.mark.parametrize("onepass", ["1", "0"])
+def test_index_join_reruns_with_its_count_pass_when_a_reference_repeats_the_query(psk, oracle, onepass, monkeypatch):
+    """The join through the database-wide seed index places a pair's anchors at the pair's item offset - room for one anchor per query seed - and counts
+    while it writes. A reference that holds the query's k-mers several times over (a tandem repeat of the query) needs more room: the batch is rerun with
+    the count pass, same answers; references that hold it once beside it keep the single walk honest in the same batch."""
+    monkeypatch.setenv("PSK_PROBE", "1"); monkeypatch.setenv("PSK_JOIN_PAIRS", "1")
+    monkeypatch.setenv("PSK_GSI_ONEPASS", onepass)
+    rng = np.random.default_rng(4242)
+    unit = random_genome(rng, 4000)
+    a = random_genome(rng, 60000)
+    refs = [("tandem", a[:20000] + unit * 7 + a[20000:]), ("once", a[:30000] + unit + a[30000:]), ("mut", mutate(rng, a[:10000] + unit * 2 + a[10000:], 0.02)), ("none", random_genome(rng, 50000))]
+    db = psk.Database(compression=30, marker_compression=200)
+    for n, sq in refs:
+        db.sketch(n, sq)
+    osk = [(n, oracle.Sketch([sq], c=30, marker_c=200)) for n, sq in refs]
+    queries = [("unit", unit), ("unit_mut", mutate(rng, unit, 0.03)), ("flank", a[15000:27000]), ("two", unit * 2)]
+    got_all = db.query_many(queries, learned_ani=False)
+    for (qn, qs), got in zip(queries, got_all):
+        want = {n: r for n, r in oracle.query(osk, oracle.Sketch([qs], c=30, marker_c=200))}
+        g = {h.reference_name: h for h in got}
+        assert set(g) == set(want), (qn, sorted(set(g) ^ set(want)))
+        for n, w in want.items():
+            for f in INT_FIELDS:
+                assert g[n]._raw[f] == getattr(w, f), (qn, n, f, g[n]._raw[f], getattr(w, f))
+            assert abs(g[n].identity - w.ani) < 1e-6 and abs(g[n].query_fraction - w.af_query) < 1e-6
+    assert any(h._raw["n_anchors"] > len(oracle.Sketch([unit], c=30, marker_c=200).seeds) for h in got_all[0])      # the case is what it claims: more anchors than query seeds
