@@ -1162,7 +1162,7 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="search at N=1: skip extras.workloads (all-vs-all 10k, metagenome 100k, mammalian 8 x 3 Gb)")
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
     ap.add_argument("--contig-mb", type=int, default=125, help="mammalian: contig length in Mb (24 contigs per genome; 125 = 3 Gb genomes)")
-    ap.add_argument("--api-queries", type=int, default=2000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
+    ap.add_argument("--api-queries", type=int, default=10000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
     ap.add_argument("--stream", action="store_true", help="mammalian: build and sketch one genome at a time through a reused device buffer (BASELINE configs[4] at full count: --refs 50), families of 10")
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
