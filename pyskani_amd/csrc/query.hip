@@ -3728,8 +3728,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
-    static const bool gsi_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // tests, A/B: the probe-table join instead
-    const bool gsi_join = !wide && !gsi_off && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
+    const bool gsi_join = !wide && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (the PLAN decides - PSK_GSI_JOIN is read there, once per round: the round's sketches carry no k-mer index to fall back on)      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
     const bool join_pairs = !wide && (gsi_join || (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048)));
     const bool gsi_one = gsi_join && L.gsi_onepass && cap >= n_items + n_items / 8 + 8 * ((size_t)n_pairs + 1);      // (gsi_room_kernel's layout fits)
     bool probe_local = false;
@@ -3834,7 +3833,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
-    { static const bool off = getenv("PSK_DP_PRUNE") && getenv("PSK_DP_PRUNE")[0] == '0'; A.dp_prune = off ? 0 : 1; }
+    { const char* e = getenv("PSK_DP_PRUNE"); A.dp_prune = e && e[0] == '0' ? 0 : 1; }      // (read per call: tests switch it within a process)
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
     const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
@@ -4427,7 +4426,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             bool refs_ok = !rq.empty() && ((uint64_t)rq.size() * n >= (pf_force ? 1ull : (1ull << 20))) && (uint64_t)rq.size() * n * 4 <= (1ull << 31);
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
             // through the database-wide seed index where the database can have one (no per-reference index, no gather, no sort); PSK_GSI_JOIN=0: the per-reference path
-            static const bool gsi_pf_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';
+            const bool gsi_pf_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // (read per call: tests switch it within a process)
             if (refs_ok && !gsi_pf_off && n <= 65536u && !join_wide_default()) {
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 if (db->gsi_state == 1) {
@@ -4537,7 +4536,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             uint64_t round_items = 0;
             for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
             want_small = !pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048));
-            static const bool gsi_join_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';
+            const bool gsi_join_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // (read per round: tests switch it within a process; chain_run follows the plan)
             if (want_small && !gsi_join_off && n <= 65536u && !join_wide_default()) {
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 round_gsi = db->gsi_state == 1;
@@ -4593,7 +4592,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : (round_probe ? 22 : 21)), max_rows = 1ull << 26;      // (2^22 pairs: 363 -> 353 ms per 100 000 contigs)
         {   // the one-pass index join lays a batch's anchors out at 9/8 of its items (gsi_room_kernel) where about two thirds of that are used: three quarters of the
             // items per batch keep the per-anchor arrays (100 bytes per slot) near what the two passes reserved
-            static const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';
+            const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';
             if (round_gsi && !one_off && !items_env && max_items == (1ull << 30)) max_items = 3ull << 28;
         }
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
@@ -4690,7 +4689,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                     L.p_cap = (pm + 63u) & ~63u;
-                    static const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';      // tests, A/B: count pass + scan + emit pass
+                    const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';      // tests, A/B: count pass + scan + emit pass
                     L.gsi_onepass = !one_off;
                 }
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
