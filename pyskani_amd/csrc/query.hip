@@ -2837,6 +2837,13 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
     uint32_t* K = L + 7 * BIG_T;
     uint32_t *l_q0 = K, *l_q1 = K + KL, *l_r0 = K + 2 * KL, *l_r1 = K + 3 * KL, *l_rc = K + 4 * KL, *l_row = K + 5 * KL;
     uint32_t *k_q0 = pm, *k_q1 = pm2, *k_r0 = idx, *k_r1 = ord, *k_rc = (uint32_t*)key, *k_row = (uint32_t*)key + C;
+    // 64 candidates at a time (a Gb-scale pair has ~1 800 conflicted chains of 150 000 - 500 000 candidates; one candidate per round of the whole workgroup
+    // was 0.8 us each, 1.5 of the kernel's 4 ms): every wave tests all 64 against its share of the kept list, then the first wave settles the 64 among
+    // themselves - lane i knows which EARLIER candidates of the block it overlaps, and a 64-step scan over a uniform mask of the accepted ones replays the
+    // sequential rule exactly (kept iff no overlap with anything kept before it, in priority order).
+    __shared__ unsigned long long s_ov[BIG_T / 64];
+    __shared__ uint32_t s_nk;
+    const int lane = tid & 63, wave = tid >> 6;
     uint32_t nk = 0;
     for (uint32_t t0 = 0; t0 < ncf; t0 += BIG_T) {
         const uint32_t nb = ncf - t0 < (uint32_t)BIG_T ? ncf - t0 : (uint32_t)BIG_T;
@@ -2847,25 +2854,50 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
             g_row[tid] = crow[j]; g_n[tid] = S.c_n[sl];
         }
         __syncthreads();
-        for (uint32_t i = 0; i < nb; i++) {
-            const uint32_t q0 = g_q0[i], q1 = g_q1[i], r0 = g_r0[i], r1 = g_r1[i], rc = g_rc[i], row = g_row[i];
-            int ov = 0;
-            for (uint32_t v = tid; v < nk; v += BIG_T) {
-                uint32_t a0, a1, b0, b1, bc, brow;
-                if (v < KL) { a0 = l_q0[v]; a1 = l_q1[v]; b0 = l_r0[v]; b1 = l_r1[v]; bc = l_rc[v]; brow = l_row[v]; }
-                else { a0 = k_q0[v]; a1 = k_q1[v]; b0 = k_r0[v]; b1 = k_r1[v]; bc = k_rc[v]; brow = k_row[v]; }
-                if (brow == row && !(q1 < a0 || q0 > a1)) ov = 1;
-                else if (bc == rc && !(r1 < b0 || r0 > b1)) ov = 1;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+            const uint32_t bn = nb - b0 < 64u ? nb - b0 : 64u;
+            const bool have = (uint32_t)lane < bn;
+            const uint32_t ci = b0 + (have ? lane : 0);
+            const uint32_t q0 = g_q0[ci], q1 = g_q1[ci], r0 = g_r0[ci], r1 = g_r1[ci], rc = g_rc[ci], row = g_row[ci];
+            bool ov = false;
+            for (uint32_t v = wave; v < nk; v += BIG_T / 64) {      // (v is the wave's: the kept entry is read once and broadcast)
+                uint32_t a0, a1, b0r, b1r, bc, brow;
+                if (v < KL) { a0 = l_q0[v]; a1 = l_q1[v]; b0r = l_r0[v]; b1r = l_r1[v]; bc = l_rc[v]; brow = l_row[v]; }
+                else { a0 = k_q0[v]; a1 = k_q1[v]; b0r = k_r0[v]; b1r = k_r1[v]; bc = k_rc[v]; brow = k_row[v]; }
+                if (brow == row && !(q1 < a0 || q0 > a1)) ov = true;
+                else if (bc == rc && !(r1 < b0r || r0 > b1r)) ov = true;
             }
-            if (!__syncthreads_or(ov)) {
-                if (tid == 0) {
-                    if (nk < KL) { l_q0[nk] = q0; l_q1[nk] = q1; l_r0[nk] = r0; l_r1[nk] = r1; l_rc[nk] = rc; l_row[nk] = row; }
-                    else { k_q0[nk] = q0; k_q1[nk] = q1; k_r0[nk] = r0; k_r1[nk] = r1; k_rc[nk] = rc; k_row[nk] = row; }
-                    sel_commit(S, row0 + row, q0, q1, g_n[i]);
+            const unsigned long long wov = __ballot(ov && have);
+            if (lane == 0) s_ov[wave] = wov;
+            __syncthreads();
+            if (wave == 0) {
+                unsigned long long dead = 0;
+#pragma unroll
+                for (int w = 0; w < BIG_T / 64; w++) dead |= s_ov[w];
+                unsigned long long mine = 0;      // earlier candidates of the block this one overlaps
+                for (uint32_t j = 0; j < bn; j++) {
+                    const uint32_t cj = b0 + j;
+                    const uint32_t a0 = g_q0[cj], a1 = g_q1[cj], b0r = g_r0[cj], b1r = g_r1[cj], bc = g_rc[cj], brow = g_row[cj];
+                    const bool hit = (brow == row && !(q1 < a0 || q0 > a1)) || (bc == rc && !(r1 < b0r || r0 > b1r));
+                    if (hit && j < (uint32_t)lane) mine |= 1ull << j;
                 }
-                nk++;
-                __syncthreads();
+                const bool alive = have && !((dead >> lane) & 1ull);
+                unsigned long long accepted = 0;
+                for (uint32_t i = 0; i < bn; i++) {
+                    const unsigned long long okm = __ballot(alive && (mine & accepted) == 0);
+                    if ((okm >> i) & 1ull) accepted |= 1ull << i;
+                }
+                if ((accepted >> lane) & 1ull) {
+                    const uint32_t at = nk + (uint32_t)__popcll(accepted & ((1ull << lane) - 1ull));
+                    if (at < KL) { l_q0[at] = q0; l_q1[at] = q1; l_r0[at] = r0; l_r1[at] = r1; l_rc[at] = rc; l_row[at] = row; }
+                    else { k_q0[at] = q0; k_q1[at] = q1; k_r0[at] = r0; k_r1[at] = r1; k_rc[at] = rc; k_row[at] = row; }
+                    sel_commit(S, row0 + row, q0, q1, g_n[ci]);
+                }
+                if (lane == 0) s_nk = nk + (uint32_t)__popcll(accepted);
+                __threadfence_block();
             }
+            __syncthreads();
+            nk = s_nk;
         }
     }
     if (tid == 0) atomicAdd(&S.stats[3], 1u);
