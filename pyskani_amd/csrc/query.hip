@@ -1902,10 +1902,12 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
     uint32_t Wq[QD], Wu[QD], Wm[QD]; int32_t Wf[QD];      // entry i = this lane's anchor 4 (i + 1) - (u - j) ... before x: its (i + 1)-th latest of EARLIER steps
 #pragma unroll
     for (int i = 0; i < QD; i++) { Wq[i] = 0; Wu[i] = 0; Wm[i] = 0xFFFFFFFFu; Wf[i] = -1; }      // (score - 1 of an EMPTY entry: below every real one, see the far bound)
-    unsigned long long bk[LANE_TREES];
-    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
-#pragma unroll
-    for (int k = 0; k < LANE_TREES; k++) { bk[k] = 0; sroot[k] = 0xFFFFFFFFu; bq[k] = br[k] = 0; }
+    // the chunk's qualifying chain trees (at most LANE_TREES = 4, as in the lane kernel): the quad's four lanes see the same anchor, root and key, so each keeps
+    // ONE slot - lane j the j-th tree to qualify - instead of all four keeping all four (a compare and three selects per anchor and lane instead of four times that);
+    // a quad-wide OR tells whether the root already has a slot, lane 0 collects the four at the end
+    static_assert(LANE_TREES == 4, "one tree slot per lane of the quad");
+    unsigned long long my_bk = 0;
+    uint32_t my_root = 0xFFFFFFFFu, my_bq = 0, my_br = 0;
     uint32_t S = 0;
     bool ovf = false;
     uint32_t (*rd)[16] = s_rd[wave];
@@ -1991,17 +1993,13 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
             if (j == u) { nq = qx + 1u; nu = ux; nm = act ? mx : 0xFFFFFFFFu; nf = act ? f - 1 : -1; }      // x is 4-aligned at u = 0: anchor x belongs to lane u
             if (act && f >= MIN_SCORE2) {
                 const unsigned long long k64 = ((unsigned long long)(uint32_t)f << 28) | ((unsigned long long)(16383u - (x - s)) << 14) | dep;
-                bool found = false;
-#pragma unroll
-                for (int k = 0; k < LANE_TREES; k++) {
-                    const bool hit = sroot[k] == ridx;
-                    found = found || hit;
-                    if (hit && k64 > bk[k]) { bk[k] = k64; bq[k] = qx; br[k] = rx; }
-                }
-                if (!found) {
+                const bool hit = my_root == ridx;
+                if (hit && k64 > my_bk) { my_bk = k64; my_bq = qx; my_br = rx; }
+                int fnd = hit ? 1 : 0;      // over the quad
+                fnd |= __builtin_amdgcn_mov_dpp(fnd, 0xB1, 0xF, 0xF, true); fnd |= __builtin_amdgcn_mov_dpp(fnd, 0x4E, 0xF, 0xF, true);
+                if (!fnd) {
                     if (S >= (uint32_t)LANE_TREES) ovf = true;
-#pragma unroll
-                    for (int k = 0; k < LANE_TREES; k++) if (S == (uint32_t)k) { sroot[k] = ridx; bk[k] = k64; bq[k] = qx; br[k] = rx; }
+                    if (S == (uint32_t)j) { my_root = ridx; my_bk = k64; my_bq = qx; my_br = rx; }
                     S++;
                 }
             }
@@ -2010,6 +2008,14 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
 #pragma unroll
         for (int i = QD - 1; i >= 1; i--) { Wq[i] = Wq[i - 1]; Wu[i] = Wu[i - 1]; Wm[i] = Wm[i - 1]; Wf[i] = Wf[i - 1]; }
         Wq[0] = nq; Wu[0] = nu; Wm[0] = nm; Wf[0] = nf;
+    }
+    unsigned long long bk[LANE_TREES];
+    uint32_t sroot[LANE_TREES], bq[LANE_TREES], br[LANE_TREES];
+#pragma unroll
+    for (int k = 0; k < LANE_TREES; k++) {      // lane k of the quad holds slot k
+        const int src = (lane & ~3) + k;
+        sroot[k] = (uint32_t)__shfl((int)my_root, src); bq[k] = (uint32_t)__shfl((int)my_bq, src); br[k] = (uint32_t)__shfl((int)my_br, src);
+        bk[k] = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(my_bk >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)my_bk, src);
     }
     if (j == 0 && slot < A.n_rows && real) {
         if (mine && !ovf) {
