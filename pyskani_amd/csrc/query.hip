@@ -4683,8 +4683,16 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             else {
                 std::vector<std::thread> th;
                 const size_t per = ((size_t)pend_n + nt - 1) / nt;
-                for (unsigned t = 1; t < nt; t++) { const size_t lo = std::min<size_t>(pend_n, t * per), hi = std::min<size_t>(pend_n, lo + per); if (hi > lo) th.emplace_back(move, lo, hi, true); }
+                size_t started = per;      // records [0, started) have a mover (this thread takes the first slice and whatever no helper could be started for)
+                try {
+                    th.reserve(nt);
+                    for (unsigned t = 1; t < nt; t++) {
+                        const size_t lo = std::min<size_t>(pend_n, t * per), hi = std::min<size_t>(pend_n, lo + per);
+                        if (hi > lo) { th.emplace_back(move, lo, hi, true); started = hi; }
+                    }
+                } catch (...) {}      // (no thread to be had: the rest is moved here - nothing may leave this function as an exception, its callers are extern "C")
                 move(0, std::min<size_t>(pend_n, per), true);
+                if (started < pend_n) move(std::max(started, std::min<size_t>(pend_n, per)), pend_n, true);
                 for (std::thread& t : th) t.join();
             }
             all.n += pend_n;
