@@ -371,9 +371,12 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32
 // segment offset; cnt[g] = number of distinct markers (cnt[n_genomes] must be pre-zeroed by the caller's scan input)
 // entries past the batch's last marker (the array is sized by the SEED count, its upper bound) get a tag beyond every genome's: they
 // sort to the end and no segment reads them
-__global__ __launch_bounds__(256) void marker_pad_kernel(uint64_t* __restrict__ dense, const uint32_t* __restrict__ total, uint32_t n, uint64_t sentinel) {
+// (n: the number of entries the sort takes - the raw markers' expected count with a wide margin, not the seed count; more raw markers than that raise *over
+// and the caller sorts again at full size)
+__global__ __launch_bounds__(256) void marker_pad_kernel(uint64_t* __restrict__ dense, const uint32_t* __restrict__ total, uint32_t n, uint64_t sentinel, uint32_t* __restrict__ over) {
     const uint32_t i = *total + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dense[i] = sentinel;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *total > n) *over = 1u;
 }
 __global__ __launch_bounds__(256) void marker_unique_kernel(const uint64_t* __restrict__ sorted, uint64_t* __restrict__ uniq,
                                                              const uint32_t* __restrict__ beg, const uint32_t* __restrict__ end,
@@ -767,6 +770,7 @@ struct SketchJob {
         JHIP(hipMemcpyAsync(store->contig_seed_start, d_coff, sizeof(uint32_t) * (n_desc + 1), hipMemcpyDeviceToDevice, st));
         PSK_TRY(R->s_mark.reserve(sizeof(uint64_t) * (3 * ns + 3)));   // tile-local stage, dense, sorted
         d_mstage = (uint64_t*)R->s_mark.p; d_mdense = d_mstage + ns + 1; d_msorted = d_mdense + ns + 1;
+        marker_dense_ready = false; marker_cap_ok = true; marker_capped = false;      // (a job object serves one batch after another)
         ctx->t_begin(K_SKETCH_EMIT, st);
         hipLaunchKernelGGL(sketch_emit_kernel, dim3((n_tiles + EMIT_WAVES - 1) / EMIT_WAVES), dim3(64 * EMIT_WAVES), 0, st, d_tinfo, d_packed, d_mask, d_toff, d_goff, n_tiles,
                            store->seed_kmer, store->seed_pos, store->seed_meta, store->seed_pm, d_mstage, d_tmc, C, 0xFFFFFFFFu);
@@ -796,6 +800,8 @@ struct SketchJob {
 
     bool marker_block = false;
     uint32_t marker_slices = 1;      // slices per genome of the distinct-marker pass (few large genomes)
+    bool marker_dense_ready = false;      // d_mdense holds the raw markers (marker_compact_kernel ran; the distinct-marker pass then overwrites the tile-local lists it read)
+    bool marker_cap_ok = true, marker_capped = false;      // the tagged sort takes the EXPECTED number of raw markers (x 2 + 65 536) instead of the seed count; capped: this attempt did
     // tile-local lists -> dense per-genome segments -> segmented radix sort -> distinct values (in d_mstage)
     psk_status marker_segsort() {
         const size_t ns = h_goff[n_genomes];
@@ -805,12 +811,23 @@ struct SketchJob {
         int gbits = 0; while ((1ull << gbits) < (uint64_t)n_genomes + 1) gbits++;      // tags 0 .. n_genomes - 1, and n_genomes for the padding
         static const bool tag_off = getenv("PSK_MARKER_TAGSORT") && getenv("PSK_MARKER_TAGSORT")[0] == '0';
         const bool tagged = !tag_off && MARKER_BITS + gbits <= 64;
-        hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense, tagged ? (const uint4*)d_tinfo : (const uint4*)nullptr);
+        if (!marker_dense_ready) hipLaunchKernelGGL(marker_compact_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, d_mstage, d_toff, d_tmoff, n_tiles, d_mdense, tagged ? (const uint4*)d_tinfo : (const uint4*)nullptr);
+        marker_dense_ready = true;      // (the sorts below leave their input as it is)
+        marker_capped = false;
         if (ns > 0 && tagged) {
-            hipLaunchKernelGGL(marker_pad_kernel, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, st, d_mdense, d_tmoff + n_tiles, (uint32_t)ns, (uint64_t)n_genomes << MARKER_BITS);
-            JHIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, 0, MARKER_BITS + gbits, st));
+            // The dense array is sized by the SEED count (the raw markers' total is only on the device), but the sort need not be: raw markers number ~ L / marker_c,
+            // an eighth of the seeds at the default parameters - sorting 192 M padded keys for 24 M markers was 4.8 ms of the 8 x 3 Gb step's sketching. Twice the
+            // expectation + 65 536 entries; a batch that holds more (low-complexity sequence) is flagged by the pad kernel and sorted again at full size (phase3).
+            uint64_t expect = 0;
+            for (uint32_t g = 0; g < n_genomes; g++) expect += sk[g]->total_len / (uint64_t)p->marker_c;
+            size_t nm = ns;
+            if (marker_cap_ok && 2 * expect + 65536 < (uint64_t)ns) { nm = (size_t)(2 * expect + 65536); marker_capped = true; }
+            JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t), st));      // overflow flag
+            hipLaunchKernelGGL(marker_pad_kernel, dim3((uint32_t)((nm + 255) / 256)), dim3(256), 0, st, d_mdense, d_tmoff + n_tiles, (uint32_t)nm, (uint64_t)n_genomes << MARKER_BITS, d_mcnt);
+            JHIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)nm, 0, MARKER_BITS + gbits, st));
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
-            JHIP(hipcub::DeviceRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)ns, 0, MARKER_BITS + gbits, st));
+            JHIP(hipcub::DeviceRadixSort::SortKeys(R->s_tmp.p, tmp_bytes, d_mdense, d_msorted, (int)nm, 0, MARKER_BITS + gbits, st));
+            JHIP(hipMemcpyAsync(h_moff + n_genomes + 1, d_mcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         } else if (ns > 0) {
             JHIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, d_mdense, d_msorted, (int)ns, (int)n_genomes, d_sbeg, d_sbeg + 1, 0, 2 * K_MARKER, st));
             PSK_TRY(R->s_tmp.reserve(tmp_bytes));
@@ -850,6 +867,14 @@ struct SketchJob {
         JHIP(hipStreamSynchronize(st));
         if (marker_block && h_moff[n_genomes + 1]) {   // a genome held more raw markers than the LDS path takes: redo on the sort path
             marker_block = false;
+            h_moff[n_genomes + 1] = 0;
+            PSK_TRY(marker_segsort());
+            PSK_TRY(marker_offsets());
+            JHIP(hipStreamSynchronize(st));
+        }
+        if (!marker_block && marker_capped && h_moff[n_genomes + 1]) {   // more raw markers than the capped sort took: again, at the seed count
+            marker_cap_ok = false;
+            h_moff[n_genomes + 1] = 0;
             PSK_TRY(marker_segsort());
             PSK_TRY(marker_offsets());
             JHIP(hipStreamSynchronize(st));

@@ -109,6 +109,38 @@ def test_marker_paths(psk, oracle):
     assert outs[0] == outs[1] == outs[2], outs
 
 
+def test_tagged_marker_sort_is_redone_at_full_size_when_markers_outnumber_its_cap(oracle):
+    """The tagged marker sort of large genomes (forced here: PSK_MARKER_SEGSORT=1) takes twice the EXPECTED number of raw markers + 65 536 entries instead
+    of the seed count. A genome whose raw markers outnumber that - a 10-base period that carries a marker, 1.2 Mb of it: >= 120 000 raw markers where
+    2 x 1.5 Mb / 200 + 65 536 = 80 536 are allowed for - is flagged on the device and sorted again at the seed count; same sets as the oracle either way."""
+    rng = np.random.default_rng(79)
+    unit = None
+    for _ in range(400):                       # a 10-base period one of whose ten 21-mers is a marker at marker_c = 200
+        u = random_genome(rng, 10)
+        if len(oracle.Sketch([u * 300], c=30, marker_c=200).markers) >= 1:
+            unit = u
+            break
+    assert unit is not None
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "sk.npz")
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import random_genome\n"
+        "import pyskani_amd\n"
+        "rng = np.random.default_rng(80); g = random_genome(rng, 150000) + %r * 120000 + random_genome(rng, 150000)\n"
+        "db = pyskani_amd.Database(compression=30, marker_compression=200)\n"
+        "sk = db._sketch('x', [g], True); seeds, markers = sk.export()\n"
+        "np.savez(%r, kmer=seeds['kmer'], pos=seeds['pos'], markers=markers)\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), unit, out)
+    env = dict(os.environ); env["PSK_MARKER_SEGSORT"] = "1"; env["PSK_SKETCH_SMALL"] = "0"
+    subprocess.check_call([sys.executable, "-c", code], env=env, timeout=600)
+    rng2 = np.random.default_rng(80); g = random_genome(rng2, 150000) + unit * 120000 + random_genome(rng2, 150000)
+    want = oracle.Sketch([g], c=30, marker_c=200)
+    got = np.load(out)
+    assert np.array_equal(got["kmer"], want.seeds["kmer"]) and np.array_equal(got["pos"], want.seeds["pos"])
+    assert np.array_equal(got["markers"], want.markers)
+
+
 def test_sketch_empty_and_short(psk, oracle):
     db, gs = gpu_sketch(psk, [b"ATGC" * 100])        # 400 bp: below MIN_LENGTH_CONTIG (test_database.py:13)
     seeds, markers = gs.export()
