@@ -3713,6 +3713,7 @@ __global__ void gsi_total_kernel(const unsigned long long* __restrict__ poff, ui
 
 struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const { return h.ani > 0.1f; } };   // lib.rs:654
 
+constexpr size_t CHAIN_ANCHOR_WORDS = 12;      // u32 per anchor in Lane::q_d: the 16-byte record, the successor / state array, the candidates' seven
 // device arrays of one chain launch sequence, carved from ctx->q_b
 struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
@@ -3853,17 +3854,21 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(pair_start_kernel, dim3((emit_pairs || probe_local) ? 1u : (n_pairs + 1 + 255) / 256), dim3(256), 0, st, (emit_pairs || probe_local) ? (const uint32_t*)nullptr : L.aoff, L.sbase, n_pairs, L.pstart, (uint32_t)cap,
                            L.bsum, small_sum ? n_sum : 0u, L.total, (const uint32_t*)(L.misc + 5));
     hipLaunchKernelGGL(pair_guard_kernel, dim3((n_pairs + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)(L.misc + 5), (const unsigned long long*)L.total, (unsigned long long)cap, L.pstart, n_pairs);
-    // ---- anchors + serial-path scratch: 16 arrays of u32 per anchor ----
+    // ---- anchors + candidates: 12 arrays of u32 per anchor (CHAIN_ANCHOR_WORDS); the lane-serial DP's four per-anchor arrays - a fallback that runs inside the DP
+    // kernels - borrow the selection's scratch, which nothing touches before the DP is through (they had four arrays of their own: 13 of the 67 GB a batch of
+    // 3 Gb pairs asks for, and a cold pass pays ~25 ms per GB it is handed)
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
-    PSK_TRY(ctx->q_d.reserve(4 * na * 16));
+    PSK_TRY(ctx->q_d.reserve(4 * na * CHAIN_ANCHOR_WORDS));
     PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
+    uint32_t* E4 = (uint32_t*)ctx->q_e.p;   // (37 bytes per anchor: room for the serial DP's 16)
     uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
     uint32_t* a_nxt = D + 4 * na;
     ChainArgs A{};
     A.anc = anc;
-    A.sc_f = (int32_t*)(D + 5 * na); A.sc_ptr = D + 6 * na; A.sc_root = D + 7 * na; A.sc_depth = D + 8 * na; A.sc_best = D + 9 * na;
-    A.c_score = (int32_t*)(D + 10 * na); A.c_q0 = D + 11 * na; A.c_q1 = D + 12 * na; A.c_r0 = D + 13 * na; A.c_r1 = D + 14 * na; A.c_n = D + 15 * na;
+    A.sc_ptr = D + 5 * na;
+    A.sc_f = (int32_t*)E4; A.sc_root = E4 + na; A.sc_depth = E4 + 2 * na; A.sc_best = E4 + 3 * na;
+    A.c_score = (int32_t*)(D + 6 * na); A.c_q0 = D + 7 * na; A.c_q1 = D + 8 * na; A.c_r0 = D + 9 * na; A.c_r1 = D + 10 * na; A.c_n = D + 11 * na;
     A.c_state = a_nxt;   // spare per-anchor array
     A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
     A.chunks = L.chunks; A.n_chunks = L.nch; A.cbase = L.cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
@@ -3908,7 +3913,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     }
     else if (use_hops) {
         if (n_items / n_pairs > (1u << 20)) {      // Gb-scale: every 64th anchor first (into the spare per-anchor array after a_nxt), then all of them between those
-            uint32_t* coarse = D + 5 * na;          // sc_f's space: the serial path is not running yet
+            uint32_t* coarse = E4;                  // sc_f's space: the serial path is not running yet
             hipLaunchKernelGGL(anchor_next_kernel<1>, dim3((uint32_t)((cap / 64 + 1 + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)nullptr, coarse);
             hipLaunchKernelGGL(anchor_next_kernel<2>, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, anc, L.pstart, n_pairs, (const uint32_t*)coarse, a_nxt);
         } else
@@ -4105,7 +4110,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
 }
 
 static uint64_t anchor_cap_for(Lane* ctx, size_t n_items, bool sparse = false, bool gb_scale = false) {
-    const uint64_t have = ctx->q_d.cap / 64 > 128 ? ctx->q_d.cap / 64 - 128 : 0;     // anchors the per-anchor arrays already hold
+    const uint64_t have = ctx->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) > 128 ? ctx->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) - 128 : 0;     // anchors the per-anchor arrays already hold
     // non-repetitive genomes: at most ~one anchor per query seed; contigs against a whole database (sparse): a third of the (pair, seed) items match
     // (100 bytes of scratch per anchor: 2^30 items would reserve 136 GB otherwise; a batch that does not fit is rerun with the true total)
     // Gb-scale pairs: a seed has ~6.5 matches (chance 15-mer hits in 3 Gb beside the true one) - sized for that at once: the first batch used to overflow, and its
