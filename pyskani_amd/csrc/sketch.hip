@@ -632,6 +632,7 @@ struct SketchJob {
     uint32_t n_genomes = 0, n_tiles = 0; int n_desc = 0;
     std::vector<ContigDesc> descs;
     std::vector<uint32_t> g_first_desc, g_first_tile;
+    std::vector<uint64_t> g_total_len;      // kept bases per genome (the sketch objects are made later: make_objects)
     std::vector<psk_sketch*> sk;
     SketchConsts C{};
     std::shared_ptr<SketchStore> store;
@@ -650,14 +651,12 @@ struct SketchJob {
     // host: contig filter (lib.rs:156) and tile layout
     psk_status prepare(const uint64_t* contig_off, const uint64_t* contig_len, const uint32_t* gfc, uint32_t ng) {
         n_genomes = ng;
-        g_first_desc.resize(ng + 1); g_first_tile.resize(ng + 1); sk.assign(ng, nullptr);
+        g_first_desc.resize(ng + 1); g_first_tile.resize(ng + 1); sk.assign(ng, nullptr); g_total_len.assign(ng, 0);
         uint64_t n_tiles64 = 0, total_bases = 0;
         for (uint32_t g = 0; g < ng; g++) {
             g_first_desc[g] = (uint32_t)descs.size();
             g_first_tile[g] = (uint32_t)n_tiles64;
-            psk_sketch* s = new psk_sketch();
-            s->ctx = ctx->dev; s->params = *p; s->has_seeds = want_seeds != 0;
-            sk[g] = s;
+            uint32_t kept = 0;
             for (uint32_t ci = gfc[g]; ci < gfc[g + 1]; ci++) {
                 uint64_t len = contig_len[ci];
                 if (len < MIN_LENGTH_CONTIG) continue;
@@ -665,10 +664,9 @@ struct SketchJob {
                 if (!packed_in && (contig_off[ci] & 15)) { psk_set_error("contig offset not 16-byte aligned"); return PSK_EINVAL; }
                 ContigDesc d{};
                 d.byte_off = contig_off[ci]; d.len = (uint32_t)len; d.first_tile = (uint32_t)n_tiles64;
-                d.genome = g; d.contig_index = (uint32_t)s->contig_len.size();
+                d.genome = g; d.contig_index = kept++;
                 descs.push_back(d);
-                s->contig_len.push_back((uint32_t)len);
-                s->total_len += len;
+                g_total_len[g] += len;
                 n_tiles64 += (len + TILE_BASES - 1) / TILE_BASES;
                 total_bases += len;
             }
@@ -680,6 +678,20 @@ struct SketchJob {
         empty = n_tiles == 0;
         C = make_sketch_consts(p);
         return PSK_OK;
+    }
+
+    // the sketch objects of the batch: made AFTER phase1 has its kernels in flight (100 000 contigs per metagenome step: 4-5 ms of allocations that used to
+    // run before the first launch, with the GPU idle)
+    void make_objects() {
+        for (uint32_t g = 0; g < n_genomes; g++) {
+            if (sk[g]) continue;      // (the single-genome path made its object up front)
+            psk_sketch* s = new psk_sketch();
+            s->ctx = ctx->dev; s->params = *p; s->has_seeds = want_seeds != 0;
+            const uint32_t d0 = g_first_desc[g], d1 = g_first_desc[g + 1];
+            for (uint32_t d = d0; d < d1; d++) s->contig_len.push_back(descs[d].len);
+            s->total_len = g_total_len[g];
+            sk[g] = s;
+        }
     }
 
     // tables up, pack + seed bits, tile offsets, per-genome / per-contig seed offsets on their way back
@@ -785,7 +797,7 @@ struct SketchJob {
         // small genomes (expected raw markers well inside MB_CAP): one workgroup per genome does it all in LDS
         marker_block = getenv("PSK_MARKER_SEGSORT") == nullptr;
         for (uint32_t g = 0; g < n_genomes && marker_block; g++)
-            if (sk[g]->total_len / (uint64_t)p->marker_c > (uint64_t)(MB_CAP * 3 / 4)) marker_block = false;
+            if (g_total_len[g] / (uint64_t)p->marker_c > (uint64_t)(MB_CAP * 3 / 4)) marker_block = false;
         if (marker_block) {
             JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t), st));      // overflow flag
             hipLaunchKernelGGL(marker_block_kernel<false>, dim3(n_genomes), dim3(MB_THREADS), 0, st, d_mstage, d_toff, d_tmoff, d_gft, d_mdense, d_moff, d_mcnt, 0xFFFFFFFFu);
@@ -819,7 +831,7 @@ struct SketchJob {
             // an eighth of the seeds at the default parameters - sorting 192 M padded keys for 24 M markers was 4.8 ms of the 8 x 3 Gb step's sketching. Twice the
             // expectation + 65 536 entries; a batch that holds more (low-complexity sequence) is flagged by the pad kernel and sorted again at full size (phase3).
             uint64_t expect = 0;
-            for (uint32_t g = 0; g < n_genomes; g++) expect += sk[g]->total_len / (uint64_t)p->marker_c;
+            for (uint32_t g = 0; g < n_genomes; g++) expect += g_total_len[g] / (uint64_t)p->marker_c;
             size_t nm = ns;
             if (marker_cap_ok && 2 * expect + 65536 < (uint64_t)ns) { nm = (size_t)(2 * expect + 65536); marker_capped = true; }
             JHIP(hipMemsetAsync(d_mcnt, 0, sizeof(uint32_t), st));      // overflow flag
@@ -835,7 +847,7 @@ struct SketchJob {
         }
         // few large genomes: their segments in slices (marker_unique_sliced_kernel); many smaller ones: a workgroup each
         uint64_t est = 0;
-        for (uint32_t g = 0; g < n_genomes; g++) est = std::max<uint64_t>(est, sk[g]->total_len / (uint64_t)p->marker_c);
+        for (uint32_t g = 0; g < n_genomes; g++) est = std::max<uint64_t>(est, g_total_len[g] / (uint64_t)p->marker_c);
         marker_slices = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(1, est / 8192));
         if (const char* e = getenv("PSK_MARKER_SLICES")) marker_slices = (uint32_t)std::max(1, std::min(1024, atoi(e)));      // tests: slices whatever the size
         if (marker_slices > 1 && (uint64_t)marker_slices * n_genomes <= (1u << 20) && !getenv("PSK_MARKER_UNSLICED")) {
@@ -1027,12 +1039,14 @@ psk_status sketch_batch_impl(Lane* ctx, const psk_params* p, const uint8_t* d_ba
     }
     if (J == 1 && n_genomes == 1 && !d_packed_in) {
         bool done = false;
+        jobs[0].make_objects();
         psk_status rc = jobs[0].run_small(out, &done);
         if (rc != PSK_OK) return abort_all(rc);
         if (done) return PSK_OK;
     }
     hipEvent_t prev = nullptr;
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase1(prev); if (rc != PSK_OK) return abort_all(rc); if (!jobs[j].empty) prev = jobs[j].R->scan_done; }
+    for (uint32_t j = 0; j < J; j++) jobs[j].make_objects();      // (while the scans run)
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase2(); if (rc != PSK_OK) return abort_all(rc); }
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].phase3(); if (rc != PSK_OK) return abort_all(rc); }
     for (uint32_t j = 0; j < J; j++) { psk_status rc = jobs[j].finish(out + cut[j]); if (rc != PSK_OK) return abort_all(rc); }
