@@ -4435,6 +4435,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
     }
     std::vector<uint32_t> h_cnt; std::vector<uint8_t> h_flag;
     std::vector<SketchDesc> h_qd;
+    int64_t h_qd_gsi_round = -1;      // the round (its first query) whose descriptors h_qd holds in the seed-index form (make_desc(.., true))
     std::vector<BatchQ> bqs;
     for (uint32_t b = 0; b < n_queries; b += QB) {
         const uint32_t m = std::min(QB, n_queries - b);
@@ -4476,6 +4477,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     const uint32_t nr = (uint32_t)rq.size();
                     h_qd.resize(m);
                     for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], true);
+                    h_qd_gsi_round = (int64_t)b;      // (the round's descriptors for the seed-index paths: built once, see below)
                     const size_t o_qd = al256(4 * (size_t)nr), o_endp = o_qd + sizeof(SketchDesc) * (size_t)m;
                     PSK_TRY(pf_buf.reserve(ctx->dev, o_endp + 256));
                     char* Bp = (char*)pf_buf.p;
@@ -4507,6 +4509,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 const uint32_t slice_shift = kbits - lg;
                 h_qd.resize(m);
                 for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i]);
+                h_qd_gsi_round = -1;
                 size_t ts = 0;
                 PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)E, 0, (int)kbits, st));
                 const size_t o_rq = 0, o_eoff = al256(4 * (size_t)nr), o_qn = al256(o_eoff + 4 * (size_t)nr), o_qd = al256(o_qn + 4 * (size_t)nr),
@@ -4614,8 +4617,10 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 }));
         }
         }
-        h_qd.resize(m);
-        for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], round_gsi);
+        if (!(round_gsi && h_qd_gsi_round == (int64_t)b && h_qd.size() == m)) {      // (65 536 descriptors: ~2 ms of pointer chasing with the GPU idle - the prefilter of this round made the same ones)
+            h_qd.resize(m);
+            for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], round_gsi);
+        }
         PSK_TRY(ctx->q_h.reserve(sizeof(SketchDesc) * (size_t)m + 256));
         SketchDesc* d_qd = (SketchDesc*)ctx->q_h.p;
         PSK_HIP(hipMemcpyAsync(d_qd, h_qd.data(), sizeof(SketchDesc) * (size_t)m, hipMemcpyHostToDevice, st));
