@@ -1868,7 +1868,8 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_kernel(ChainArgs A
 // that either joins the candidates (u > j) or not, one select per field (v_cndmask is the slowest VALU instruction: the shifting
 // window of chain_quad_kernel would cost 84 of them per anchor). 16 chunks per wave step: ~66 SIMD cycles per anchor.
 constexpr int QD = 21;            // own anchors per lane: bands up to 4 * QD = 84
-constexpr int QD_NEAR = 5;        // entries per lane that are always scored (the quad's last 20 anchors); the others only when they could win
+constexpr int QD_NEAR = 2;        // entries per lane that are always scored (with the step's own anchors: the quad's last 8-11); the others only when they could win. Measured on the
+                                  // 100 000 x 5 000 step: 5 -> 48.1 ms, 3 -> 44.5, 2 -> 42.4, 1 -> 41.1 (the far pass becomes more frequent as the near part shrinks)
 constexpr int QD_RING = 128;      // root / depth ring per quad (power of two > 4 * QD + 3)
 __device__ __forceinline__ int32_t quad_eval(uint32_t qx, uint32_t ux, uint32_t mx, uint32_t yq1, uint32_t yu, uint32_t ym, int32_t yf1, int32_t dpj, int32_t bj) {
     // dpj = the distance of the two anchors PLUS j (a compile-time number for the window entries, one select for the extra entry); bj = band + j
@@ -1920,7 +1921,7 @@ __global__ __launch_bounds__(64 * LANE_WAVES) void chain_quad_deep_kernel(ChainA
         if (t0 < len) { an0 = A.anc[x0]; an1 = A.anc[x0 + 1]; an2 = A.anc[x0 + 2]; an3 = A.anc[x0 + 3]; }      // 64 contiguous bytes per lane
         const uint32_t qs[4] = {an0.x, an1.x, an2.x, an3.x}, rs[4] = {an0.y, an1.y, an2.y, an3.y}, ms[4] = {an0.z, an1.z, an2.z, an3.z};
         uint32_t nq = 0, nu = 0, nm = 0xFFFFFFFFu; int32_t nf = -1;      // this lane's own anchor of the step (from u = j on)
-        // The FAR part of the window - a lane's entries QD_NEAR .. QD - 1: the quad's anchors more than 4 QD_NEAR back - can only win with a score above the
+        // The FAR part of the window - a lane's entries QD_NEAR .. QD - 1: the quad's anchors more than 4 QD_NEAR + 3 back - can only win with a score above the
         // best near one: a predecessor y scores f[y] + ANCHOR_SCORE2 - gap <= f[y] + ANCHOR_SCORE2, and on equal scores the NEARER one is taken. far_top =
         // the largest f - 1 among the far entries of the quad (-1: all empty), one pass per step (the window does not move within a step). Along a chain f
         // grows by ~ANCHOR_SCORE2 per anchor, so the nearest predecessors nearly always beat that bound and the far three quarters of the band are not scored
