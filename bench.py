@@ -1226,7 +1226,7 @@ def main():
             # SURVEY.md §8d's harder shapes (every measured pair above is the easiest chaining case: one contig, substitutions only)
             wl["allvsall_1k_contigs"] = run_allvsall(job, 2, 1, 1000, 0, variant="contigs", verify_hits=8 if cpu_n > 0 else 0)
             wl["allvsall_1k_sv"] = run_allvsall(job, 2, 1, 1000, 0, variant="sv", verify_hits=8 if cpu_n > 0 else 0)
-            meta = run_metagenome(job, 2, 1, 5000, 100000, (False, True), min(cpu_n, 512), 2000)
+            meta = run_metagenome(job, 2, 1, 5000, 100000, (False, True), min(cpu_n, 512), 10000)
             wl["metagenome_100k"], wl["metagenome_100k_faster_small"], wl["metagenome_api"] = meta["rescue"], meta["faster_small"], meta.get("api")
             wl["mammalian_8x3Gb"] = run_mammalian(job, 2, 1, 8, 125, 2 if cpu_n > 0 else 0)
             line["extras"]["workloads"] = wl
