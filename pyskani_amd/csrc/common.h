@@ -207,6 +207,7 @@ struct Lane {
     }
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
+    Scratch q_j;                                                                           // slice join (slice_join.hip): wave table, per-(pair, slice) records and bitmaps of a batch
     Scratch q_small;                                                                       // the one-launch-sequence query's workspace (small_query.hip)
     uint32_t sq_last_short = 192;                                                          // ... and the shortlist length of its last call on this lane: sizes the next chain launch
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
@@ -223,7 +224,7 @@ struct Lane {
         return PSK_OK;
     }
     void release_all() {
-        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small};
+        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small, &q_j};
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (Scratch* s : all) s->release();
         jobs_release();

@@ -6,6 +6,7 @@
 // Semantics are normative in oracle/skani_oracle.c (orc_screen / orc_chain).
 #include "common.h"
 #include "chain_dev.h"
+#include "slice_join.h"
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <algorithm>
@@ -3472,7 +3473,7 @@ __global__ __launch_bounds__(256) void pair_build_list_kernel(const uint2* __res
 // Device-side shortlist: one workgroup per batch entry walks its query's row of the pass matrix and turns the passing
 // references with rank in [rank_lo, rank_hi) into pairs. Every pair of one query has the same item and row count, so the
 // item / row offsets follow from the rank: no scan, no pass[] on the host (lib.rs:617-637 + 640-645 in one kernel).
-struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
+// (struct BatchQ: slice_join.h)
 __global__ __launch_bounds__(256) void pair_build_rows_kernel(const BatchQ* __restrict__ bq, const uint8_t* __restrict__ pass, uint32_t n_refs,
                                                               const SketchDesc* __restrict__ qd, const SketchDesc* __restrict__ rd,
                                                               PairDesc* __restrict__ pairs, uint32_t* __restrict__ sbase, uint32_t* __restrict__ cbase,
@@ -3534,7 +3535,7 @@ __global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restri
 //     every lane its place in the group, the group's last lane moves the cursor.
 // COUNT pass: the cursors' final values are the pairs' anchor counts (-> scan -> pstart). EMIT pass: the same walk writes the 16-byte anchors.
 // The item records, their scan and the per-item emit of the other joins do not exist here.
-constexpr uint32_t GSI_PMAX = 256;      // (an entry's LDS: 4 B (count) / 20 B (emit) per pair; a query with more passing references is walked by several entries - cheap for the short contigs that have them)
+// GSI_PMAX (slice_join.h) = 256      // (an entry's LDS: 4 B (count) / 20 B (emit) per pair; a query with more passing references is walked by several entries - cheap for the short contigs that have them)
 struct GsiJoinArgs {
     const BatchQ* bq; const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
     const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;
@@ -3726,6 +3727,8 @@ struct ChainBufs {
     // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
+    // mid-sized pairs (all-vs-all of genomes): the index join by (query, slice) waves (slice_join.hip); the batch's wave table, record offsets and per-record arrays
+    bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint32_t* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr; uint4* gsl_rec = nullptr;
     bool gsi_onepass = false;      // the index join without its COUNT pass (GsiJoinArgs::onepass): asked for by the caller, which reruns the batch without it when err bit 2 comes back
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -3770,14 +3773,24 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
     const bool gsi_join = !wide && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (the PLAN decides - PSK_GSI_JOIN is read there, once per round: the round's sketches carry no k-mer index to fall back on)      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
     const bool join_pairs = !wide && (gsi_join || (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048)));
-    const bool gsi_one = gsi_join && L.gsi_onepass && cap >= n_items + n_items / 8 + 8 * ((size_t)n_pairs + 1);      // (gsi_room_kernel's layout fits)
+    const bool gsl = gsi_join && L.gsi_slice;      // one wave per (query, slice of its seeds): count walk -> scan over the pairs -> heads -> emit walk
+    const bool gsi_one = gsi_join && !gsl && L.gsi_onepass && cap >= n_items + n_items / 8 + 8 * ((size_t)n_pairs + 1);      // (gsi_room_kernel's layout fits)
     bool probe_local = false;
     GsiJoinArgs GA{};
+    GslArgs GL{};
     const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
         GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
-        if (!gsi_one) hipLaunchKernelGGL(gsi_join_kernel<false>, dim3(L.n_bq), dim3(64), gsi_lds_count, st, GA);
+        if (gsl) {
+            GL.bq = L.bq; GL.n_entries = L.n_bq; GL.tab = L.gsl_tab; GL.n_tab = L.gsl_n_tab; GL.ebase = L.gsl_ebase; GL.pass = L.d_pass; GL.n_refs = L.n_refs; GL.qd = d_qd;
+            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm;
+            GL.pair_cnt = L.big_list; GL.pstart = L.pstart; GL.cap = (uint32_t)cap; GL.err = L.misc; GL.p_cap = L.p_cap; GL.chunks = L.chunks; GL.n_chunks = L.nch;
+            { const char* e = getenv("PSK_GSL_STAGE"); GL.stage = e && e[0] == '0' ? 0 : 1; }      // (A/B: every anchor its own 16-byte store)
+            PSK_HIP(hipMemsetAsync(L.big_list, 0, 4 * ((size_t)n_pairs + 1), st));      // the slices of a pair add their counts
+            PSK_TRY(gsl_count_launch(GL, st));
+        }
+        else if (!gsi_one) hipLaunchKernelGGL(gsi_join_kernel<false>, dim3(L.n_bq), dim3(64), gsi_lds_count, st, GA);
         probe_local = true;      // (the scan over the pairs' counts below is the probe join's)
     }
     else if (join_pairs) {
@@ -3884,7 +3897,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
-    if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; GA.onepass = gsi_one ? 1 : 0; GA.total = L.total; if (gsi_one) GA.pair_cnt = L.aoff;      /* (the per-item offsets array: not used by this join) */
+    if (gsl) { GL.anc = anc; PSK_TRY(gsl_heads_launch(GL, st)); PSK_TRY(gsl_emit_launch(GL, st)); }
+    else if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; GA.onepass = gsi_one ? 1 : 0; GA.total = L.total; if (gsi_one) GA.pair_cnt = L.aoff;      /* (the per-item offsets array: not used by this join) */
                     hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit, st, GA); }
     else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
@@ -4438,6 +4452,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
     std::vector<SketchDesc> h_qd;
     int64_t h_qd_gsi_round = -1;      // the round (its first query) whose descriptors h_qd holds in the seed-index form (make_desc(.., true))
     std::vector<BatchQ> bqs;
+    std::vector<uint2> gsl_tab; std::vector<uint32_t> gsl_ebase, gsl_qn;      // slice join: a batch's wave table (host copies live until the batch's synchronisation)
     for (uint32_t b = 0; b < n_queries; b += QB) {
         const uint32_t m = std::min(QB, n_queries - b);
         // ---- screen: pass matrix on the device, counts + flags to the host
@@ -4576,7 +4591,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         // index (one lookup per query SEED finds its matches in every reference: gsi_join_kernel; no per-sketch index is read, so none is built for such a
         // round - neither for the references nor for the round's 65 536 contigs) or, where the database cannot have one, through per-reference probe tables
         // (one 64-byte line per (pair, seed)). PSK_PROBE=0 never, =1 whatever the round's shape; PSK_GSI_JOIN=0: the probe tables (tests, A/B)
-        bool round_probe = false, round_gsi = false, want_small = false;
+        bool round_probe = false, round_gsi = false, want_small = false, round_slice = false;
         {
             const char* pb_env = getenv("PSK_PROBE");
             const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
@@ -4584,13 +4599,20 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
             want_small = !pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048));
             const bool gsi_join_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // (read per round: tests switch it within a process; chain_run follows the plan)
-            if (want_small && !gsi_join_off && n <= 65536u && !join_wide_default()) {
+            // Rounds of many MID-SIZED pairs (all-vs-all of ~5 Mb genomes: every query passes against its family) go through the same index by (query, slice) waves
+            // (slice_join.hip) instead of one merge join per pair: one lookup per query SEED where the per-pair join makes one per (pair, seed). PSK_GSI_SLICE=0 never,
+            // =1 whatever the round's shape (tests, A/B)
+            const char* sl_env = getenv("PSK_GSI_SLICE");      // (read per round: tests switch it within a process)
+            const bool sl_off = sl_env && sl_env[0] == '0', sl_force = sl_env && sl_env[0] == '1';
+            const bool want_slice = !want_small && !sl_off && (sl_force || (round_pairs >= 2048 && round_items / round_pairs >= 2048 && round_items / round_pairs <= (1u << 18)));
+            if ((want_small || want_slice) && !gsi_join_off && n <= 65536u && !join_wide_default()) {
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 round_gsi = db->gsi_state == 1;
+                round_slice = round_gsi && want_slice;
             }
         }
         if (round_gsi) {
-            round_probe = true;      // (the round's batches are sized for small pairs)
+            round_probe = !round_slice;      // (the round's batches are sized for small pairs)
             if (db->desc_dirty || db->desc_n != n) PSK_TRY(exclusive([&]() -> psk_status { return refresh_ref_descs(ctx, db); }));
         } else {
         {   // references first (shared state: exclusive), then this call's own query sketches
@@ -4747,7 +4769,24 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                     L.p_cap = (pm + 63u) & ~63u;
                     const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';      // tests, A/B: count pass + scan + emit pass
-                    L.gsi_onepass = !one_off;
+                    L.gsi_onepass = !one_off && !round_slice;
+                    if (round_slice && lrc == PSK_OK) {      // wave table + per-(pair, slice) records of the batch
+                        gsl_qn.resize(bqs.size());
+                        for (size_t e = 0; e < bqs.size(); e++) gsl_qn[e] = h_qd[bqs[e].q].n;
+                        uint64_t n_rec = 0;
+                        gsl_make_tab(bqs.data(), bqs.size(), gsl_qn.data(), gsl_tab, gsl_ebase, &n_rec);
+                        if (n_rec >= 0x7FFFFF00ull) { psk_set_error("internal: %llu (pair, slice) records in one batch", (unsigned long long)n_rec); return PSK_ELIMIT; }
+                        const size_t o_tab = 0, o_eb = al256(o_tab + 8 * gsl_tab.size()), o_cnt = al256(o_eb + 4 * gsl_ebase.size()), o_rec = al256(o_cnt + 4 * (size_t)n_rec),
+                                     o_bm = al256(o_rec + 16 * (size_t)n_rec), o_endj = o_bm + 4 * (size_t)GSL_WORDS * (size_t)n_rec;
+                        lrc = ctx->q_j.reserve(o_endj + 256);
+                        if (lrc == PSK_OK) {
+                            char* J = (char*)ctx->q_j.p;
+                            PSK_HIP(hipMemcpyAsync(J + o_tab, gsl_tab.data(), 8 * gsl_tab.size(), hipMemcpyHostToDevice, st));
+                            PSK_HIP(hipMemcpyAsync(J + o_eb, gsl_ebase.data(), 4 * gsl_ebase.size(), hipMemcpyHostToDevice, st));
+                            L.gsi_slice = true; L.gsl_tab = (const uint2*)(J + o_tab); L.gsl_n_tab = (uint32_t)gsl_tab.size(); L.gsl_ebase = (const uint32_t*)(J + o_eb);
+                            L.gsl_cnt = (uint32_t*)(J + o_cnt); L.gsl_rec = (uint4*)(J + o_rec); L.gsl_bm = (uint32_t*)(J + o_bm);
+                        }
+                    }
                 }
                 if (lrc == PSK_ENOMEM && n_pairs > 1 && max_items > (1ull << 22)) { max_items >>= 2; continue; }
                 PSK_TRY(lrc);

@@ -1,0 +1,36 @@
+// The join of batches of MID-SIZED pairs (all-vs-all of ~5 Mb genomes) through the database-wide seed index, one wave per
+// (query, slice of GSL_SEEDS query seeds): slice_join.hip. Shared with query.hip, which plans the batches and launches the rest
+// of the chain stage (lib.rs:640-657 is the loop this replaces: chain_seeds of the query against every shortlisted reference).
+#pragma once
+#include "common.h"
+
+// one entry of a batch: query q against its passing references of rank [rank_lo, rank_hi); the entry's pairs, (pair, query seed)
+// items and chunk-table rows start at pair_off / item_off / row_off (query.hip: pair_build_rows_kernel)
+struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
+constexpr uint32_t GSI_PMAX = 256;      // most pairs of one entry: their cursors (and staged anchor lines) sit in one wave's LDS
+
+constexpr uint32_t GSL_SEEDS = 512;     // query seeds per slice = per wave (~64 kb of a genome at c = 125: about three chunks)
+constexpr uint32_t GSL_WORDS = GSL_SEEDS / 32;
+struct GslArgs {
+    const BatchQ* bq; uint32_t n_entries;
+    const uint2* tab; uint32_t n_tab;       // wave -> (entry, slice); entry 0xFFFFFFFF: padding (see gsl_make_tab)
+    const uint32_t* ebase;                  // entry -> its first (pair, slice) record; record of (entry e, slice s, pair j) = ebase[e] + s * pairs(e) + j
+    const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
+    const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;      // psk_db::gsi_*
+    uint32_t* cnt;       // per record: anchors of the (pair, slice) (count walk)
+    uint4* rec;          // per record, from the heads kernel: {first anchor of the (pair, slice), chunk-table rows of the pair before the slice, lim1 lo, lim1 hi} -
+                         // lim1 = (key of the chunk head open at the slice's start) + 1 + FRAGMENT_LENGTH, 0 before the pair's first anchor (key = q contig << 32 | q pos)
+    uint32_t* bm;        // per record GSL_WORDS words: the slice's seeds that have an anchor with the pair (count walk)
+    uint32_t* pair_cnt;  // per pair: anchors (count walk, atomics over the slices)
+    const uint32_t* pstart; uint4* anc; uint32_t cap; uint32_t* err;      // err = the launch sequence's status words (bit 0: chunk table overflow, bit 1: capacity; [5]: rerun wide; [16..17]: 64-bit anchor total)
+    uint32_t p_cap;      // most pairs any entry of the batch holds, rounded up to 64
+    uint2* chunks; uint32_t* n_chunks;
+    int stage;           // emit walk: 1 = a pair's anchors leave as whole 64-byte lines staged in LDS, 0 = every anchor its own 16-byte store (A/B)
+};
+
+// wave table of a batch: the slices in groups of eight, entry-major inside a group, so that wave w = ((group * entries) + e) * 8 + x runs on XCD x (workgroups are dealt
+// round-robin) and one XCD's L2 sees ONE slice position of every query - queries of a family hold the same k-mers at the same place and re-read the same index runs
+void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds /* per entry */, std::vector<uint2>& tab, std::vector<uint32_t>& ebase, uint64_t* n_records);
+psk_status gsl_count_launch(const GslArgs& A, hipStream_t st);
+psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st);
+psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st);

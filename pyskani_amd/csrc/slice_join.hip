@@ -1,0 +1,349 @@
+// Seed-index join of batches of MID-SIZED pairs (all-vs-all of ~5 Mb genomes): the anchors of lib.rs:640-657's chain_seeds calls,
+// for every pair of a batch at once, through the database-wide seed index (psk_db::gsi_*: EVERY reference's seeds sorted by k-mer,
+// within a k-mer by reference, contig, position).
+//
+// The per-pair join (anchor_join4_kernel + anchor_emit_pairs_kernel) looks every query seed up once per PAIR: 4 x 10^10 (pair, seed)
+// lookups and as many 8-byte records written in k-mer order and read back in position order for 10 000 x 10 000 genomes, where the
+// batch holds 4 x 10^8 distinct query seeds. Here ONE lookup per query seed returns the seed's matches in every reference (a
+// contiguous run of the index), and the wave deals them to the query's pairs, as gsi_join_kernel does for contigs. What is different
+// for genomes: a query has 40 000 seeds - one wave per query would be 10 000 dependent chains of 2 M index entries each - so a query
+// is cut into SLICES of GSL_SEEDS seeds, one wave per (query, slice), and a pair's anchors, which must end up contiguous and in
+// (q contig, q pos, r contig, r pos) order, get their places from a COUNT walk:
+//
+//   gsl_walk_kernel<false>  COUNT: per (pair, slice) the number of anchors and a bitmap of the slice's seeds that have one
+//   (scan over the pairs' totals -> pstart: query.hip)
+//   gsl_heads_kernel        per pair, slice after slice: first anchor of every (pair, slice), and - from the bitmaps - which seeds head
+//                           a CHUNK (a chunk = the anchors of one query contig within FRAGMENT_LENGTH of its first anchor - a property of
+//                           the query's seed positions, so no anchor is read for it): the rows before, and the head open at, every slice
+//   gsl_walk_kernel<true>   EMIT: the same walk writes the 16-byte anchors, every pair's through a 64-byte line staged in LDS, so
+//                           that they leave as whole lines (a scattered 16-byte store costs 32 bytes of HBM write traffic), and the chunk
+//                           table's rows as it meets the heads
+//
+// Bit-exactness: the anchors and chunk tables are the ones anchor_emit_pairs_kernel / chunk_heads_kernel produce (same order, same
+// rows); everything downstream (DP, selection, reduce) is unchanged.
+#include "slice_join.h"
+#include "chain_dev.h"
+
+void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, std::vector<uint2>& tab, std::vector<uint32_t>& ebase, uint64_t* n_records) {
+    tab.clear(); ebase.resize(n_entries);
+    uint64_t rec = 0; uint32_t max_sl = 0;
+    for (size_t e = 0; e < n_entries; e++) {
+        const uint32_t nsl = (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS;
+        ebase[e] = (uint32_t)rec;
+        rec += (uint64_t)nsl * (bq[e].rank_hi - bq[e].rank_lo);
+        max_sl = std::max(max_sl, nsl);
+    }
+    *n_records = rec;
+    for (uint32_t s0 = 0; s0 < max_sl; s0 += 8)
+        for (size_t e = 0; e < n_entries; e++) {
+            const uint32_t nsl = (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS;
+            if (s0 >= nsl) continue;
+            for (uint32_t x = 0; x < 8; x++) tab.push_back(s0 + x < nsl ? make_uint2((uint32_t)e, s0 + x) : make_uint2(0xFFFFFFFFu, 0u));
+        }
+}
+
+// LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][pass bitset: nw x 8][prefix counts: nw x 4, even]
+// [cursors: p_cap x 4][EMIT: first anchor, rows so far per pair: 2 x p_cap x 4 | COUNT: anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words]
+static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
+    const size_t nw = (A.n_refs + 63) / 64;
+    return (emit ? (64 + 8) * (size_t)A.p_cap : 0) + 8 * nw + 4 * ((nw + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 8 * (size_t)A.p_cap : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
+    extern __shared__ uint4 s_gsl[];
+    const int lane = threadIdx.x;
+    const uint2 te = A.tab[blockIdx.x];
+    if (te.x == 0xFFFFFFFFu) return;
+    if (EMIT && (A.err[5] || *(const unsigned long long*)(A.err + 16) > A.cap)) return;      // the attempt is rerun whatever it writes (pair_guard_kernel)
+    const BatchQ B = A.bq[te.x];
+    const SketchDesc Q = A.qd[B.q];
+    const uint32_t sb = te.y * GSL_SEEDS;
+    if (sb >= Q.n) return;
+    const uint32_t se = Q.n - sb > GSL_SEEDS ? sb + GSL_SEEDS : Q.n;
+    const uint32_t P = B.rank_hi - B.rank_lo, pc = A.p_cap;
+    const uint32_t rec0 = A.ebase[te.x] + te.y * P;
+    const uint32_t nw = (A.n_refs + 63u) / 64u;
+    uint4* s_line = s_gsl;                                                                  // EMIT: slot t of pair j at [t * pc + j]
+    unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? 4u * pc : 0u));       // EMIT: lim1 of the pair's open chunk
+    unsigned long long* s_bits = s_lim + (EMIT ? pc : 0u);
+    uint32_t* s_pref = (uint32_t*)(s_bits + nw);
+    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);
+    uint32_t* s_st = s_cur + pc;                                                            // EMIT: first anchor of the (pair, slice)
+    uint32_t* s_rows = s_st + pc;                                                           // EMIT: chunk-table rows of the pair so far
+    uint32_t* s_bm = s_cur + pc;                                                            // COUNT: word w of pair j at [w * (pc + 1) + j]
+    {   // the query's row of the pass matrix -> bitset + prefix counts (reference -> rank -> pair of the entry: two LDS reads)
+        const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 4) {
+            uint8_t f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t r = (w0 + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(f[u] != 0);
+                if (w0 + u < nw && lane == 0) { s_bits[w0 + u] = m; s_pref[w0 + u] = run; }
+                run += (uint32_t)__popcll(m);
+            }
+        }
+        if (EMIT) for (uint32_t j = lane; j < P; j += 64) { const uint4 v = A.rec[rec0 + j]; s_st[j] = v.x; s_cur[j] = v.x; s_rows[j] = v.y; s_lim[j] = ((unsigned long long)v.w << 32) | v.z; }
+        else {
+            for (uint32_t j = lane; j < P; j += 64) s_cur[j] = 0;
+            for (uint32_t x = lane; x < GSL_WORDS * (pc + 1u); x += 64) s_bm[x] = 0;
+        }
+    }
+    lds_wave_sync();
+    // The walk (gsi_join_kernel's): a batch of 64 seeds has its k-mers loaded two batches ahead and its bucket bounds one batch ahead; its runs are cut into STEPS
+    // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
+    constexpr uint32_t GSL_AHEAD = 4;
+    uint32_t km1 = sb + (uint32_t)lane < se ? Q.kmer[sb + lane] : 0u, km2 = sb + 64u + (uint32_t)lane < se ? Q.kmer[sb + 64u + lane] : 0u;
+    uint32_t lo1 = 0, hi1 = 0;
+    if (sb + (uint32_t)lane < se) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+    for (uint32_t c0 = sb; c0 < se; c0 += 64) {
+        const uint32_t i = c0 + (uint32_t)lane;
+        const uint32_t km = km1, lo = lo1, hi = hi1;
+        km1 = km2; lo1 = 0; hi1 = 0;
+        if (i + 64u < se) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+        km2 = i + 128u < se ? Q.kmer[i + 128u] : 0u;
+        uint32_t qp = 0, qm = 0;
+        if (EMIT && i < se) { qp = Q.pos[i]; qm = Q.meta[i]; }
+        const uint32_t nst = (hi - lo + 63u) >> 6;
+        uint32_t pre = nst;      // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (lane >= o) pre += y; }
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+        pre -= nst;
+        uint32_t ns[GSL_AHEAD], nx[GSL_AHEAD], nh[GSL_AHEAD], nk[GSL_AHEAD]; unsigned long long nv[GSL_AHEAD];
+#define GSL_FETCH(t, u) do { \
+            ns[u] = 0; nx[u] = 0; nh[u] = 0; nk[u] = 0xFFFFFFFFu; nv[u] = 0ull; \
+            if ((t) < T) { \
+                const unsigned long long own = __ballot(nst != 0 && pre <= (t)); \
+                ns[u] = 63u - (uint32_t)__clzll((long long)own); \
+                nx[u] = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)ns[u]) + 64u * ((t) - (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)ns[u])); \
+                nh[u] = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)ns[u]); \
+                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = A.g_key[nx[u] + lane]; nv[u] = A.g_val[nx[u] + lane]; } \
+            } } while (0)
+#pragma unroll
+        for (uint32_t u = 0; u < GSL_AHEAD; u++) GSL_FETCH(u, u);
+        for (uint32_t t0 = 0; t0 < T; t0 += GSL_AHEAD) {
+            uint32_t cs[GSL_AHEAD], cx[GSL_AHEAD], ch[GSL_AHEAD], ck[GSL_AHEAD]; unsigned long long cv[GSL_AHEAD];
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) { cs[u] = ns[u]; cx[u] = nx[u]; ch[u] = nh[u]; ck[u] = nk[u]; cv[u] = nv[u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) GSL_FETCH(t0 + GSL_AHEAD + u, u);
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) {
+                if (t0 + u >= T) break;
+                const uint32_t s = cs[u], shi = ch[u], x = cx[u] + (uint32_t)lane, k = ck[u]; const unsigned long long v = cv[u];
+                const uint32_t skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)s);
+                const bool match = x < shi && k == skm;
+                if (!__any(match)) continue;
+                const uint32_t ref = (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;
+                uint32_t slot = 0xFFFFFFFFu;
+                if (match) {
+                    const unsigned long long bits = s_bits[w];
+                    const uint32_t rk = s_pref[w] + (uint32_t)__popcll(bits & ((1ull << bpos) - 1ull));
+                    if (((bits >> bpos) & 1ull) && rk >= B.rank_lo && rk < B.rank_hi) slot = rk - B.rank_lo;
+                }
+                const bool valid = slot != 0xFFFFFFFFu;
+                if (!__any(valid)) continue;
+                const uint32_t jl = c0 - sb + s;      // the step's seed within the slice
+                if (!EMIT) {      // no order needed: one LDS atomic per anchor, one for the seed's bit
+                    if (valid) { atomicAdd(&s_cur[slot], 1u); atomicOr(&s_bm[(jl >> 5) * (pc + 1u) + slot], 1u << (jl & 31u)); }
+                    continue;
+                }
+                const uint32_t sqp = (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s), sqm = (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s);
+                const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
+                const uint4 av = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
+                const uint32_t prev = __shfl_up(slot, 1);
+                const bool same = valid && lane > 0 && prev == slot;      // not the first lane of its (seed, reference) group
+                const bool dup = __ballot(same) != 0;
+                const uint32_t st0 = valid ? s_st[slot] : 0u;
+                const uint32_t base = valid ? s_cur[slot] : 0u;
+                // chunk table: the group's first lane opens a new chunk when the seed's key is beyond the reach of the pair's open head (chunk_heads_kernel's rule; a
+                // group cut by a step boundary meets its own head again: not beyond) - the new row's first anchor and, with it, the end of the row before
+                if (valid && !same) {
+                    const unsigned long long key1 = (((unsigned long long)(sqm >> 1) << 32) | sqp) + 1ull;
+                    if (key1 > s_lim[slot]) {
+                        const uint32_t row = s_rows[slot], idxc = base < A.cap ? base : A.cap;
+                        if (row < Q.rows) {
+                            uint2* r = A.chunks + ((size_t)B.row_off + (size_t)slot * Q.rows + row);
+                            r->x = idxc;
+                            if (row > 0) r[-1].y = idxc;
+                        } else atomicOr(A.err, 1u);
+                        s_rows[slot] = row + 1u; s_lim[slot] = key1 + FRAGMENT_LENGTH;
+                    }
+                }
+                if (!dup) {      // every valid lane has a pair of its own (a reference holds a k-mer once, nearly always): nothing to order between lanes
+                    if (valid) {
+                        const uint32_t d = base;
+                        s_cur[slot] = d + 1u;
+                        if (!A.stage) { if (d < A.cap) A.anc[d] = av; else atomicOr(A.err, 2u); }
+                        else if ((d & 3u) != 3u) s_line[(d & 3u) * pc + slot] = av;
+                        else {      // the line is complete: out it goes (from the pair's first anchor in this slice on - what is before belongs to the previous slice's wave)
+                            const uint32_t f0 = (d & ~3u) > st0 ? (d & ~3u) : st0;
+                            if (d < A.cap) {
+                                for (uint32_t t = f0; t < d; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
+                                A.anc[d] = av;
+                            } else atomicOr(A.err, 2u);
+                        }
+                    }
+                    continue;
+                }
+                // a reference that holds the k-mer several times sits in consecutive lanes: the group's anchors take consecutive places
+                const uint32_t next = __shfl_down(slot, 1);
+                const bool last = valid && !(lane < 63 && next == slot);
+                const unsigned long long starts = __ballot(valid && !same);
+                const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                const uint32_t jj = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
+                const unsigned long long ends = __ballot(last);
+                const uint32_t tail = valid ? (uint32_t)__ffsll((long long)(ends >> lane)) - 1u : 0u;      // lanes of the group after this one
+                const uint32_t d = base + jj, e = d + tail, lastline = e >> 2;
+                if (!A.stage) {
+                    if (valid) { if (d < A.cap) A.anc[d] = av; else atomicOr(A.err, 2u); }
+                    lds_wave_sync();
+                    if (last) s_cur[slot] = e + 1u;
+                    lds_wave_sync();
+                    continue;
+                }
+                // (A) a group that runs past the line being staged: its first lane sends out what the line holds so far
+                if (valid && jj == 0 && (base >> 2) != lastline && e < A.cap) {
+                    const uint32_t f0 = (base & ~3u) > st0 ? (base & ~3u) : st0;
+                    for (uint32_t t = f0; t < base; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
+                }
+                lds_wave_sync();
+                // (B) anchors of the group's last line are staged, the others complete their lines and go out directly
+                if (valid) {
+                    if ((d >> 2) == lastline) s_line[(d & 3u) * pc + slot] = av;
+                    else if (e < A.cap) A.anc[d] = av;
+                }
+                lds_wave_sync();
+                // (C) the group's last lane moves the cursor and sends the line out if the group completed it
+                if (last) {
+                    if (e >= A.cap) atomicOr(A.err, 2u);
+                    else if ((e & 3u) == 3u) {
+                        const uint32_t f0 = (e & ~3u) > st0 ? (e & ~3u) : st0;
+                        for (uint32_t t = f0; t <= e; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
+                    }
+                    s_cur[slot] = e + 1u;
+                }
+                lds_wave_sync();
+            }
+        }
+#undef GSL_FETCH
+    }
+    lds_wave_sync();
+    if (!EMIT) {
+        for (uint32_t j = lane; j < P; j += 64) {
+            const uint32_t c = s_cur[j];
+            A.cnt[rec0 + j] = c;
+            if (c) atomicAdd(&A.pair_cnt[B.pair_off + j], c);
+        }
+        for (uint32_t x = lane; x < P * GSL_WORDS; x += 64) { const uint32_t j = x / GSL_WORDS, w = x % GSL_WORDS; A.bm[(size_t)(rec0 + j) * GSL_WORDS + w] = s_bm[w * (pc + 1u) + j]; }
+    } else if (A.stage) {
+        for (uint32_t j = lane; j < P; j += 64) {      // what is left in the lines: the pairs' last anchors of the slice
+            const uint32_t c = s_cur[j], st0 = s_st[j];
+            if (c > st0 && (c & 3u) && c <= A.cap) {
+                const uint32_t f0 = ((c - 1u) & ~3u) > st0 ? ((c - 1u) & ~3u) : st0;
+                for (uint32_t t = f0; t < c; t++) A.anc[t] = s_line[(t & 3u) * pc + j];
+            }
+        }
+    }
+}
+
+// Per pair, slice after slice: the first anchor of every (pair, slice) and the state of the pair's chunk table at the slice's start. One wave per (entry, 64 of its
+// pairs), a lane per pair; the slice's seed keys (q contig << 32 | q pos) and the lanes' bitmaps sit in LDS, the next slice's are loaded while this one is walked. A
+// chunk head = the first seed WITH an anchor whose key is beyond the previous head's + FRAGMENT_LENGTH (chunk_heads_kernel's rule on anchors: an anchor carries its
+// seed's key): which seeds are heads follows from the bitmaps alone; the emit walk, which knows the anchors' indices, writes the rows.
+constexpr uint32_t GSL_HK = GSL_SEEDS / 64;      // keys per lane
+__global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
+    __shared__ unsigned long long s_key[GSL_SEEDS];
+    __shared__ uint32_t s_bm[64 * (GSL_WORDS + 1)];
+    const int lane = threadIdx.x;
+    const uint32_t e = blockIdx.x;
+    const BatchQ B = A.bq[e];
+    const uint32_t P = B.rank_hi - B.rank_lo, j = blockIdx.y * 64u + (uint32_t)lane;
+    if (blockIdx.y * 64u >= P) return;
+    const SketchDesc Q = A.qd[B.q];
+    const bool act = j < P;
+    const uint32_t nsl = (Q.n + GSL_SEEDS - 1u) / GSL_SEEDS;
+    const uint32_t p = B.pair_off + j;
+    const bool guard = A.err[5] || *(const unsigned long long*)(A.err + 16) > A.cap;      // the attempt is rerun: no chunk tables
+    uint32_t cursor = act ? A.pstart[p] : 0u;
+    const uint32_t pend = act ? A.pstart[p + 1] : 0u;
+    const bool live = act && !guard && pend - cursor >= MIN_ANCHORS;      // fewer: no chain can form, no chunk table
+    uint32_t rows = 0; unsigned long long lim1 = live ? 0ull : ~0ull;      // (a pair without a chunk table: no key is beyond the limit, the emit walk opens no chunk)
+    uint32_t* my_bm = s_bm + lane * (GSL_WORDS + 1);
+    uint32_t kp[GSL_HK], kmt[GSL_HK]; uint4 bw[GSL_WORDS / 4]; uint32_t c_next = 0;
+    auto load_slice = [&](uint32_t sl) {
+        const uint32_t sb = sl * GSL_SEEDS;
+#pragma unroll
+        for (uint32_t u = 0; u < GSL_HK; u++) { const uint32_t i = sb + u * 64u + (uint32_t)lane; kp[u] = 0; kmt[u] = 0; if (i < Q.n) { kp[u] = Q.pos[i]; kmt[u] = Q.meta[i]; } }
+        const size_t r = (size_t)A.ebase[e] + (size_t)sl * P + j;
+        c_next = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) bw[u] = make_uint4(0, 0, 0, 0);
+        if (act) {
+            c_next = A.cnt[r];
+            const uint4* __restrict__ src = (const uint4*)(A.bm + r * GSL_WORDS);
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_WORDS / 4; u++) bw[u] = src[u];
+        }
+    };
+    load_slice(0);
+    for (uint32_t sl = 0; sl < nsl; sl++) {
+        const uint32_t sb = sl * GSL_SEEDS, ns = Q.n - sb > GSL_SEEDS ? GSL_SEEDS : Q.n - sb;
+        const size_t r = (size_t)A.ebase[e] + (size_t)sl * P + j;
+        lds_wave_sync();
+#pragma unroll
+        for (uint32_t u = 0; u < GSL_HK; u++) s_key[u * 64u + lane] = (((unsigned long long)(kmt[u] >> 1) << 32) | kp[u]) + 1ull;
+#pragma unroll
+        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) { my_bm[4 * u] = bw[u].x; my_bm[4 * u + 1] = bw[u].y; my_bm[4 * u + 2] = bw[u].z; my_bm[4 * u + 3] = bw[u].w; }
+        const uint32_t c = c_next;
+        if (sl + 1 < nsl) load_slice(sl + 1);
+        lds_wave_sync();
+        if (act) {
+            A.rec[r] = make_uint4(cursor, rows, (uint32_t)lim1, (uint32_t)(lim1 >> 32));
+            if (live && c) {
+                uint32_t from = 0;
+                for (;;) {
+                    {   // first seed of the slice at or after `from` whose key is beyond the open head's reach (keys ascend; lim1 = 0: the pair's first anchor)
+                        uint32_t lo = from, hi = ns;
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_key[mid] > lim1) hi = mid; else lo = mid + 1; }
+                        from = lo;
+                    }
+                    if (from >= ns) break;
+                    uint32_t w = from >> 5, x = my_bm[w] & (~0u << (from & 31u));
+                    while (!x && ++w < GSL_WORDS) x = my_bm[w];
+                    if (!x) break;
+                    const uint32_t jl = w * 32u + (uint32_t)__ffs((int)x) - 1u;      // ... that has an anchor: a head
+                    lim1 = s_key[jl] + FRAGMENT_LENGTH; rows++;
+                    from = jl + 1u;
+                }
+            }
+            cursor += c;
+        }
+    }
+    if (act) {
+        if (live && rows) {      // the last row's end (its first anchor comes from the emit walk)
+            if (rows - 1u < Q.rows) A.chunks[(size_t)B.row_off + (size_t)j * Q.rows + rows - 1u].y = pend < A.cap ? pend : A.cap; else atomicOr(A.err, 1u);
+        }
+        A.n_chunks[p] = live ? (rows < Q.rows ? rows : Q.rows) : 0u;
+    }
+}
+
+psk_status gsl_count_launch(const GslArgs& A, hipStream_t st) {
+    hipLaunchKernelGGL(gsl_walk_kernel<false>, dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
+    PSK_HIP(hipGetLastError());
+    return PSK_OK;
+}
+psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st) {
+    hipLaunchKernelGGL(gsl_heads_kernel, dim3(A.n_entries, (A.p_cap + 63u) / 64u), dim3(64), 0, st, A);
+    PSK_HIP(hipGetLastError());
+    return PSK_OK;
+}
+psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st) {
+    hipLaunchKernelGGL(gsl_walk_kernel<true>, dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    PSK_HIP(hipGetLastError());
+    return PSK_OK;
+}

@@ -66,6 +66,10 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included
         monkeypatch.setenv("PSK_SKETCH_SMALL", "0") # ... behind the count-then-allocate sketch pipeline (a single genome takes the one-synchronisation path otherwise)
+        if seed % 8 == 6:
+            monkeypatch.setenv("PSK_GSI_SLICE", "1")    # ... or (every other time) the seed-index join by (query, slice) waves - the all-vs-all default - forced on one pair:
+            if seed % 16 == 14:                         # repeats (several anchors per seed and pair), strands, contigs, slices of 512 seeds; staged whole-line stores or plain ones
+                monkeypatch.setenv("PSK_GSL_STAGE", "0")
     for _ in range(4):
         k, c, mc, ref, qry = _case(rng)
         kw = {"median": True} if rng.random() < 0.2 else ({"robust": True} if rng.random() < 0.2 else {})
@@ -96,6 +100,8 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
     if seed % 2:
         monkeypatch.setenv("PSK_PREFILTER", "1")      # seed prefilter of rescued queries whatever the batch size
+        if seed % 4 == 1:
+            monkeypatch.setenv("PSK_GSI_SLICE", "1")  # ... and the rounds' pairs joined through the database-wide seed index by (query, slice) waves (the all-vs-all default)
     else:
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")     # the join of many small pairs whatever the batch size: through the database-wide seed index,
         monkeypatch.setenv("PSK_PROBE", "1")          # or (every other seed) through the references' probe tables

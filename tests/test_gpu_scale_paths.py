@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -67,8 +67,67 @@ def test_all_vs_all_batch_paths_agree():
     base = _run(ALL_VS_ALL, {})
     assert base[0] >= 320 * 40                      # every genome finds its family: >= 1 024 chained pairs in one batch
     # (switches that act on different stages share a run: every run is a process that loads the library and sketches the genomes again)
-    for extra in ({"PSK_EMIT_PAIRS": "0"}, {"PSK_EMIT_HEADS": "0", "PSK_XCD_GROUP": "0"}, {"PSK_BATCH_ITEMS_LOG2": "22", "PSK_ROW_SORT": "0"}, {"PSK_CHUNK_HOPS": "1", "PSK_REDUCE_SMALL": "0"}):
+    # (the default joins such a batch through the database-wide seed index, one wave per (query, slice of 512 seeds): slice_join.hip; PSK_GSI_SLICE=0 = the per-pair
+    # merge join + per-pair emit it replaced, which stays the route of databases that cannot have the index - its switches only act there)
+    for extra in ({"PSK_GSI_SLICE": "0"}, {"PSK_GSL_STAGE": "0", "PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_PAIRS": "0"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_HEADS": "0", "PSK_XCD_GROUP": "0"},
+                  {"PSK_GSI_SLICE": "0", "PSK_BATCH_ITEMS_LOG2": "22", "PSK_ROW_SORT": "0"}, {"PSK_GSI_SLICE": "0", "PSK_CHUNK_HOPS": "1", "PSK_REDUCE_SMALL": "0"}):
         assert _run(ALL_VS_ALL, extra) == base, extra
+
+
+ONE_FAMILY = COMMON + r"""
+anc = rng.integers(0, 4, 90_000, dtype=np.uint8)
+rep = rng.integers(0, 4, 2_500, dtype=np.uint8)
+def member(j):
+    a = mutate(anc, 0.0004 * j)
+    if j % 3 == 0: a = np.concatenate([a[:30_000], rep, a[30_000:60_000], mutate(rep, 0.01), a[60_000:]])      # a repeat: seeds with two anchors in one pair
+    parts = [a] if j % 4 else [a[:41_000], a[41_000:41_600], a[41_600:]]                                       # every fourth genome in three contigs (one of them a single chunk)
+    return [lut[x].tobytes() for x in parts]
+genomes = [(f"m{j}", member(j)) for j in range(300)]      # ONE family of 300: every query passes against all 300 references - two entries (256 + 44 pairs) per query
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many([(n, *c) for n, c in genomes])
+res = db.query_many([(n, *c) for n, c in genomes], learned_ani=False)
+print(*digest(res))
+"""
+
+
+def test_slice_join_with_more_pairs_than_one_entry_holds(oracle):
+    """The seed-index join by (query, slice) waves where a query has more passing references than one wave's LDS holds cursors for (300 > 256: two entries per query,
+    the heads kernel's second 64-pair group partly filled), genomes of several contigs and a planted repeat (seeds with two anchors in one pair: the heads kernel cannot
+    place those slices' chunk heads from the bitmap, the emit walk rewrites their rows) - against the per-pair join, and eight sampled hits against the oracle."""
+    base = _run(ONE_FAMILY, {})
+    assert base[0] > 80000      # (the far ends of the family - 12 % apart - fall below the screen or the aligned fraction)
+    assert _run(ONE_FAMILY, {"PSK_GSI_SLICE": "0"}) == base
+    assert _run(ONE_FAMILY, {"PSK_GSL_STAGE": "0"}) == base
+    import numpy as np
+    import pyskani_amd as psk
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(77)
+
+    def mutate(a, d):
+        b = a.copy(); m = rng.random(len(a)) < d; b[m] = (b[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3; return b
+    anc = rng.integers(0, 4, 90_000, dtype=np.uint8)
+    rep = rng.integers(0, 4, 2_500, dtype=np.uint8)
+
+    def member(j):
+        a = mutate(anc, 0.0004 * j)
+        if j % 3 == 0:
+            a = np.concatenate([a[:30_000], rep, a[30_000:60_000], mutate(rep, 0.01), a[60_000:]])
+        parts = [a] if j % 4 else [a[:41_000], a[41_000:41_600], a[41_600:]]
+        return [lut[x].tobytes() for x in parts]
+    genomes = [(f"m{j}", member(j)) for j in range(300)]
+    db = psk.Database(compression=30, marker_compression=200)
+    db.sketch_many([(n, *c) for n, c in genomes])
+    pick = np.random.default_rng(11)
+    qs = [int(x) for x in pick.choice(300, 8, replace=False)]
+    res = db.query_many([(genomes[q][0], *genomes[q][1]) for q in qs], learned_ani=False)
+    for q, hits in zip(qs, res):
+        assert len(hits) > 256      # (more pairs than one entry holds)
+        h = hits[int(pick.integers(0, len(hits)))] if q % 2 else next(x for x in hits if x.reference_name == f"m{(q // 3) * 3}")      # (half of them against a reference with the repeat)
+        r = int(h.reference_name[1:])
+        want = oracle.chain(oracle.Sketch(genomes[r][1], c=30, marker_c=200), oracle.Sketch(genomes[q][1], c=30, marker_c=200))
+        for f in ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds"):
+            assert int(h._raw[f]) == int(getattr(want, f)), (q, r, f, int(h._raw[f]), int(getattr(want, f)))
+        assert abs(h.identity - want.ani) < 1e-6 and abs(h.query_fraction - want.af_query) < 1e-6 and abs(h.reference_fraction - want.af_ref) < 1e-6
 
 
 def test_rescue_prefilter_agrees_at_scale():
