@@ -3728,7 +3728,7 @@ struct ChainBufs {
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
     // mid-sized pairs (all-vs-all of genomes): the index join by (query, slice) waves (slice_join.hip); the batch's wave table, record offsets and per-record arrays
-    bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint32_t* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr; uint4* gsl_rec = nullptr;
+    bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint2* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr, *gsl_un = nullptr, gsl_n_slices = 0; uint4* gsl_rec = nullptr;
     bool gsi_onepass = false;      // the index join without its COUNT pass (GsiJoinArgs::onepass): asked for by the caller, which reruns the batch without it when err bit 2 comes back
 };
 static psk_status chain_layout(Lane* ctx, size_t n_pairs, size_t n_items, size_t n_rows, size_t n_bq, ChainBufs* L) {
@@ -3784,9 +3784,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
         if (gsl) {
             GL.bq = L.bq; GL.n_entries = L.n_bq; GL.tab = L.gsl_tab; GL.n_tab = L.gsl_n_tab; GL.ebase = L.gsl_ebase; GL.pass = L.d_pass; GL.n_refs = L.n_refs; GL.qd = d_qd;
-            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm;
+            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm; GL.un = L.gsl_un; GL.n_slices = L.gsl_n_slices;
             GL.pair_cnt = L.big_list; GL.pstart = L.pstart; GL.cap = (uint32_t)cap; GL.err = L.misc; GL.p_cap = L.p_cap; GL.chunks = L.chunks; GL.n_chunks = L.nch;
-            { const char* e = getenv("PSK_GSL_STAGE"); GL.stage = e && e[0] == '0' ? 0 : 1; }      // (A/B: every anchor its own 16-byte store)
+            { const char* e = getenv("PSK_GSL_STAGE"); GL.stage = e ? atoi(e) : 1; }      // (A/B: every anchor its own 16-byte store)
             PSK_HIP(hipMemsetAsync(L.big_list, 0, 4 * ((size_t)n_pairs + 1), st));      // the slices of a pair add their counts
             PSK_TRY(gsl_count_launch(GL, st));
         }
@@ -4452,7 +4452,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
     std::vector<SketchDesc> h_qd;
     int64_t h_qd_gsi_round = -1;      // the round (its first query) whose descriptors h_qd holds in the seed-index form (make_desc(.., true))
     std::vector<BatchQ> bqs;
-    std::vector<uint2> gsl_tab; std::vector<uint32_t> gsl_ebase, gsl_qn;      // slice join: a batch's wave table (host copies live until the batch's synchronisation)
+    std::vector<uint2> gsl_tab, gsl_ebase; std::vector<uint32_t> gsl_qn;      // slice join: a batch's wave table (host copies live until the batch's synchronisation)
     for (uint32_t b = 0; b < n_queries; b += QB) {
         const uint32_t m = std::min(QB, n_queries - b);
         // ---- screen: pass matrix on the device, counts + flags to the host
@@ -4660,11 +4660,14 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         // cached (join 142 -> 124 ms per 100 000 contigs). PSK_BATCH_PAIRS_LOG2 overrides (tests, A/B).
         static const int pairs_env = getenv("PSK_BATCH_PAIRS_LOG2") ? std::min(24, std::max(10, atoi(getenv("PSK_BATCH_PAIRS_LOG2")))) : 0;
         if (!items_env && items_log2 == 29 && round_probe) items_log2 = 30;
+        // ... and rounds of mid-sized pairs joined by (query, slice) waves: a launch of 10 000 waves is three waves deep on the chip and its last third runs half empty;
+        // 2^30 seeds (268 genomes of 5 Mb and their ~27 000 pairs) per batch: 860 -> 796 ms per 10 000 x 10 000 step (2^28: 969)
+        if (!items_env && items_log2 == 29 && round_slice) items_log2 = 30;
         uint64_t max_items = 1ull << items_log2, max_pairs = 1ull << (pairs_env ? pairs_env : (round_probe ? 22 : 21)), max_rows = 1ull << 26;      // (2^22 pairs: 363 -> 353 ms per 100 000 contigs)
         {   // the one-pass index join lays a batch's anchors out at 9/8 of its items (gsi_room_kernel) where about two thirds of that are used: three quarters of the
             // items per batch keep the per-anchor arrays (100 bytes per slot) near what the two passes reserved
             const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';
-            if (round_gsi && !one_off && !items_env && max_items == (1ull << 30)) max_items = 3ull << 28;
+            if (round_gsi && !round_slice && !one_off && !items_env && max_items == (1ull << 30)) max_items = 3ull << 28;
         }
         uint32_t qi = 0, rank = 0;      // next (query, rank) to chain
         std::vector<uint64_t> q_hits(m, 0);            // hits per query of the round
@@ -4767,23 +4770,23 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift;
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
-                    L.p_cap = (pm + 63u) & ~63u;
+                    L.p_cap = round_slice ? (pm + 15u) & ~15u : (pm + 63u) & ~63u;      // (the slice join's LDS arrays are indexed by pair alone: no need for whole waves of them)
                     const bool one_off = getenv("PSK_GSI_ONEPASS") && getenv("PSK_GSI_ONEPASS")[0] == '0';      // tests, A/B: count pass + scan + emit pass
                     L.gsi_onepass = !one_off && !round_slice;
                     if (round_slice && lrc == PSK_OK) {      // wave table + per-(pair, slice) records of the batch
                         gsl_qn.resize(bqs.size());
                         for (size_t e = 0; e < bqs.size(); e++) gsl_qn[e] = h_qd[bqs[e].q].n;
-                        uint64_t n_rec = 0;
-                        gsl_make_tab(bqs.data(), bqs.size(), gsl_qn.data(), gsl_tab, gsl_ebase, &n_rec);
+                        uint64_t n_rec = 0, n_sl = 0;
+                        gsl_make_tab(bqs.data(), bqs.size(), gsl_qn.data(), gsl_tab, gsl_ebase, &n_rec, &n_sl);
                         if (n_rec >= 0x7FFFFF00ull) { psk_set_error("internal: %llu (pair, slice) records in one batch", (unsigned long long)n_rec); return PSK_ELIMIT; }
-                        const size_t o_tab = 0, o_eb = al256(o_tab + 8 * gsl_tab.size()), o_cnt = al256(o_eb + 4 * gsl_ebase.size()), o_rec = al256(o_cnt + 4 * (size_t)n_rec),
-                                     o_bm = al256(o_rec + 16 * (size_t)n_rec), o_endj = o_bm + 4 * (size_t)GSL_WORDS * (size_t)n_rec;
+                        const size_t o_tab = 0, o_eb = al256(o_tab + 8 * gsl_tab.size()), o_cnt = al256(o_eb + 8 * gsl_ebase.size()), o_rec = al256(o_cnt + 4 * (size_t)n_rec),
+                                     o_bm = al256(o_rec + 16 * (size_t)n_rec), o_un = al256(o_bm + 4 * (size_t)GSL_WORDS * (size_t)n_rec), o_endj = o_un + 4 * (size_t)GSL_WORDS * (size_t)n_sl;
                         lrc = ctx->q_j.reserve(o_endj + 256);
                         if (lrc == PSK_OK) {
                             char* J = (char*)ctx->q_j.p;
                             PSK_HIP(hipMemcpyAsync(J + o_tab, gsl_tab.data(), 8 * gsl_tab.size(), hipMemcpyHostToDevice, st));
-                            PSK_HIP(hipMemcpyAsync(J + o_eb, gsl_ebase.data(), 4 * gsl_ebase.size(), hipMemcpyHostToDevice, st));
-                            L.gsi_slice = true; L.gsl_tab = (const uint2*)(J + o_tab); L.gsl_n_tab = (uint32_t)gsl_tab.size(); L.gsl_ebase = (const uint32_t*)(J + o_eb);
+                            PSK_HIP(hipMemcpyAsync(J + o_eb, gsl_ebase.data(), 8 * gsl_ebase.size(), hipMemcpyHostToDevice, st));
+                            L.gsi_slice = true; L.gsl_tab = (const uint2*)(J + o_tab); L.gsl_n_tab = (uint32_t)gsl_tab.size(); L.gsl_ebase = (const uint2*)(J + o_eb); L.gsl_un = (uint32_t*)(J + o_un); L.gsl_n_slices = (uint32_t)n_sl;
                             L.gsl_cnt = (uint32_t*)(J + o_cnt); L.gsl_rec = (uint4*)(J + o_rec); L.gsl_bm = (uint32_t*)(J + o_bm);
                         }
                     }
@@ -4807,6 +4810,9 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
                 ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe, items / n_pairs > (1u << 20));
+                // (pairs of one family: (1 - d)^15 of a query's seeds match, half of them over the divergences met - three quarters of the items is room enough,
+                // and a batch that needs more is rerun with the count walk's total)
+                if (round_slice) cap = std::min<uint64_t>(cap, std::max<uint64_t>(ctx->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) > 128 ? ctx->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) - 128 : 0, (uint64_t)items / 4 * 3 + 65536));
                 if (L.gsi_onepass) cap = std::min<uint64_t>(std::max<uint64_t>(cap, items + items / 8 + 8 * ((uint64_t)n_pairs + 1) + 64), 0x7FFFFF00ull);      // gsi_room_kernel's layout
                 bool too_big = false, wide = join_wide_default();
                 static const bool trace_batch = getenv("PSK_TRACE_BATCH") != nullptr;      // diagnostics: host wall clock of every batch (launching, waiting)
@@ -4907,7 +4913,8 @@ static psk_status build_gsi(Lane* ctx, psk_db* db) {
     }
     if (N == 0) return PSK_OK;
     const int kbits = 2 * db->params.k;
-    int bits = 4; while (bits < 26 && (8ull << bits) < N) bits++;      // ~8 entries per bucket
+    static const int bits_cap = getenv("PSK_GSI_BITS") ? std::min(30, std::max(8, atoi(getenv("PSK_GSI_BITS")))) : 26;      // (A/B)
+    int bits = 4; while (bits < bits_cap && (8ull << bits) < N) bits++;      // ~8 entries per bucket
     if (bits > kbits) bits = kbits;
     const uint32_t nb = 1u << bits;
     size_t ts = 0;

@@ -14,7 +14,8 @@ constexpr uint32_t GSL_WORDS = GSL_SEEDS / 32;
 struct GslArgs {
     const BatchQ* bq; uint32_t n_entries;
     const uint2* tab; uint32_t n_tab;       // wave -> (entry, slice); entry 0xFFFFFFFF: padding (see gsl_make_tab)
-    const uint32_t* ebase;                  // entry -> its first (pair, slice) record; record of (entry e, slice s, pair j) = ebase[e] + s * pairs(e) + j
+    const uint2* ebase;                     // entry -> (x: its first (pair, slice) record, y: its first slice); record of (entry e, slice s, pair j) = ebase[e].x + s * pairs(e) + j
+    uint32_t* un; uint32_t n_slices;        // per (entry, slice) GSL_WORDS words: the seeds that head a chunk of some pair of the entry (heads kernel; zeroed by its launcher)
     const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
     const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;      // psk_db::gsi_*
     uint32_t* cnt;       // per record: anchors of the (pair, slice) (count walk)
@@ -30,7 +31,7 @@ struct GslArgs {
 
 // wave table of a batch: the slices in groups of eight, entry-major inside a group, so that wave w = ((group * entries) + e) * 8 + x runs on XCD x (workgroups are dealt
 // round-robin) and one XCD's L2 sees ONE slice position of every query - queries of a family hold the same k-mers at the same place and re-read the same index runs
-void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds /* per entry */, std::vector<uint2>& tab, std::vector<uint32_t>& ebase, uint64_t* n_records);
+void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds /* per entry */, std::vector<uint2>& tab, std::vector<uint2>& ebase, uint64_t* n_records, uint64_t* n_slices);
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st);
 psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st);
 psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st);

@@ -24,16 +24,20 @@
 #include "slice_join.h"
 #include "chain_dev.h"
 
-void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, std::vector<uint2>& tab, std::vector<uint32_t>& ebase, uint64_t* n_records) {
+void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, std::vector<uint2>& tab, std::vector<uint2>& ebase, uint64_t* n_records, uint64_t* n_slices) {
     tab.clear(); ebase.resize(n_entries);
-    uint64_t rec = 0; uint32_t max_sl = 0;
+    uint64_t rec = 0, nsl_all = 0; uint32_t max_sl = 0;
     for (size_t e = 0; e < n_entries; e++) {
         const uint32_t nsl = (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS;
-        ebase[e] = (uint32_t)rec;
+        ebase[e] = make_uint2((uint32_t)rec, (uint32_t)nsl_all);
         rec += (uint64_t)nsl * (bq[e].rank_hi - bq[e].rank_lo);
+        nsl_all += nsl;
         max_sl = std::max(max_sl, nsl);
     }
-    *n_records = rec;
+    *n_records = rec; *n_slices = nsl_all;
+    static const int order = getenv("PSK_GSL_ORDER") ? atoi(getenv("PSK_GSL_ORDER")) : 1;      // A/B: 0 = a query's slices one after the other, 2 = slice-major without the XCD grouping
+    if (order == 0) { for (size_t e = 0; e < n_entries; e++) for (uint32_t sl = 0; sl < (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS; sl++) tab.push_back(make_uint2((uint32_t)e, sl)); return; }
+    if (order == 2) { for (uint32_t sl = 0; sl < max_sl; sl++) for (size_t e = 0; e < n_entries; e++) if (sl < (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS) tab.push_back(make_uint2((uint32_t)e, sl)); return; }
     for (uint32_t s0 = 0; s0 < max_sl; s0 += 8)
         for (size_t e = 0; e < n_entries; e++) {
             const uint32_t nsl = (q_seeds[e] + GSL_SEEDS - 1) / GSL_SEEDS;
@@ -43,13 +47,22 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
 }
 
 // LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][pass bitset: nw x 8][prefix counts: nw x 4, even]
-// [cursors: p_cap x 4][EMIT: first anchor, rows so far per pair: 2 x p_cap x 4 | COUNT: anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words]
+// [COUNT: cursors: p_cap x 4; anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words | EMIT: (cursor, first anchor) per pair: p_cap x 8; rows so far per pair: p_cap x 4]
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
-    return (emit ? (64 + 8) * (size_t)A.p_cap : 0) + 8 * nw + 4 * ((nw + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 8 * (size_t)A.p_cap : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 8 * nw + 4 * ((nw + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
-template <bool EMIT>
+// an anchor leaves for HBM and is not read again before the DP kernels: a streaming store does not claim L2 lines the walk's index reads want to find again
+// - measured on the 10 000 x 10 000 step (PSK_GSL_STAGE=5): the walk takes the same time, and the DP kernel that reads the anchors next 178 instead of 165 ms; NT = false is the default
+typedef uint32_t gsl_u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void gsl_store_anchor(uint4* dst, const uint4 v) {
+    if (NT) { gsl_u4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w; __builtin_nontemporal_store(x, (gsl_u4*)dst); }
+    else *dst = v;
+}
+
+template <bool EMIT, bool STAGE, bool NT>
 __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     extern __shared__ uint4 s_gsl[];
     const int lane = threadIdx.x;
@@ -62,15 +75,17 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     if (sb >= Q.n) return;
     const uint32_t se = Q.n - sb > GSL_SEEDS ? sb + GSL_SEEDS : Q.n;
     const uint32_t P = B.rank_hi - B.rank_lo, pc = A.p_cap;
-    const uint32_t rec0 = A.ebase[te.x] + te.y * P;
+    const uint2 eb = A.ebase[te.x];
+    const uint32_t rec0 = eb.x + te.y * P;
     const uint32_t nw = (A.n_refs + 63u) / 64u;
     uint4* s_line = s_gsl;                                                                  // EMIT: slot t of pair j at [t * pc + j]
     unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? 4u * pc : 0u));       // EMIT: lim1 of the pair's open chunk
-    unsigned long long* s_bits = s_lim + (EMIT ? pc : 0u);
+    uint2* s_cs = (uint2*)(s_lim + (EMIT ? pc : 0u));                                       // EMIT: (cursor, first anchor of the (pair, slice)): one 8-byte read
+    uint2* s_fl = s_cs + (EMIT ? pc : 0u);                                                  // EMIT: the step's complete lines (pair | first slot << 16, first anchor of the line)
+    unsigned long long* s_bits = (unsigned long long*)(s_fl + (EMIT ? 64u : 0u));
     uint32_t* s_pref = (uint32_t*)(s_bits + nw);
-    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);
-    uint32_t* s_st = s_cur + pc;                                                            // EMIT: first anchor of the (pair, slice)
-    uint32_t* s_rows = s_st + pc;                                                           // EMIT: chunk-table rows of the pair so far
+    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);                                           // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
+    uint32_t* s_rows = s_cur;
     uint32_t* s_bm = s_cur + pc;                                                            // COUNT: word w of pair j at [w * (pc + 1) + j]
     {   // the query's row of the pass matrix -> bitset + prefix counts (reference -> rank -> pair of the entry: two LDS reads)
         const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
@@ -86,12 +101,15 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 run += (uint32_t)__popcll(m);
             }
         }
-        if (EMIT) for (uint32_t j = lane; j < P; j += 64) { const uint4 v = A.rec[rec0 + j]; s_st[j] = v.x; s_cur[j] = v.x; s_rows[j] = v.y; s_lim[j] = ((unsigned long long)v.w << 32) | v.z; }
+        if (EMIT) for (uint32_t j = lane; j < P; j += 64) { const uint4 v = A.rec[rec0 + j]; s_cs[j] = make_uint2(v.x, v.x); s_rows[j] = v.y; s_lim[j] = ((unsigned long long)v.w << 32) | v.z; }
         else {
             for (uint32_t j = lane; j < P; j += 64) s_cur[j] = 0;
             for (uint32_t x = lane; x < GSL_WORDS * (pc + 1u); x += 64) s_bm[x] = 0;
         }
     }
+    // EMIT: the slice's seeds that head a chunk of SOME pair of the entry (heads kernel), word w in lane w: the chunk-table code only runs in those seeds' steps
+    uint32_t unw = 0;
+    if (EMIT && lane < (int)GSL_WORDS) unw = A.un[(size_t)(eb.y + te.y) * GSL_WORDS + lane];
     lds_wave_sync();
     // The walk (gsi_join_kernel's): a batch of 64 seeds has its k-mers loaded two batches ahead and its bucket bounds one batch ahead; its runs are cut into STEPS
     // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
@@ -155,54 +173,63 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 const uint32_t sqp = (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s), sqm = (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s);
                 const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
                 const uint4 av = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
-                const uint32_t prev = __shfl_up(slot, 1);
-                const bool same = valid && lane > 0 && prev == slot;      // not the first lane of its (seed, reference) group
+                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)slot, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);      // (lane 0: no lane before it)
+                const bool same = valid && prev == slot;      // not the first lane of its (seed, reference) group
                 const bool dup = __ballot(same) != 0;
-                const uint32_t st0 = valid ? s_st[slot] : 0u;
-                const uint32_t base = valid ? s_cur[slot] : 0u;
+                const uint2 cs = valid ? s_cs[slot] : make_uint2(0u, 0u);
+                const uint32_t base = cs.x;
                 // chunk table: the group's first lane opens a new chunk when the seed's key is beyond the reach of the pair's open head (chunk_heads_kernel's rule; a
                 // group cut by a step boundary meets its own head again: not beyond) - the new row's first anchor and, with it, the end of the row before
-                if (valid && !same) {
-                    const unsigned long long key1 = (((unsigned long long)(sqm >> 1) << 32) | sqp) + 1ull;
-                    if (key1 > s_lim[slot]) {
-                        const uint32_t row = s_rows[slot], idxc = base < A.cap ? base : A.cap;
-                        if (row < Q.rows) {
-                            uint2* r = A.chunks + ((size_t)B.row_off + (size_t)slot * Q.rows + row);
-                            r->x = idxc;
-                            if (row > 0) r[-1].y = idxc;
-                        } else atomicOr(A.err, 1u);
-                        s_rows[slot] = row + 1u; s_lim[slot] = key1 + FRAGMENT_LENGTH;
+                if (((uint32_t)__builtin_amdgcn_readlane((int)unw, (int)(jl >> 5)) >> (jl & 31u)) & 1u) {
+                    if (valid && !same) {
+                        const unsigned long long key1 = (((unsigned long long)(sqm >> 1) << 32) | sqp) + 1ull;
+                        if (key1 > s_lim[slot]) {
+                            const uint32_t row = s_rows[slot], idxc = base < A.cap ? base : A.cap;
+                            if (row < Q.rows) {
+                                uint2* r = A.chunks + ((size_t)B.row_off + (size_t)slot * Q.rows + row);
+                                r->x = idxc;
+                                if (row > 0) r[-1].y = idxc;
+                            } else atomicOr(A.err, 1u);
+                            s_rows[slot] = row + 1u; s_lim[slot] = key1 + FRAGMENT_LENGTH;
+                        }
                     }
                 }
                 if (!dup) {      // every valid lane has a pair of its own (a reference holds a k-mer once, nearly always): nothing to order between lanes
-                    if (valid) {
-                        const uint32_t d = base;
-                        s_cur[slot] = d + 1u;
-                        if (!A.stage) { if (d < A.cap) A.anc[d] = av; else atomicOr(A.err, 2u); }
-                        else if ((d & 3u) != 3u) s_line[(d & 3u) * pc + slot] = av;
-                        else {      // the line is complete: out it goes (from the pair's first anchor in this slice on - what is before belongs to the previous slice's wave)
-                            const uint32_t f0 = (d & ~3u) > st0 ? (d & ~3u) : st0;
-                            if (d < A.cap) {
-                                for (uint32_t t = f0; t < d; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
-                                A.anc[d] = av;
-                            } else atomicOr(A.err, 2u);
+                    // (no capacity test on this path: the count walk's total was held against the capacity before this kernel started - see the guard at its top)
+                    if (!STAGE) { if (valid) { s_cs[slot].x = base + 1u; A.anc[base] = av; } continue; }
+                    const uint32_t t3 = base & 3u;
+                    if (valid) { s_cs[slot].x = base + 1u; s_line[t3 * pc + slot] = av; }
+                    // complete lines leave TOGETHER: four consecutive lanes write one pair's 64 bytes (one request per line where a lane writing its own line makes four)
+                    const bool fl = valid && t3 == 3u;
+                    const unsigned long long fm = __ballot(fl);
+                    if (fm) {
+                        if (fl) {      // (from the pair's first anchor in this slice on - what is before belongs to the previous slice's wave)
+                            const uint32_t st0 = cs.y, lb = base & ~3u, ft = lb >= st0 ? 0u : st0 - lb;
+                            s_fl[__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(slot | (ft << 16), lb);
+                        }
+                        lds_wave_sync();
+                        const uint32_t nf = (uint32_t)__popcll(fm), t = (uint32_t)lane & 3u;
+                        for (uint32_t g0 = 0; g0 < nf; g0 += 16) {
+                            const uint32_t r2 = g0 + ((uint32_t)lane >> 2);
+                            if (r2 < nf) { const uint2 f = s_fl[r2]; if (t >= (f.x >> 16)) gsl_store_anchor<NT>(A.anc + (f.y + t), s_line[t * pc + (f.x & 0xFFFFu)]); }
                         }
                     }
                     continue;
                 }
+                const uint32_t st0 = cs.y;
                 // a reference that holds the k-mer several times sits in consecutive lanes: the group's anchors take consecutive places
-                const uint32_t next = __shfl_down(slot, 1);
-                const bool last = valid && !(lane < 63 && next == slot);
+                const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)slot, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);      // (lane 63: no lane after it)
+                const bool last = valid && next != slot;
                 const unsigned long long starts = __ballot(valid && !same);
                 const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
                 const uint32_t jj = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
                 const unsigned long long ends = __ballot(last);
                 const uint32_t tail = valid ? (uint32_t)__ffsll((long long)(ends >> lane)) - 1u : 0u;      // lanes of the group after this one
                 const uint32_t d = base + jj, e = d + tail, lastline = e >> 2;
-                if (!A.stage) {
+                if (!STAGE) {
                     if (valid) { if (d < A.cap) A.anc[d] = av; else atomicOr(A.err, 2u); }
                     lds_wave_sync();
-                    if (last) s_cur[slot] = e + 1u;
+                    if (last) s_cs[slot].x = e + 1u;
                     lds_wave_sync();
                     continue;
                 }
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                         const uint32_t f0 = (e & ~3u) > st0 ? (e & ~3u) : st0;
                         for (uint32_t t = f0; t <= e; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
                     }
-                    s_cur[slot] = e + 1u;
+                    s_cs[slot].x = e + 1u;
                 }
                 lds_wave_sync();
             }
@@ -240,9 +267,9 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
             if (c) atomicAdd(&A.pair_cnt[B.pair_off + j], c);
         }
         for (uint32_t x = lane; x < P * GSL_WORDS; x += 64) { const uint32_t j = x / GSL_WORDS, w = x % GSL_WORDS; A.bm[(size_t)(rec0 + j) * GSL_WORDS + w] = s_bm[w * (pc + 1u) + j]; }
-    } else if (A.stage) {
+    } else if (STAGE) {
         for (uint32_t j = lane; j < P; j += 64) {      // what is left in the lines: the pairs' last anchors of the slice
-            const uint32_t c = s_cur[j], st0 = s_st[j];
+            const uint32_t c = s_cs[j].x, st0 = s_cs[j].y;
             if (c > st0 && (c & 3u) && c <= A.cap) {
                 const uint32_t f0 = ((c - 1u) & ~3u) > st0 ? ((c - 1u) & ~3u) : st0;
                 for (uint32_t t = f0; t < c; t++) A.anc[t] = s_line[(t & 3u) * pc + j];
@@ -259,6 +286,7 @@ constexpr uint32_t GSL_HK = GSL_SEEDS / 64;      // keys per lane
 __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
     __shared__ unsigned long long s_key[GSL_SEEDS];
     __shared__ uint32_t s_bm[64 * (GSL_WORDS + 1)];
+    __shared__ uint32_t s_un[GSL_WORDS];      // the slice's seeds that head a chunk of some pair of the group
     const int lane = threadIdx.x;
     const uint32_t e = blockIdx.x;
     const BatchQ B = A.bq[e];
@@ -268,6 +296,7 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
     const bool act = j < P;
     const uint32_t nsl = (Q.n + GSL_SEEDS - 1u) / GSL_SEEDS;
     const uint32_t p = B.pair_off + j;
+    const uint2 eb = A.ebase[e];
     const bool guard = A.err[5] || *(const unsigned long long*)(A.err + 16) > A.cap;      // the attempt is rerun: no chunk tables
     uint32_t cursor = act ? A.pstart[p] : 0u;
     const uint32_t pend = act ? A.pstart[p + 1] : 0u;
@@ -279,7 +308,7 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
         const uint32_t sb = sl * GSL_SEEDS;
 #pragma unroll
         for (uint32_t u = 0; u < GSL_HK; u++) { const uint32_t i = sb + u * 64u + (uint32_t)lane; kp[u] = 0; kmt[u] = 0; if (i < Q.n) { kp[u] = Q.pos[i]; kmt[u] = Q.meta[i]; } }
-        const size_t r = (size_t)A.ebase[e] + (size_t)sl * P + j;
+        const size_t r = (size_t)eb.x + (size_t)sl * P + j;
         c_next = 0;
 #pragma unroll
         for (uint32_t u = 0; u < GSL_WORDS / 4; u++) bw[u] = make_uint4(0, 0, 0, 0);
@@ -293,8 +322,9 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
     load_slice(0);
     for (uint32_t sl = 0; sl < nsl; sl++) {
         const uint32_t sb = sl * GSL_SEEDS, ns = Q.n - sb > GSL_SEEDS ? GSL_SEEDS : Q.n - sb;
-        const size_t r = (size_t)A.ebase[e] + (size_t)sl * P + j;
+        const size_t r = (size_t)eb.x + (size_t)sl * P + j;
         lds_wave_sync();
+        if (lane < (int)GSL_WORDS) s_un[lane] = 0;
 #pragma unroll
         for (uint32_t u = 0; u < GSL_HK; u++) s_key[u * 64u + lane] = (((unsigned long long)(kmt[u] >> 1) << 32) | kp[u]) + 1ull;
 #pragma unroll
@@ -318,11 +348,14 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
                     if (!x) break;
                     const uint32_t jl = w * 32u + (uint32_t)__ffs((int)x) - 1u;      // ... that has an anchor: a head
                     lim1 = s_key[jl] + FRAGMENT_LENGTH; rows++;
+                    atomicOr(&s_un[w], 1u << (jl & 31u));
                     from = jl + 1u;
                 }
             }
             cursor += c;
         }
+        lds_wave_sync();
+        if (lane < (int)GSL_WORDS && s_un[lane]) atomicOr(&A.un[(size_t)(eb.y + sl) * GSL_WORDS + lane], s_un[lane]);
     }
     if (act) {
         if (live && rows) {      // the last row's end (its first anchor comes from the emit walk)
@@ -333,17 +366,20 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
 }
 
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st) {
-    hipLaunchKernelGGL(gsl_walk_kernel<false>, dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
+    hipLaunchKernelGGL((gsl_walk_kernel<false, false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
     PSK_HIP(hipGetLastError());
     return PSK_OK;
 }
 psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st) {
+    PSK_HIP(hipMemsetAsync(A.un, 0, 4 * (size_t)GSL_WORDS * A.n_slices, st));
     hipLaunchKernelGGL(gsl_heads_kernel, dim3(A.n_entries, (A.p_cap + 63u) / 64u), dim3(64), 0, st, A);
     PSK_HIP(hipGetLastError());
     return PSK_OK;
 }
 psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st) {
-    hipLaunchKernelGGL(gsl_walk_kernel<true>, dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    if (A.stage != 5 && A.stage) hipLaunchKernelGGL((gsl_walk_kernel<true, true, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    else if (A.stage == 5) hipLaunchKernelGGL((gsl_walk_kernel<true, true, true>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    else hipLaunchKernelGGL((gsl_walk_kernel<true, false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
     PSK_HIP(hipGetLastError());
     return PSK_OK;
 }
