@@ -9,7 +9,10 @@
 struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
 constexpr uint32_t GSI_PMAX = 256;      // most pairs of one entry: their cursors (and staged anchor lines) sit in one wave's LDS
 
-constexpr uint32_t GSL_SEEDS = 512;     // query seeds per slice = per wave (~64 kb of a genome at c = 125: about three chunks)
+#ifndef GSL_SEEDS_N
+#define GSL_SEEDS_N 256
+#endif
+constexpr uint32_t GSL_SEEDS = GSL_SEEDS_N;    // query seeds per slice = per wave (~64 kb of a genome at c = 125: about three chunks)
 constexpr uint32_t GSL_WORDS = GSL_SEEDS / 32;
 struct GslArgs {
     const BatchQ* bq; uint32_t n_entries;

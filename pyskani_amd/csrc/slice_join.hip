@@ -46,11 +46,11 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
         }
 }
 
-// LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][pass bitset: nw x 8][prefix counts: nw x 4, even]
+// LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][pass row as (32 bits, prefix count) entries: 2 nw x 8]
 // [COUNT: cursors: p_cap x 4; anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words | EMIT: (cursor, first anchor) per pair: p_cap x 8; rows so far per pair: p_cap x 4]
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
-    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 8 * nw + 4 * ((nw + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 16 * nw + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
 // an anchor leaves for HBM and is not read again before the DP kernels: a streaming store does not claim L2 lines the walk's index reads want to find again
@@ -82,9 +82,8 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? 4u * pc : 0u));       // EMIT: lim1 of the pair's open chunk
     uint2* s_cs = (uint2*)(s_lim + (EMIT ? pc : 0u));                                       // EMIT: (cursor, first anchor of the (pair, slice)): one 8-byte read
     uint2* s_fl = s_cs + (EMIT ? pc : 0u);                                                  // EMIT: the step's complete lines (pair | first slot << 16, first anchor of the line)
-    unsigned long long* s_bits = (unsigned long long*)(s_fl + (EMIT ? 64u : 0u));
-    uint32_t* s_pref = (uint32_t*)(s_bits + nw);
-    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);                                           // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
+    uint2* s_bp = s_fl + (EMIT ? 64u : 0u);                                                 // the query's row of the pass matrix, 32 references per entry: (bits, passing references before them)
+    uint32_t* s_cur = (uint32_t*)(s_bp + 2u * nw);                                        // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
     uint32_t* s_rows = s_cur;
     uint32_t* s_bm = s_cur + pc;                                                            // COUNT: word w of pair j at [w * (pc + 1) + j]
     {   // the query's row of the pass matrix -> bitset + prefix counts (reference -> rank -> pair of the entry: two LDS reads)
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const unsigned long long m = __ballot(f[u] != 0);
-                if (w0 + u < nw && lane == 0) { s_bits[w0 + u] = m; s_pref[w0 + u] = run; }
+                if (w0 + u < nw && lane == 0) { s_bp[2u * (w0 + u)] = make_uint2((uint32_t)m, run); s_bp[2u * (w0 + u) + 1u] = make_uint2((uint32_t)(m >> 32), run + (uint32_t)__popc((uint32_t)m)); }
                 run += (uint32_t)__popcll(m);
             }
         }
@@ -149,20 +148,23 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
             for (uint32_t u = 0; u < GSL_AHEAD; u++) { cs[u] = ns[u]; cx[u] = nx[u]; ch[u] = nh[u]; ck[u] = nk[u]; cv[u] = nv[u]; }
 #pragma unroll
             for (uint32_t u = 0; u < GSL_AHEAD; u++) GSL_FETCH(t0 + GSL_AHEAD + u, u);
+            // the pairs of the group's entries first, all four steps' LDS reads in flight together (they depend on nothing but the entries), then the steps one by one:
+            // what is sequential - a pair's cursor - is only in the second part
+            uint32_t slots[GSL_AHEAD]; uint2 bps[GSL_AHEAD];
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) bps[u] = s_bp[(uint32_t)(cv[u] >> 53)];      // (every lane reads: a lane without an entry has v = 0 - reference 0's word)
+#pragma unroll
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) {
+                const uint32_t skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)cs[u]);
+                const uint32_t b = (uint32_t)(cv[u] >> 48) & 31u, rk = bps[u].y + (uint32_t)__popc(bps[u].x & ~(~0u << b)) - B.rank_lo;
+                const bool ok = cx[u] + (uint32_t)lane < ch[u] && ck[u] == skm && ((bps[u].x >> b) & 1u) && rk < P;      // (steps past the batch's last: nk = 0xFFFFFFFF is no k-mer, nh = 0)
+                slots[u] = ok ? rk : 0xFFFFFFFFu;
+            }
 #pragma unroll
             for (uint32_t u = 0; u < GSL_AHEAD; u++) {
                 if (t0 + u >= T) break;
-                const uint32_t s = cs[u], shi = ch[u], x = cx[u] + (uint32_t)lane, k = ck[u]; const unsigned long long v = cv[u];
-                const uint32_t skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)s);
-                const bool match = x < shi && k == skm;
-                if (!__any(match)) continue;
-                const uint32_t ref = (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;
-                uint32_t slot = 0xFFFFFFFFu;
-                if (match) {
-                    const unsigned long long bits = s_bits[w];
-                    const uint32_t rk = s_pref[w] + (uint32_t)__popcll(bits & ((1ull << bpos) - 1ull));
-                    if (((bits >> bpos) & 1ull) && rk >= B.rank_lo && rk < B.rank_hi) slot = rk - B.rank_lo;
-                }
+                const uint32_t s = cs[u]; const unsigned long long v = cv[u];
+                const uint32_t slot = slots[u];
                 const bool valid = slot != 0xFFFFFFFFu;
                 if (!__any(valid)) continue;
                 const uint32_t jl = c0 - sb + s;      // the step's seed within the slice
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)slot, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);      // (lane 0: no lane before it)
                 const bool same = valid && prev == slot;      // not the first lane of its (seed, reference) group
                 const bool dup = __ballot(same) != 0;
-                const uint2 cs = valid ? s_cs[slot] : make_uint2(0u, 0u);
+                const uint2 cs = s_cs[valid ? slot : 0u];      // (every lane reads - no branch around the read)
                 const uint32_t base = cs.x;
                 // chunk table: the group's first lane opens a new chunk when the seed's key is beyond the reach of the pair's open head (chunk_heads_kernel's rule; a
                 // group cut by a step boundary meets its own head again: not beyond) - the new row's first anchor and, with it, the end of the row before
