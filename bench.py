@@ -113,8 +113,12 @@ def compact_workload(e):
         return None
     if "ms_per_step" not in e:      # the API leg: rates only
         return {k: _sig(v) for k, v in e.items() if isinstance(v, (int, float))}
-    out = _pick(e, ("ms_per_step", "value", "unit", "hits", "hits_digest"))
+    out = _pick(e, ("ms_per_step", "value", "unit", "hits", "hits_digest", "scaling"))
     out["roofline"] = compact_roofline(e.get("roofline"), short=True)
+    if e.get("host_to_host") and "value" in e["host_to_host"]:
+        out["host_to_host"] = _pick(e["host_to_host"], ("value", "ms_per_step", "ingest", "vs_cpu_all_cores"))
+    if e.get("exchange"):
+        out["exchange"] = _pick(e["exchange"], ("ranks", "backend", "bytes_sent_per_rank_last_step", "collective_s_last_step", "psk_s_last_step"))
     if e.get("cpu_baseline"):
         out["cpu_baseline"] = compact_cpu(e["cpu_baseline"], short=True)
     if "oracle_check" in e:
@@ -136,6 +140,8 @@ def compact_line(full, full_path=None):
     if full.get("roofline") and full["roofline"].get("valu"):
         line["roofline"]["valu_issue_frac"] = _sig(full["roofline"]["valu"].get("valu_issue_frac_at_probed_clock"))
     line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    if full.get("host_to_host"):
+        line["host_to_host"] = _pick(full["host_to_host"], ("value", "unit", "ms_per_step", "ingest", "vs_cpu_1_core", "vs_cpu_all_cores"))
     if "clock" in full and full["clock"]:
         line["clock_mhz"] = _sig(full["clock"].get("shader_clock_mhz"))
     if "copy_bw" in full:
@@ -148,7 +154,7 @@ def compact_line(full, full_path=None):
         if k in ex_full:
             ex[k] = _sig(ex_full[k])
     if "exchange" in ex_full:
-        ex["exchange"] = _pick(ex_full["exchange"], ("rccl_ranks", "bytes_sent_per_rank_last_step", "collective_s_last_step", "psk_s_last_step", "outside_psk_and_collectives_frac"))
+        ex["exchange"] = _pick(ex_full["exchange"], ("ranks", "backend", "bytes_sent_per_rank_last_step", "collective_s_last_step", "psk_s_last_step", "outside_psk_and_collectives_frac"))
     if "workloads" in ex_full:
         ex["workloads"] = {k: compact_workload(v) for k, v in ex_full["workloads"].items() if v}
     line["extras"] = ex
@@ -165,10 +171,10 @@ def compact_line(full, full_path=None):
 
 
 def write_full(full, tag):
-    """the complete object: profiles/r4/ (tracked) and gpurun_out/ (what travels back from the GPU box). Returns the repo-relative path."""
+    """the complete object: profiles/r5/ (tracked) and gpurun_out/ (what travels back from the GPU box). Returns the repo-relative path."""
     name = f"bench_full_{tag}_{time.strftime('%Y%m%d_%H%M%S')}.json"
     rel = None
-    for d in (os.path.join("gpurun_out"), os.path.join("profiles", "r4")):
+    for d in (os.path.join("gpurun_out"), os.path.join("profiles", "r5")):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
             with open(os.path.join(ROOT, d, name), "w") as f:
@@ -376,6 +382,7 @@ class Engine:
         _capi.check(self.lib.psk_ctx_create(device, C.byref(self.ctx)))
         self.params = _capi.Params(c, marker_c, k)
         self.hit_dtype = np.dtype(_capi.Hit)
+        self.hit_min_dtype = np.dtype(_capi.HitMin)
 
     def close(self):
         if self.ctx:
@@ -415,16 +422,18 @@ class Engine:
         self.capi.check(self.lib.psk_db_add_batch(db, names, handles, n))
         return db
 
-    def query_many(self, db, handles, n, faster_small=False, keep=False):
-        """psk_query_many -> number of hits (keep=True: the psk_hit records and the per-query offsets as numpy arrays)"""
+    def query_many(self, db, handles, n, faster_small=False, keep=False, raw=False):
+        """psk_query_many_min -> number of hits (keep=True: the 20-byte psk_hit_min records and the per-query offsets as numpy arrays). The timed steps
+        take these records - what the reference's Hit holds (hit.rs:77-104); raw=True: psk_query_many, the 80-byte psk_hit with every chaining integer,
+        which the oracle checks outside the timed regions read."""
         opts = self.capi.QueryOpts(0, 0, 0, int(faster_small), 0.0, 0.0, None)
-        hits_p = C.POINTER(self.capi.Hit)()
+        hits_p = C.POINTER(self.capi.Hit if raw else self.capi.HitMin)()
         offsets = (C.c_uint64 * (n + 1))()
-        self.capi.check(self.lib.psk_query_many(db, handles, n, C.byref(opts), C.byref(hits_p), offsets))
+        self.capi.check((self.lib.psk_query_many if raw else self.lib.psk_query_many_min)(db, handles, n, C.byref(opts), C.byref(hits_p), offsets))
         nh = int(offsets[n])
         recs = None
         if keep:
-            recs = (self.capi.hit_records(hits_p, 0, nh, self.hit_dtype),
+            recs = (self.capi.hit_records(hits_p, 0, nh, self.hit_dtype if raw else self.hit_min_dtype),
                     np.frombuffer(offsets, dtype=np.uint64).astype(np.int64))
         if hits_p:
             self.lib.psk_free(hits_p)
@@ -448,7 +457,9 @@ class Engine:
     def work(self, reset=False):
         p, i, a = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.capi.check(self.lib.psk_ctx_work(self.ctx, C.byref(p), C.byref(i), C.byref(a), int(reset)))
-        return {"chained_pairs": p.value, "items": i.value, "anchors": a.value}
+        lk, vis, cands, rows = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.capi.check(self.lib.psk_ctx_join_work(self.ctx, C.byref(lk), C.byref(vis), C.byref(cands), C.byref(rows), int(reset)))
+        return {"chained_pairs": p.value, "items": i.value, "anchors": a.value, "index_lookups": lk.value, "index_entries_visited": vis.value, "candidates": cands.value, "chunk_rows": rows.value}
 
 
 def timed_loop(eng, step, steps, warmup, fence):
@@ -484,7 +495,7 @@ def load_pmc():
         for wl in ("search", "allvsall", "metagenome", "mammalian"):
             out.setdefault(wl, {})["sketch_scan"] = ss
     # (round 4: scale factors calibrated per access shape, profiles/r4/r4k_pmc_calibration.md; the round-3 file for whatever the newer one lacks)
-    for rel in (("profiles", "r3", "pmc_kernels.json"), ("profiles", "r4", "pmc_kernels.json")):
+    for rel in (("profiles", "r3", "pmc_kernels.json"), ("profiles", "r4", "pmc_kernels.json"), ("profiles", "r5", "pmc_kernels.json")):
         p = os.path.join(ROOT, *rel)
         if os.path.exists(p):
             for wl, timers in json.load(open(p)).items():
@@ -496,35 +507,53 @@ def load_pmc():
 
 
 def kernel_rooflines(kern, steps, units, pmc):
-    """Per-kernel roofline table of one workload. `units` = per STEP {bases, c, marker_c, items, anchors}. ALGORITHMIC bytes (DESIGN.md §4,
-    SURVEY.md §8d B_sk / B_ch terms):
+    """Per-kernel roofline table of one workload. `units` = per STEP {bases, c, marker_c, items, anchors, index_lookups, index_entries_visited, candidates,
+    chunk_rows, chained_pairs} (the library's own work counters: psk_ctx_work / psk_ctx_join_work). ALGORITHMIC bytes (SURVEY.md §8d B_sk / B_ch terms):
        sketch_scan   L (ASCII read) + L/4 (2-bit packed write)                                    per base
        sketch_emit   L/8 (seed mask) + L/4 (packed read) + 20 L/c (seed records) + 8 L/marker_c   per base
-       anchor        8 B (query k-mer + its position order) read + 8 B record written             per (pair, query seed) item
-       anchor_emit   8 B record read per item + 16 B anchor written per anchor
+       sketch_sort   20 B per seed (k-mer index) + 16 B per marker
+       the join, per-pair merge join (no index lookups counted):
+         anchor        8 B (query k-mer + its position order) read + 8 B record written           per (pair, query seed) item
+         anchor_emit   8 B record read per item + 16 B anchor written per anchor
+       the join through the database-wide seed index (index_lookups > 0: one lookup per query SEED finds its matches in every reference):
+         anchor        COUNT walk (where it runs: the two-pass forms): 12 B per lookup (k-mer, two bucket bounds) + 12 B per index entry of the looked-up runs
+         anchor_emit   EMIT walk: the same reads + 8 B per lookup (the seed's position and contig|strand) + 16 B per anchor written
        chain_chunk   16 B per anchor read (the DP; its candidates are a few bytes per chunk)
-    Kernels without a stated byte count (screen, select, pair_reduce, the sorts) are reported as time only."""
+       select        32 B per candidate chain (seven 4-byte fields read, the verdict written) + 8 B per chunk row (its table entry)
+       pair_reduce   32 B per chunk row (the chunk's totals) + 80 B per pair (the record written)
+    A bracket that did not do the work its formula counts (a join pass that was not launched: ~0 ms) would price above the HBM peak: such rows carry no fraction
+    (tests/test_bench_line_cpu.py rejects frac > 1). The screen (an inverted-index lookup, below 3 % of every step) is reported as time only."""
     bases, items, anchors = units["bases"], units.get("items", 0.0), units.get("anchors", 0.0)
+    lookups, visited = units.get("index_lookups", 0.0), units.get("index_entries_visited", 0.0)
+    cands, rows, pairs = units.get("candidates", 0.0), units.get("chunk_rows", 0.0), units.get("chained_pairs", 0.0)
     alg = {"sketch_scan": (1.25 * bases, "L + L/4 per base"),
            "sketch_sort": ((20.0 / units["c"] + 16.0 / units["marker_c"]) * bases, "k-mer index: 20 B per seed (key, position|meta, order); marker sets: 16 B per marker; per base: 20/c + 16/marker_c"),
            "sketch_emit": ((0.125 + 0.25 + 20.0 / units["c"] + 8.0 / units["marker_c"]) * bases, "L/8 + L/4 + 20 L/c + 8 L/marker_c per base"),
-           "anchor": (16.0 * items, "16 B per (pair, query seed) item"),
-           "anchor_emit": (8.0 * items + 16.0 * anchors, "8 B per item + 16 B per anchor"),
-           "chain_chunk": (16.0 * anchors, "16 B per anchor")}
-    unit_of = {"sketch_scan": ("base", bases), "sketch_emit": ("base", bases), "sketch_sort": ("base", bases), "anchor": ("item", items), "anchor_emit": ("item", items), "chain_chunk": ("anchor", anchors)}
+           "chain_chunk": (16.0 * anchors, "16 B per anchor"),
+           "select": (32.0 * cands + 8.0 * rows, "32 B per candidate chain + 8 B per chunk row"),
+           "pair_reduce": (32.0 * rows + 80.0 * pairs, "32 B per chunk row + 80 B per pair")}
+    if lookups > 0:
+        alg["anchor"] = (12.0 * lookups + 12.0 * visited, "seed-index COUNT walk: 12 B per query-seed lookup + 12 B per index entry visited")
+        alg["anchor_emit"] = (20.0 * lookups + 12.0 * visited + 16.0 * anchors, "seed-index EMIT walk: 20 B per query-seed lookup + 12 B per index entry visited + 16 B per anchor")
+    else:
+        alg["anchor"] = (16.0 * items, "16 B per (pair, query seed) item")
+        alg["anchor_emit"] = (8.0 * items + 16.0 * anchors, "8 B per item + 16 B per anchor")
+    unit_n = {"base": bases, "item": items, "anchor": anchors, "lookup": lookups, "candidate": cands, "row": rows}
     table = {}
     for k in KERNELS:
         ms_total, launches = kern[k]
         ms_step = ms_total / max(1, steps)
         row = {"ms_per_step": ms_step, "launches_per_step": launches / max(1, steps)}
-        if k in alg and alg[k][0] > 0 and ms_step > 0:
+        if k in alg and alg[k][0] > 0 and ms_step > 0 and launches > 0:
             b = alg[k][0]
-            row.update(algorithmic_bytes_per_step=b, bytes=alg[k][1], achieved_GBps=b / (ms_step * 1e-3) / 1e9, frac_of_hbm_peak=b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS)
-            pm = pmc.get(k)
-            per = {"base": bases, "item": items, "anchor": anchors}
-            if pm and per.get(pm.get("unit"), 0) > 0:      # (the counter pass states its own unit: the Gb-scale emit bracket is counted per anchor, the others per item)
-                row["traffic_bytes_per_step"] = pm["bytes_per_unit"] * per[pm["unit"]]
-                row["traffic_source"] = f"offline rocprofv3 --pmc pass ({pm['source']}), scaled by {pm['unit']}s"
+            frac = b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if frac <= 1.0:      # (above the peak: the bracket was empty - e.g. the one-walk index join has no COUNT pass)
+                row.update(algorithmic_bytes_per_step=b, bytes=alg[k][1], achieved_GBps=b / (ms_step * 1e-3) / 1e9, frac_of_hbm_peak=frac)
+                pm = pmc.get(k)
+                same_join = k not in ("anchor", "anchor_emit") or (lookups > 0) == bool(pm.get("index_join", False)) if pm else False      # (a join's counters only price the join that was measured)
+                if pm and unit_n.get(pm.get("unit"), 0) > 0 and same_join:
+                    row["traffic_bytes_per_step"] = pm["bytes_per_unit"] * unit_n[pm["unit"]]      # (the counter pass states its own unit)
+                    row["traffic_source"] = f"offline rocprofv3 --pmc pass ({pm['source']}), scaled by {pm['unit']}s"
         table[k] = row
     return table
 
@@ -757,7 +786,7 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
             "metric": "genome-pairs/sec (sketch+ANI)", "value": n_refs * world * steps / dt, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15; device-resident ASCII in, hit list on host out (from host memory, packed ingest: extras.host_packed_pairs_per_s)",
+            "config": {"workload": f"1 query vs {n_refs} synthetic ~5 Mb refs per GPU (10 families x {n_refs // N_FAMILIES}), c=125 marker_c=1000 k=15; device-resident ASCII in, hit list on host out (the same step from ASCII in host memory, packed ingest: host_to_host)",
                        "refs_per_gpu": n_refs, "hits": int(n_hits), "parallelism": f"refs sharded over {world} GPU(s)" + (f", hit lists all-gathered ({job.args.comm})" if world > 1 else "")},
             "roofline": roof, "clock": clock,
             "kernel_ms_per_step": {k: table[k]["ms_per_step"] for k in KERNELS},
@@ -765,7 +794,7 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
                        "reported_hits_per_step": int(n_hits), "chain_work_per_step": work},
         }
         if comm is not None:
-            line["extras"]["exchange"] = {"rccl_ranks": int(job.dist.get_world_size()), "backend": job.args.backend, "bytes_sent_per_rank_last_step": int(sent["bytes"])}
+            line["extras"]["exchange"] = {"ranks": int(job.dist.get_world_size()), "backend": job.args.backend, "bytes_sent_per_rank_last_step": int(sent["bytes"])}
         if world == 1 and (cpu_sample > 0 or with_api):
             host = buf.cpu().numpy()
             fetch = lambda i: host[offs[i]:offs[i] + lens[i]].tobytes()
@@ -773,6 +802,9 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
                 import pyskani_amd as psk
                 r = api_rates(psk, [fetch(i) for i in range(n_refs)], fetch(-1))
                 psk.database.release_default_context(job.local_rank)
+                hp = r["host_packed"]
+                line["host_to_host"] = {"value": hp["pairs_per_s"], "unit": "genome-pairs/s", "ms_per_step": n_refs / hp["pairs_per_s"] * 1e3, "ingest": "packed (2 bits per base over PCIe)",
+                                        "note": "the contract's timed region (SURVEY.md 8d): ASCII contigs in HOST memory -> Database.sketch_many + Database.query -> hit list on host; `value` above is the same step from device-resident ASCII"}
                 line["extras"].update(api_pairs_per_s=r["api"]["pairs_per_s"], host_ascii_pairs_per_s=r["host_ascii"]["pairs_per_s"], host_packed_pairs_per_s=r["host_packed"]["pairs_per_s"],
                                       api_detail=r["api"], host_ascii_detail=r["host_ascii"], host_packed_detail=r["host_packed"],
                                       api_note="same 1 query vs refs workload from ASCII bytes in HOST memory through pyskani_amd.Database: "
@@ -780,6 +812,10 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
                                                "host_packed = the same with the ingest threads packing 2 bits per base (the library's default for genomes of long contigs)")
             if cpu_sample > 0:
                 line["cpu_baseline"] = cpu_baseline_search(fetch, min(cpu_sample, n_refs), os.cpu_count() or 1)
+                if "host_to_host" in line:
+                    line["host_to_host"]["vs_cpu_1_core"] = line["host_to_host"]["value"] / line["cpu_baseline"]["value"]
+                    if "all_cores" in line["cpu_baseline"]:
+                        line["host_to_host"]["vs_cpu_all_cores"] = line["host_to_host"]["value"] / line["cpu_baseline"]["all_cores"]["value"]
             del host
     if comm is not None and hasattr(comm, "close"):
         comm.close()
@@ -790,14 +826,18 @@ def run_search(job, steps, warmup, n_refs, cpu_sample, with_api):
 
 
 def records_digest(recs):
-    """order-independent-free digest of a sorted hit-record array: (query, ref, the three floats' bits, the chain integers)"""
+    """digest of a hit-record array sorted by (query, reference): the query and reference indices and the bits of the three floats - the fields of psk_hit_min, which
+    both record kinds carry (psk_hit: the query index in `reserved`). ANI and both aligned fractions are functions of every chaining integer, which the oracle
+    checks compare one by one on the raw records."""
     h = hashlib.sha256()
-    for f in ("reserved", "ref_index", "ani", "af_query", "af_ref", "n_anchors", "n_chunks", "covered_query", "sum_chain_anchors", "sum_chunk_seeds"):
+    q = (recs["query"] & np.uint32(0x7FFFFFFF)) if "query" in recs.dtype.names else recs["reserved"]
+    h.update(np.ascontiguousarray(q, dtype=np.uint32).tobytes())
+    for f in ("ref_index", "ani", "af_query", "af_ref"):
         h.update(np.ascontiguousarray(recs[f]).tobytes())
     return h.hexdigest()[:16]
 
 
-def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", verify_hits=0):
+def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", verify_hits=0, host_leg=False):
     """BASELINE configs[2] shape: every genome against a database of all of them (families of 100). N=1: one psk_query_many. N>1: the
     FIXED job of n_total genomes is sharded over the ranks (strong scaling) and run through parallel.ShardedDatabase.all_vs_all_records."""
     torch, rank, world, args = job.torch, job.rank, job.world, job.args
@@ -833,8 +873,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
             finally:
                 eng.lib.psk_db_destroy(db)
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
-        recs = last["recs"]
-        recs["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(last["offs"]))
+        recs = last["recs"]      # psk_hit_min: `query` = the hit's query within the call
         digest = records_digest(recs)
         table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
         shape = {"plain": "single-contig genomes, substitutions only", "contigs": "every genome cut into 1-80 contigs",
@@ -843,12 +882,54 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
                 "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}; {shape}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
                 "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
-        if cpu_queries > 0 and variant == "plain":
-            host = buf.cpu().numpy()
+        host = None
+        if (cpu_queries > 0 and variant == "plain") or host_leg:
+            try:
+                host = buf.cpu().numpy()
+            except (RuntimeError, MemoryError) as e:      # (50 GB of pageable host memory for 10 000 genomes)
+                line["host_to_host"] = {"skipped": f"no host copy of the genomes: {e}"[:200]}
+        if cpu_queries > 0 and variant == "plain" and host is not None:
             line["cpu_baseline"] = cpu_baseline_allvsall(lambda i: host[offs[i]:offs[i] + lens[i]].tobytes(), n_total, min(cpu_queries, n_total), os.cpu_count() or 1)
-            del host
-        if verify_hits > 0 and len(recs):      # outside the timed region: random hits of the last step recomputed by the CPU oracle, every chain integer compared
-            line["oracle_check"] = allvsall_verify(buf, offs, lens, gfc_list, recs, verify_hits)
+        if host_leg and host is not None:
+            # The contract's timed region for this job: ASCII contigs in HOST memory -> hit list on host. The genomes cross PCIe through the
+            # library's ingest pipeline (worker threads pack 2 bits per base into pinned slots, L/4 bytes per genome over PCIe, sketch kernels on the previous
+            # sub-batch), then the database is loaded and queried as in the device-resident step. The two halves do not overlap: an all-vs-all query needs every
+            # reference in the database before its first round.
+            ptrs = (C.c_char_p * n)(*[C.cast(C.c_void_p(host.ctypes.data + offs[i]), C.c_char_p) for i in range(n)])
+            hl = (C.c_uint64 * n)(*[int(x) for x in lens])
+            hg = (C.c_uint32 * (n + 1))(*range(n + 1))
+            best = None
+            for _ in range(2):      # (the second pass is the warm one: pinned slots and device blocks exist)
+                outh = (C.c_void_p * n)()
+                eng.sync()
+                t0 = time.perf_counter()
+                eng.capi.check(eng.lib.psk_sketch_many_host(eng.ctx, C.byref(eng.params), ptrs, hl, hg, n, 1, outh))
+                t1 = time.perf_counter()
+                db = eng.make_db(names, outh, n)
+                try:
+                    nh2, (recs2, _) = eng.query_many(db, outh, n, keep=True)
+                finally:
+                    eng.lib.psk_db_destroy(db)
+                t2 = time.perf_counter()
+                best = {"ms_per_step": (t2 - t0) * 1e3, "value": float(n_total) * n_total / (t2 - t0), "unit": "genome-pairs/s", "ingest": "packed (2 bits per base over PCIe)",
+                        "ingest_s": t1 - t0, "ingest_host_GBps": float(sum(lens)) / (t1 - t0) / 1e9, "query_s": t2 - t1, "hits": int(nh2), "hits_digest": records_digest(recs2)}
+            assert best["hits_digest"] == digest, "the host-memory run and the device-resident run disagree"
+            if line.get("cpu_baseline"):
+                best["vs_cpu_1_core"] = best["value"] / line["cpu_baseline"]["value"]
+                if "all_cores" in line["cpu_baseline"]:
+                    best["vs_cpu_all_cores"] = best["value"] / line["cpu_baseline"]["all_cores"]["value"]
+            line["host_to_host"] = best
+        del host
+        if verify_hits > 0 and len(recs):      # outside the timed region: the same step once more with the 80-byte records, random hits recomputed by the CPU oracle, every chain integer compared
+            out = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, n)
+            db = eng.make_db(names, out, n)
+            try:
+                _, (raw, roffs) = eng.query_many(db, out, n, keep=True, raw=True)
+            finally:
+                eng.lib.psk_db_destroy(db)
+            raw["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(roffs))
+            assert records_digest(raw) == digest, "the 80-byte and the 20-byte records of the same step disagree"
+            line["oracle_check"] = allvsall_verify(buf, offs, lens, gfc_list, raw, verify_hits)
         eng.close()
     else:
         import pyskani_amd as psk
@@ -882,7 +963,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
                     "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15, device-resident ASCII; "
                                 f"query side = all-gather of the shards' packed sketch records, {args.exchange_batch} genomes per rank and round; hit records all-gathered once ({args.comm})",
                     "hits": int(n_hits), "hits_digest": records_digest(state["recs"]), "scaling": "strong",
-                    "exchange": {"rccl_ranks": int(job.dist.get_world_size()), "backend": args.backend, "bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
+                    "exchange": {"ranks": int(job.dist.get_world_size()), "backend": args.backend, "record_bytes": int(state["recs"].dtype.itemsize), "overlap": True, "bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
                                  "python_s_last_step": other, "all_vs_all_s_last_step": st["total_s"],
                                  "outside_psk_and_collectives_frac": other / st["total_s"] if st["total_s"] > 0 else None,
                                  "note": "rank 0's split of the last step's ShardedDatabase.all_vs_all_records call (sketching the shard and loading the database come before it)"},
@@ -1025,7 +1106,7 @@ def run_mammalian(job, steps, warmup, n_genomes, contig_mb, verify_pairs):
         handles = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, c_gfc, n)
         db = eng.make_db(names, handles, n)
         try:
-            nh, (recs, qoffs) = eng.query_many(db, handles, n, keep=True)
+            nh, (recs, qoffs) = eng.query_many(db, handles, n, keep=True, raw=True)      # (a few dozen hits: the oracle check below reads their chaining integers)
             last["recs"], last["offs"] = recs, qoffs
             return nh
         finally:
@@ -1075,7 +1156,7 @@ def run_mammalian_stream(job, n_genomes, contig_mb, fam_size, verify_pairs):
     free0 = torch.cuda.mem_get_info()[0]
     t0 = time.perf_counter()
     db = eng.make_db(names, handles, n_genomes)
-    nh, (recs, qoffs) = eng.query_many(db, handles, n_genomes, keep=True)
+    nh, (recs, qoffs) = eng.query_many(db, handles, n_genomes, keep=True, raw=True)
     eng.sync()
     t_query = time.perf_counter() - t0
     free1 = torch.cuda.mem_get_info()[0]
@@ -1172,6 +1253,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000, help="CPU-baseline sample size (0 = skip): search: references (1000 = the whole workload, ~10-20 s); allvsall: queries (capped at 128); metagenome: contigs (capped at 512)")
     ap.add_argument("--variant", choices=["plain", "contigs", "sv"], default="plain", help="allvsall at N=1: the generator variant of SURVEY.md 8(d) - genomes cut into 1-80 contigs / 20 block rearrangements per genome")
     ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
+    ap.add_argument("--ava-genomes", type=int, default=10000, help="search at N>1: genomes of the strong-scaling all-vs-all job under extras.workloads.allvsall_10k (dry runs on one GPU: a few hundred)")
+    ap.add_argument("--no-host-leg", action="store_true", help="search at N=1: skip the all-vs-all job from ASCII in HOST memory (extras.workloads.allvsall_10k.host_to_host; needs ~55 GB of host memory)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: this process starts the N ranks itself, BEFORE torch is imported or any HIP call is made
@@ -1222,7 +1305,7 @@ def main():
         if world == 1 and not args.no_workloads:
             t0 = time.perf_counter()
             wl = {}
-            wl["allvsall_10k"] = run_allvsall(job, 2, 1, 10000, min(cpu_n, 128))
+            wl["allvsall_10k"] = run_allvsall(job, 2, 1, 10000, min(cpu_n, 128), host_leg=not args.no_host_leg)
             # SURVEY.md §8d's harder shapes (every measured pair above is the easiest chaining case: one contig, substitutions only)
             wl["allvsall_1k_contigs"] = run_allvsall(job, 2, 1, 1000, 0, variant="contigs", verify_hits=8 if cpu_n > 0 else 0)
             wl["allvsall_1k_sv"] = run_allvsall(job, 2, 1, 1000, 0, variant="sv", verify_hits=8 if cpu_n > 0 else 0)
@@ -1231,6 +1314,15 @@ def main():
             wl["mammalian_8x3Gb"] = run_mammalian(job, 2, 1, 8, 125, 2 if cpu_n > 0 else 0)
             line["extras"]["workloads"] = wl
             line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
+        elif world > 1 and not args.no_workloads:
+            # N > 1: after the (weak-scaled) search headline, the north-star job itself - a FIXED set of genomes sharded over the ranks (strong scaling): every rank
+            # sketches its shard, the shards' sketches are all-gathered round by round as the query side (round b + 1 travels while round b is queried),
+            # the 20-byte hit records are all-gathered once; hits_digest equals the N = 1 entry's
+            t0 = time.perf_counter()
+            e = run_allvsall(job, 2, 1, args.ava_genomes, 0)
+            if rank == 0 and e:
+                line["extras"]["workloads"] = {"allvsall_10k": e}
+                line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
     elif args.workload == "allvsall":
         e = run_allvsall(job, args.steps, args.warmup, args.refs or 1000, min(cpu_n, 128), variant=args.variant, verify_hits=8 if (cpu_n > 0 and args.variant != "plain") else 0)
         line = as_line(e, "allvsall") if e else None

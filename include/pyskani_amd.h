@@ -88,6 +88,14 @@ typedef struct {
     uint32_t reserved;
 } psk_hit;
 
+/* What the reference's Hit holds (hit.rs:77-104: identity, query_fraction, reference_fraction, the two names) and nothing else, in 20 bytes: the record of
+ * psk_query_many_min and psk_gather_hits_min - what crosses PCIe and xGMI when the caller did not ask for the chaining integers. */
+typedef struct {
+    float ani, af_query, af_ref;
+    uint32_t ref_index; /* insertion index in the db (sharded runs: the global index) */
+    uint32_t query;     /* index of the query within the call (sharded runs: the global index); bit 31: the regression model produced `ani` */
+} psk_hit_min;
+
 typedef struct { uint32_t kmer, pos, contig, canon; } psk_seed; /* export record (parity tests) */
 
 const char* psk_last_error(void);
@@ -110,6 +118,10 @@ psk_status psk_ctx_timing(psk_ctx* ctx, const char* kernel, double* total_ms, ui
 /* Work of the chain stage since the last reset: pairs that reached chain_seeds (lib.rs:652-653), (pair, query seed) items joined,
  * anchors emitted. The per-kernel algorithmic bytes of bench.py are counted from these. Any pointer may be NULL. */
 psk_status psk_ctx_work(psk_ctx* ctx, uint64_t* pairs, uint64_t* items, uint64_t* anchors, int reset);
+/* ... and of the joins that go through the database-wide seed index (metagenome contigs, all-vs-all of genomes): query seeds looked up per walk of the index and index
+ * entries in the runs the lookups found (what those kernels' algorithmic bytes are counted from: 12 B per lookup, 12 B per entry, 16 B per anchor); while the timers
+ * are on (psk_ctx_set_timing) also the candidate chains the selection read and the chunk-table rows the reduce read. Any pointer may be NULL. */
+psk_status psk_ctx_join_work(psk_ctx* ctx, uint64_t* lookups, uint64_t* visited, uint64_t* candidates, uint64_t* rows, int reset);
 /* Measurement: psk_query_host calls since the context was created that ran as one launch sequence (`taken`), that exceeded one of its
  * capacities and were rerun on the general path (`rerun`), and that went to the general path at once (`general`, which includes `rerun`). */
 psk_status psk_ctx_small_query_stats(psk_ctx* ctx, uint64_t* taken, uint64_t* rerun, uint64_t* general);
@@ -232,6 +244,8 @@ psk_status psk_comm_info(const psk_comm* comm, int* rank, int* world, uint64_t* 
  * index in ref_index and the global query index in `reserved`. *all (psk_free) = every rank's list in rank order, identical on
  * every rank; counts (world entries, may be NULL) = the ranks' list lengths. */
 psk_status psk_gather_hits(psk_comm* comm, const psk_hit* local, uint64_t n_local, psk_hit** all, uint64_t* n_all, uint64_t* counts);
+/* ... the same for 20-byte records (the caller has put the global indices in ref_index / query): a quarter of the bytes per link */
+psk_status psk_gather_hits_min(psk_comm* comm, const psk_hit_min* local, uint64_t n_local, psk_hit_min** all, uint64_t* n_all, uint64_t* counts);
 /* All-gather of device-resident sketches as packed records, HBM -> xGMI -> HBM (no host hop): every rank contributes n sketches
  * and receives everybody's as sketches on ITS GPU. *all (psk_free; each entry psk_sketch_free) = the ranks' sketches in rank
  * order; counts[r] (world entries) = how many came from rank r. */
@@ -272,6 +286,10 @@ psk_status psk_query_host(psk_db* db, const uint8_t* const* contigs, const uint6
  * configs[2]/[3]); offsets has n_queries+1 entries, hits of query i are hits[offsets[i]..offsets[i+1]). */
 psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries,
                           const psk_query_opts* o, psk_hit** hits, uint64_t* offsets);
+/* psk_query_many returning psk_hit_min records: same hits, same order; `query` of a record = the index of its query in `queries`. The chaining integers of
+ * psk_hit stay on the device (what a parity test reads through psk_query_many); a metagenome step's 9.5 M hits are 190 MB instead of 763 MB over PCIe. */
+psk_status psk_query_many_min(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries,
+                              const psk_query_opts* opts, psk_hit_min** hits, uint64_t* offsets);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,11 @@ class Hit(C.Structure):
                 ("ani_raw", C.c_float), ("ani_std", C.c_float), ("learned", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class HitMin(C.Structure):
+    """psk_hit_min: what the reference's Hit holds (hit.rs:77-104) in 20 bytes; `query` = index of the query within the call, bit 31 = learned"""
+    _fields_ = [("ani", C.c_float), ("af_query", C.c_float), ("af_ref", C.c_float), ("ref_index", C.c_uint32), ("query", C.c_uint32)]
+
+
 class TreeNode(C.Structure):
     _fields_ = [("feature", C.c_int32), ("threshold", C.c_float), ("left", C.c_int32), ("right", C.c_int32),
                 ("value", C.c_float), ("missing", C.c_int32), ("is_leaf", C.c_int32), ("reserved", C.c_int32)]
@@ -51,8 +56,8 @@ SYMBOLS = [
     "psk_ctx_synchronize", "psk_pack2bit_host", "psk_ctx_small_query_stats", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_free_many", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
-    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_host", "psk_query_many",
-    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe", "psk_ctx_work",
+    "psk_db_name", "psk_db_sketch", "psk_screen", "psk_chain", "psk_query", "psk_query_host", "psk_query_many", "psk_query_many_min", "psk_gather_hits_min",
+    "psk_sketch_pack_size", "psk_sketch_pack", "psk_sketch_unpack", "psk_sketch_pack_many", "psk_ctx_clock_probe", "psk_ctx_work", "psk_ctx_join_work",
     "psk_comm_unique_id", "psk_comm_create", "psk_comm_destroy", "psk_comm_info", "psk_gather_hits", "psk_gather_sketches",
     "psk_model_create", "psk_model_load_json", "psk_model_load_file", "psk_model_free", "psk_model_info", "psk_model_predict",
 ]
@@ -113,12 +118,15 @@ def load():
     lib.psk_query.argtypes = [vp, vp, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_query_host.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
     lib.psk_query_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(Hit)), C.POINTER(u64)]
+    lib.psk_query_many_min.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(QueryOpts), C.POINTER(C.POINTER(HitMin)), C.POINTER(u64)]
+    lib.psk_gather_hits_min.argtypes = [vp, vp, u64, C.POINTER(C.POINTER(HitMin)), C.POINTER(u64), C.POINTER(u64)]
     lib.psk_sketch_pack_size.argtypes = [vp, C.POINTER(u64)]
     lib.psk_sketch_pack.argtypes = [vp, vp, u64]
     lib.psk_sketch_unpack.argtypes = [vp, vp, u64, C.POINTER(u64), u32, C.POINTER(vp)]
     lib.psk_sketch_pack_many.argtypes = [C.POINTER(vp), u32, vp, C.POINTER(u64), u64]
     lib.psk_ctx_clock_probe.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.psk_ctx_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_int]
+    lib.psk_ctx_join_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_int]
     lib.psk_comm_unique_id.argtypes = [vp]
     lib.psk_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.psk_comm_destroy.argtypes = [vp]

@@ -221,6 +221,16 @@ psk_status psk_ctx_work(psk_ctx* c, uint64_t* pairs, uint64_t* items, uint64_t* 
     return PSK_OK;
 }
 
+psk_status psk_ctx_join_work(psk_ctx* c, uint64_t* lookups, uint64_t* visited, uint64_t* candidates, uint64_t* rows, int reset) {
+    if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
+    if (lookups) *lookups = c->w_lookups.load();
+    if (visited) *visited = c->w_visited.load();
+    if (candidates) *candidates = c->w_cands.load();
+    if (rows) *rows = c->w_rows.load();
+    if (reset) { c->w_lookups = 0; c->w_visited = 0; c->w_cands = 0; c->w_rows = 0; }
+    return PSK_OK;
+}
+
 psk_status psk_ctx_small_query_stats(psk_ctx* c, uint64_t* taken, uint64_t* rerun, uint64_t* general) {
     if (!c) { psk_set_error("NULL ctx"); return PSK_EINVAL; }
     if (taken) *taken = c->sq_taken.load();
@@ -521,6 +531,19 @@ psk_status psk_query_many(psk_db* db, const psk_sketch* const* queries, uint32_t
     HitList all;
     PSK_TRY(query_many_impl(lg.lane, db, queries, n_queries, o, all, offsets));
     return hits_out(all, hits);
+}
+
+psk_status psk_query_many_min(psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                              psk_hit_min** hits, uint64_t* offsets) {
+    if (!db || (!queries && n_queries) || !o || !hits || !offsets) { psk_set_error("query_many_min: NULL argument"); return PSK_EINVAL; }
+    *hits = nullptr;
+    offsets[0] = 0;
+    PSK_LANE(lg, db->ctx);
+    HitListMin all;
+    PSK_TRY(query_many_min_impl(lg.lane, db, queries, n_queries, o, all, offsets));
+    if (!all.p) { all.p = (psk_hit_min*)malloc(sizeof(psk_hit_min)); if (!all.p) { psk_set_error("out of host memory"); return PSK_ENOMEM; } }      // no hit: still a pointer psk_free takes
+    *hits = all.release();
+    return PSK_OK;
 }
 
 }  // extern "C"

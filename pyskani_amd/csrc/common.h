@@ -94,6 +94,9 @@ struct psk_ctx {
     uint64_t acc_n[K_COUNT] = {0};
     // work done by the chain stage since the last reset (psk_ctx_work): what the algorithmic bytes of its kernels are counted from
     std::atomic<uint64_t> w_pairs{0}, w_items{0}, w_anchors{0};
+    // ... of the joins through the database-wide seed index: query seeds looked up (per walk) and index entries in the runs they found; and, while the timers
+    // are on, candidate chains the selection read and chunk-table rows the reduce read (psk_ctx_join_work)
+    std::atomic<uint64_t> w_lookups{0}, w_visited{0}, w_cands{0}, w_rows{0};
     // psk_query_host calls that ran as one launch sequence / were rerun on the general path because a capacity was exceeded / never qualified (psk_ctx_small_query_stats)
     std::atomic<uint64_t> sq_taken{0}, sq_rerun{0}, sq_general{0};
     // lanes: created on demand, at most max_lanes; a call takes a free one (LaneGuard) and gives it back
@@ -597,36 +600,42 @@ psk_status chain_pairs_impl(Lane* ctx, const psk_sketch* const* refs, const psk_
 void* hit_block_alloc(size_t bytes);      // nullptr: out of host memory
 bool hit_block_free(void* p);             // false: not one of these blocks (the caller frees it)
 void hit_block_trim();                    // drop the kept block (psk_ctx_destroy)
-struct HitList {
-    psk_hit* p = nullptr; size_t n = 0, cap = 0;
-    HitList() = default;
-    HitList(const HitList&) = delete; HitList& operator=(const HitList&) = delete;
-    ~HitList() { drop(p); }
+template <class H>
+struct HitListT {
+    H* p = nullptr; size_t n = 0, cap = 0;
+    HitListT() = default;
+    HitListT(const HitListT&) = delete; HitListT& operator=(const HitListT&) = delete;
+    ~HitListT() { drop(p); }
     static void drop(void* q) { if (q && !hit_block_free(q)) free(q); }
     // room for `want` hits in all; pages that are never touched cost nothing
     bool reserve(size_t want) {
         if (want <= cap) return true;
         if (n && want < 2 * cap) want = 2 * cap;      // a list that already holds hits moves them when it grows: at least double, so a long result is copied O(1) times
-        const size_t bytes = sizeof(psk_hit) * want;
-        psk_hit* q = (psk_hit*)(bytes >= ((size_t)8 << 20) ? hit_block_alloc(bytes) : malloc(bytes));
+        const size_t bytes = sizeof(H) * want;
+        H* q = (H*)(bytes >= ((size_t)8 << 20) ? hit_block_alloc(bytes) : malloc(bytes));
         if (!q) return false;
-        if (n) memcpy(q, p, sizeof(psk_hit) * n);
+        if (n) memcpy(q, p, sizeof(H) * n);
         drop(p);
         p = q; cap = want;
         return true;
     }
     bool reserve_for(size_t k) { return n + k <= cap || reserve(std::max<size_t>(n + k, cap + cap / 2 + 64)); }      // room for k more hits (the caller writes them, then adds k to n)
-    bool append(const psk_hit* src, size_t k) {
+    bool append(const H* src, size_t k) {
         if (n + k > cap && !reserve(std::max<size_t>(n + k, cap + cap / 2 + 64))) return false;
-        if (k) memcpy(p + n, src, sizeof(psk_hit) * k);
+        if (k) memcpy(p + n, src, sizeof(H) * k);
         n += k;
         return true;
     }
-    psk_hit* release() { psk_hit* q = p; p = nullptr; n = cap = 0; return q; }
+    H* release() { H* q = p; p = nullptr; n = cap = 0; return q; }
 };
+using HitList = HitListT<psk_hit>;
+using HitListMin = HitListT<psk_hit_min>;      // the 20-byte records of psk_query_many_min: what the reference's Hit holds (hit.rs:77-104)
 // Database.query for n_queries sketches (lib.rs:569-659): hits of query i are all[offsets[i] .. offsets[i+1]), ref insertion order
 psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
                            HitList& all, uint64_t* offsets);
+// ... the same with psk_hit_min records (query = index of the query within the call | learned << 31)
+psk_status query_many_min_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                               HitListMin& all, uint64_t* offsets);
 psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
                       const psk_sketch* query, const psk_query_opts* o, psk_hit* out);
 // Database.query from host bytes (lib.rs:549-660 with the _sketch call inside it): the one-launch-sequence path for a small genome

@@ -358,7 +358,9 @@ psk_status psk_comm_info(const psk_comm* cm, int* rank, int* world, uint64_t* by
 // All-gather of ragged per-shard hit lists. The records travel as they are: the caller has put the GLOBAL reference index in
 // ref_index and the global query index in `reserved`. Two collectives: the counts (8 bytes per rank), then the lists padded to the
 // largest count. *all (psk_free) holds the ranks' lists in rank order; counts[r] (world entries, may be NULL) their lengths.
-psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local, psk_hit** all, uint64_t* n_all, uint64_t* counts) {
+extern "C++" {
+template <class H>
+static psk_status gather_hits_t(psk_comm* cm, const H* local, uint64_t n_local, H** all, uint64_t* n_all, uint64_t* counts) {
     if (!cm || !all || !n_all) { psk_set_error("gather_hits: NULL argument"); return PSK_EINVAL; }
     *all = nullptr; *n_all = 0;
     std::lock_guard<std::mutex> lk(cm->mu);
@@ -377,14 +379,14 @@ psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local,
     for (size_t r = 0; r < W; r++) { cnt[r] = ctl[4 * r]; maxc = std::max(maxc, cnt[r]); total += cnt[r]; }
     if (counts) for (size_t r = 0; r < W; r++) counts[r] = cnt[r];
     // local work that can fail (host and device memory, the upload), then ONE more exchange of status words: all ranks enter the payload collective or none
-    const size_t row = sizeof(psk_hit) * (size_t)maxc;
-    psk_hit* res = (psk_hit*)malloc(sizeof(psk_hit) * std::max<uint64_t>(total, 1));
+    const size_t row = sizeof(H) * (size_t)maxc;
+    H* res = (H*)malloc(sizeof(H) * std::max<uint64_t>(total, 1));
     PoolScratch buf;
     if (!res) { psk_set_error("out of host memory"); mine = PSK_ENOMEM; }
     if (mine == PSK_OK && maxc) mine = buf.reserve(cm->ctx, row * (W + 1) + 256);
     char* d_send = buf.p ? (char*)buf.p + row * W : nullptr;
     if (mine == PSK_OK && maxc && n_local) {
-        const hipError_t e = hipMemcpyAsync(d_send, local, sizeof(psk_hit) * (size_t)n_local, hipMemcpyHostToDevice, st);
+        const hipError_t e = hipMemcpyAsync(d_send, local, sizeof(H) * (size_t)n_local, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { psk_set_error("gather_hits: %s", hipGetErrorString(e)); mine = PSK_EHIP; }
     }
     {
@@ -396,7 +398,7 @@ psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local,
         hipError_t e = hipSuccess;
         uint64_t w = 0;
         for (size_t r = 0; r < W && e == hipSuccess && rc == PSK_OK; r++) {
-            if (cnt[r]) e = hipMemcpyAsync(res + w, (char*)buf.p + row * r, sizeof(psk_hit) * (size_t)cnt[r], hipMemcpyDeviceToHost, st);
+            if (cnt[r]) e = hipMemcpyAsync(res + w, (char*)buf.p + row * r, sizeof(H) * (size_t)cnt[r], hipMemcpyDeviceToHost, st);
             w += cnt[r];
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st); else (void)hipStreamSynchronize(st);
@@ -405,6 +407,10 @@ psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local,
     *all = res; *n_all = total;
     return PSK_OK;
 }
+
+}  // extern "C++"
+psk_status psk_gather_hits(psk_comm* cm, const psk_hit* local, uint64_t n_local, psk_hit** all, uint64_t* n_all, uint64_t* counts) { return gather_hits_t<psk_hit>(cm, local, n_local, all, n_all, counts); }
+psk_status psk_gather_hits_min(psk_comm* cm, const psk_hit_min* local, uint64_t n_local, psk_hit_min** all, uint64_t* n_all, uint64_t* counts) { return gather_hits_t<psk_hit_min>(cm, local, n_local, all, n_all, counts); }
 
 // All-gather of device-resident sketches (the query side of a sharded all-vs-all): every rank contributes n sketches and receives
 // everybody's as sketches on ITS GPU. Packed records HBM -> xGMI -> HBM; two collectives per call: (count, bytes) of every rank,

@@ -3586,6 +3586,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     // STEPS of 64 index entries, numbered through the batch (a prefix sum over the lanes' step counts), and the entries of step t + GSI_AHEAD are requested
     // before step t is dealt out - the second and third step of a long run (a k-mer that a whole family of references holds) included.
     constexpr uint32_t GSI_AHEAD = 4;
+    unsigned long long visited = 0;      // index entries in the runs this lane's seeds found (psk_ctx_join_work)
     uint32_t km1 = (uint32_t)lane < nq ? Q.kmer[lane] : 0u, km2 = 64u + (uint32_t)lane < nq ? Q.kmer[64 + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
     if ((uint32_t)lane < nq) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
@@ -3598,6 +3599,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         uint32_t qp = 0, qm = 0;
         if (EMIT && i < nq) { qp = Q.pos[i]; qm = Q.meta[i]; }
         const uint32_t nst = (hi - lo + 63u) >> 6;
+        visited += hi - lo;
         uint32_t pre = nst;      // inclusive prefix sum over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (lane >= o) pre += y; }
@@ -3684,6 +3686,11 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
 #undef GSI_FETCH
     }
     lds_wave_sync();
+    if (EMIT) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
+        if (lane == 0 && visited) atomicAdd((unsigned long long*)(A.err + 18), visited);
+    }
     if (!EMIT) for (uint32_t j = lane; j < P; j += 64) A.pair_cnt[B.pair_off + j] = s_cur[j];
     else {
         unsigned long long sum = 0;
@@ -3714,6 +3721,17 @@ __global__ __launch_bounds__(256) void gsi_room_kernel(const uint32_t* __restric
 __global__ void gsi_total_kernel(const unsigned long long* __restrict__ poff, uint32_t n_pairs, unsigned long long* __restrict__ total64) { *total64 = poff[n_pairs]; }
 
 struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const { return h.ani > 0.1f; } };   // lib.rs:654
+
+// measurement only (psk_ctx_set_timing): out[0] += candidate chains, out[1] += chunk-table rows that hold a chunk
+__global__ __launch_bounds__(256) void work_rows_kernel(const ChunkOut* __restrict__ cout, const uint32_t* __restrict__ n_chunks, const uint32_t* __restrict__ cbase,
+                                                        const uint32_t* __restrict__ row_pair, uint32_t n_rows, unsigned long long* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0, live = 0;
+    if (r < n_rows) { const uint32_t p = row_pair[r]; if (r - cbase[p] < n_chunks[p]) { c = cout[r].n_cand; live = 1; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); live += __shfl_xor(live, o); }
+    if ((threadIdx.x & 63) == 0 && live) { atomicAdd(&out[0], c); atomicAdd(&out[1], live); }
+}
 
 constexpr size_t CHAIN_ANCHOR_WORDS = 12;      // u32 per anchor in Lane::q_d: the 16-byte record, the successor / state array, the candidates' seven
 // device arrays of one chain launch sequence, carved from ctx->q_b
@@ -4118,6 +4136,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
     if (n_rows > (size_t)RED_SMALL && L.rows_pair_max > (uint32_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
+    // measurement (timers on): candidate chains and live chunk-table rows of the batch, for the selection's and the reduce's byte counts
+    if (ctx->dev->timing) hipLaunchKernelGGL(work_rows_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, (const ChunkOut*)L.cout, (const uint32_t*)L.nch, (const uint32_t*)L.cbase, (const uint32_t*)L.row_pair, (uint32_t)n_rows, (unsigned long long*)(L.misc + 20));
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
     const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
     if (learned) learned_apply_launch(o->model, L.hits, L.pair_qr, d_qd, d_rd, n_pairs, st);
@@ -4135,7 +4155,7 @@ static uint64_t anchor_cap_for(Lane* ctx, size_t n_items, bool sparse = false, b
 }
 
 // outcome of a launch sequence, read back with the hits
-struct ChainTail { uint32_t misc[16]; unsigned long long total64; };
+struct ChainTail { uint32_t misc[16]; unsigned long long total64, visited, cands, rows; };      // (misc[16..23]: the anchor total; index entries the join visited; with the timers on, candidates and live chunk rows)
 static bool join_wide_default() { const char* e = getenv("PSK_JOIN"); return e && !strcmp(e, "wide"); }
 static psk_status chain_check(const ChainTail& T, uint32_t n_pairs, uint64_t* cap, bool* wide, bool* retry) {
     *retry = false;
@@ -4194,7 +4214,7 @@ static psk_status chain_batch(Lane* ctx, const HostPair* hp, uint32_t n_pairs, c
         ctx->huge_release();
         bool retry;
         PSK_TRY(chain_check(*T, n_pairs, &cap, &wide, &retry));
-        if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
+        if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; ctx->dev->w_cands += T->cands; ctx->dev->w_rows += T->rows; break; }
         if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
     }
     for (uint32_t p = 0; p < n_pairs; p++) { out[p] = h_hits[p]; out[p].reserved = 0; }
@@ -4403,8 +4423,26 @@ static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
 }
 
 static psk_status build_gsi(Lane* ctx, psk_db* db);
-psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
-                           HitList& all, uint64_t* offsets) {
+// The record a query call hands back: psk_hit (the reference's three numbers, the reference's index and every chaining integer behind them: parity tests) or
+// psk_hit_min (hit.rs:77-104's fields in 20 bytes: what crosses PCIe - and xGMI - when nobody asked for the integers: 9.5 M hits of a metagenome step are 763 MB
+// as psk_hit). The chain stage writes psk_hit per pair on the device either way; the ani > 0.1 selection (lib.rs:654) converts on its way out.
+template <class H> struct HitRec;
+template <> struct HitRec<psk_hit> {
+    __host__ __device__ static psk_hit from_raw(const psk_hit& r) { return r; }
+    static uint32_t local_query(const psk_hit& h) { return h.reserved; }      // pair_reduce left the round-local query index there
+    static void finish(psk_hit& h, uint32_t) { h.reserved = 0; }
+};
+template <> struct HitRec<psk_hit_min> {
+    __host__ __device__ static psk_hit_min from_raw(const psk_hit& r) { psk_hit_min m; m.ani = r.ani; m.af_query = r.af_query; m.af_ref = r.af_ref; m.ref_index = r.ref_index; m.query = r.reserved | (r.learned ? 0x80000000u : 0u); return m; }
+    static uint32_t local_query(const psk_hit_min& h) { return h.query & 0x7FFFFFFFu; }
+    static void finish(psk_hit_min& h, uint32_t q) { h.query = (h.query & 0x80000000u) | q; }      // the query's index within the call
+};
+template <class H> struct ToRec { __host__ __device__ H operator()(const psk_hit& r) const { return HitRec<H>::from_raw(r); } };
+template <class H> struct RecPasses { __host__ __device__ bool operator()(const H& h) const { return h.ani > 0.1f; } };   // lib.rs:654
+
+template <class H>
+static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o,
+                               HitListT<H>& all, uint64_t* offsets) {
     hipStream_t st = ctx->stream;
     offsets[0] = 0;
     if (o->learned_ani == 1 && !o->model) { psk_set_error("learned ANI requested but no regression model is loaded"); return PSK_ENOMODEL; }
@@ -4690,13 +4728,13 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             if (round_pairs > 4096 && !all.reserve(want)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
         }
         int parity = 0;
-        const psk_hit* pend_hits = nullptr; uint32_t pend_n = 0;
+        const H* pend_hits = nullptr; uint32_t pend_n = 0;
         bool pend_copy = false;      // the pending hits are still crossing on the copy stream
         hipStream_t cst = nullptr;
         // every way out of the round (an error return between two batches included) waits for a copy that is still crossing: the lane's pinned staging and the
         // selection halves it reads go back to the next caller with the lane
         struct CopyDrain { bool& pend; hipStream_t& s; ~CopyDrain() { if (pend && s) (void)hipStreamSynchronize(s); } } copy_drain{pend_copy, cst};
-        const size_t sel_half = al256(sizeof(psk_hit) * half_pairs + 256);
+        const size_t sel_half = al256(sizeof(H) * half_pairs + 256);
         auto consume = [&]() -> psk_status {
             if (!pend_n) return PSK_OK;
             if (pend_copy) { PSK_HIP(hipStreamSynchronize(cst)); pend_copy = false; }
@@ -4705,16 +4743,17 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             // pair_reduce left the round-local query index in `reserved`: counted per query, then cleared. A large batch (130 MB of records per metagenome batch)
             // is moved by a few threads: after the LAST batch of a round nothing is left to hide the move behind (12 ms of a 214 ms step with the GPU idle)
             auto move = [&](size_t lo, size_t hi, bool shared) {
-                memcpy(all.p + old + lo, pend_hits + lo, sizeof(psk_hit) * (hi - lo));
+                memcpy(all.p + old + lo, pend_hits + lo, sizeof(H) * (hi - lo));
                 for (size_t i = lo; i < hi; i++) {
-                    psk_hit& h = all.p[old + i];
-                    if (shared) __atomic_fetch_add(&q_hits[h.reserved], 1u, __ATOMIC_RELAXED); else q_hits[h.reserved]++;      // (slices meet inside a query's hits)
-                    h.reserved = 0;
+                    H& h = all.p[old + i];
+                    const uint32_t lq = HitRec<H>::local_query(h);
+                    if (shared) __atomic_fetch_add(&q_hits[lq], 1u, __ATOMIC_RELAXED); else q_hits[lq]++;      // (slices meet inside a query's hits)
+                    HitRec<H>::finish(h, b + lq);
                 }
             };
             static const unsigned move_threads = [] { const char* e = getenv("PSK_HIT_THREADS"); const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
                                                       return e ? (unsigned)std::max(1, atoi(e)) : std::min(8u, std::max(1u, hw / 8)); }();
-            const unsigned nt = (size_t)pend_n * sizeof(psk_hit) >= ((size_t)16 << 20) ? move_threads : 1u;
+            const unsigned nt = (size_t)pend_n * sizeof(H) >= ((size_t)16 << 20) ? move_threads : 1u;
             if (nt <= 1) move(0, pend_n, false);
             else {
                 std::vector<std::thread> th;
@@ -4759,7 +4798,7 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
             const uint32_t n_pairs = (uint32_t)pairs;
             if (items >= 0xFFFFFF00ull || rows >= 0xFFFFFF00ull) { psk_set_error("a single pair exceeds the per-launch limits (%llu query seeds)", (unsigned long long)items); return PSK_ELIMIT; }
             uint32_t n_sel = 0;
-            psk_hit* h_sel = nullptr;
+            H* h_sel = nullptr;
             if (items == 0 || rows == 0) {
                 // nothing to chain (queries without seeds): no hits
             } else {
@@ -4800,15 +4839,15 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                 // stream WHILE THE NEXT BATCH COMPUTES (600 MB per metagenome step: 15 ms of copies that kept the compute queues idle), out of one of two
                 // device halves so that the next batch's selection does not write what is still being read
                 const bool host_filter = n_pairs <= 4096;
-                psk_hit* d_sel = nullptr;
+                H* d_sel = nullptr;
                 if (!host_filter) {
                     PSK_TRY(ctx->copy_lane(&cst));
                     PSK_TRY(ctx->q_sel.reserve(2 * sel_half));
-                    d_sel = (psk_hit*)((char*)ctx->q_sel.p + (parity ? sel_half : 0));
+                    d_sel = (H*)((char*)ctx->q_sel.p + (parity ? sel_half : 0));
                 }
                 if (sizeof(psk_hit) * (size_t)n_pairs + 512 > half_bytes) { psk_set_error("internal: batch larger than its staging half"); return PSK_EHIP; }
                 hpin = (char*)hpin2 + (parity ? half_bytes : 0);
-                ChainTail* T = (ChainTail*)hpin; h_sel = (psk_hit*)((char*)hpin + 256);
+                ChainTail* T = (ChainTail*)hpin; h_sel = (H*)((char*)hpin + 256);
                 uint64_t cap = anchor_cap_for(ctx, (size_t)items, round_probe, items / n_pairs > (1u << 20));
                 // (pairs of one family: (1 - d)^15 of a query's seeds match, half of them over the divergences met - three quarters of the items is room enough,
                 // and a batch that needs more is rerun with the count walk's total)
@@ -4825,8 +4864,10 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     PSK_TRY(rrc);
                     if (!host_filter) {      // (the ani > 0.1 filter of a small batch runs on the host: three launches fewer)
                         size_t tmp3 = 0;
-                        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, L.hits, d_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));
-                        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, L.hits, d_sel, L.misc + 12, (int)n_pairs, HitPasses(), st));   // order-preserving: hits stay in (query, ref) order
+                        hipcub::TransformInputIterator<H, ToRec<H>, const psk_hit*> rec_it(L.hits, ToRec<H>());      // (the record that crosses is made here)
+                        PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, rec_it, d_sel, L.misc + 12, (int)n_pairs, RecPasses<H>(), st));
+                        PSK_TRY(ctx->q_c.reserve(tmp3));
+                        PSK_HIP(hipcub::DeviceSelect::If(ctx->q_c.p, tmp3, rec_it, d_sel, L.misc + 12, (int)n_pairs, RecPasses<H>(), st));   // order-preserving: hits stay in (query, ref) order
                     }
                     if (host_filter) PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));      // status, anchor total, hits: one copy
                     else PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, st));
@@ -4846,18 +4887,23 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
                     if (rc == PSK_ELIMIT && n_pairs > 1) { too_big = true; break; }
                     PSK_TRY(rc);
                     if (!retry && L.gsi_onepass && (T->misc[0] & 4u)) { L.gsi_onepass = false; retry = true; }      // a pair with more anchors than query seeds: with the count pass
-                    if (!retry) { ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; break; }
+                    if (!retry) {
+                        ctx->dev->w_pairs += n_pairs; ctx->dev->w_items += items; ctx->dev->w_anchors += T->total64; ctx->dev->w_cands += T->cands; ctx->dev->w_rows += T->rows;
+                        if (round_gsi) { uint64_t lk = 0; for (const BatchQ& e : bqs) lk += h_qd[e.q].n; ctx->dev->w_lookups += lk; ctx->dev->w_visited += T->visited; }
+                        break;
+                    }
                     if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
                 }
                 if (too_big) { max_items = std::max<uint64_t>(1, items / 4); max_pairs = std::max<uint64_t>(1, pairs / 4); continue; }   // repeat-rich: plan smaller batches from the same position
                 n_sel = T->misc[12];
-                if (n_pairs <= 4096) {      // host-side filter of a small batch (lib.rs:654), order kept
+                if (n_pairs <= 4096) {      // host-side filter of a small batch (lib.rs:654), order kept; the raw records become H where they stand (H is no larger)
+                    const psk_hit* raw = (const psk_hit*)((char*)hpin + 256);
                     uint32_t w = 0;
-                    for (uint32_t i = 0; i < n_pairs; i++) if (h_sel[i].ani > 0.1f) h_sel[w++] = h_sel[i];
+                    for (uint32_t i = 0; i < n_pairs; i++) { const psk_hit r = raw[i]; if (r.ani > 0.1f) h_sel[w++] = HitRec<H>::from_raw(r); }
                     n_sel = w;
                 }
                 else if (n_sel) {
-                    PSK_HIP(hipMemcpyAsync(h_sel, d_sel, sizeof(psk_hit) * (size_t)n_sel, hipMemcpyDeviceToHost, cst));      // (the batch is complete: its one synchronisation is behind us)
+                    PSK_HIP(hipMemcpyAsync(h_sel, d_sel, sizeof(H) * (size_t)n_sel, hipMemcpyDeviceToHost, cst));      // (the batch is complete: its one synchronisation is behind us)
                     pend_copy = true;
                 }
             }
@@ -4869,6 +4915,12 @@ psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queri
         for (uint32_t i = 0; i < m; i++) offsets[b + i + 1] = offsets[b + i] + q_hits[i];
     }
     return PSK_OK;
+}
+psk_status query_many_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o, HitList& all, uint64_t* offsets) {
+    return query_many_t<psk_hit>(ctx, db, queries, n_queries, o, all, offsets);
+}
+psk_status query_many_min_impl(Lane* ctx, psk_db* db, const psk_sketch* const* queries, uint32_t n_queries, const psk_query_opts* o, HitListMin& all, uint64_t* offsets) {
+    return query_many_t<psk_hit_min>(ctx, db, queries, n_queries, o, all, offsets);
 }
 
 

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     // The walk (gsi_join_kernel's): a batch of 64 seeds has its k-mers loaded two batches ahead and its bucket bounds one batch ahead; its runs are cut into STEPS
     // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
     constexpr uint32_t GSL_AHEAD = 4;
+    unsigned long long visited = 0;      // COUNT: index entries in the runs this lane's seeds found (psk_ctx_join_work)
     uint32_t km1 = sb + (uint32_t)lane < se ? Q.kmer[sb + lane] : 0u, km2 = sb + 64u + (uint32_t)lane < se ? Q.kmer[sb + 64u + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
     if (sb + (uint32_t)lane < se) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
         uint32_t qp = 0, qm = 0;
         if (EMIT && i < se) { qp = Q.pos[i]; qm = Q.meta[i]; }
         const uint32_t nst = (hi - lo + 63u) >> 6;
+        if (!EMIT) visited += hi - lo;
         uint32_t pre = nst;      // inclusive prefix sum over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (lane >= o) pre += y; }
@@ -263,6 +265,9 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     }
     lds_wave_sync();
     if (!EMIT) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
+        if (lane == 0 && visited) atomicAdd((unsigned long long*)(A.err + 18), visited);
         for (uint32_t j = lane; j < P; j += 64) {
             const uint32_t c = s_cur[j];
             A.cnt[rec0 + j] = c;

@@ -641,6 +641,7 @@ class Database:
         return o
 
     _HIT_DTYPE = np.dtype(_capi.Hit)
+    _HIT_MIN_DTYPE = np.dtype(_capi.HitMin)
 
     def _hit(self, r, qname):
         """One psk_hit (ctypes struct) -> Hit (the lazy path: a handful of hits)."""
@@ -683,17 +684,18 @@ class Database:
         n = len(self._names)
         return (C.c_void_p * max(n, 1))(*[self._lib.psk_db_sketch(self._h, i) for i in range(n)])
 
-    def query_handles(self, handles, n, *, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False):
-        """psk_query_many over n raw sketch handles -> (records, offsets): a numpy array of psk_hit (own memory) and the n+1
-        int64 offsets of every query's hits in it."""
+    def query_handles(self, handles, n, *, learned_ani=None, median=False, robust=False, cutoff=None, faster_small=False, raw=False):
+        """psk_query_many_min over n raw sketch handles -> (records, offsets): a numpy array of 20-byte psk_hit_min records (own memory;
+        `query` = index of the hit's query among the handles, bit 31 = learned) and the n+1 int64 offsets of every query's hits in it.
+        raw=True: psk_query_many, the 80-byte psk_hit records with every chaining integer (parity tests)."""
         opts = self._opts(learned_ani, median, robust, cutoff, faster_small)
         with Database._Borrow(self, False):
-            hits_p = C.POINTER(_capi.Hit)()
+            hits_p = C.POINTER(_capi.Hit if raw else _capi.HitMin)()
             offs = (C.c_uint64 * (n + 1))()
-            _capi.check(self._lib.psk_query_many(self._h, handles, n, C.byref(opts), C.byref(hits_p), offs))
+            _capi.check((self._lib.psk_query_many if raw else self._lib.psk_query_many_min)(self._h, handles, n, C.byref(opts), C.byref(hits_p), offs))
             try:
                 total = int(offs[n])
-                recs = _capi.hit_records(hits_p, 0, total, self._HIT_DTYPE)
+                recs = _capi.hit_records(hits_p, 0, total, self._HIT_DTYPE if raw else self._HIT_MIN_DTYPE)
             finally:
                 if hits_p:
                     self._lib.psk_free(hits_p)

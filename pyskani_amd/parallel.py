@@ -8,11 +8,15 @@ Two interchangeable transports carry them:
   TorchComm   torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests and one-GPU dry runs)
   CapiComm    the library's own RCCL communicator behind the C-ABI (psk_comm_create / psk_gather_hits / psk_gather_sketches,
               include/pyskani_amd.h): what a non-Python host binds; torch.distributed (any backend) only hands the 128-byte id round
-Hits travel as the library's 80-byte psk_hit records (numpy structured arrays): the GLOBAL reference index in `ref_index`, the
-global query index in `reserved`. No Python object exists per hit until a caller asks for `Hit`s at the very end.
+Hits travel as the library's 20-byte psk_hit_min records (numpy structured arrays; SURVEY.md §8e's record): the GLOBAL reference index
+in `ref_index`, the global query index in `query` (bit 31: the regression model produced the ANI). `raw=True` moves the 80-byte psk_hit
+records with every chaining integer instead (global query index in `reserved`): parity tests. No Python object exists per hit until a
+caller asks for `Hit`s at the very end.
 """
 import ctypes as C
+import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch  # noqa: F401  (before the HIP library: torch bundles its own HIP runtime, which must initialise first)
@@ -21,7 +25,14 @@ from . import _capi
 
 HIT_VALS = 3  # ani, af_query, af_ref
 HIT_DTYPE = np.dtype(_capi.Hit)
+HIT_MIN_DTYPE = np.dtype(_capi.HitMin)
 HIT_BYTES = HIT_DTYPE.itemsize
+QUERY_MASK = 0x7FFFFFFF      # psk_hit_min.query: the index below bit 31, `learned` in it
+
+
+def _qfield(dtype):
+    """name of the field that carries the query index in records of `dtype`"""
+    return "query" if "query" in dtype.names else "reserved"
 
 
 def shard_bounds(n_items, rank, world):
@@ -57,19 +68,22 @@ def all_gather_hit_records(recs, dist, device="cpu", group=None, state=None):
     """All-gather ragged per-shard arrays of psk_hit records. Returns (all records in rank order, per-rank counts), identical on
     every rank.
 
-    ONE collective in the steady state: every rank sends a fixed number of 80-byte rows — row 0 carries its true count — sized by
+    ONE collective in the steady state: every rank sends a fixed number of rows of one record each (20 or 80 bytes) — row 0 carries its true count — sized by
     `state["cap"]`, the largest count seen lately. If a count does not fit (every rank sees every header, so all agree), the
     capacity grows and the gather is repeated once. The capacity decays (halves towards the latest maximum), so one large exchange
     does not tax every later small one. `state` is a dict the CALLER owns (one per ShardedDatabase); without it every call
     exchanges the counts first."""
     world = dist.get_world_size(group)
-    recs = np.ascontiguousarray(recs, dtype=HIT_DTYPE).reshape(-1)
+    recs = np.asarray(recs)
+    rec_dtype = recs.dtype if recs.dtype.names else HIT_DTYPE      # psk_hit or psk_hit_min records: rows of their own width
+    recs = np.ascontiguousarray(recs, dtype=rec_dtype).reshape(-1)
+    row_bytes = rec_dtype.itemsize
     n = recs.shape[0]
     cap = int(state.get("cap", 0)) if state is not None else 0
-    raw = recs.view(np.uint8).reshape(n, HIT_BYTES)
+    raw = recs.view(np.uint8).reshape(n, row_bytes)
     while True:
-        mine = torch.empty((cap + 1, HIT_BYTES), dtype=torch.uint8, device=device)
-        head = np.zeros(HIT_BYTES, np.uint8)
+        mine = torch.empty((cap + 1, row_bytes), dtype=torch.uint8, device=device)
+        head = np.zeros(row_bytes, np.uint8)
         head[:8] = np.frombuffer(np.int64(n).tobytes(), np.uint8)
         k = min(n, cap)
         host = np.concatenate([head[None, :], raw[:k]], axis=0) if k else head[None, :]
@@ -85,9 +99,9 @@ def all_gather_hit_records(recs, dist, device="cpu", group=None, state=None):
         state["cap"] = max(max(counts), cap // 2)
     if sum(counts):
         got = np.concatenate([p[1:1 + c].cpu().numpy() for p, c in zip(parts, counts) if c], axis=0)
-        out = np.ascontiguousarray(got).view(HIT_DTYPE).reshape(-1)
+        out = np.ascontiguousarray(got).view(rec_dtype).reshape(-1)
     else:
-        out = np.zeros(0, HIT_DTYPE)
+        out = np.zeros(0, rec_dtype)
     return out, counts
 
 
@@ -124,8 +138,9 @@ class TorchComm:
         self.bytes_sent = 0
 
     def gather_hit_records(self, recs):
-        out, counts = all_gather_hit_records(recs, self.dist, device=self.device, group=self.group, state=self._hit_state)
-        self.bytes_sent += (self._hit_state.get("cap", 0) + 1) * HIT_BYTES * (self.world - 1)
+        state = self._hit_state.setdefault(np.asarray(recs).dtype.itemsize, {})      # (one capacity per record width)
+        out, counts = all_gather_hit_records(recs, self.dist, device=self.device, group=self.group, state=state)
+        self.bytes_sent += (state.get("cap", 0) + 1) * out.dtype.itemsize * (self.world - 1)
         return out, counts
 
     def gather_sketch_handles(self, ctx, handles, cuda_device):
@@ -167,7 +182,7 @@ class TorchComm:
         self.bytes_sent += width * (world - 1)
         maxn = max(counts) if counts else 0
         tables = big[:world, :8 * maxn].cpu().numpy() if maxn else np.zeros((world, 0), np.uint8)
-        torch.cuda.synchronize(cuda_device)              # the library reads the gathered tensor on its own stream
+        torch.cuda.current_stream(cuda_device).synchronize()      # the library reads the gathered tensor on its own stream (not a device-wide wait: with overlap the previous round is being queried)
         roffs = []
         for r in range(world):
             sz_r = np.ascontiguousarray(tables[r, :8 * counts[r]]).view(np.uint64)
@@ -216,14 +231,18 @@ class CapiComm:
         return b.value
 
     def gather_hit_records(self, recs):
-        recs = np.ascontiguousarray(recs, dtype=HIT_DTYPE).reshape(-1)
-        out_p = C.POINTER(_capi.Hit)()
+        recs = np.asarray(recs)
+        small = recs.dtype == HIT_MIN_DTYPE
+        dtype = HIT_MIN_DTYPE if small else HIT_DTYPE
+        recs = np.ascontiguousarray(recs, dtype=dtype).reshape(-1)
+        out_p = C.POINTER(_capi.HitMin if small else _capi.Hit)()
         n_all = C.c_uint64()
         counts = (C.c_uint64 * self.world)()
-        _capi.check(self._lib.psk_gather_hits(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), C.byref(out_p), C.byref(n_all), counts))
+        fn = self._lib.psk_gather_hits_min if small else self._lib.psk_gather_hits
+        _capi.check(fn(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), C.byref(out_p), C.byref(n_all), counts))
         try:
             n = n_all.value
-            out = _capi.hit_records(out_p, 0, n, HIT_DTYPE)
+            out = _capi.hit_records(out_p, 0, n, dtype)
         finally:
             if out_p:
                 self._lib.psk_free(out_p)
@@ -253,11 +272,12 @@ class ShardedDatabase:
 
     `local` is any object with the `Database` interface; by default a `pyskani_amd.Database` on this rank's GPU.
     `comm`: "torch" (collectives through torch.distributed), "capi" (the library's RCCL communicator, psk_comm_*), or an instance.
-    `stats` accumulates where the wall time of the exchange-carrying calls went: seconds inside psk_* calls, inside collectives,
-    and in Python around them.
+    `stats` accumulates where the wall time of the exchange-carrying calls went: seconds inside psk_* calls, inside collectives
+    (with `overlap` the sketch gather of round b + 1 runs beside round b's query: the two sums then overlap), and in Python around them.
+    `raw`: the hit lists travel as 80-byte psk_hit records with every chaining integer (parity tests) instead of the 20-byte psk_hit_min.
     """
 
-    def __init__(self, dist, local=None, device=None, group=None, comm="torch", **params):
+    def __init__(self, dist, local=None, device=None, group=None, comm="torch", raw=False, **params):
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.coll_device = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
@@ -278,6 +298,9 @@ class ShardedDatabase:
         self._cuts = None        # shard cut points (world + 1), identical on every rank
         self.device = device
         self.stats = {"psk_s": 0.0, "collective_s": 0.0, "total_s": 0.0}
+        self.raw = bool(raw)
+        self.rec_dtype = HIT_DTYPE if raw else HIT_MIN_DTYPE
+        self.trace = None        # a list: all_vs_all_records appends (event, round) as it goes (tests)
 
     def __len__(self):
         return len(self.names)
@@ -326,31 +349,50 @@ class ShardedDatabase:
     def query(self, name, *contigs, **opts):
         from .database import Hit
         t0 = time.perf_counter()
-        if hasattr(self.local, "query_records"):
-            recs = self._timed("psk_s", self.local.query_records, name, *contigs, **opts)
-        else:       # a stand-in local database (tests): Hit objects in, records out
-            by_name = {n: j for j, n in enumerate(self.names[self._lo:self._lo + len(self.local)])}
-            local = self.local.query(name, *contigs, **opts)
-            recs = np.zeros(len(local), HIT_DTYPE)
-            for i, h in enumerate(local):
-                raw = getattr(h, "_raw", None)
-                recs[i]["ref_index"] = int(raw["ref_index"]) if raw is not None else by_name[h.reference_name]
-                recs[i]["ani"], recs[i]["af_query"], recs[i]["af_ref"] = h.identity, h.query_fraction, h.reference_fraction
-        recs = recs.copy()
-        recs["ref_index"] += self._lo
-        recs["reserved"] = 0
+        dt, qf = self.rec_dtype, _qfield(self.rec_dtype)
+        failure = None
+        recs = np.zeros(0, dt)
+        try:
+            if hasattr(self.local, "query_records"):
+                got_local = self._timed("psk_s", self.local.query_records, name, *contigs, **opts)
+                recs = np.zeros(len(got_local), dt)
+                for f in dt.names:
+                    if f in got_local.dtype.names:
+                        recs[f] = got_local[f]
+                if qf == "query" and "learned" in got_local.dtype.names:
+                    recs["query"] = np.where(got_local["learned"] != 0, np.uint32(0x80000000), np.uint32(0))
+            else:       # a stand-in local database (tests): Hit objects in, records out
+                by_name = {n: j for j, n in enumerate(self.names[self._lo:self._lo + len(self.local)])}
+                local = self.local.query(name, *contigs, **opts)
+                recs = np.zeros(len(local), dt)
+                for i, h in enumerate(local):
+                    raw = getattr(h, "_raw", None)
+                    recs[i]["ref_index"] = int(raw["ref_index"]) if raw is not None else by_name[h.reference_name]
+                    recs[i]["ani"], recs[i]["af_query"], recs[i]["af_ref"] = h.identity, h.query_fraction, h.reference_fraction
+            recs["ref_index"] += self._lo
+            if qf == "reserved":
+                recs["reserved"] = 0
+        except Exception as e:      # a rank whose local query failed still enters the collective (its peers are waiting in it) and raises afterwards
+            failure = e
+            recs = np.zeros(0, dt)
         got, _ = self._timed("collective_s", self.comm.gather_hit_records, recs)
         self.stats["total_s"] += time.perf_counter() - t0
-        return [Hit(float(r["ani"]), name, float(r["af_query"]), self.names[int(r["ref_index"])], float(r["af_ref"])) for r in got]
+        if failure is not None:
+            raise failure
+        learned = ((got["query"] >> 31) != 0) if qf == "query" else (got["learned"] != 0)
+        base = Hit.__mro__[1]      # (the storage class takes `learned`; Hit's own constructor is the reference's five arguments, hit.rs:26-33)
+        return [base.__new__(Hit, float(r["ani"]), name, float(r["af_query"]), self.names[int(r["ref_index"])], float(r["af_ref"]), bool(l)) for r, l in zip(got, learned.tolist())]
 
-    def all_vs_all_records(self, batch=256, **opts):
-        """Every genome of the job against every other (and itself), as RECORDS: a numpy array of psk_hit sorted by (query,
-        reference) with GLOBAL indices (`reserved` = query, `ref_index` = reference), identical on every rank.
+    def all_vs_all_records(self, batch=256, overlap=True, **opts):
+        """Every genome of the job against every other (and itself), as RECORDS: a numpy array of psk_hit_min (psk_hit with `raw`)
+        sorted by (query, reference) with GLOBAL indices (`query` - `reserved` in raw records - and `ref_index`), identical on every rank.
 
         Each rank's shard IS its share of the genomes, so the query side is the all-gather of the shards' sketches, `batch`
         genomes per rank at a time, as packed device records (HBM -> xGMI -> HBM); each received batch is queried against
-        the local shard in one psk_query_many, the hits get their global indices with numpy, and ONE all-gather of the hit
-        records ends the call. No Python object per hit or per pair anywhere."""
+        the local shard in one psk_query_many(_min), the hits get their global indices with numpy, and ONE all-gather of the hit
+        records ends the call. No Python object per hit or per pair anywhere. With `overlap` the gather of round b + 1 is
+        issued (on a helper thread: its collectives and the library's packing run on their own streams) BEFORE round b is queried,
+        so the exchange leaves the critical path: two rounds' gathered sketches are alive at a time."""
         t_all = time.perf_counter()
         local = self.local
         n_local = len(local)
@@ -359,27 +401,63 @@ class ShardedDatabase:
         lib = local._lib
         mine_all = local.sketch_handles()            # ctypes array of the shard's psk_sketch*
         chunks = []
-        for b in range((max(sizes) + batch - 1) // batch if sizes else 0):
+        rounds = (max(sizes) + batch - 1) // batch if sizes else 0
+        dt, qf = self.rec_dtype, _qfield(self.rec_dtype)
+        trace = self.trace
+        if len(self.names) >= 1 << 31:      # (the records' index fields are 32-bit, psk_hit_min's query index 31: refuse rather than wrap)
+            raise OverflowError("a sharded job of 2^31 genomes or more does not fit the hit records' index fields")
+
+        def gather(b):
+            if trace is not None:
+                trace.append(("gather_start", b))
             i0, i1 = min(b * batch, n_local), min((b + 1) * batch, n_local)
             mine_n = (C.c_void_p * (i1 - i0))(*[mine_all[i] for i in range(i0, i1)])
-            handles, counts = self._timed("collective_s", self.comm.gather_sketch_handles, local._ctx, mine_n, dev)
-            total = sum(counts)
-            try:
+            out = self._timed("collective_s", self.comm.gather_sketch_handles, local._ctx, mine_n, dev)
+            if trace is not None:
+                trace.append(("gather_end", b))
+            return out
+        pool = ThreadPoolExecutor(max_workers=1) if (overlap and rounds > 1) else None
+        nxt = pool.submit(gather, 0) if pool else None
+        nxt_taken = False      # the future in `nxt` has been waited for (its sketches are in `held`)
+        held = []      # gathered handle sets not yet freed: (handles, total)
+        try:
+            for b in range(rounds):
+                handles, counts = nxt.result() if pool else gather(b)
+                nxt_taken = True
+                total = sum(counts)
+                held.append((handles, total))
+                if pool and b + 1 < rounds:
+                    nxt = pool.submit(gather, b + 1)      # round b + 1's sketches travel while round b is queried
+                    nxt_taken = False
                 if total:
-                    recs, offs = self._timed("psk_s", local.query_handles, handles, total, **opts)
+                    if trace is not None:
+                        trace.append(("query_start", b))
+                    recs, offs = self._timed("psk_s", local.query_handles, handles, total, raw=self.raw, **opts)
+                    if trace is not None:
+                        trace.append(("query_end", b))
                     # global query index of every hit: the batch's queries are rank-major, rank r contributes counts[r]
                     qglob = np.concatenate([self._shard(r)[0] + b * batch + np.arange(counts[r], dtype=np.int64) for r in range(self.world)])
-                    per_q = np.diff(offs)
-                    if len(self.names) >= 1 << 32:      # (the records' index fields are 32-bit: refuse rather than wrap)
-                        raise OverflowError("a sharded job of 2^32 genomes or more does not fit the hit records' 32-bit index fields")
-                    recs["reserved"] = np.repeat(qglob, per_q).astype(np.uint32)
+                    if qf == "query":      # the library numbered the hits' queries within the call; bit 31 (learned) rides along
+                        q = recs["query"]
+                        recs["query"] = (qglob[q & QUERY_MASK].astype(np.uint32) | (q & np.uint32(0x80000000)))
+                    else:
+                        recs["reserved"] = np.repeat(qglob, np.diff(offs)).astype(np.uint32)
                     recs["ref_index"] += self._lo
                     chunks.append(recs)
-            finally:
                 lib.psk_sketch_free_many(handles, total)
-        mine_recs = np.concatenate(chunks) if chunks else np.zeros(0, HIT_DTYPE)
+                held.pop()
+        finally:
+            if pool:
+                pool.shutdown(wait=True)
+                if not nxt_taken and nxt is not None and nxt.exception() is None:      # an error between two rounds: the gather in flight has its sketches too
+                    h, c = nxt.result()
+                    held.append((h, sum(c)))
+            for h, t in held:
+                lib.psk_sketch_free_many(h, t)
+        mine_recs = np.concatenate(chunks) if chunks else np.zeros(0, dt)
         got, _ = self._timed("collective_s", self.comm.gather_hit_records, mine_recs)
-        order = np.lexsort((got["ref_index"], got["reserved"]))
+        qkey = (got["query"] & QUERY_MASK) if qf == "query" else got["reserved"]
+        order = np.lexsort((got["ref_index"], qkey))
         out = got[order]
         self.stats["total_s"] += time.perf_counter() - t_all
         return out
@@ -390,7 +468,8 @@ class ShardedDatabase:
         from .database import Hit
         out = {n: [] for n in self.names}
         names = self.names
-        for q, r, ani, afq, afr in zip(recs["reserved"].tolist(), recs["ref_index"].tolist(), recs["ani"].tolist(), recs["af_query"].tolist(), recs["af_ref"].tolist()):
+        qidx = (recs["query"] & QUERY_MASK) if "query" in recs.dtype.names else recs["reserved"]
+        for q, r, ani, afq, afr in zip(qidx.tolist(), recs["ref_index"].tolist(), recs["ani"].tolist(), recs["af_query"].tolist(), recs["af_ref"].tolist()):
             qn = names[q]
             out[qn].append(Hit(ani, qn, afq, names[r], afr))
         return out

@@ -31,6 +31,9 @@ pub struct PskHit {
     pub sum_chain_anchors: u64, pub sum_chunk_seeds: u64,
     pub ani_raw: f32, pub ani_std: f32, pub learned: u32, pub reserved: u32,
 }
+/// psk_hit_min: what `Hit` holds (hit.rs:77-104) in 20 bytes; `query` = index of the query within the call, bit 31 = the model produced `ani`
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct PskHitMin { pub ani: f32, pub af_query: f32, pub af_ref: f32, pub ref_index: u32, pub query: u32 }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct PskSeed { pub kmer: u32, pub pos: u32, pub contig: u32, pub canon: u32 }
 #[repr(C)] #[derive(Clone, Copy)]
@@ -51,6 +54,7 @@ extern "C" {
     pub fn psk_ctx_timing(ctx: *mut PskCtx, kernel: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn psk_ctx_clock_probe(ctx: *mut PskCtx, mhz: *mut f64, ms: *mut f64) -> c_int;
     pub fn psk_ctx_work(ctx: *mut PskCtx, pairs: *mut u64, items: *mut u64, anchors: *mut u64, reset: c_int) -> c_int;
+    pub fn psk_ctx_join_work(ctx: *mut PskCtx, lookups: *mut u64, visited: *mut u64, candidates: *mut u64, rows: *mut u64, reset: c_int) -> c_int;
     pub fn psk_device_alloc(ctx: *mut PskCtx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
     pub fn psk_device_free(ctx: *mut PskCtx, dptr: *mut c_void) -> c_int;
     pub fn psk_memcpy_h2d(ctx: *mut PskCtx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
@@ -86,6 +90,7 @@ extern "C" {
     pub fn psk_comm_destroy(comm: *mut PskComm);
     pub fn psk_comm_info(comm: *const PskComm, rank: *mut c_int, world: *mut c_int, bytes_sent: *mut u64, collectives: *mut u64) -> c_int;
     pub fn psk_gather_hits(comm: *mut PskComm, local: *const PskHit, n_local: u64, all: *mut *mut PskHit, n_all: *mut u64, counts: *mut u64) -> c_int;
+    pub fn psk_gather_hits_min(comm: *mut PskComm, local: *const PskHitMin, n_local: u64, all: *mut *mut PskHitMin, n_all: *mut u64, counts: *mut u64) -> c_int;
     pub fn psk_gather_sketches(comm: *mut PskComm, mine: *const *const PskSketch, n: u32, all: *mut *mut *mut PskSketch, counts: *mut u32) -> c_int;
     // learned-ANI regression: regression::get_model (lib.rs:614)
     pub fn psk_model_create(ctx: *mut PskCtx, nodes: *const PskTreeNode, n_nodes: u64, tree_first_node: *const u32,
@@ -116,6 +121,8 @@ extern "C" {
     // many queries in one call (all-vs-all, bins of a metagenome): hits of query i are hits[offsets[i]..offsets[i+1]]
     pub fn psk_query_many(db: *mut PskDb, qs: *const *const PskSketch, n: u32, o: *const PskQueryOpts,
                           hits: *mut *mut PskHit, offsets: *mut u64) -> c_int;
+    pub fn psk_query_many_min(db: *mut PskDb, qs: *const *const PskSketch, n: u32, o: *const PskQueryOpts,
+                              hits: *mut *mut PskHitMin, offsets: *mut u64) -> c_int;
     // the two halves of `query`, for a disk-backed Database (markers resident, sketches loaded per query)
     pub fn psk_screen(db: *mut PskDb, q: *const PskSketch, screen_val: f64, rescue_small: c_int,
                       pass: *mut u8, shared: *mut u32) -> c_int;

@@ -70,3 +70,20 @@ def test_spawn_happens_before_torch_is_imported_or_hip_is_touched():
     main = src[src.index("def main():"):]
     assert main.index("spawn_decision(") < main.index("import torch")
     assert "os.exec" not in src and "execv" not in src
+
+
+def test_no_kernel_row_prices_above_the_hbm_peak():
+    """a bracket that did not run the work its byte formula counts (the one-walk index join has no COUNT pass: ~0.05 ms in the `anchor` timer) came out at
+    227 x the HBM peak. Such rows carry no fraction; every row that does stays at or below 1."""
+    import bench
+    kern = {k: (0.0, 0) for k in bench.KERNELS}
+    kern.update(sketch_scan=(7.0, 2), anchor=(0.1, 16), anchor_emit=(100.0, 16), chain_chunk=(80.0, 16), select=(9.0, 16), pair_reduce=(7.0, 16))
+    units = {"bases": 1.4e9, "c": 30, "marker_c": 200, "items": 5.7e9, "anchors": 1.77e9, "index_lookups": 3.3e7, "index_entries_visited": 1.77e9, "candidates": 4e7, "chunk_rows": 2e7, "chained_pairs": 1.7e7}
+    table = bench.kernel_rooflines(kern, 2, units, {})
+    assert "frac_of_hbm_peak" not in table["anchor"]                       # 21 GB in 0.05 ms: not what that bracket did
+    assert 0 < table["anchor_emit"]["frac_of_hbm_peak"] <= 1 and "index" in table["anchor_emit"]["bytes"]
+    for k, row in table.items():
+        assert row.get("frac_of_hbm_peak", 0.0) <= 1.0, (k, row)
+    assert "frac_of_hbm_peak" in table["select"] and "frac_of_hbm_peak" in table["pair_reduce"]      # the kernels that had no byte count
+    merge = bench.kernel_rooflines(kern, 2, dict(units, index_lookups=0.0, index_entries_visited=0.0), {})
+    assert "item" in merge["anchor_emit"]["bytes"]

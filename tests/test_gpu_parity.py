@@ -606,6 +606,32 @@ def test_lanes_overlap_queries(psk):
     assert r4 > 0.9 * max(r1, r1b)
 
 
+def test_min_records_equal_the_raw_records(psk):
+    """psk_query_many_min (20-byte records: what the reference's Hit holds, hit.rs:77-104 - the default of the record-level entry points) against
+    psk_query_many (80 bytes with every chaining integer): the same hits in the same order, the same three floats bit for bit, `query` = the
+    index of the hit's query in the call. A batch the host filters (few pairs) and one the device selects (> 4 096 pairs: the records are converted
+    by the selection itself), over two calls on one database (the per-round numbering starts again in every call)."""
+    import ctypes as C
+    rng = np.random.default_rng(2024)
+    anc = [random_genome(rng, 120_000) for _ in range(3)]
+    genomes = [(f"g{f}_{j}", mutate(rng, anc[f], 0.003 * j)) for f in range(3) for j in range(40)]      # 120 genomes: 3 x 1 600 pairs in one batch
+    db = psk.Database()
+    db.sketch_many(genomes)
+    sk = db._sketch_many(genomes, True)
+    for part in (sk[:5], sk):
+        n = len(part)
+        handles = (C.c_void_p * n)(*[x._h for x in part])
+        raw, roffs = db.query_handles(handles, n, learned_ani=False, raw=True)
+        small, soffs = db.query_handles(handles, n, learned_ani=False)
+        assert raw.dtype.itemsize == 80 and small.dtype.itemsize == 20
+        assert len(raw) == len(small) >= n * 20 and np.array_equal(roffs, soffs)
+        for f in ("ani", "af_query", "af_ref"):
+            assert np.array_equal(raw[f].view(np.uint32), small[f].view(np.uint32)), f
+        assert np.array_equal(raw["ref_index"], small["ref_index"])
+        assert np.array_equal(small["query"], np.repeat(np.arange(n, dtype=np.uint32), np.diff(soffs)))      # (no model: bit 31 is clear)
+        assert not raw["learned"].any() and not raw["reserved"].any()
+
+
 def test_sharded_database_over_rccl_world1(psk):
     """The N>1 code path on the real backend: torch.distributed "nccl" (= RCCL) with a one-rank group, real
     Database underneath. (Two ranks cannot share this box's single GPU under RCCL; world 2 runs on gloo in
@@ -646,6 +672,14 @@ for s in (sdb, sdb2):
         g = [(h.reference_name, h.identity, h.query_fraction, h.reference_fraction) for h in ava[n]]
         assert g == w, (s.comm.kind, n, g, w)
 assert sdb2.comm.kind == "capi" and sdb2.stats["collective_s"] > 0
+# the exchange's records: 20 bytes by default (psk_hit_min), the 80-byte psk_hit with every chaining integer on request - the same hits either way
+small = sdb2.all_vs_all_records(batch=3, learned_ani=False)
+sdb3 = ShardedDatabase(dist, device=dev, comm=sdb2.comm, raw=True)
+sdb3.sketch_all(names, lambda i: (refs[i],))
+big = sdb3.all_vs_all_records(batch=3, learned_ani=False)
+assert small.dtype.itemsize == 20 and big.dtype.itemsize == 80 and len(small) == len(big) > 0
+assert np.array_equal(small["ani"].view(np.uint32), big["ani"].view(np.uint32)) and np.array_equal(small["ref_index"], big["ref_index"])
+assert np.array_equal(small["query"], big["reserved"]) and big["n_anchors"].min() > 0
 sdb2.comm.close()
 dist.destroy_process_group()
 print("sharded ok")

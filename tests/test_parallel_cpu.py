@@ -71,6 +71,66 @@ w = [5e6, 5e6, 3e9, 5e6, 5e6, 5e6, 5e6]
 sdb2.sketch_all(names, lambda i: (names[i].encode(),), weights=w)
 assert sdb2._cuts == weighted_shard_cuts(w, world) == [0, 3, 7], sdb2._cuts
 assert [h.reference_name for h in sdb2.query("q", b"ACGT")] == ["g0", "g2", "g4", "g6"]
+# all-vs-all over stand-ins: 20-byte records (psk_hit_min: query index below bit 31, `learned` in it), three rounds of two genomes per rank, and the
+# exchange of round b + 1 STARTED before round b's query returns (the stand-in query waits for it: without the overlap it would time out)
+import ctypes as C, threading
+from pyskani_amd.parallel import TorchComm, HIT_MIN_DTYPE, HIT_DTYPE, QUERY_MASK
+N = 11
+class Lib:
+    freed = 0
+    def psk_sketch_free_many(self, handles, n): Lib.freed += n
+class ALocal:
+    _device = 0; _ctx = None
+    def __init__(self, lo, hi): self.lo, self.hi, self._lib, self.round, self.comm = lo, hi, Lib(), 0, None
+    def __len__(self): return self.hi - self.lo
+    def sketch_handles(self): return (C.c_void_p * max(1, self.hi - self.lo))(*[1000 + g for g in range(self.lo, self.hi)])      # a genome's "handle" is 1000 + its global index
+    def query_handles(self, handles, total, raw=False, **kw):
+        b = self.round; self.round += 1
+        if b + 1 < self.comm.rounds: assert self.comm.started[b + 1].wait(20), "round %%d's gather had not started while round %%d was queried" %% (b + 1, b)
+        dt = HIT_DTYPE if raw else HIT_MIN_DTYPE
+        rows, offs = [], [0]
+        for qi in range(total):
+            q = handles[qi] - 1000
+            for r in range(self.lo, self.hi):
+                if (q + r) %% 3 == 0:
+                    rec = np.zeros(1, dt)
+                    rec["ani"], rec["af_query"], rec["af_ref"], rec["ref_index"] = 0.5 + q / 100 + r / 10000, 0.25, 0.75, r - self.lo
+                    if raw: rec["learned"] = q %% 2
+                    else: rec["query"] = qi | ((q %% 2) << 31)
+                    rows.append(rec)
+            offs.append(len(rows))
+        return (np.concatenate(rows) if rows else np.zeros(0, dt)), np.array(offs, np.int64)
+class AComm(TorchComm):
+    def __init__(self, dist, rounds): super().__init__(dist); self.rounds, self.calls, self.started = rounds, 0, [threading.Event() for _ in range(rounds)]
+    def gather_sketch_handles(self, ctx, handles, dev):
+        b = self.calls; self.calls += 1
+        self.started[b].set()
+        box = [None] * self.world
+        self.dist.all_gather_object(box, [int(h) for h in handles])
+        flat = [h for part in box for h in part]
+        return (C.c_void_p * max(1, len(flat)))(*flat), [len(part) for part in box]
+for raw in (False, True):
+    lo, hi = shard_bounds(N, rank, world)
+    loc = ALocal(lo, hi)
+    comm = AComm(dist, rounds=3)
+    loc.comm = comm
+    sdb3 = ShardedDatabase(dist, local=loc, comm=comm, raw=raw)
+    sdb3.adopt_local(["g%%d" %% i for i in range(N)])
+    sdb3.trace = []
+    Lib.freed = 0
+    recs = sdb3.all_vs_all_records(batch=2)
+    assert recs.dtype == (HIT_DTYPE if raw else HIT_MIN_DTYPE) and recs.dtype.itemsize == (80 if raw else 20)
+    want = [(q, r) for q in range(N) for r in range(N) if (q + r) %% 3 == 0]
+    qs = (recs["reserved"] if raw else recs["query"] & QUERY_MASK).tolist()
+    assert list(zip(qs, recs["ref_index"].tolist())) == want, (raw, list(zip(qs, recs["ref_index"].tolist()))[:8])
+    assert np.allclose(recs["ani"], [0.5 + q / 100 + r / 10000 for q, r in want], atol=1e-6)
+    learned = (recs["learned"] != 0) if raw else ((recs["query"] >> 31) != 0)
+    assert learned.tolist() == [q %% 2 == 1 for q, r in want]
+    assert Lib.freed == N, Lib.freed                      # every gathered handle set was released (N genomes over the three rounds)
+    tr = sdb3.trace
+    for b in range(2):
+        assert tr.index(("gather_start", b + 1)) < tr.index(("query_end", b)), tr       # the next round's exchange runs beside this round's query
+    assert comm.calls == 3
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
