@@ -471,6 +471,14 @@ struct psk_db {
     int gsi_state = 0;      // 0 = not built, 1 = built, 2 = this database cannot have one (limits, memory)
     PoolScratch gsi_key, gsi_val, gsi_bucket;
     uint64_t gsi_n = 0; int gsi_shift = 0;
+    // the same index in BLOCKS of 2^BSI_BLOG consecutive references, each block sorted by k-mer with a bucket table of its own (query.hip build_bsi): what the seed-index
+    // join of mid-sized pairs walks (slice_join.hip). A random genome of L bases holds a given 15-mer with probability 2 L / 4^15 ~ 1 %, and a k-mer that is a seed in one
+    // genome is a seed in every genome that holds it (seeds are chosen by content): one run of the database-wide index holds ~0.01 N chance entries beside the query's
+    // relatives - 93 of 147 entries per lookup at 10 000 genomes. A query's passing references are few and usually neighbours in insertion order: walking only the
+    // blocks that hold one of them leaves 256 x 0.01 = 2.4 chance entries per lookup whatever the database size.
+    int bsi_state = 0;      // 0 = not built, 1 = built, 2 = this database cannot have one
+    PoolScratch bsi_key, bsi_val, bsi_bucket;
+    uint64_t bsi_n = 0; int bsi_shift = 0; uint32_t bsi_nb1 = 0, bsi_blocks = 0;      // nb1 = bucket-table entries per block (2^bits + 1)
     // the one-launch-sequence query (small_query.hip): 1 = every device table it reads is up to date, 2 = this database cannot take it; reset when references are added
     std::atomic<int> small_state{0};
 };
@@ -511,6 +519,7 @@ struct SketchConsts {
 
 // ---- the one-launch-sequence query of a small genome from host bytes (psk_query_host; small_query.hip) -------------------------
 // Fixed capacities: a call whose genome does not fit them takes the general path (psk_sketch_host + psk_query).
+constexpr int BSI_BLOG = 8;                 // references per block of the blocked seed index: 2^8
 constexpr uint32_t SQ_MAX_TILES = 64, SQ_MAX_DESC = 64;     // tiles of 16 384 bases / kept contigs of the query
 constexpr uint32_t SQ_SEEDS = 3072;        // query seeds, and anchors of one (query, reference) pair, the fused chain kernel holds in LDS
 constexpr uint32_t SQ_MARKERS = 2048;      // raw query markers the screen workgroup sorts in LDS

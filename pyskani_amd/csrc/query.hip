@@ -3512,16 +3512,29 @@ __global__ __launch_bounds__(256) void pass_canon_kernel(uint8_t* __restrict__ p
     uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
     for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (row[r] && canon[r] != r) { row[canon[r]] = 1; row[r] = 0; }   // canon[r] > r and canon[canon[r]] == canon[r]
 }
-__global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restrict__ pass, uint32_t n_refs, uint32_t* __restrict__ row_count, uint8_t* __restrict__ col_flag) {
-    __shared__ uint32_t s_c[4];
+// ... and (row_blocks) the number of 2^BSI_BLOG-reference blocks that hold one of the query's passing references: what the slice join's plan looks at
+static_assert((1 << BSI_BLOG) == 256, "pass_count_kernel: one sweep of its 256 threads = one block of references");
+__global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restrict__ pass, uint32_t n_refs, uint32_t* __restrict__ row_count, uint8_t* __restrict__ col_flag, uint32_t* __restrict__ row_blocks) {
+    __shared__ uint32_t s_c[4], s_any;
     const uint8_t* row = pass + (size_t)blockIdx.x * n_refs;
-    uint32_t c = 0;
-    for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (row[r]) { c++; col_flag[r] = 1; }
+    uint32_t c = 0, blocks = 0;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    for (uint32_t r0 = 0; r0 < n_refs; r0 += 256) {
+        const uint32_t r = r0 + threadIdx.x;
+        const bool f = r < n_refs && row[r];
+        if (f) { c++; col_flag[r] = 1; s_any = 1; }
+        __syncthreads();
+        blocks += s_any;
+        __syncthreads();
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) row_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (threadIdx.x == 0) { row_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3]; row_blocks[blockIdx.x] = blocks; }
 }
 
 // ------------------------------------------------------------------ join of MANY SMALL pairs through the database-wide seed index (psk_db::gsi_*)
@@ -3725,12 +3738,21 @@ struct HitPasses { __host__ __device__ bool operator()(const psk_hit& h) const {
 // measurement only (psk_ctx_set_timing): out[0] += candidate chains, out[1] += chunk-table rows that hold a chunk
 __global__ __launch_bounds__(256) void work_rows_kernel(const ChunkOut* __restrict__ cout, const uint32_t* __restrict__ n_chunks, const uint32_t* __restrict__ cbase,
                                                         const uint32_t* __restrict__ row_pair, uint32_t n_rows, unsigned long long* __restrict__ out) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a fixed grid, one pair of atomics per WORKGROUP: an atomic per wave on two addresses serialised 110 000 waves - 2.5 ms per batch)
+    __shared__ unsigned long long s_c[4], s_l[4];
     unsigned long long c = 0, live = 0;
-    if (r < n_rows) { const uint32_t p = row_pair[r]; if (r - cbase[p] < n_chunks[p]) { c = cout[r].n_cand; live = 1; } }
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+        const uint32_t p = row_pair[r];
+        if (r - cbase[p] < n_chunks[p]) { c += cout[r].n_cand; live++; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); live += __shfl_xor(live, o); }
-    if ((threadIdx.x & 63) == 0 && live) { atomicAdd(&out[0], c); atomicAdd(&out[1], live); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c; s_l[threadIdx.x >> 6] = live; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = s_c[0] + s_c[1] + s_c[2] + s_c[3]; live = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+        if (live) { atomicAdd(&out[0], c); atomicAdd(&out[1], live); }
+    }
 }
 
 constexpr size_t CHAIN_ANCHOR_WORDS = 12;      // u32 per anchor in Lane::q_d: the 16-byte record, the successor / state array, the candidates' seven
@@ -3744,6 +3766,7 @@ struct ChainBufs {
     uint32_t rows_pair_max = 0xFFFFFFFFu;      // most chunk-table rows any pair of the batch can have (the host knows its queries): which reduce kernels have work
     // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
+    uint32_t g_nb1 = 0, g_blocks = 0;      // (the slice join's index comes in blocks of references: psk_db::bsi_*)
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
     // mid-sized pairs (all-vs-all of genomes): the index join by (query, slice) waves (slice_join.hip); the batch's wave table, record offsets and per-record arrays
     bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint2* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr, *gsl_un = nullptr, gsl_n_slices = 0; uint4* gsl_rec = nullptr;
@@ -3802,7 +3825,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
         if (gsl) {
             GL.bq = L.bq; GL.n_entries = L.n_bq; GL.tab = L.gsl_tab; GL.n_tab = L.gsl_n_tab; GL.ebase = L.gsl_ebase; GL.pass = L.d_pass; GL.n_refs = L.n_refs; GL.qd = d_qd;
-            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm; GL.un = L.gsl_un; GL.n_slices = L.gsl_n_slices;
+            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.g_nb1 = L.g_nb1; GL.g_blocks = L.g_blocks; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm; GL.un = L.gsl_un; GL.n_slices = L.gsl_n_slices;
             GL.pair_cnt = L.big_list; GL.pstart = L.pstart; GL.cap = (uint32_t)cap; GL.err = L.misc; GL.p_cap = L.p_cap; GL.chunks = L.chunks; GL.n_chunks = L.nch;
             { const char* e = getenv("PSK_GSL_STAGE"); GL.stage = e ? atoi(e) : 1; }      // (A/B: every anchor its own 16-byte store)
             PSK_HIP(hipMemsetAsync(L.big_list, 0, 4 * ((size_t)n_pairs + 1), st));      // the slices of a pair add their counts
@@ -4137,7 +4160,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if (n_rows > (size_t)RED_SMALL && L.rows_pair_max > (uint32_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
     // measurement (timers on): candidate chains and live chunk-table rows of the batch, for the selection's and the reduce's byte counts
-    if (ctx->dev->timing) hipLaunchKernelGGL(work_rows_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, (const ChunkOut*)L.cout, (const uint32_t*)L.nch, (const uint32_t*)L.cbase, (const uint32_t*)L.row_pair, (uint32_t)n_rows, (unsigned long long*)(L.misc + 20));
+    if (ctx->dev->timing) hipLaunchKernelGGL(work_rows_kernel, dim3((uint32_t)std::min<size_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, (const ChunkOut*)L.cout, (const uint32_t*)L.nch, (const uint32_t*)L.cbase, (const uint32_t*)L.row_pair, (uint32_t)n_rows, (unsigned long long*)(L.misc + 20));
     // learned-ANI regression (lib.rs:611-614): explicit request, or the default rule c >= 70 && !median when a model is given
     const bool learned = o->model && (o->learned_ani == 1 || (o->learned_ani == -1 && prm.c >= 70 && !o->median));
     if (learned) learned_apply_launch(o->model, L.hits, L.pair_qr, d_qd, d_rd, n_pairs, st);
@@ -4423,6 +4446,7 @@ static psk_status refresh_ref_descs(Lane* ctx, psk_db* db) {
 }
 
 static psk_status build_gsi(Lane* ctx, psk_db* db);
+static psk_status build_bsi(Lane* ctx, psk_db* db);
 // The record a query call hands back: psk_hit (the reference's three numbers, the reference's index and every chaining integer behind them: parity tests) or
 // psk_hit_min (hit.rs:77-104's fields in 20 bytes: what crosses PCIe - and xGMI - when nobody asked for the integers: 9.5 M hits of a metagenome step are 763 MB
 // as psk_hit). The chain stage writes psk_hit per pair on the device either way; the ani > 0.1 selection (lib.rs:654) converts on its way out.
@@ -4494,7 +4518,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
     for (uint32_t b = 0; b < n_queries; b += QB) {
         const uint32_t m = std::min(QB, n_queries - b);
         // ---- screen: pass matrix on the device, counts + flags to the host
-        const size_t o_pass = 0, o_cnt = al256((size_t)m * n), o_flag = al256(o_cnt + 4 * (size_t)m), o_end = o_flag + n;
+        const size_t o_pass = 0, o_cnt = al256((size_t)m * n), o_flag = al256(o_cnt + 8 * (size_t)m), o_end = o_flag + n;      // (d_cnt: the queries' pass counts, then their counts of index blocks with a passing reference)
         PSK_TRY(ctx->q_i.reserve(o_end + 256));
         uint8_t* d_pass = (uint8_t*)ctx->q_i.p + o_pass; uint32_t* d_cnt = (uint32_t*)((char*)ctx->q_i.p + o_cnt); uint8_t* d_flag = (uint8_t*)ctx->q_i.p + o_flag;
         // a single query (psk_query: one contig against the database) is as slow as its chain of waits: its k-mer index is launched here,
@@ -4590,22 +4614,27 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             }
         }
         void* hpin;
+        uint64_t round_blocks = 0;      // over the round's queries: index blocks (2^BSI_BLOG references each) that hold a passing reference
         if ((size_t)m * n <= 65536) {     // a handful of queries: the pass rows themselves cross (<= 64 kB), counted on the host (two launches fewer)
             PSK_TRY(ctx->pinned((size_t)m * n + 64, &hpin));
             PSK_HIP(hipMemcpyAsync(hpin, d_pass, (size_t)m * n, hipMemcpyDeviceToHost, st));
             PSK_HIP(hipStreamSynchronize(st));
             h_cnt.assign(m, 0); h_flag.assign(n, 0);
             const uint8_t* hp = (const uint8_t*)hpin;
-            for (uint32_t i = 0; i < m; i++) for (uint32_t r = 0; r < n; r++) if (hp[(size_t)i * n + r]) { h_cnt[i]++; h_flag[r] = 1; }
+            for (uint32_t i = 0; i < m; i++) {
+                uint32_t last_blk = 0xFFFFFFFFu;
+                for (uint32_t r = 0; r < n; r++) if (hp[(size_t)i * n + r]) { h_cnt[i]++; h_flag[r] = 1; if ((r >> BSI_BLOG) != last_blk) { last_blk = r >> BSI_BLOG; round_blocks++; } }
+            }
         } else {
             PSK_HIP(hipMemsetAsync(d_flag, 0, n, st));
-            hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag);
-            PSK_TRY(ctx->pinned(4 * (size_t)m + n + 64, &hpin));
-            PSK_HIP(hipMemcpyAsync(hpin, d_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
-            PSK_HIP(hipMemcpyAsync((char*)hpin + 4 * (size_t)m, d_flag, n, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(pass_count_kernel, dim3(m), dim3(256), 0, st, d_pass, n, d_cnt, d_flag, d_cnt + m);
+            PSK_TRY(ctx->pinned(8 * (size_t)m + n + 64, &hpin));
+            PSK_HIP(hipMemcpyAsync(hpin, d_cnt, 8 * (size_t)m, hipMemcpyDeviceToHost, st));
+            PSK_HIP(hipMemcpyAsync((char*)hpin + 8 * (size_t)m, d_flag, n, hipMemcpyDeviceToHost, st));
             PSK_HIP(hipStreamSynchronize(st));
             h_cnt.assign((uint32_t*)hpin, (uint32_t*)hpin + m);
-            h_flag.assign((uint8_t*)hpin + 4 * (size_t)m, (uint8_t*)hpin + 4 * (size_t)m + n);
+            for (uint32_t i = 0; i < m; i++) round_blocks += ((const uint32_t*)hpin)[m + i];
+            h_flag.assign((uint8_t*)hpin + 8 * (size_t)m, (uint8_t*)hpin + 8 * (size_t)m + n);
         }
         // ---- the references and queries about to be chained: validate, index, describe
         std::vector<const psk_sketch*> need;
@@ -4643,10 +4672,17 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             const char* sl_env = getenv("PSK_GSI_SLICE");      // (read per round: tests switch it within a process)
             const bool sl_off = sl_env && sl_env[0] == '0', sl_force = sl_env && sl_env[0] == '1';
             const bool want_slice = !want_small && !sl_off && (sl_force || (round_pairs >= 2048 && round_items / round_pairs >= 2048 && round_items / round_pairs <= (1u << 18)));
-            if ((want_small || want_slice) && !gsi_join_off && n <= 65536u && !join_wide_default()) {
+            if (want_small && !gsi_join_off && n <= 65536u && !join_wide_default()) {
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 round_gsi = db->gsi_state == 1;
-                round_slice = round_gsi && want_slice;
+            }
+            // (the slice join walks, per query, the index BLOCKS that hold one of its passing references: worth it while those are few - relatives that sit next to each
+            // other in the database; a query whose references are scattered over many blocks would walk its seeds once per block: PSK_GSL_MAX_BLOCKS, default 4 on average)
+            static const double max_blocks = getenv("PSK_GSL_MAX_BLOCKS") ? atof(getenv("PSK_GSL_MAX_BLOCKS")) : 4.0;
+            uint64_t q_with = 0; for (uint32_t i = 0; i < m; i++) q_with += h_cnt[i] != 0;
+            if (want_slice && !gsi_join_off && n <= 65536u && !join_wide_default() && (sl_force || (double)round_blocks <= max_blocks * (double)std::max<uint64_t>(q_with, 1))) {
+                if (db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));
+                round_gsi = round_slice = db->bsi_state == 1;
             }
         }
         if (round_gsi) {
@@ -4806,7 +4842,8 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                 psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
                 L.rows_pair_max = (uint32_t)std::min<uint64_t>(rows_pair_max, 0xFFFFFFFFu);
                 if (round_gsi) {
-                    L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift;
+                    if (round_slice) { L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks; }
+                    else { L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift; }
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                     L.p_cap = round_slice ? (pm + 15u) & ~15u : (pm + 63u) & ~63u;      // (the slice join's LDS arrays are indexed by pair alone: no need for whole waves of them)
@@ -4987,6 +5024,83 @@ static psk_status build_gsi(Lane* ctx, psk_db* db) {
     PSK_HIP(hipStreamSynchronize(st));      // (segs and tmp die with this frame)
     db->gsi_n = N; db->gsi_shift = kbits - bits;
     db->gsi_state = 1;
+    return PSK_OK;
+}
+
+// ------------------------------------------------------------------ the seed index in blocks of 2^BSI_BLOG references (psk_db::bsi_*: what the slice join walks)
+// bucket table of one block: bucket[b] = base + first entry of the block whose k-mer >> shift is >= b (b = 0 .. nb); an empty block: every entry = base
+__global__ __launch_bounds__(256) void bsi_bucket_kernel(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nb, uint32_t* __restrict__ bucket, uint32_t base) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (n == 0) { for (uint32_t x = i; x <= nb; x += gridDim.x * 256u) bucket[x] = base; return; }
+    if (i >= n) return;
+    const uint32_t b = key[i] >> shift;
+    const uint32_t from = i ? (key[i - 1] >> shift) + 1u : 0u;
+    for (uint32_t x = from; x <= b; x++) bucket[x] = base + i;
+    if (i == n - 1) for (uint32_t x = b + 1; x <= nb; x++) bucket[x] = base + n;
+}
+// called with the database locked exclusively; leaves bsi_state 1 (built) or 2 (this database cannot have one)
+static psk_status build_bsi(Lane* ctx, psk_db* db) {
+    if (db->bsi_state) return PSK_OK;
+    static const bool off = getenv("PSK_GSI") && getenv("PSK_GSI")[0] == '0';
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)db->refs.size();
+    db->bsi_state = 2;
+    if (off || n == 0 || n > 65536u || db->params.k > 16) return PSK_OK;
+    std::vector<GsiSeg> segs(n);
+    uint64_t N = 0; uint32_t maxn = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const psk_sketch* r = db->refs[i];
+        if (!r->has_seeds || r->contig_len.size() > 32768u || r->params.k != db->params.k || r->params.c != db->params.c) return PSK_OK;
+        const uint32_t ns = r->store ? (uint32_t)r->n_seeds : 0u;
+        segs[i] = GsiSeg{ns ? r->store->seed_kmer + r->seed_off : nullptr, ns ? r->store->seed_pm + r->seed_off : nullptr, ns, (uint32_t)N};
+        N += ns; maxn = std::max(maxn, ns);
+        if (N >= 0x7FFFFF00ull) return PSK_OK;
+    }
+    if (N == 0) return PSK_OK;
+    const uint32_t n_blocks = (n + (1u << BSI_BLOG) - 1) >> BSI_BLOG;
+    uint64_t max_block = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const uint32_t r0 = b << BSI_BLOG, r1 = std::min<uint32_t>(n, (b + 1) << BSI_BLOG);
+        max_block = std::max<uint64_t>(max_block, (uint64_t)segs[r1 - 1].off + segs[r1 - 1].n - segs[r0].off);
+    }
+    const int kbits = 2 * db->params.k;
+    int bits = 4; while (bits < 24 && (8ull << bits) < max_block) bits++;      // ~8 entries per bucket of the largest block
+    if (bits > kbits) bits = kbits;
+    const uint32_t nb = 1u << bits;
+    if ((uint64_t)n_blocks * (nb + 1) >= 0x7FFFFF00ull) return PSK_OK;
+    size_t ts = 0;
+    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)std::min<uint64_t>(max_block, 0x7FFFFFFFull), 0, kbits, st));
+    PoolScratch tmp;      // unsorted copies + sort scratch + segment table: back to the pool when the build is done
+    const size_t o_k = 0, o_v = al256(4 * (size_t)N), o_t = al256(o_v + 8 * (size_t)N), o_s = al256(o_t + ts), o_end = o_s + sizeof(GsiSeg) * (size_t)n;
+    psk_status rc = tmp.reserve(ctx->dev, o_end + 256);
+    if (rc == PSK_OK) rc = db->bsi_key.reserve(ctx->dev, 4 * (size_t)N + 256);
+    if (rc == PSK_OK) rc = db->bsi_val.reserve(ctx->dev, 8 * (size_t)N + 256);
+    if (rc == PSK_OK) rc = db->bsi_bucket.reserve(ctx->dev, 4 * ((size_t)n_blocks * (nb + 1) + 2));
+    if (rc != PSK_OK) { db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); if (rc == PSK_ENOMEM) return PSK_OK; return rc; }      // no room: the join takes its other route
+    char* T = (char*)tmp.p;
+    auto fail = [&](hipError_t e, const char* what) -> psk_status {      // (an optional index: a failed build leaves nothing behind and does not fail the query)
+        (void)hipStreamSynchronize(st);
+        db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release();
+        psk_set_error("%s: %s", what, hipGetErrorString(e));
+        return PSK_OK;
+    };
+    hipError_t e = hipMemcpyAsync(T + o_s, segs.data(), sizeof(GsiSeg) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(e, "bsi: upload");
+    hipLaunchKernelGGL(gsi_gather_kernel, dim3(std::max(1u, std::min(64u, (maxn + 4095u) / 4096u)), n), dim3(256), 0, st, (const GsiSeg*)(T + o_s), (uint32_t*)(T + o_k), (unsigned long long*)(T + o_v));
+    for (uint32_t b = 0; b < n_blocks; b++) {      // one stable sort per block: within a k-mer the entries stay in (reference, contig, position) order
+        const uint32_t r0 = b << BSI_BLOG, r1 = std::min<uint32_t>(n, (b + 1) << BSI_BLOG);
+        const size_t o = segs[r0].off; const uint32_t cnt = (uint32_t)((uint64_t)segs[r1 - 1].off + segs[r1 - 1].n - o);
+        if (cnt) {
+            size_t ts_b = ts;
+            e = hipcub::DeviceRadixSort::SortPairs(T + o_t, ts_b, (const uint32_t*)(T + o_k) + o, (uint32_t*)db->bsi_key.p + o, (const unsigned long long*)(T + o_v) + o, (unsigned long long*)db->bsi_val.p + o, (int)cnt, 0, kbits, st);
+            if (e != hipSuccess) return fail(e, "bsi: sort");
+        }
+        hipLaunchKernelGGL(bsi_bucket_kernel, dim3(std::max(1u, (cnt + 255u) / 256u)), dim3(256), 0, st, (const uint32_t*)db->bsi_key.p + o, cnt, kbits - bits, nb, (uint32_t*)db->bsi_bucket.p + (size_t)b * (nb + 1), (uint32_t)o);
+    }
+    e = hipStreamSynchronize(st);      // (segs and tmp die with this frame)
+    if (e != hipSuccess) return fail(e, "bsi: build");
+    db->bsi_n = N; db->bsi_shift = kbits - bits; db->bsi_nb1 = nb + 1; db->bsi_blocks = n_blocks;
+    db->bsi_state = 1;
     return PSK_OK;
 }
 

@@ -20,7 +20,8 @@ struct GslArgs {
     const uint2* ebase;                     // entry -> (x: its first (pair, slice) record, y: its first slice); record of (entry e, slice s, pair j) = ebase[e].x + s * pairs(e) + j
     uint32_t* un; uint32_t n_slices;        // per (entry, slice) GSL_WORDS words: the seeds that head a chunk of some pair of the entry (heads kernel; zeroed by its launcher)
     const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
-    const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;      // psk_db::gsi_*
+    const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;      // psk_db::bsi_*: the seed index in blocks of 2^BSI_BLOG references
+    uint32_t g_nb1, g_blocks;               // bucket-table entries per block; blocks
     uint32_t* cnt;       // per record: anchors of the (pair, slice) (count walk)
     uint4* rec;          // per record, from the heads kernel: {first anchor of the (pair, slice), chunk-table rows of the pair before the slice, lim1 lo, lim1 hi} -
                          // lim1 = (key of the chunk head open at the slice's start) + 1 + FRAGMENT_LENGTH, 0 before the pair's first anchor (key = q contig << 32 | q pos)

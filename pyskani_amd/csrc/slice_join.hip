@@ -114,14 +114,31 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
     constexpr uint32_t GSL_AHEAD = 4;
     unsigned long long visited = 0;      // COUNT: index entries in the runs this lane's seeds found (psk_ctx_join_work)
+    // The index comes in blocks of 2^BSI_BLOG references: only the blocks that hold a passing reference of the query are walked (a run of the whole database's index
+    // holds ~1 % of ALL genomes by chance - see psk_db::bsi_*). A pair's reference sits in one block, so its anchors still come out in seed order.
+    for (uint32_t blk0 = 0; blk0 < A.g_blocks; blk0 += 64) {
+    unsigned long long blk_mask;
+    {
+        const uint32_t bk = blk0 + (uint32_t)lane;
+        uint32_t any = 0;
+        if (bk < A.g_blocks) {
+            const uint32_t w0 = bk << (BSI_BLOG - 5), w1 = (w0 + (1u << (BSI_BLOG - 5))) < 2u * nw ? w0 + (1u << (BSI_BLOG - 5)) : 2u * nw;
+            for (uint32_t w = w0; w < w1; w++) any |= s_bp[w].x;
+        }
+        blk_mask = __ballot(any != 0);
+    }
+    while (blk_mask) {
+    const uint32_t blk = blk0 + (uint32_t)__ffsll((long long)blk_mask) - 1u;
+    blk_mask &= blk_mask - 1ull;
+    const uint32_t* __restrict__ bkt = A.g_bucket + (size_t)blk * A.g_nb1;
     uint32_t km1 = sb + (uint32_t)lane < se ? Q.kmer[sb + lane] : 0u, km2 = sb + 64u + (uint32_t)lane < se ? Q.kmer[sb + 64u + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
-    if (sb + (uint32_t)lane < se) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+    if (sb + (uint32_t)lane < se) { const uint32_t b = km1 >> A.g_shift; lo1 = bkt[b]; hi1 = bkt[b + 1]; }
     for (uint32_t c0 = sb; c0 < se; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
         const uint32_t km = km1, lo = lo1, hi = hi1;
         km1 = km2; lo1 = 0; hi1 = 0;
-        if (i + 64u < se) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+        if (i + 64u < se) { const uint32_t b = km1 >> A.g_shift; lo1 = bkt[b]; hi1 = bkt[b + 1]; }
         km2 = i + 128u < se ? Q.kmer[i + 128u] : 0u;
         uint32_t qp = 0, qm = 0;
         if (EMIT && i < se) { qp = Q.pos[i]; qm = Q.meta[i]; }
@@ -263,6 +280,8 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
         }
 #undef GSL_FETCH
     }
+    }      // the group's blocks that hold a passing reference
+    }      // groups of 64 blocks
     lds_wave_sync();
     if (!EMIT) {
 #pragma unroll

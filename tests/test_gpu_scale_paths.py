@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -88,6 +88,25 @@ db.sketch_many([(n, *c) for n, c in genomes])
 res = db.query_many([(n, *c) for n, c in genomes], learned_ani=False)
 print(*digest(res))
 """
+
+
+INTERLEAVED = COMMON + r"""
+anc = [rng.integers(0, 4, 50_000, dtype=np.uint8) for _ in range(3)]
+genomes = [(f"i{j}", lut[mutate(anc[j % 3], 0.0002 * (j // 3))].tobytes()) for j in range(700)]      # three families dealt out in turn: a query's ~233 relatives sit in all three index blocks
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many(genomes)
+print(*digest(db.query_many(genomes[::7], learned_ani=False)))
+"""
+
+
+def test_slice_join_walks_every_index_block_that_holds_a_passing_reference():
+    """The slice join's seed index comes in blocks of 256 references and a query walks the blocks that hold one of its passing references. Here every query's relatives
+    are spread over all three blocks (the plan still takes the slice join: three blocks per query), each pair's anchors come from the walk of its reference's block;
+    with PSK_GSL_MAX_BLOCKS=1 the plan refuses (too many blocks per query) and the per-pair join runs: the same hits."""
+    base = _run(INTERLEAVED, {})
+    assert base[0] > 100 * 150
+    assert _run(INTERLEAVED, {"PSK_GSI_SLICE": "0"}) == base
+    assert _run(INTERLEAVED, {"PSK_GSL_MAX_BLOCKS": "1"}) == base
 
 
 def test_slice_join_with_more_pairs_than_one_entry_holds(oracle):

@@ -27,7 +27,7 @@ res = {}
 for mode in ("1", "0"):
     os.environ["PSK_GSI_SLICE"] = mode
     db = eng.make_db(names, out, n)      # (a fresh database per mode: the first builds the seed index, the second the per-sketch indexes)
-    nh, (recs, qoffs) = eng.query_many(db, out, n, keep=True)
+    nh, (recs, qoffs) = eng.query_many(db, out, n, keep=True, raw=True)
     recs = recs.copy()
     recs["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(qoffs))
     res[mode] = recs
