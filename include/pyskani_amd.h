@@ -100,6 +100,11 @@ typedef struct { uint32_t kmer, pos, contig, canon; } psk_seed; /* export record
 
 const char* psk_last_error(void);
 const char* psk_version(void);
+/* The C-ABI's revision: raised whenever an entry point's parameters or a structure's layout change (4: psk_sketch_unpack takes the extent of its source buffer as third
+ * argument; 5: psk_hit_min / psk_query_many_min / psk_gather_hits_min / psk_ctx_join_work added). A binding compares psk_abi_version() with the PSK_ABI_VERSION it was
+ * written against before it calls anything else: an argument list that moved is a memory error, not a link error. */
+#define PSK_ABI_VERSION 5
+int psk_abi_version(void);
 /* Releases an array the library returned (hit lists, gathered lists). Never release such an array with free(): large hit arrays are
  * huge-page blocks the library keeps one of for its next call ($PSK_HIT_CACHE=0: returned to the system at once). */
 void psk_free(void* p);

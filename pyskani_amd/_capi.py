@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("PSK_LIB_PATH") or os.path.join(_HERE, "libpyskani_amd
 
 PSK_OK, PSK_EINVAL, PSK_ENOMEM, PSK_EHIP, PSK_ENOMODEL, PSK_EKEY, PSK_ELIMIT, PSK_ERCCL = range(8)
 COMM_ID_BYTES = 128
+ABI_VERSION = 5      # PSK_ABI_VERSION of include/pyskani_amd.h this binding was written against
 
 
 class Params(C.Structure):
@@ -52,7 +53,7 @@ class Seed(C.Structure):
 
 # every symbol include/pyskani_amd.h declares
 SYMBOLS = [
-    "psk_last_error", "psk_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
+    "psk_last_error", "psk_version", "psk_abi_version", "psk_free", "psk_ctx_create", "psk_ctx_destroy",
     "psk_ctx_synchronize", "psk_pack2bit_host", "psk_ctx_small_query_stats", "psk_ctx_set_timing", "psk_ctx_timing", "psk_db_add_batch", "psk_device_alloc", "psk_device_free", "psk_memcpy_h2d",
     "psk_sketch_host", "psk_sketch_many_host", "psk_sketch_batch_device", "psk_sketch_free", "psk_sketch_free_many", "psk_sketch_info",
     "psk_sketch_export", "psk_sketch_contig_lens", "psk_sketch_import", "psk_db_create", "psk_db_destroy", "psk_db_add", "psk_db_size",
@@ -76,6 +77,9 @@ def load():
             "or `make -C pyskani_amd/csrc`. pyskani_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    lib.psk_abi_version.restype = C.c_int
+    if lib.psk_abi_version() != ABI_VERSION:      # (an argument list that moved would be a memory error, not a link error)
+        raise ImportError(f"{LIB_PATH} speaks C-ABI revision {lib.psk_abi_version()}, this binding {ABI_VERSION}: rebuild with `make -C pyskani_amd/csrc`")
     lib.psk_last_error.restype = C.c_char_p
     lib.psk_version.restype = C.c_char_p
     lib.psk_free.argtypes = [vp]

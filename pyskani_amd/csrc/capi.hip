@@ -72,7 +72,8 @@ static psk_status ingest_impl(psk_ctx* ctx, Lane* lane, const psk_params* p, con
 extern "C" {
 
 const char* psk_last_error(void) { return g_err; }
-const char* psk_version(void) { return "pyskani_amd 0.1.0 (gfx950; algorithm: skani 0.3.0 restatement)"; }
+const char* psk_version(void) { return "pyskani_amd 0.5.0 (gfx950; algorithm: skani 0.3.0 restatement)"; }
+int psk_abi_version(void) { return PSK_ABI_VERSION; }
 void psk_free(void* p) { if (p && !hit_block_free(p)) free(p); }
 
 psk_status psk_ctx_create(int device, psk_ctx** out) {
@@ -438,7 +439,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     db->refs.push_back(s);
     db->names.emplace_back(name);
     db->note_added((uint32_t)db->refs.size() - 1);
-    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; if (db->gsi_state == 1) { db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); } db->gsi_state = 0;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); db->gsi_state = 0;
     db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_state = 0;
     return PSK_OK;
 }
@@ -453,7 +454,7 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
         db->names.emplace_back(names[i]);
         db->note_added((uint32_t)db->refs.size() - 1);
     }
-    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; if (db->gsi_state == 1) { db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); } db->gsi_state = 0;
+    db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); db->gsi_state = 0;
     db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_state = 0;
     return PSK_OK;
 }

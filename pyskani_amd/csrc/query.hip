@@ -3552,6 +3552,9 @@ __global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restri
 struct GsiJoinArgs {
     const BatchQ* bq; const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
     const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;
+    // b_blocks > 0: the index is ALSO there in blocks of 2^BSI_BLOG references with a bucket table of b_nb1 entries each (psk_db::bsi_*): a wave whose query has its passing
+    // references in at most b_max of them walks those blocks (a run of the database-wide index holds ~1 % of all genomes by chance), any other wave the database-wide index
+    const uint32_t* b_key; const unsigned long long* b_val; const uint32_t* b_bucket; int b_shift; uint32_t b_nb1, b_blocks, b_max;
     uint32_t* pair_cnt; const uint32_t* pstart; uint4* anc; uint32_t cap; uint32_t* err;
     uint32_t p_cap;      // most pairs any entry of the batch holds, rounded up: what the cursor arrays in LDS are sized for (<= GSI_PMAX)
     uint2* chunks; uint32_t* n_chunks;      // EMIT: the pairs' chunk tables, written by the same walk (rows at entry.row_off + slot * query rows)
@@ -3600,14 +3603,41 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     // before step t is dealt out - the second and third step of a long run (a k-mer that a whole family of references holds) included.
     constexpr uint32_t GSI_AHEAD = 4;
     unsigned long long visited = 0;      // index entries in the runs this lane's seeds found (psk_ctx_join_work)
+    // (blocked index: one walk of the query's seeds per block that holds a passing reference - a pair's reference sits in ONE block, so its anchors keep their order)
+    unsigned long long masks[4] = {1ull, 0ull, 0ull, 0ull};      // blocks to walk, 64 per word (the database-wide index: "block" 0)
+    bool blocked = false;
+    if (A.b_blocks && A.b_blocks <= 256u) {
+        uint32_t n_with = 0; unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint32_t bk = g * 64u + (uint32_t)lane;
+            unsigned long long any = 0;
+            if (bk < A.b_blocks) {
+                const uint32_t w0 = bk << (BSI_BLOG - 6), w1 = (w0 + (1u << (BSI_BLOG - 6))) < nw ? w0 + (1u << (BSI_BLOG - 6)) : nw;
+                for (uint32_t w = w0; w < w1; w++) any |= s_bits[w];
+            }
+            mk[g] = __ballot(any != 0);
+            n_with += (uint32_t)__popcll(mk[g]);
+        }
+        if (n_with <= A.b_max) { blocked = true; masks[0] = mk[0]; masks[1] = mk[1]; masks[2] = mk[2]; masks[3] = mk[3]; }
+    }
+    const uint32_t* __restrict__ x_key = blocked ? A.b_key : A.g_key; const unsigned long long* __restrict__ x_val = blocked ? A.b_val : A.g_val;
+    const int x_shift = blocked ? A.b_shift : A.g_shift;
+#pragma unroll 1
+    for (uint32_t blk0 = 0; blk0 < 256u; blk0 += 64) {
+    unsigned long long blk_mask = masks[blk0 >> 6];
+    while (blk_mask) {
+    const uint32_t blk = blk0 + (uint32_t)__ffsll((long long)blk_mask) - 1u;
+    blk_mask &= blk_mask - 1ull;
+    const uint32_t* __restrict__ bkt = blocked ? A.b_bucket + (size_t)blk * A.b_nb1 : A.g_bucket;
     uint32_t km1 = (uint32_t)lane < nq ? Q.kmer[lane] : 0u, km2 = 64u + (uint32_t)lane < nq ? Q.kmer[64 + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
-    if ((uint32_t)lane < nq) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+    if ((uint32_t)lane < nq) { const uint32_t b = km1 >> x_shift; lo1 = bkt[b]; hi1 = bkt[b + 1]; }
     for (uint32_t c0 = 0; c0 < nq; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
         const uint32_t km = km1, lo = lo1, hi = hi1;
         km1 = km2; lo1 = 0; hi1 = 0;
-        if (i + 64u < nq) { const uint32_t b = km1 >> A.g_shift; lo1 = A.g_bucket[b]; hi1 = A.g_bucket[b + 1]; }
+        if (i + 64u < nq) { const uint32_t b = km1 >> x_shift; lo1 = bkt[b]; hi1 = bkt[b + 1]; }
         km2 = i + 128u < nq ? Q.kmer[i + 128u] : 0u;
         uint32_t qp = 0, qm = 0;
         if (EMIT && i < nq) { qp = Q.pos[i]; qm = Q.meta[i]; }
@@ -3626,7 +3656,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 ns[u] = 63u - (uint32_t)__clzll((long long)own); \
                 nx[u] = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)ns[u]) + 64u * ((t) - (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)ns[u])); \
                 nh[u] = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)ns[u]); \
-                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = A.g_key[nx[u] + lane]; nv[u] = A.g_val[nx[u] + lane]; } \
+                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = x_key[nx[u] + lane]; nv[u] = x_val[nx[u] + lane]; } \
             } } while (0)
 #pragma unroll
         for (uint32_t u = 0; u < GSI_AHEAD; u++) GSI_FETCH(u, u);
@@ -3698,6 +3728,8 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         }
 #undef GSI_FETCH
     }
+    }      // the group's blocks that hold a passing reference
+    }      // groups of 64 blocks
     lds_wave_sync();
     if (EMIT) {
 #pragma unroll
@@ -3767,6 +3799,7 @@ struct ChainBufs {
     // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
     uint32_t g_nb1 = 0, g_blocks = 0;      // (the slice join's index comes in blocks of references: psk_db::bsi_*)
+    const uint32_t* b_key = nullptr; const unsigned long long* b_val = nullptr; const uint32_t* b_bucket = nullptr; int b_shift = 0; uint32_t b_nb1 = 0, b_blocks = 0, b_max = 0;      // the contig join: the blocked index beside the database-wide one
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
     // mid-sized pairs (all-vs-all of genomes): the index join by (query, slice) waves (slice_join.hip); the batch's wave table, record offsets and per-record arrays
     bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint2* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr, *gsl_un = nullptr, gsl_n_slices = 0; uint4* gsl_rec = nullptr;
@@ -3822,6 +3855,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
+        GA.b_key = L.b_key; GA.b_val = L.b_val; GA.b_bucket = L.b_bucket; GA.b_shift = L.b_shift; GA.b_nb1 = L.b_nb1; GA.b_blocks = L.b_blocks; GA.b_max = L.b_max;
         GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
         if (gsl) {
             GL.bq = L.bq; GL.n_entries = L.n_bq; GL.tab = L.gsl_tab; GL.n_tab = L.gsl_n_tab; GL.ebase = L.gsl_ebase; GL.pass = L.d_pass; GL.n_refs = L.n_refs; GL.qd = d_qd;
@@ -4658,7 +4692,8 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
         // index (one lookup per query SEED finds its matches in every reference: gsi_join_kernel; no per-sketch index is read, so none is built for such a
         // round - neither for the references nor for the round's 65 536 contigs) or, where the database cannot have one, through per-reference probe tables
         // (one 64-byte line per (pair, seed)). PSK_PROBE=0 never, =1 whatever the round's shape; PSK_GSI_JOIN=0: the probe tables (tests, A/B)
-        bool round_probe = false, round_gsi = false, want_small = false, round_slice = false;
+        bool round_probe = false, round_gsi = false, want_small = false, round_slice = false, round_bsi = false;
+        static const double max_blocks_join = getenv("PSK_GSL_MAX_BLOCKS") ? atof(getenv("PSK_GSL_MAX_BLOCKS")) : 4.0;
         {
             const char* pb_env = getenv("PSK_PROBE");
             const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
@@ -4672,17 +4707,25 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             const char* sl_env = getenv("PSK_GSI_SLICE");      // (read per round: tests switch it within a process)
             const bool sl_off = sl_env && sl_env[0] == '0', sl_force = sl_env && sl_env[0] == '1';
             const bool want_slice = !want_small && !sl_off && (sl_force || (round_pairs >= 2048 && round_items / round_pairs >= 2048 && round_items / round_pairs <= (1u << 18)));
+            static const double max_blocks = getenv("PSK_GSL_MAX_BLOCKS") ? atof(getenv("PSK_GSL_MAX_BLOCKS")) : 4.0;
+            uint64_t q_with = 0; for (uint32_t i = 0; i < m; i++) q_with += h_cnt[i] != 0;
+            const bool few_blocks = (double)round_blocks <= max_blocks * (double)std::max<uint64_t>(q_with, 1);
             if (want_small && !gsi_join_off && n <= 65536u && !join_wide_default()) {
+                // contigs: through the index in blocks of references when their passing references sit in few of them (a contig's relatives - what the marker screen and the
+                // prefilter of rescued contigs leave), through the database-wide index otherwise (a rescued contig against EVERY reference: one walk instead of one per block)
+                static const bool bsi_small_off = getenv("PSK_BSI_SMALL") && getenv("PSK_BSI_SMALL")[0] == '0';      // (tests, A/B)
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 round_gsi = db->gsi_state == 1;
+                if (round_gsi && !bsi_small_off) {      // (every wave of the join chooses by its own query: both indexes are handed over)
+                    if (db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));
+                    round_bsi = db->bsi_state == 1;
+                }
             }
             // (the slice join walks, per query, the index BLOCKS that hold one of its passing references: worth it while those are few - relatives that sit next to each
             // other in the database; a query whose references are scattered over many blocks would walk its seeds once per block: PSK_GSL_MAX_BLOCKS, default 4 on average)
-            static const double max_blocks = getenv("PSK_GSL_MAX_BLOCKS") ? atof(getenv("PSK_GSL_MAX_BLOCKS")) : 4.0;
-            uint64_t q_with = 0; for (uint32_t i = 0; i < m; i++) q_with += h_cnt[i] != 0;
-            if (want_slice && !gsi_join_off && n <= 65536u && !join_wide_default() && (sl_force || (double)round_blocks <= max_blocks * (double)std::max<uint64_t>(q_with, 1))) {
+            if (want_slice && !gsi_join_off && n <= 65536u && !join_wide_default() && (sl_force || few_blocks)) {
                 if (db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));
-                round_gsi = round_slice = db->bsi_state == 1;
+                round_gsi = round_slice = round_bsi = db->bsi_state == 1;
             }
         }
         if (round_gsi) {
@@ -4843,7 +4886,10 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                 L.rows_pair_max = (uint32_t)std::min<uint64_t>(rows_pair_max, 0xFFFFFFFFu);
                 if (round_gsi) {
                     if (round_slice) { L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks; }
-                    else { L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift; }
+                    else {
+                        L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift;
+                        if (round_bsi) { L.b_key = (const uint32_t*)db->bsi_key.p; L.b_val = (const unsigned long long*)db->bsi_val.p; L.b_bucket = (const uint32_t*)db->bsi_bucket.p; L.b_shift = db->bsi_shift; L.b_nb1 = db->bsi_nb1; L.b_blocks = db->bsi_blocks; L.b_max = (uint32_t)std::max(1.0, max_blocks_join); }
+                    }
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                     L.p_cap = round_slice ? (pm + 15u) & ~15u : (pm + 63u) & ~63u;      // (the slice join's LDS arrays are indexed by pair alone: no need for whole waves of them)
@@ -5014,14 +5060,22 @@ static psk_status build_gsi(Lane* ctx, psk_db* db) {
     if (rc == PSK_OK) rc = db->gsi_key.reserve(ctx->dev, 4 * (size_t)N + 256);
     if (rc == PSK_OK) rc = db->gsi_val.reserve(ctx->dev, 8 * (size_t)N + 256);
     if (rc == PSK_OK) rc = db->gsi_bucket.reserve(ctx->dev, 4 * ((size_t)nb + 2));
-    if (rc == PSK_ENOMEM) { db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); return PSK_OK; }      // no room: the paths that would use it take their other route
-    PSK_TRY(rc);
+    if (rc != PSK_OK) { db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); return rc == PSK_ENOMEM ? PSK_OK : rc; }      // no room: the paths that would use it take their other route
     char* T = (char*)tmp.p;
-    PSK_HIP(hipMemcpyAsync(T + o_s, segs.data(), sizeof(GsiSeg) * (size_t)n, hipMemcpyHostToDevice, st));
+    auto fail = [&](hipError_t e, const char* what) -> psk_status {      // an OPTIONAL index: a failed build leaves no buffer behind, state 2, and does not fail the caller's query
+        (void)hipStreamSynchronize(st);
+        db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release();
+        psk_set_error("%s: %s", what, hipGetErrorString(e));
+        return PSK_OK;
+    };
+    hipError_t e = hipMemcpyAsync(T + o_s, segs.data(), sizeof(GsiSeg) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(e, "gsi: upload");
     hipLaunchKernelGGL(gsi_gather_kernel, dim3(std::max(1u, std::min(64u, (maxn + 4095u) / 4096u)), n), dim3(256), 0, st, (const GsiSeg*)(T + o_s), (uint32_t*)(T + o_k), (unsigned long long*)(T + o_v));
-    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(T + o_t, ts, (const uint32_t*)(T + o_k), (uint32_t*)db->gsi_key.p, (const unsigned long long*)(T + o_v), (unsigned long long*)db->gsi_val.p, (int)N, 0, kbits, st));
+    e = hipcub::DeviceRadixSort::SortPairs(T + o_t, ts, (const uint32_t*)(T + o_k), (uint32_t*)db->gsi_key.p, (const unsigned long long*)(T + o_v), (unsigned long long*)db->gsi_val.p, (int)N, 0, kbits, st);
+    if (e != hipSuccess) return fail(e, "gsi: sort");
     hipLaunchKernelGGL(gsi_bucket_kernel, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, (const uint32_t*)db->gsi_key.p, (uint32_t)N, kbits - bits, nb, (uint32_t*)db->gsi_bucket.p);
-    PSK_HIP(hipStreamSynchronize(st));      // (segs and tmp die with this frame)
+    e = hipStreamSynchronize(st);      // (segs and tmp die with this frame)
+    if (e != hipSuccess) return fail(e, "gsi: build");
     db->gsi_n = N; db->gsi_shift = kbits - bits;
     db->gsi_state = 1;
     return PSK_OK;

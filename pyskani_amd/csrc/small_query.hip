@@ -674,7 +674,7 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
         if (L > (uint64_t)SQ_MAX_TILES * TILE_BASES) return PSK_OK;
         n_desc++; n_tiles += (uint32_t)((L + TILE_BASES - 1) / TILE_BASES); bases += L; rows += L / (FRAGMENT_LENGTH + 1) + 1;
         ascii_bytes += (L + 15 + 16) & ~15ull;
-        if (n_desc > SQ_MAX_DESC || n_tiles > SQ_MAX_TILES) return PSK_OK;
+        if (n_desc >= SQ_MAX_DESC || n_tiles > SQ_MAX_TILES) return PSK_OK;      // (>=: the emit wave fills coff[0 .. n_desc] one entry per lane - 64 kept contigs would need a 65th lane for the total: ADVICE r4)
     }
     if (n_desc == 0 || rows > SQ_ROWS) return PSK_OK;
     auto cap_of = [](double expect) { return expect * 1.1 + 6.0 * sqrt(expect) + 64.0; };
@@ -748,7 +748,11 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
     std::call_once(lds_once, [] { lds_rc = hipFuncSetAttribute((const void*)sq_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SQ_MAX_REFS)); });
     PSK_HIP(lds_rc);
     ctx->t_begin(K_SCREEN);
+    // (the status block in pinned memory is the device's to fill: until it has, it says "rerun on the general path" - a launch that never ran must not leave
+    // the PREVIOUS call's status and hits to be read as this call's: ADVICE r4)
+    if (zc) ((SmallQHead*)Hout)->flags = 0xFFFFFFFFu;
     hipLaunchKernelGGL(sq_screen_kernel, dim3(1), dim3(SQ_SCREEN_T), 4 * (size_t)n_refs, st, SA);
+    PSK_HIP(hipGetLastError());
     ctx->t_end();
     SqChainArgs CA{};
     CA.head = d_head; CA.head_w = d_head; CA.shortlist = SA.shortlist; CA.q_kmer = S.seed_kmer; CA.q_pos = S.seed_pos; CA.q_meta = S.seed_meta;
@@ -769,6 +773,7 @@ psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs
     static const uint32_t grid_env = getenv("PSK_SQ_GRID") ? (uint32_t)std::max(1, atoi(getenv("PSK_SQ_GRID"))) : 0u;
     const uint32_t grid = grid_env ? grid_env : std::max(64u, std::min(1024u, ctx->sq_last_short + ctx->sq_last_short / 4 + 16u));
     hipLaunchKernelGGL(sq_chain_kernel, dim3(std::min<uint32_t>(n_refs, grid)), dim3(SQ_CHAIN_T), 0, st, CA);
+    PSK_HIP(hipGetLastError());
     ctx->t_end();
     if (!zc) PSK_HIP(hipMemcpyAsync(Hout, d_head, out_first, hipMemcpyDeviceToHost, st));
     PSK_HIP(hipStreamSynchronize(st));      // the ONE synchronisation of the call

@@ -723,7 +723,7 @@ class Database:
         n = C.c_uint64(0)
         _capi.check(self._lib.psk_query_host(self._h, arr, lens, nc, 1 if seed else 0, C.byref(opts), C.byref(hits_p), C.byref(n)))
         try:      # (one C-level copy into an immutable bytes object; a structured np.empty + memmove costs five times as much for a hundred hits)
-            return np.frombuffer(C.string_at(hits_p, n.value * self._HIT_DTYPE.itemsize), dtype=self._HIT_DTYPE) if n.value else np.empty(0, self._HIT_DTYPE)
+            return _capi.hit_records(hits_p, 0, n.value, self._HIT_DTYPE)      # (an array that owns its memory and can be written: callers add shard offsets in place)
         finally:
             if hits_p:
                 self._lib.psk_free(hits_p)

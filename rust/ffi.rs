@@ -45,6 +45,7 @@ extern "C" {
     // errors, version, memory
     pub fn psk_last_error() -> *const c_char;
     pub fn psk_version() -> *const c_char;
+    pub fn psk_abi_version() -> c_int;      // compare with PSK_ABI_VERSION (5) before anything else is called
     pub fn psk_free(p: *mut c_void);
     // context (one per GPU)
     pub fn psk_ctx_create(device: c_int, out: *mut *mut PskCtx) -> c_int;

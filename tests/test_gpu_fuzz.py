@@ -109,6 +109,8 @@ def test_random_databases_match_oracle(psk, oracle, seed, monkeypatch):
             monkeypatch.setenv("PSK_GSI_JOIN", "0")
         elif seed % 8 == 4:
             monkeypatch.setenv("PSK_GSI_ONEPASS", "0")
+        else:
+            monkeypatch.setenv("PSK_BSI_SMALL", "0")  # ... the database-wide index in one walk (default: the index in blocks of 256 references)
     k = int(rng.integers(11, 17)); c = int(rng.choice([30, 60, 125, 200])); mc = int(c * rng.choice([4, 8]))
     fams = [random_genome(rng, int(rng.integers(60000, 250000))) for _ in range(int(rng.integers(1, 4)))]
     refs = []
