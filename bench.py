@@ -488,10 +488,11 @@ def load_pmc():
     """offline counter passes (rocprofv3 --pmc, separate runs; profiles/scripts/pmc_summary.py writes the JSON): HBM bytes per unit of work of
     the profiled kernels, {workload: {timer name: {"bytes_per_unit": x, "unit": "base" | "item" | "anchor", "source": ...}}}"""
     out = {}
-    p = os.path.join(ROOT, "profiles", "r2", "r2n_pmc_sketch_scan.json")
-    if os.path.exists(p):      # sketch_scan is unchanged since round 2 (same counters in round 1)
+    rel = "profiles/r5/r5_pmc_sketch_scan.json" if os.path.exists(os.path.join(ROOT, "profiles", "r5", "r5_pmc_sketch_scan.json")) else "profiles/r2/r2n_pmc_sketch_scan.json"
+    p = os.path.join(ROOT, *rel.split("/"))
+    if os.path.exists(p):      # (counted again in round 5: the kernel's body became a template in round 4)
         d = json.load(open(p))
-        ss = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": "profiles/r2/r2n_pmc_sketch_scan.json", "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
+        ss = {"bytes_per_unit": d["traffic_bytes_per_base"], "unit": "base", "source": rel, "valu_per_base": d["valu_wave_instructions_per_launch"] / d["bases_per_launch"]}
         for wl in ("search", "allvsall", "metagenome", "mammalian"):
             out.setdefault(wl, {})["sketch_scan"] = ss
     # (round 4: scale factors calibrated per access shape, profiles/r4/r4k_pmc_calibration.md; the round-3 file for whatever the newer one lacks)
@@ -519,7 +520,8 @@ def kernel_rooflines(kern, steps, units, pmc):
          anchor        COUNT walk (where it runs: the two-pass forms): 12 B per lookup (k-mer, two bucket bounds) + 12 B per index entry of the looked-up runs
          anchor_emit   EMIT walk: the same reads + 8 B per lookup (the seed's position and contig|strand) + 16 B per anchor written
        chain_chunk   16 B per anchor read (the DP; its candidates are a few bytes per chunk)
-       select        32 B per candidate chain (seven 4-byte fields read, the verdict written) + 8 B per chunk row (its table entry)
+       select        32 B per candidate chain (seven 4-byte fields read, the verdict written) + 8 B per chunk row (its table entry) + 128 B per chunk row (chunk_seeds_kernel,
+                     inside this timer: two binary searches of ~16 four-byte probes in the query's seed positions)
        pair_reduce   32 B per chunk row (the chunk's totals) + 80 B per pair (the record written)
     A bracket that did not do the work its formula counts (a join pass that was not launched: ~0 ms) would price above the HBM peak: such rows carry no fraction
     (tests/test_bench_line_cpu.py rejects frac > 1). The screen (an inverted-index lookup, below 3 % of every step) is reported as time only."""
@@ -530,7 +532,7 @@ def kernel_rooflines(kern, steps, units, pmc):
            "sketch_sort": ((20.0 / units["c"] + 16.0 / units["marker_c"]) * bases, "k-mer index: 20 B per seed (key, position|meta, order); marker sets: 16 B per marker; per base: 20/c + 16/marker_c"),
            "sketch_emit": ((0.125 + 0.25 + 20.0 / units["c"] + 8.0 / units["marker_c"]) * bases, "L/8 + L/4 + 20 L/c + 8 L/marker_c per base"),
            "chain_chunk": (16.0 * anchors, "16 B per anchor"),
-           "select": (32.0 * cands + 8.0 * rows, "32 B per candidate chain + 8 B per chunk row"),
+           "select": (32.0 * cands + 136.0 * rows, "32 B per candidate chain + 8 B per chunk row (its table entry) + 128 B per chunk row (chunk_seeds: two binary searches of ~16 probes in the query's seed positions)"),
            "pair_reduce": (32.0 * rows + 80.0 * pairs, "32 B per chunk row + 80 B per pair")}
     if lookups > 0:
         alg["anchor"] = (12.0 * lookups + 12.0 * visited, "seed-index COUNT walk: 12 B per query-seed lookup + 12 B per index entry visited")

@@ -4160,8 +4160,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
             }
         }
     }
+    hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);      // (inside the selection's timer: the seeds between a chunk's outermost kept anchors - 3.9 % of the 10 000 x 10 000 step that no timer held)
     ctx->t_end();
-    hipLaunchKernelGGL(chunk_seeds_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, A);
     ReduceArgs R{};
     R.chunks = L.cout; R.n_chunks = L.nch; R.cbase = L.cbase; R.pstart = L.pstart; R.pcnt = gsi_one ? L.aoff : nullptr; R.pairs = L.pairs; R.pair_qr = L.pair_qr;
     R.k = prm.k; R.median = o->median; R.robust = o->robust;

@@ -198,6 +198,61 @@ def test_large_batch_sample_matches_oracle(oracle):
     assert checked == 40
 
 
+MANY_REFS = COMMON + r"""
+import time, torch
+N = int(os.environ.get("PSK_TEST_MANY_REFS", "70000"))
+fam = N // 100
+anc = rng.integers(0, 4, (fam, 2800), dtype=np.uint8)
+refs = []
+for i in range(N):
+    a = anc[i // 100].copy(); m = rng.random(2800) < 0.0003 * (i % 100); a[m] = (a[m] + 1) & 3
+    refs.append((f"r{i}", lut[a[: 2000 + (i * 7) % 800]].tobytes()))
+contigs = []
+for j in range(2000):
+    i = int(rng.integers(0, N)); a = anc[i // 100].copy(); m = rng.random(2800) < 0.01; a[m] = (a[m] + 2) & 3
+    contigs.append((f"c{j}", lut[a[100:2700]].tobytes()))
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many(refs)
+t0 = time.perf_counter(); res = db.query_many(contigs, learned_ani=False); t1 = time.perf_counter()
+free0 = torch.cuda.mem_get_info()[0]
+res2 = db.query_many(contigs, learned_ani=False); t2 = time.perf_counter()
+free1 = torch.cuda.mem_get_info()[0]
+n, d = digest(res)
+assert digest(res2) == (n, d)
+import pickle
+pick = np.random.default_rng(3).choice(2000, 40, replace=False)
+sample = []
+for j in pick:
+    hs = res[int(j)]
+    if hs:
+        h = hs[len(hs) // 2]
+        sample.append((int(j), h.reference_name, {f: int(h._raw[f]) for f in ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")}, h.identity, h.query_fraction))
+pickle.dump((sample, {n: g for n, g in refs if any(n == s[1] for s in sample)}, {j: contigs[j][1] for j, *_ in sample}), open(os.environ["PSK_TEST_SAMPLE"], "wb"))
+print(n, d, free0 - free1, round(t2 - t1, 3))
+"""
+
+
+def test_database_beyond_the_seed_index_limit(oracle, tmp_path):
+    """the seed indexes carry 16-bit reference ids and are not built for more than 65 536 references; the plan then joins contigs through the
+    references' probe tables (and filters rescued contigs through the per-reference indexes). 70 000 references of 2-2.8 kb, 2 000 contig queries (every contig has fewer
+    than 20 markers: rescued, i.e. screened against EVERY reference): the same hits from a second call, free device memory flat across it, 40 sampled hits recomputed by
+    the oracle. (The cost of the cliff is measured by tools/many_refs_cliff.py: DESIGN.md section 8.)"""
+    import pickle
+    sample_file = str(tmp_path / "sample.pkl")
+    env = dict(os.environ, PSK_TEST_SAMPLE=sample_file)
+    for k in ("PSK_GSI_JOIN", "PSK_PROBE", "PSK_PREFILTER", "PSK_BSI_SMALL"):
+        env.pop(k, None)
+    out = subprocess.check_output([sys.executable, "-c", "import os\n" + MANY_REFS], env=env, timeout=1500).decode().split()
+    assert int(out[0]) > 2000 * 20 and int(out[2]) < (64 << 20), out      # hits; device memory the second call kept
+    sample, refs, contigs = pickle.load(open(sample_file, "rb"))
+    assert len(sample) >= 30
+    for j, rname, ints, ani, afq in sample:
+        want = oracle.chain(oracle.Sketch([refs[rname]], c=30, marker_c=200), oracle.Sketch([contigs[j]], c=30, marker_c=200))
+        for f, v in ints.items():
+            assert v == int(getattr(want, f)), (j, rname, f, v, int(getattr(want, f)))
+        assert abs(ani - want.ani) < 1e-6 and abs(afq - want.af_query) < 1e-6
+
+
 def test_prefilter_scratch_returns_to_the_pool():
     """the seed prefilter's scratch block was a PoolScratch local without a destructor and leaked one block per
     query_many round. Free device memory must stay flat over repeated calls with the prefilter forced on."""
