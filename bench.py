@@ -112,8 +112,10 @@ def compact_workload(e):
     if not e:
         return None
     if "ms_per_step" not in e:      # the API leg: rates only
-        return {k: _sig(v) for k, v in e.items() if isinstance(v, (int, float))}
-    out = _pick(e, ("ms_per_step", "value", "unit", "hits", "hits_digest", "scaling"))
+        return {k: _sig(v) for k, v in e.items() if isinstance(v, (int, float)) and not isinstance(v, bool) and k not in ("api_query_ms", "api_db_load_s")}
+    out = _pick(e, ("ms_per_step", "value", "unit", "hits", "hits_digest"))
+    if str(e.get("scaling", "")).startswith(("strong", "weak")):
+        out["scaling"] = e["scaling"]
     out["roofline"] = compact_roofline(e.get("roofline"), short=True)
     if e.get("host_to_host") and "value" in e["host_to_host"]:
         out["host_to_host"] = _pick(e["host_to_host"], ("value", "ms_per_step", "ingest", "vs_cpu_all_cores"))
@@ -503,7 +505,7 @@ def load_pmc():
                 if wl.startswith("_"):
                     continue
                 for k, v in timers.items():
-                    out.setdefault(wl, {})[k] = dict(v, source="/".join(rel))
+                    out.setdefault(wl, {})[k] = dict(out.get(wl, {}).get(k, {}), **dict(v, source="/".join(rel)))      # (keeps what an earlier file alone carries: sketch_scan's VALU count)
     return out
 
 

@@ -3852,7 +3852,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     bool probe_local = false;
     GsiJoinArgs GA{};
     GslArgs GL{};
-    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
+    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5 + (getenv("PSK_GSI_LDS_PAD") ? (size_t)atoi(getenv("PSK_GSI_LDS_PAD")) : 0);      // (experiment: what staging anchor lines in LDS would cost in residency)
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
         GA.b_key = L.b_key; GA.b_val = L.b_val; GA.b_bucket = L.b_bucket; GA.b_shift = L.b_shift; GA.b_nb1 = L.b_nb1; GA.b_blocks = L.b_blocks; GA.b_max = L.b_max;
