@@ -1460,6 +1460,13 @@ __global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __
 
 // ------------------------------------------------------------------ chaining
 struct ChunkOut { uint32_t anchors, seeds, n_intervals, n_cand; uint32_t left, right; uint64_t cov_q; };
+// One field of the 32-byte candidate-chain records {score, q0, q1, r0, r1, anchors, ref contig, state}: element i of the field at p[8 i]. The fields were eight arrays of
+// their own until round 5: a chunk holds one or two candidates, so the selection read one 64-byte line PER FIELD per chunk - 1.0-1.9 kB of HBM traffic per candidate
+// (profiles/r5/pmc_kernels.json) for 32 bytes of content, at 5 TB/s: its whole run time. As records a chunk's candidates are one line.
+template <class T> struct Strided {
+    T* p;
+    __host__ __device__ __forceinline__ T& operator[](size_t i) const { return p[i * 8]; }
+};
 
 struct ChainArgs {
     const uint4* anc;      // anchors, array of (q pos, r pos, ref contig << 1 | reverse_match, q contig): a lane's chunk is one contiguous run of 16-byte records
@@ -1470,7 +1477,7 @@ struct ChainArgs {
     ChunkOut* out;
     // serial-path scratch, one entry per anchor
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
-    int32_t* c_score; uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_state, *c_rc;   // candidate chains, chunk s writes at [s, s + n_cand)
+    Strided<int32_t> c_score; Strided<uint32_t> c_q0, c_q1, c_r0, c_r1, c_n, c_state, c_rc;   // candidate chains, chunk s writes at [s, s + n_cand): fields of 32-byte records
     uint32_t two_c; int band; int force_serial; int lane_dp;
     int dp_prune;      // the lane / quad DP kernels score the far part of the band only where it could win ($PSK_DP_PRUNE=0: always)
     uint32_t* ovf_list; uint32_t* ovf_count;   // rows the lane kernel hands to the wave kernel (more than LANE_TREES qualifying chain trees, >= 16 384 anchors)
@@ -2351,7 +2358,7 @@ constexpr int CMAX = 1024;
 
 struct SelArgs {
     const uint2* chunks; const uint32_t* n_chunks; const uint32_t* cbase; uint32_t n_pairs;
-    const int32_t* c_score; const uint32_t *c_q0, *c_q1, *c_r0, *c_r1, *c_n, *c_rc; uint32_t* c_state;
+    Strided<int32_t> c_score; Strided<uint32_t> c_q0, c_q1, c_r0, c_r1, c_n, c_rc, c_state;
     ChunkOut* out; uint32_t two_c; int force_serial; uint32_t* stats;
     const uint32_t* live; const uint32_t* n_live;      // pairs that have a chunk table (every other pair has no candidate chain)
     uint32_t* rest_list; uint32_t* rest_count;         // select_tiny_kernel: the live pairs it did NOT take (what the wave kernel still has to visit)
@@ -3787,7 +3794,7 @@ __global__ __launch_bounds__(256) void work_rows_kernel(const ChunkOut* __restri
     }
 }
 
-constexpr size_t CHAIN_ANCHOR_WORDS = 12;      // u32 per anchor in Lane::q_d: the 16-byte record, the successor / state array, the candidates' seven
+constexpr size_t CHAIN_ANCHOR_WORDS = 14;      // u32 per anchor in Lane::q_d: the 16-byte record, the successor array, the serial DP's back-pointers, the 32-byte candidate record
 // device arrays of one chain launch sequence, carved from ctx->q_b
 struct ChainBufs {
     PairDesc* pairs; uint32_t *sbase, *cbase, *pstart; uint2* lbcnt; uint32_t* aoff; uint32_t* nch; uint2* chunks; ChunkOut* cout;
@@ -3957,9 +3964,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.anc = anc;
     A.sc_ptr = D + 5 * na;
     A.sc_f = (int32_t*)E4; A.sc_root = E4 + na; A.sc_depth = E4 + 2 * na; A.sc_best = E4 + 3 * na;
-    A.c_score = (int32_t*)(D + 6 * na); A.c_q0 = D + 7 * na; A.c_q1 = D + 8 * na; A.c_r0 = D + 9 * na; A.c_r1 = D + 10 * na; A.c_n = D + 11 * na;
-    A.c_state = a_nxt;   // spare per-anchor array
-    A.c_rc = A.sc_ptr;   // the serial DP keeps no back-pointers: the array holds the candidates' ref contig
+    uint32_t* CAND = D + 6 * na;      // 8 words per anchor slot: one 32-byte record per candidate chain
+    A.c_score.p = (int32_t*)CAND; A.c_q0.p = CAND + 1; A.c_q1.p = CAND + 2; A.c_r0.p = CAND + 3; A.c_r1.p = CAND + 4; A.c_n.p = CAND + 5; A.c_rc.p = CAND + 6; A.c_state.p = CAND + 7;
     A.chunks = L.chunks; A.n_chunks = L.nch; A.cbase = L.cbase; A.n_pairs = n_pairs; A.n_rows = (uint32_t)n_rows;
     A.row_pair = L.row_pair;
     A.pairs = L.pairs;
