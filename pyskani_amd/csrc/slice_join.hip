@@ -46,11 +46,13 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
         }
 }
 
-// LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][pass row as (32 bits, prefix count) entries: 2 nw x 8]
+// LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][EMIT: (cursor, first anchor) per pair, the step's lines]
+// [the walked block's pass row as eight (32 bits, prefix count) entries][passing references before every block: g_blocks x 4]
 // [COUNT: cursors: p_cap x 4; anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words | EMIT: (cursor, first anchor) per pair: p_cap x 8; rows so far per pair: p_cap x 4]
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
-    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 16 * nw + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+    (void)nw;
+    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (((size_t)A.g_blocks + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
 // an anchor leaves for HBM and is not read again before the DP kernels: a streaming store does not claim L2 lines the walk's index reads want to find again
@@ -77,28 +79,32 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     const uint32_t P = B.rank_hi - B.rank_lo, pc = A.p_cap;
     const uint2 eb = A.ebase[te.x];
     const uint32_t rec0 = eb.x + te.y * P;
-    const uint32_t nw = (A.n_refs + 63u) / 64u;
     uint4* s_line = s_gsl;                                                                  // EMIT: slot t of pair j at [t * pc + j]
     unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? 4u * pc : 0u));       // EMIT: lim1 of the pair's open chunk
     uint2* s_cs = (uint2*)(s_lim + (EMIT ? pc : 0u));                                       // EMIT: (cursor, first anchor of the (pair, slice)): one 8-byte read
     uint2* s_fl = s_cs + (EMIT ? pc : 0u);                                                  // EMIT: the step's complete lines (pair | first slot << 16, first anchor of the line)
-    uint2* s_bp = s_fl + (EMIT ? 64u : 0u);                                                 // the query's row of the pass matrix, 32 references per entry: (bits, passing references before them)
-    uint32_t* s_cur = (uint32_t*)(s_bp + 2u * nw);                                        // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
+    uint2* s_bp = s_fl + (EMIT ? 64u : 0u);                                                 // the block being walked: its 256 references of the query's pass row, 32 per entry: (bits, passing references before them)
+    uint32_t* s_bpre = (uint32_t*)(s_bp + 8u);                                              // passing references before every block of the index
+    uint32_t* s_cur = s_bpre + ((A.g_blocks + 1u) & ~1u);                                   // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
     uint32_t* s_rows = s_cur;
     uint32_t* s_bm = s_cur + pc;                                                            // COUNT: word w of pair j at [w * (pc + 1) + j]
-    {   // the query's row of the pass matrix -> bitset + prefix counts (reference -> rank -> pair of the entry: two LDS reads)
-        const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
+    // The index comes in blocks of 2^BSI_BLOG references: only the blocks that hold a passing reference of the query are walked (a run of the whole database's index
+    // holds ~1 % of ALL genomes by chance - see psk_db::bsi_*). A pair's reference sits in one block, so its anchors still come out in seed order.
+    const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
+    unsigned long long masks[4] = {0ull, 0ull, 0ull, 0ull};      // blocks with a passing reference (g_blocks <= 256: the indexes carry 16-bit reference ids)
+    {   // one sweep over the query's row of the pass matrix, a block (four 64-reference words) at a time: which blocks to walk, passing references before each
+        static_assert(BSI_BLOG == 8, "four ballots of 64 references = one index block");
         uint32_t run = 0;
-        for (uint32_t w0 = 0; w0 < nw; w0 += 4) {
+        for (uint32_t blk = 0; blk < A.g_blocks; blk++) {
             uint8_t f[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t r = (w0 + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
+            for (int u = 0; u < 4; u++) { const uint32_t r = (blk * 4u + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
+            if (lane == 0) s_bpre[blk] = run;
+            uint32_t n_here = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned long long m = __ballot(f[u] != 0);
-                if (w0 + u < nw && lane == 0) { s_bp[2u * (w0 + u)] = make_uint2((uint32_t)m, run); s_bp[2u * (w0 + u) + 1u] = make_uint2((uint32_t)(m >> 32), run + (uint32_t)__popc((uint32_t)m)); }
-                run += (uint32_t)__popcll(m);
-            }
+            for (int u = 0; u < 4; u++) n_here += (uint32_t)__popcll(__ballot(f[u] != 0));
+            if (n_here) { const unsigned long long bit = 1ull << (blk & 63u); const uint32_t g = blk >> 6; masks[0] |= g == 0 ? bit : 0ull; masks[1] |= g == 1 ? bit : 0ull; masks[2] |= g == 2 ? bit : 0ull; masks[3] |= g == 3 ? bit : 0ull; }
+            run += n_here;
         }
         if (EMIT) for (uint32_t j = lane; j < P; j += 64) { const uint4 v = A.rec[rec0 + j]; s_cs[j] = make_uint2(v.x, v.x); s_rows[j] = v.y; s_lim[j] = ((unsigned long long)v.w << 32) | v.z; }
         else {
@@ -114,22 +120,26 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
     constexpr uint32_t GSL_AHEAD = 4;
     unsigned long long visited = 0;      // COUNT: index entries in the runs this lane's seeds found (psk_ctx_join_work)
-    // The index comes in blocks of 2^BSI_BLOG references: only the blocks that hold a passing reference of the query are walked (a run of the whole database's index
-    // holds ~1 % of ALL genomes by chance - see psk_db::bsi_*). A pair's reference sits in one block, so its anchors still come out in seed order.
-    for (uint32_t blk0 = 0; blk0 < A.g_blocks; blk0 += 64) {
-    unsigned long long blk_mask;
-    {
-        const uint32_t bk = blk0 + (uint32_t)lane;
-        uint32_t any = 0;
-        if (bk < A.g_blocks) {
-            const uint32_t w0 = bk << (BSI_BLOG - 5), w1 = (w0 + (1u << (BSI_BLOG - 5))) < 2u * nw ? w0 + (1u << (BSI_BLOG - 5)) : 2u * nw;
-            for (uint32_t w = w0; w < w1; w++) any |= s_bp[w].x;
-        }
-        blk_mask = __ballot(any != 0);
-    }
+    for (uint32_t blk0 = 0; blk0 < 256u && blk0 < A.g_blocks; blk0 += 64) {
+    unsigned long long blk_mask = blk0 == 0 ? masks[0] : blk0 == 64 ? masks[1] : blk0 == 128 ? masks[2] : masks[3];
+#pragma unroll 1
     while (blk_mask) {
     const uint32_t blk = blk0 + (uint32_t)__ffsll((long long)blk_mask) - 1u;
     blk_mask &= blk_mask - 1ull;
+    {   // the block's 256 references of the pass row -> eight (32 bits, passing references before them) entries: reference -> pair of the entry in ONE 8-byte LDS read
+        uint8_t f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t r = (blk * 4u + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
+        lds_wave_sync();      // (the previous block's last lookups are through)
+        uint32_t run = s_bpre[blk];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long m = __ballot(f[u] != 0);
+            if (lane == 0) { s_bp[2 * u] = make_uint2((uint32_t)m, run); s_bp[2 * u + 1] = make_uint2((uint32_t)(m >> 32), run + (uint32_t)__popc((uint32_t)m)); }
+            run += (uint32_t)__popcll(m);
+        }
+        lds_wave_sync();
+    }
     const uint32_t* __restrict__ bkt = A.g_bucket + (size_t)blk * A.g_nb1;
     uint32_t km1 = sb + (uint32_t)lane < se ? Q.kmer[sb + lane] : 0u, km2 = sb + 64u + (uint32_t)lane < se ? Q.kmer[sb + 64u + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
             // what is sequential - a pair's cursor - is only in the second part
             uint32_t slots[GSL_AHEAD]; uint2 bps[GSL_AHEAD];
 #pragma unroll
-            for (uint32_t u = 0; u < GSL_AHEAD; u++) bps[u] = s_bp[(uint32_t)(cv[u] >> 53)];      // (every lane reads: a lane without an entry has v = 0 - reference 0's word)
+            for (uint32_t u = 0; u < GSL_AHEAD; u++) bps[u] = s_bp[(uint32_t)(cv[u] >> 53) & 7u];      // (every lane reads: a lane without an entry has v = 0 - the block's first word; an entry's reference is of this block)
 #pragma unroll
             for (uint32_t u = 0; u < GSL_AHEAD; u++) {
                 const uint32_t skm = (uint32_t)__builtin_amdgcn_readlane((int)km, (int)cs[u]);
