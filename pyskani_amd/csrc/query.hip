@@ -505,96 +505,6 @@ __global__ __launch_bounds__(256) void anchor_count_kernel(const PairDesc* __res
 // (a sparse query against a dense reference) or that straddle two pairs fall back to one independent lookup per lane.
 constexpr int JOIN_WIN = 256;
 struct PackedCount { __host__ __device__ uint32_t operator()(const uint2& v) const { return v.y >> 24; } };
-__global__ __launch_bounds__(256) void anchor_join_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
-                                                          uint32_t n_pairs, uint32_t n_items,
-                                                          uint2* __restrict__ item_out, unsigned long long* __restrict__ block_sum,
-                                                          uint32_t* __restrict__ need_wide, const uint32_t* __restrict__ blk_pair) {
-    __shared__ uint32_t s_key[4][JOIN_WIN];
-    const uint32_t lb = xcd_block_id();
-    const uint32_t i = lb * blockDim.x + threadIdx.x;
-    const uint32_t p = pair_from_hint(sbase, n_pairs, i < n_items ? i : n_items - 1, blk_pair[lb]);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool valid = i < n_items;
-    uint32_t km = 0, dst = 0, lo = 0, cnt = 0;
-    if (valid) {
-        const PairDesc& P = pairs[p];
-        const uint32_t iq = i - sbase[p];
-        km = P.q_key[iq];
-        dst = sbase[p] + P.q_perm[iq];     // results are stored in (contig,pos) order
-    }
-    const unsigned long long vm = __ballot(valid);
-    bool done = false;
-    if (vm) {
-        const int l0 = __ffsll((long long)vm) - 1, l1 = 63 - __clzll((long long)vm);
-        const uint32_t p0 = __shfl(p, l0);
-        if (__all(!valid || p == p0)) {          // the whole wave joins one pair
-            const PairDesc& P0 = pairs[p0];
-            if (P0.r_n == 0) done = true;
-            else {
-                const uint32_t km_a = __shfl(km, l0), km_b = __shfl(km, l1);
-                const uint32_t w_lo = P0.r_bucket[km_a >> P0.r_bshift], w_hi = P0.r_bucket[(km_b >> P0.r_bshift) + 1];
-                const uint32_t wn = w_hi - w_lo;
-                if (wn <= (uint32_t)JOIN_WIN) {
-                    done = true;
-                    uint32_t* sk = s_key[wave];
-                    for (uint32_t j = lane; j < wn; j += 64) sk[j] = P0.r_key[w_lo + j];
-                    lds_wave_sync();
-                    if (valid) {
-                        uint32_t a = 0, b = wn;
-                        while (a < b) { const uint32_t mid = (a + b) >> 1; if (sk[mid] < km) a = mid + 1; else b = mid; }
-                        lo = w_lo + a;
-                        uint32_t e = a;
-                        while (e < wn && sk[e] == km) e++;      // equal k-mers share a bucket: the run ends inside the stretch
-                        cnt = e - a;
-                    }
-                }
-            }
-        }
-    }
-    if (!done && valid) { const PairDesc& P = pairs[p]; lookup_lane(P.r_key, P.r_n, P.r_bucket, P.r_bshift, km, lo, cnt); }
-    if (valid) {
-        uint32_t x = 0, y = 0;
-        if (cnt) {
-            const uint64_t pm = pairs[p].r_pms[lo];
-            const uint32_t rmeta = (uint32_t)pm;
-            x = cnt > 1 ? lo : (uint32_t)(pm >> 32);      // one match: its reference position; a run: where it starts in the reference index
-            if (cnt >= 255u || (rmeta >> 24)) { atomicOr(need_wide, 1u); y = (rmeta & 0xFFFFFFu) | (255u << 24); }
-            else y = rmeta | (cnt << 24);
-        }
-        item_out[dst] = make_uint2(x, y);      // one 8-byte scattered store per item
-    }
-    block_total(cnt, lb, block_sum);
-}
-
-__global__ __launch_bounds__(256) void anchor_emit_packed_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase,
-                                                                 uint32_t n_pairs, uint32_t n_items,
-                                                                 const uint2* __restrict__ item, const uint32_t* __restrict__ aoff,
-                                                                 uint4* __restrict__ anc, uint32_t cap, uint32_t* __restrict__ err,
-                                                                 const uint32_t* __restrict__ blk_pair) {
-    const uint32_t lb = xcd_block_id();
-    uint32_t i = lb * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[lb]);
-    const uint2 it = item[i];
-    const uint32_t c = it.y >> 24;
-    if (c == 0) return;
-    const PairDesc& P = pairs[p];
-    const uint32_t j0 = i - sbase[p];
-    const uint32_t dst = aoff[i];
-    if ((uint64_t)dst + c > cap) { atomicOr(err, 2u); return; }   // beyond the optimistic capacity: the host reruns the batch with the true total
-    const uint32_t qp = P.q_pos[j0], qm = P.q_meta[j0];
-    if (c == 1) {
-        anc[dst] = make_uint4(qp, it.x, (it.y & 0xFFFFFEu) | ((it.y ^ qm) & 1u), qm >> 1);   // (q pos, r pos, ref contig << 1 | reverse_match, q contig): one 16-byte store
-        return;
-    }
-    const uint32_t l = it.x;     // a k-mer with several matches: the record holds where its run starts in the reference index
-    for (uint32_t j = 0; j < c; j++) {
-        const uint64_t pm = P.r_pms[l + j];
-        const uint32_t rmeta = (uint32_t)pm;
-        anc[dst + j] = make_uint4(qp, (uint32_t)(pm >> 32), (rmeta & ~1u) | ((rmeta ^ qm) & 1u), qm >> 1);
-    }
-}
-
 // The join kernels are bound by the LATENCY of their chain of dependent loads (pair table -> pair descriptor -> query k-mer ->
 // bucket table -> reference k-mers -> reference position) and by instruction issue, at a wave residency the register file
 // already caps (profiles/r2/r2e_pmc_join_kernels_sq.txt: 79 % of residency waiting, 7 waves per SIMD). The *4 variants put
@@ -3569,12 +3479,14 @@ struct GsiJoinArgs {
     // eight more), the walk leaves every pair's count in pair_cnt and adds the batch's total to *total; a pair that would need more room (a reference that
     // holds the query's k-mers several times over) raises err bit 2 and the batch is rerun with the two passes
     int onepass; unsigned long long* total;
+    int stage;      // EMIT: anchors leave in pairs of 32 bytes (an even-indexed anchor waits in LDS for its neighbour); 0: every anchor its own 16-byte store ($PSK_GSI_STAGE=0)
 };
 template <bool EMIT>
 __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     extern __shared__ unsigned long long s_gsi[];
     const uint32_t nw = (A.n_refs + 63u) / 64u;
-    unsigned long long* s_bits = s_gsi;
+    uint4* s_line = (uint4*)s_gsi;      // EMIT with A.stage: the even-indexed anchor every pair holds back (16 B per pair, at the front: 16-byte aligned)
+    unsigned long long* s_bits = s_gsi + ((EMIT && A.stage) ? 2u * A.p_cap : 0u);
     uint32_t* s_pref = (uint32_t*)(s_bits + nw);
     uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);
     uint32_t* s_ps = s_cur + A.p_cap;       // EMIT: first anchor of every pair of the entry (GSI_DEAD: fewer than MIN_ANCHORS anchors - it cannot chain: no anchors, no chunk table),
@@ -3709,12 +3621,23 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                     j = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
                 }
                 const uint32_t base = valid ? s_cur[slot] : 0u;
+                // Anchors leave in PAIRS (A.stage): a scattered 16-byte store costs 32 bytes of HBM write traffic (profiles/r4/r4k_pmc_calibration.md), so an anchor
+                // with an even index waits in LDS (one 16-byte slot per pair) for its odd neighbour, and the lane that brings that one writes both: one 32-byte granule.
+                // Inside a group of several lanes (a reference holding the k-mer several times) neighbours go out directly; only a group's last even anchor waits.
+                bool hold = false; uint4 av = make_uint4(0, 0, 0, 0);
                 if (EMIT && valid) {
                     const unsigned long long dst = (unsigned long long)s_ps[slot] + base + j;
                     if (A.onepass && base + j >= nq + (nq >> 3) + 8u) atomicOr(A.err, 4u);      // the pair's room (gsi_room_kernel) is used up
                     else if (dst < A.cap) {
                         const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
-                        A.anc[dst] = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
+                        av = make_uint4(sqp, (uint32_t)(v >> 1), (rmeta & ~1u) | ((rmeta ^ sqm) & 1u), sqm >> 1);
+                        const uint32_t d32 = (uint32_t)dst;
+                        if (!A.stage) A.anc[dst] = av;
+                        else if (d32 & 1u) {      // odd: out it goes - with its even neighbour from LDS when that one is the pair's own and is not the lane before this one
+                            if (!same && d32 > s_ps[slot]) A.anc[d32 - 1u] = s_line[slot];
+                            A.anc[d32] = av;
+                        } else if (last) hold = true;      // even and the group's last: waits (written to LDS below, after the step's reads of the slots)
+                        else A.anc[d32] = av;                // even with its odd neighbour in the next lane: both go out directly
                     } else atomicOr(A.err, 2u);
                     // chunk table: a chunk = the pair's anchors of one query contig within FRAGMENT_LENGTH of its first anchor (chunk_heads_kernel's rule), decided
                     // by the first lane of the (seed, reference) group - one group per pair and step
@@ -3729,6 +3652,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                     }
                 }
                 if (dup) lds_wave_sync();
+                if (EMIT && hold) s_line[slot] = av;
                 if (last) s_cur[slot] = base + j + 1u;
                 if (dup) lds_wave_sync();
             }
@@ -3749,6 +3673,10 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
             uint32_t rows = 0;
             const uint32_t n = s_cur[j];
+            if (A.stage && n && s_ps[j] != GSI_DEAD && !(A.onepass && n > nq + (nq >> 3) + 8u)) {      // an even last anchor is still waiting for a neighbour that never came
+                const unsigned long long e = (unsigned long long)s_ps[j] + n - 1u;
+                if (!(e & 1ull) && e < A.cap) A.anc[e] = s_line[j];
+            }
             if (s_ps[j] != GSI_DEAD && n && !(A.onepass && n < MIN_ANCHORS)) {      // (fewer than MIN_ANCHORS anchors: no chain, no chunk table - the rows written on the way are not counted)
                 rows = s_hc[j] & 0xFFFFu;
                 const unsigned long long e = (unsigned long long)s_ps[j] + n;
@@ -3848,7 +3776,6 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                        L.misc, L.lbcnt + n_items);
     ctx->t_begin(K_ANCHOR);
     if (wide) hipLaunchKernelGGL(anchor_count_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.blk_pair);
-    static const bool join1 = getenv("PSK_JOIN_T") && atoi(getenv("PSK_JOIN_T")) == 1;     // A/B: one tile per workgroup
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = getenv("PSK_JOIN_PAIRS");      // "1" / "0" force / forbid the pair-major join (tests, A/B)
@@ -3859,7 +3786,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     bool probe_local = false;
     GsiJoinArgs GA{};
     GslArgs GL{};
-    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5 + (getenv("PSK_GSI_LDS_PAD") ? (size_t)atoi(getenv("PSK_GSI_LDS_PAD")) : 0);      // (experiment: what staging anchor lines in LDS would cost in residency)
+    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
         GA.b_key = L.b_key; GA.b_val = L.b_val; GA.b_bucket = L.b_bucket; GA.b_shift = L.b_shift; GA.b_nb1 = L.b_nb1; GA.b_blocks = L.b_blocks; GA.b_max = L.b_max;
@@ -3896,18 +3823,17 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         else hipLaunchKernelGGL(anchor_join_pairs_kernel, dim3(nb), dim3(256), 0, st, L.pairs, L.sbase, order, n_pairs, L.lbcnt, L.bsum, L.misc + 5);
         n_sum = nb;
     }
-    else if (!wide && join1) hipLaunchKernelGGL(anchor_join_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair);
     // many mid-sized pairs (all-vs-all): the join counts every pair's anchors, one workgroup per pair then emits with a running offset
     // (anchor_emit_pairs_kernel) instead of a scan over all items; PSK_EMIT_PAIRS=1 / 0 force / forbid it (tests, A/B)
     const char* ep_env = getenv("PSK_EMIT_PAIRS");
-    const bool emit_pairs = !wide && !join1 && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
+    const bool emit_pairs = !wide && !join_pairs && n_items >= 2 * ((size_t)n_pairs + 1) &&      // (its 64-bit pair offsets live in the per-item offsets array)
                             (ep_env ? ep_env[0] == '1' : (n_pairs >= 1024 && n_items / n_pairs >= 1024 && n_items / n_pairs <= (1u << 17)));
     uint32_t* pair_cnt = L.live;      // free until the live list is built
     if (emit_pairs) PSK_HIP(hipMemsetAsync(pair_cnt, 0, 4 * ((size_t)n_pairs + 1), st));
     // workgroups of one pair per XCD turn (0 = contiguous eighths of the grid; PSK_XCD_GROUP overrides): see xcd_group_block_id
     static const int xg_env = getenv("PSK_XCD_GROUP") ? atoi(getenv("PSK_XCD_GROUP")) : -1;
     const uint32_t xcd_group = xg_env >= 0 ? (uint32_t)xg_env : (n_pairs >= 64 ? (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, 4 * (n_items / n_pairs) / (JT * 256))) : 0u);      // four pairs per turn (measured: 1 pair 38.5, 2: 37.4, 4 and more: 36.8 ms of join per 10^5 pairs; contiguous eighths: 44.0)
-    if (!wide && !join_pairs && !join1) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
+    if (!wide && !join_pairs) { hipLaunchKernelGGL(anchor_join4_kernel, dim3(gi4), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, gi, L.lbcnt, L.bsum, L.misc + 5, L.blk_pair, emit_pairs ? pair_cnt : (uint32_t*)nullptr, xcd_group); n_sum = gi4; }
     ctx->t_end();
     size_t tmp = 0, tmp2 = 0;
     hipcub::TransformInputIterator<uint32_t, CountOf, const uint2*> cnt_it(L.lbcnt, CountOf());
@@ -3980,9 +3906,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
     if (gsl) { GL.anc = anc; PSK_TRY(gsl_heads_launch(GL, st)); PSK_TRY(gsl_emit_launch(GL, st)); }
     else if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; GA.onepass = gsi_one ? 1 : 0; GA.total = L.total; if (gsi_one) GA.pair_cnt = L.aoff;      /* (the per-item offsets array: not used by this join) */
-                    hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit, st, GA); }
+                    { const char* e = getenv("PSK_GSI_STAGE"); GA.stage = e && e[0] == '0' ? 0 : 1; }      // (read per batch: tests switch it within a process)
+                    hipLaunchKernelGGL(gsi_join_kernel<true>, dim3(L.n_bq), dim3(64), gsi_lds_emit + (GA.stage ? 16 * (size_t)L.p_cap : 0), st, GA); }
     else if (wide) hipLaunchKernelGGL(anchor_emit_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
-    else if (join1) hipLaunchKernelGGL(anchor_emit_packed_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, L.aoff, anc, (uint32_t)cap, L.misc, L.blk_pair);
     else if (emit_pairs) hipLaunchKernelGGL(anchor_emit_pairs_kernel, dim3(n_pairs), dim3(EP_T), 0, st, L.pairs, L.sbase, n_pairs, L.lbcnt, poff, anc, (uint32_t)cap, L.misc,
                                             L.cbase, emit_heads ? L.chunks : (uint2*)nullptr, L.nch);
     else {
@@ -5054,8 +4980,7 @@ static psk_status build_gsi(Lane* ctx, psk_db* db) {
     }
     if (N == 0) return PSK_OK;
     const int kbits = 2 * db->params.k;
-    static const int bits_cap = getenv("PSK_GSI_BITS") ? std::min(30, std::max(8, atoi(getenv("PSK_GSI_BITS")))) : 26;      // (A/B)
-    int bits = 4; while (bits < bits_cap && (8ull << bits) < N) bits++;      // ~8 entries per bucket
+    int bits = 4; while (bits < 26 && (8ull << bits) < N) bits++;      // ~8 entries per bucket
     if (bits > kbits) bits = kbits;
     const uint32_t nb = 1u << bits;
     size_t ts = 0;

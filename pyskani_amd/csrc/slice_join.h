@@ -16,7 +16,7 @@ constexpr uint32_t GSL_SEEDS = GSL_SEEDS_N;    // query seeds per slice = per wa
 constexpr uint32_t GSL_WORDS = GSL_SEEDS / 32;
 struct GslArgs {
     const BatchQ* bq; uint32_t n_entries;
-    const uint2* tab; uint32_t n_tab;       // wave -> (entry, slice); entry 0xFFFFFFFF: padding (see gsl_make_tab)
+    const uint2* tab; uint32_t n_tab;       // wave -> (entry, slice)
     const uint2* ebase;                     // entry -> (x: its first (pair, slice) record, y: its first slice); record of (entry e, slice s, pair j) = ebase[e].x + s * pairs(e) + j
     uint32_t* un; uint32_t n_slices;        // per (entry, slice) GSL_WORDS words: the seeds that head a chunk of some pair of the entry (heads kernel; zeroed by its launcher)
     const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
@@ -33,8 +33,7 @@ struct GslArgs {
     int stage;           // emit walk: 1 = a pair's anchors leave as whole 64-byte lines staged in LDS, 0 = every anchor its own 16-byte store (A/B)
 };
 
-// wave table of a batch: the slices in groups of eight, entry-major inside a group, so that wave w = ((group * entries) + e) * 8 + x runs on XCD x (workgroups are dealt
-// round-robin) and one XCD's L2 sees ONE slice position of every query - queries of a family hold the same k-mers at the same place and re-read the same index runs
+// wave table of a batch: (entry, slice) for every slice of every entry's query, a query's slices one after the other; ebase: per entry (first record, first slice)
 void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds /* per entry */, std::vector<uint2>& tab, std::vector<uint2>& ebase, uint64_t* n_records, uint64_t* n_slices);
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st);
 psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st);

@@ -62,6 +62,8 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
                 monkeypatch.setenv("PSK_GSI_JOIN", "0")
             elif seed % 32 == 9:
                 monkeypatch.setenv("PSK_GSI_ONEPASS", "0")      # ... the index join with its count pass (without: anchors placed at the pairs' item offsets, one walk)
+            elif seed % 32 == 25:
+                monkeypatch.setenv("PSK_GSI_STAGE", "0")        # ... every anchor its own 16-byte store (default: an even-indexed anchor waits in LDS for its neighbour)
     if seed % 4 == 2:
         monkeypatch.setenv("PSK_EMIT_PAIRS", "1")   # ... and the one-workgroup-per-pair emit (join's pair totals) another,
         monkeypatch.setenv("PSK_CHUNK_HOPS", "0")   # chunk table included

@@ -309,8 +309,7 @@ def test_alternative_device_paths_agree(ecoli):
     """Every switchable device path must give the same integers: the default (lane-per-chunk DP), the wave-per-chunk DP
     (PSK_CHAIN_LANE=0), both ways of building the chunk table (PSK_CHUNK_HOPS=1 pointer chase, =0 head walk) the lane-serial transliteration of the oracle (PSK_CHAIN_SERIAL=1), and the radix-sorted k-mer index
     (PSK_INDEX_RADIX=1) against the one-workgroup-per-sketch builder, and the wide (lower bound, count) join format
-    (PSK_JOIN=wide), the one-wave-per-pair reference-major join (PSK_JOIN_PAIRS=1) and the one-tile-per-workgroup join
-    (PSK_JOIN_T=1) against the default four-tile packed merge join, and the one-workgroup-per-pair emit from the join's pair
+    (PSK_JOIN=wide), the one-wave-per-pair reference-major join (PSK_JOIN_PAIRS=1) against the default four-tile packed merge join, and the one-workgroup-per-pair emit from the join's pair
     totals (PSK_EMIT_PAIRS=1; the default for batches of >= 1 024 mid-sized pairs; with PSK_CHUNK_HOPS=0 it also builds the chunk
     table) against scan + emit over all items."""
     code = (
@@ -322,10 +321,10 @@ def test_alternative_device_paths_agree(ecoli):
         "print(h._raw['n_chunks'], h._raw['n_intervals'], h._raw['covered_query'], h._raw['covered_ref'], h._raw['sum_chain_anchors'], h._raw['sum_chunk_seeds'], repr(h.identity))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     outs = {}
-    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("hops_over_items", {"PSK_CHUNK_HOPS": "1", "PSK_HOPS_ITEMS": "1"}), ("hops_over_items_wide", {"PSK_CHUNK_HOPS": "1", "PSK_HOPS_ITEMS": "1", "PSK_JOIN": "wide"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"}), ("wide_join", {"PSK_JOIN": "wide"}), ("pair_join", {"PSK_JOIN_PAIRS": "1"}), ("tile_join", {"PSK_JOIN_T": "1"}), ("emit_per_pair", {"PSK_EMIT_PAIRS": "1"}), ("emit_per_pair_with_chunk_table", {"PSK_EMIT_PAIRS": "1", "PSK_CHUNK_HOPS": "0"}),
+    for name, extra in (("default", {}), ("wave_dp", {"PSK_CHAIN_LANE": "0"}), ("lane_dp", {"PSK_CHAIN_LANE": "64"}), ("quad_dp", {"PSK_CHAIN_LANE": "q"}), ("hops", {"PSK_CHUNK_HOPS": "1"}), ("hops_over_items", {"PSK_CHUNK_HOPS": "1", "PSK_HOPS_ITEMS": "1"}), ("hops_over_items_wide", {"PSK_CHUNK_HOPS": "1", "PSK_HOPS_ITEMS": "1", "PSK_JOIN": "wide"}), ("walk", {"PSK_CHUNK_HOPS": "0"}), ("serial", {"PSK_CHAIN_SERIAL": "1"}), ("radix_index", {"PSK_INDEX_RADIX": "1"}), ("wide_join", {"PSK_JOIN": "wide"}), ("pair_join", {"PSK_JOIN_PAIRS": "1"}), ("emit_per_pair", {"PSK_EMIT_PAIRS": "1"}), ("emit_per_pair_with_chunk_table", {"PSK_EMIT_PAIRS": "1", "PSK_CHUNK_HOPS": "0"}),
                         ("reduce_by_workgroup", {"PSK_REDUCE_WAVE": "0"}), ("reduce_by_workgroup_only", {"PSK_REDUCE_SMALL": "0"}), ("rows_in_table_order", {"PSK_ROW_SORT": "0"})):      # (the pair's ~230 chunk rows: reduced by one wave, four rows per lane, by default)
         env = dict(os.environ)
-        for k in ("PSK_HOPS_ITEMS", "PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX", "PSK_JOIN", "PSK_JOIN_PAIRS", "PSK_JOIN_T", "PSK_EMIT_PAIRS", "PSK_REDUCE_WAVE", "PSK_REDUCE_SMALL", "PSK_ROW_SORT"):
+        for k in ("PSK_HOPS_ITEMS", "PSK_CHAIN_SERIAL", "PSK_CHAIN_LANE", "PSK_CHUNK_HOPS", "PSK_INDEX_RADIX", "PSK_JOIN", "PSK_JOIN_PAIRS", "PSK_EMIT_PAIRS", "PSK_REDUCE_WAVE", "PSK_REDUCE_SMALL", "PSK_ROW_SORT"):
             env.pop(k, None)
         env.update(extra)
         outs[name] = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().strip()

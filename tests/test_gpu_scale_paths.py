@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL", "PSK_GSI_STAGE"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -156,6 +156,7 @@ def test_rescue_prefilter_agrees_at_scale():
     # pairs of a handful of rows by one lane each, takes the anchor offsets from the join's running counts; switches of different stages share a run)
     for extra in ({"PSK_PREFILTER": "0"},
                   {"PSK_GSI_ONEPASS": "0", "PSK_DP_PRUNE": "0"},                                              # the index join with its count pass; every DP scoring its whole band
+                  {"PSK_GSI_STAGE": "0"},                                                                   # every anchor of the index join its own 16-byte store (default: pairs of 32 bytes)
                   {"PSK_BSI_SMALL": "0"},                                                                   # the database-wide seed index in one walk instead of its blocks of 256 references
                   {"PSK_GSI_JOIN": "0"},                                                                    # the probe-table join instead of the database-wide seed index
                   {"PSK_GSI_JOIN": "0", "PSK_PREFILTER": "0"},
