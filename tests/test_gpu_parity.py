@@ -631,6 +631,34 @@ def test_min_records_equal_the_raw_records(psk):
         assert not raw["learned"].any() and not raw["reserved"].any()
 
 
+def test_min_records_number_their_queries_through_the_whole_call():
+    """psk_hit_min.query is the index of the hit's query in the CALL, also when the call runs as several rounds of queries (here 37 per round, and chain batches of
+    2^18 seeds): every round numbers its own queries from zero on the device, the host adds the round's first index."""
+    code = r'''
+import sys, os, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+from conftest import random_genome, mutate
+import pyskani_amd as psk
+rng = np.random.default_rng(31)
+anc = [random_genome(rng, 80_000) for _ in range(2)]
+genomes = [(f"g{i}", mutate(rng, anc[i %% 2], 0.002 * (i // 2))) for i in range(100)]
+db = psk.Database()
+db.sketch_many(genomes)
+sk = db._sketch_many(genomes, True)
+h = (C.c_void_p * 100)(*[x._h for x in sk])
+raw, ro = db.query_handles(h, 100, learned_ani=False, raw=True)
+small, so = db.query_handles(h, 100, learned_ani=False)
+assert len(raw) == len(small) > 100 * 40 and np.array_equal(ro, so)
+assert np.array_equal(small["query"], np.repeat(np.arange(100, dtype=np.uint32), np.diff(so)))
+assert np.array_equal(raw["ani"].view(np.uint32), small["ani"].view(np.uint32)) and np.array_equal(raw["ref_index"], small["ref_index"])
+print("ok", len(small))
+''' % (ROOT, ROOT)
+    env = dict(os.environ, PSK_ROUND_QUERIES="37", PSK_BATCH_ITEMS_LOG2="18")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_sharded_database_over_rccl_world1(psk):
     """The N>1 code path on the real backend: torch.distributed "nccl" (= RCCL) with a one-rank group, real
     Database underneath. (Two ranks cannot share this box's single GPU under RCCL; world 2 runs on gloo in
