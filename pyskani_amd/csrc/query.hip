@@ -1389,6 +1389,7 @@ struct ChainArgs {
     int32_t* sc_f; uint32_t *sc_ptr, *sc_root, *sc_depth, *sc_best;
     Strided<int32_t> c_score; Strided<uint32_t> c_q0, c_q1, c_r0, c_r1, c_n, c_state, c_rc;   // candidate chains, chunk s writes at [s, s + n_cand): fields of 32-byte records
     uint32_t two_c; int band; int force_serial; int lane_dp;
+    uint32_t cap;      // anchors the arrays hold (chunk_seeds_kernel's bound on what a chunk row may point at)
     int dp_prune;      // the lane / quad DP kernels score the far part of the band only where it could win ($PSK_DP_PRUNE=0: always)
     uint32_t* ovf_list; uint32_t* ovf_count;   // rows the lane kernel hands to the wave kernel (more than LANE_TREES qualifying chain trees, >= 16 384 anchors)
     uint32_t* stats;   // [1] chunks / [3] pairs that took a serial fallback (rare paths only: a counter every wave bumps
@@ -2876,7 +2877,14 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
     if (row >= A.n_rows) return;
     if (row - A.cbase[pair] >= A.n_chunks[pair]) return;
     ChunkOut* o = &A.out[row];
-    if (o->n_intervals) o->seeds = seeds_between(A.pairs[pair], A.anc[A.chunks[row].x].w, o->left, o->right);
+    if (!o->n_intervals) return;
+    // (an attempt that is going to be rerun - a pair that outgrew its room in the one-walk index join, an anchor total beyond the capacity - leaves rows whose anchors
+    // were never written: what they point at is a previous batch's, and this kernel is the one that uses an anchor's content as an INDEX. Nothing is read through it
+    // unchecked: found by a 480-seed fuzz sweep as a memory fault that needed seventeen earlier cases' leftovers in the scratch arrays)
+    const uint2 ch0 = A.chunks[row];
+    if (ch0.x > ch0.y || ch0.y > A.cap) return;
+    const uint32_t qc = A.anc[ch0.x].w;
+    if (qc < A.pairs[pair].q_nc) o->seeds = seeds_between(A.pairs[pair], qc, o->left, o->right);
 }
 
 // ------------------------------------------------------------------ per-pair ANI / AF
@@ -3897,6 +3905,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     A.pairs = L.pairs;
     A.out = L.cout; A.two_c = 2u * (uint32_t)prm.c; A.force_serial = force_serial; A.stats = L.misc + 1;
     A.band = std::max(1, std::min(MAX_CHAIN_BAND, BP_CHAIN_BAND / (int)prm.c));
+    A.cap = (uint32_t)cap;
     { const char* e = getenv("PSK_DP_PRUNE"); A.dp_prune = e && e[0] == '0' ? 0 : 1; }      // (read per call: tests switch it within a process)
     // the per-pair emit also writes the chunk table unless the pointer-chase builder is asked for (PSK_CHUNK_HOPS) or PSK_EMIT_HEADS=0
     const char* hops_env = getenv("PSK_CHUNK_HOPS");
