@@ -1408,6 +1408,7 @@ __device__ uint32_t seeds_between(const PairDesc& P, uint32_t qc, uint32_t lo, u
     uint32_t l = a, r = b;
     while (l < r) { uint32_t m = (l + r) >> 1; if (pos[m] < lo) l = m + 1; else r = m; }
     uint32_t first = l; r = b;
+    if (first + 256u < b && pos[first + 256u] > hi) r = first + 256u;      // (a chunk spans FRAGMENT_LENGTH bases: ~160 seeds at c = 125 - eight probes instead of sixteen)
     while (l < r) { uint32_t m = (l + r) >> 1; if (pos[m] <= hi) l = m + 1; else r = m; }
     return l - first;
 }
