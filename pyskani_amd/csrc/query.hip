@@ -1304,31 +1304,19 @@ __global__ __launch_bounds__(64) void chunk_hops_sliced_kernel(const uint32_t* _
 // ---- the chunk table of Gb-scale pairs in ITEM space ---------------------------------------------------------------------------------------------
 // anchor_next_kernel finds, for EVERY anchor, the first anchor past its 20 kb window: 155 M searches of 6-7 probes per 3 Gb pair into 16-byte records at
 // random (58 GB of 64-byte lines per 8-genome step, profiles/r4/pmc_kernels.json) - for a table of 150 000 heads. But a chunk boundary is a property of the
-// QUERY's seed positions, and an anchor-bearing (pair, query seed) item already knows where its anchors start (the scan's offsets): the successor is searched
-// per ITEM (24 M per pair, 6.5 x fewer, in a 4-byte position array where FRAGMENT_LENGTH bases are ~160 entries away: a short gallop), and the walk from head
-// to head hops over items; a chunk's row is (offset of the head item, offset of the successor item) - items without anchors have the offset of the next one.
-// nxtp[i] = first item of the pair whose (contig, position) lies more than FRAGMENT_LENGTH past item i's | 0x80000000 if item i has anchors.
-__global__ __launch_bounds__(256) void item_next_kernel(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t n_items,
-                                                        const uint2* __restrict__ item, int wide, const uint32_t* __restrict__ blk_pair, uint32_t* __restrict__ nxtp) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_items) return;
-    const uint32_t p = pair_from_hint(sbase, n_pairs, i, blk_pair[blockIdx.x]);
-    const PairDesc& P = pairs[p];
-    const uint32_t j = i - sbase[p], n = P.q_n;
-    const uint64_t target = (((uint64_t)(P.q_meta[j] >> 1)) << 32) + (uint64_t)P.q_pos[j] + FRAGMENT_LENGTH;
-    auto key = [&](uint32_t x) { return (((uint64_t)(P.q_meta[x] >> 1)) << 32) | P.q_pos[x]; };
-    uint32_t lo = j + 1, hi = n, step = 64;      // first x in (j, n) with key(x) > target; a gallop: the answer is ~FRAGMENT_LENGTH / c seeds away
-    while (lo + step < hi) { if (key(lo + step) > target) { hi = lo + step; break; } lo += step + 1; step <<= 1; }
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key(mid) <= target) lo = mid + 1; else hi = mid; }
-    const uint32_t cnt = wide ? item[i].y : item[i].y >> 24;
-    nxtp[i] = (sbase[p] + lo) | (cnt ? 0x80000000u : 0u);
-}
-// pass 0 of chunk_hops_sliced_kernel over items (pass 1 - the copy of the slices' rows to their dense places - is that kernel's own)
-__global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ nxtp, const uint32_t* __restrict__ aoff,
+// QUERY's seed positions, and an anchor-bearing (pair, query seed) item already knows where its anchors start (the scan's offsets): the walk from head to head
+// hops over ITEMS; a chunk's row is (offset of the head item, offset of the successor item) - items without anchors have the offset of the next one, so an item
+// has anchors iff its offset differs from the next item's.
+// HOP_SLICES waves per pair, each over whole contigs (a contig's first anchor is a head whatever came before). The wave stages a window of the query's seed
+// positions and of the items' offsets in LDS and walks it TOGETHER: the next head = first item with anchors (64 items per ballot), its successor = first seed more
+// than FRAGMENT_LENGTH past it (64 probes 16 seeds apart, then the 16 between). Round 4 searched the successor of every item beforehand (item_next_kernel: 24 M
+// gallops per pair for 150 000 heads, 9.4 ms per 8 x 3 Gb step) and walked the result with one lane.
+// Pass 0 of chunk_hops_sliced_kernel over items (pass 1 - the copy of the slices' rows to their dense places - is that kernel's own).
+__global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ aoff,
                                                                const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ sbase, const uint32_t* __restrict__ cbase,
                                                                uint32_t n_pairs, uint32_t* __restrict__ slice_cnt, uint2* __restrict__ scratch, uint32_t* __restrict__ err) {
-    __shared__ uint32_t s_nx[HOP_WIN], s_ao[HOP_WIN + 1];
-    __shared__ uint32_t s_h, s_n;
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[HOP_WIN], s_ao[HOP_WIN + 4];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));      // (a window starts at any seed: 4-byte aligned 16-byte loads)
     const uint32_t p = blockIdx.x, w = blockIdx.y;
     const int lane = threadIdx.x;
     const PairDesc& P = pairs[p];
@@ -1342,28 +1330,86 @@ __global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __
     for (int o = 32; o > 0; o >>= 1) ub += __shfl_xor(ub, o);
     const uint32_t seed0 = (uint32_t)(P.q_pos - P.q_seed_pos_base);      // the query's first seed in its store: q_contig_start holds store offsets
     const uint32_t base = sbase[p];
-    uint32_t h = base + (P.q_contig_start[c_lo] - seed0);
-    const uint32_t hend = base + (P.q_contig_start[c_hi] - seed0);
+    const uint32_t* __restrict__ qpos = P.q_pos;
     uint32_t n = 0;
-    while (h < hend) {
-        const uint32_t w0 = h, wn = hend - w0 < (uint32_t)HOP_WIN ? hend - w0 : (uint32_t)HOP_WIN;
-        for (uint32_t i = lane; i < wn; i += 64) { s_nx[i] = nxtp[w0 + i]; s_ao[i] = aoff[w0 + i]; }
-        if (lane == 0) s_ao[wn] = aoff[w0 + wn];
-        lds_wave_sync();
-        if (lane == 0) {
-            while (h < hend && h - w0 < wn) {
-                const uint32_t v = s_nx[h - w0];
-                if (!(v & 0x80000000u)) { h++; continue; }      // no anchor: not a head
-                const uint32_t e = v & 0x7FFFFFFFu;             // first item past the window (<= the first item of the next contig)
-                const uint32_t ee = e < hend ? e : hend;
-                const uint32_t a0 = s_ao[h - w0], a1 = ee - w0 <= wn ? s_ao[ee - w0] : aoff[ee];
-                if (ub + n < max_chunks) scratch[(size_t)row0 + ub + n] = make_uint2(a0, a1); else atomicOr(err, 1u);
-                n++; h = ee;
+    constexpr uint32_t STRIDE = 16;
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        uint32_t h = P.q_contig_start[c] - seed0;                  // (seed numbers of the query = item numbers of the pair less `base`)
+        const uint32_t hend = P.q_contig_start[c + 1] - seed0;
+        uint32_t guess = 0;      // seeds the previous chunk spanned: the next one's successor is looked for around there first
+        while (h < hend) {
+            const uint32_t w0 = h, wn = hend - w0 < (uint32_t)HOP_WIN ? hend - w0 : (uint32_t)HOP_WIN;
+            lds_wave_sync();
+            {   // the window: sixteen 16-byte loads per lane in flight (one dword at a time, a window cost eight dependent round trips: more than walking it)
+                const uint32_t full = wn & ~3u;
+                const uint32_t* __restrict__ gp = qpos + w0; const uint32_t* __restrict__ ga = aoff + base + w0;
+                for (uint32_t i0 = 0; i0 < full; i0 += 2048) {
+                    u32x4 vp[8], va[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const uint32_t x = i0 + (uint32_t)r * 256u + (uint32_t)lane * 4u; if (x < full) { vp[r] = *(const u32x4*)(gp + x); va[r] = *(const u32x4*)(ga + x); } }
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const uint32_t x = i0 + (uint32_t)r * 256u + (uint32_t)lane * 4u; if (x < full) { *(uint4*)&s_pos[x] = make_uint4(vp[r].x, vp[r].y, vp[r].z, vp[r].w); *(uint4*)&s_ao[x] = make_uint4(va[r].x, va[r].y, va[r].z, va[r].w); } }
+                }
+                if (lane < 4) { const uint32_t x = full + (uint32_t)lane; if (x < wn) s_pos[x] = gp[x]; if (x <= wn) s_ao[x] = ga[x]; }      // (the items' offsets hold one entry past the last item)
             }
-            s_h = h; s_n = n;
+            lds_wave_sync();
+            // (a hop is a chain of dependent LDS round trips: the head's offsets and position are read with its predecessor's closing offset - two round trips per chunk)
+            uint32_t i = 0, ao_i = s_ao[0], ao_n = s_ao[1], pos_i = s_pos[0];
+            const uint64_t pos_last = s_pos[wn - 1];
+            for (;;) {
+                // the next head: first item of the window at or after i with anchors (nearly always item i itself)
+                bool found = i < wn && ao_n != ao_i;
+                if (!found) {
+                    while (i < wn) {
+                        const uint32_t x = i + lane;
+                        const unsigned long long m = __ballot(x < wn && s_ao[x + 1] != s_ao[x]);
+                        if (m) { i += (uint32_t)__ffsll((long long)m) - 1u; found = true; break; }
+                        i += 64;
+                    }
+                    if (!found) { h = w0 + wn; break; }
+                    ao_i = s_ao[i]; pos_i = s_pos[i];
+                }
+                const uint64_t target = (uint64_t)pos_i + FRAGMENT_LENGTH;
+                uint32_t e = 0xFFFFFFFFu;      // first item of the window past the head's fragment; wn = none in the window
+                if (pos_last <= target) e = wn;
+                else {
+                    if (guess > 32u && i + guess + 32u <= wn) {      // 64 consecutive seeds around where the last chunk ended
+                        const uint32_t x0 = i + guess - 32u;
+                        const unsigned long long m = __ballot((uint64_t)s_pos[x0 + lane] > target);
+                        if (m && !(m & 1ull)) e = x0 + (uint32_t)__ffsll((long long)m) - 1u;
+                    }
+                    if (e == 0xFFFFFFFFu) {
+                        uint32_t lo = i + 1;      // s_pos[lo - 1] <= target
+                        for (;;) {
+                            const uint32_t x = lo + (uint32_t)lane * STRIDE + (STRIDE - 1);      // last seed of the lane's group
+                            const unsigned long long m = __ballot(x >= wn || (uint64_t)s_pos[x] > target);      // (true from some lane on: positions ascend)
+                            if (m) { lo += ((uint32_t)__ffsll((long long)m) - 1u) * STRIDE; break; }
+                            lo += 64 * STRIDE;
+                        }
+                        const uint32_t x = lo + (uint32_t)lane;
+                        const unsigned long long m = __ballot(lane < (int)STRIDE && x < wn && (uint64_t)s_pos[x] > target);
+                        e = lo + (uint32_t)__ffsll((long long)m) - 1u;      // (m != 0: the group's last seed, or the window's, is past the target)
+                    }
+                    guess = e - i;
+                }
+                uint32_t a1;
+                if (e < wn) { a1 = s_ao[e]; ao_n = s_ao[e + 1]; pos_i = s_pos[e]; }
+                else if (w0 + wn == hend) a1 = s_ao[wn];          // (the contig's end closes its last chunk)
+                else if (i > 0) { h = w0 + i; break; }            // the successor lies beyond the window: stage again from this head
+                else {      // more than HOP_WIN seeds inside one fragment (c < 5): search the rest of the contig in global memory
+                    uint32_t lo = w0 + wn, hi = hend;
+                    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)qpos[mid] <= target) lo = mid + 1; else hi = mid; }
+                    a1 = aoff[base + lo];
+                    if (lane == 0) { if (ub + n < max_chunks) scratch[(size_t)row0 + ub + n] = make_uint2(ao_i, a1); else atomicOr(err, 1u); }
+                    n++; h = lo;
+                    break;
+                }
+                if (lane == 0) { if (ub + n < max_chunks) scratch[(size_t)row0 + ub + n] = make_uint2(ao_i, a1); else atomicOr(err, 1u); }
+                n++;
+                i = e; ao_i = a1;
+                if (e >= wn) { h = w0 + wn; break; }
+            }
         }
-        lds_wave_sync();
-        h = s_h; n = s_n;
     }
     if (lane == 0) slice_cnt[p * HOP_SLICES + w] = n;
 }
@@ -3930,7 +3976,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                                 probe_local ? (const uint32_t*)L.pstart : (const uint32_t*)nullptr);
     }
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    // Gb-scale pairs: successors and the walk in ITEM space where the join left per-item counts and offsets (item_next_kernel); PSK_HOPS_ITEMS=1 / 0 force / forbid (tests, A/B)
+    // Gb-scale pairs: the walk in ITEM space where the join left per-item offsets (chunk_hops_items_kernel); PSK_HOPS_ITEMS=1 / 0 force / forbid (tests, A/B)
     const char* hi_env = getenv("PSK_HOPS_ITEMS");
     const bool hops_items = use_hops && !emit_pairs && !join_pairs && !getenv("PSK_HOPS_UNSLICED") && n_items <= 0x7FFFFFFFull &&
                             (hi_env ? hi_env[0] == '1' : n_items / n_pairs > (1u << 20));
@@ -3939,8 +3985,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         PSK_TRY(ctx->q_g.reserve(o_scr + sizeof(uint2) * n_rows + 256));
         uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
         uint2* scratch_rows = (uint2*)((char*)ctx->q_g.p + o_scr);
-        hipLaunchKernelGGL(item_next_kernel, dim3(gi), dim3(256), 0, st, L.pairs, L.sbase, n_pairs, (uint32_t)n_items, L.lbcnt, wide ? 1 : 0, L.blk_pair, a_nxt);      // (a_nxt: one u32 per anchor - at least as many as items)
-        hipLaunchKernelGGL(chunk_hops_items_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, (const uint32_t*)a_nxt, (const uint32_t*)L.aoff, L.pairs, L.sbase, L.cbase, n_pairs, slice_cnt, scratch_rows, L.misc);
+        hipLaunchKernelGGL(chunk_hops_items_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, (const uint32_t*)L.aoff, L.pairs, L.sbase, L.cbase, n_pairs, slice_cnt, scratch_rows, L.misc);
         hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, 1, scratch_rows, L.chunks, L.nch, L.misc);
     }
     else if (use_hops) {
@@ -4714,6 +4759,13 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
         static const int items_env = getenv("PSK_BATCH_ITEMS_LOG2") ? std::min(31, std::max(16, atoi(getenv("PSK_BATCH_ITEMS_LOG2")))) : 0;
         int items_log2 = items_env ? items_env : 29;
         if (!items_env) for (uint32_t i = 0; i < m; i++) if (h_qd[i].n > (1u << 20)) { items_log2 = 27; break; }
+        if (!items_env && items_log2 == 27) {
+            // ... 2^28 where the device has the room (7 anchors per seed x 93 bytes of per-anchor arrays, with the buffers' growth slack: 204 GiB; the lane's own arrays count as room): eleven 3 Gb pairs
+            // per batch instead of five - the per-pair chains of the chunk walk, the selection's group barriers and the reduction overlap across twice the pairs
+            // (8 x 3 Gb: 234 -> 211 ms per step). 2^29 would pass the 2^31 anchors one launch sequence addresses.
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->q_d.cap + ctx->q_e.cap > ((size_t)212 << 30)) items_log2 = 28;
+        }
         // Rounds of many small pairs (contigs): up to 2^22 pairs and 2^30 seeds per batch. The probe join visits a batch's pairs reference by reference, and a line of a
         // reference's table is probed about once per 2^20 pairs of a 5 000-reference database: with twice the pairs every line is probed twice while it is still
         // cached (join 142 -> 124 ms per 100 000 contigs). PSK_BATCH_PAIRS_LOG2 overrides (tests, A/B).

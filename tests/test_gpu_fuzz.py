@@ -50,9 +50,13 @@ def test_random_pairs_match_oracle(psk, oracle, seed, monkeypatch):
     if seed % 4 == 0:
         monkeypatch.setenv("PSK_LANE_XTREES", "1")  # sixteen tree slots per chunk in the lane DP (twelve in LDS): the Gb-scale variant, forced on small pairs
         monkeypatch.setenv("PSK_CHAIN_LANE", "64")  # (a small launch would take the four-lanes-per-chunk kernel otherwise)
+        if seed % 8 == 4:
+            monkeypatch.setenv("PSK_CHUNK_HOPS", "1"); monkeypatch.setenv("PSK_HOPS_ITEMS", "1")      # ... and the Gb-scale chunk table: waves hopping over the items' offsets
     if seed % 4 == 3:
         monkeypatch.setenv("PSK_JOIN", "wide")      # the fallback join format gets a quarter of the sweep
         monkeypatch.setenv("PSK_CHAIN_WAVE_REG", "0")   # ... with the throughput DP kernels of wide bands (c < 105) instead of the small launch's register-window one
+        if seed % 8 == 7:
+            monkeypatch.setenv("PSK_CHUNK_HOPS", "1"); monkeypatch.setenv("PSK_HOPS_ITEMS", "1")
     if seed % 4 == 1:
         monkeypatch.setenv("PSK_JOIN_PAIRS", "1")   # ... and the pair-major join another,
         monkeypatch.setenv("PSK_EMIT_EXPAND", "1")  # with the anchor-major emit of Gb-scale pairs behind it

@@ -331,6 +331,27 @@ def test_alternative_device_paths_agree(ecoli):
     assert len(set(outs.values())) == 1, outs
 
 
+@pytest.mark.parametrize("c", [3, 40])
+def test_item_hops_dense_seeds(psk, oracle, monkeypatch, c):
+    """The Gb-scale chunk table (waves hopping over item offsets, chunk_hops_items_kernel) where one 20 kb fragment holds more seeds than the
+    wave stages at a time (c = 3: ~6 700 against a window of 4 096 - the successor is searched in global memory) and where a window holds several
+    fragments (c = 40): contigs with and without anchors, a query contig shorter than a fragment."""
+    monkeypatch.setenv("PSK_CHUNK_HOPS", "1"); monkeypatch.setenv("PSK_HOPS_ITEMS", "1")
+    rng = np.random.default_rng(77 + c)
+    anc = random_genome(rng, 260000)
+    ref = [anc[:120000], mutate(rng, anc[120000:], 0.01)]
+    qry = [mutate(rng, anc[5000:95000], 0.02), random_genome(rng, 30000), mutate(rng, anc[130000:142000], 0.01), mutate(rng, anc[150000:255000], 0.03, 0.0005)]
+    r, q = oracle.Sketch(ref, c=c, marker_c=8 * c, k=15), oracle.Sketch(qry, c=c, marker_c=8 * c, k=15)
+    want = oracle.query([("ref", r)], q)
+    db = psk.Database(compression=c, marker_compression=8 * c, k=15)
+    db.sketch("ref", *ref)
+    got = db.query_sketches([db._sketch("q", qry, True)], learned_ani=False)[0]
+    assert len(got) == len(want) == 1
+    for f in INT_FIELDS:
+        assert got[0]._raw[f] == getattr(want[0][1], f), (c, f)
+    assert abs(got[0].identity - want[0][1].ani) < 1e-6
+
+
 def test_learned_ani_without_model_raises(psk, ecoli):
     db = psk.Database()
     db.sketch("a", ecoli[0][:100000])
