@@ -153,6 +153,16 @@ struct Lane {
         *out = copy_stream;
         return PSK_OK;
     }
+    hipStream_t side_stream = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;      // a few latency-bound waves beside a kernel that fills the chip (chain_run: the chunk walk of Gb-scale pairs beside the emit)
+    psk_status side_lane(hipStream_t* out) {
+        if (!side_stream) {
+            PSK_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            PSK_HIP(hipEventCreateWithFlags(&side_fork, hipEventDisableTiming));
+            PSK_HIP(hipEventCreateWithFlags(&side_join, hipEventDisableTiming));
+        }
+        *out = side_stream;
+        return PSK_OK;
+    }
     bool holds_huge = false;       // between the launch of select_huge_kernel and the synchronisation that follows it
     void huge_acquire() { if (!holds_huge) { dev->huge_mu.lock(); holds_huge = true; } }
     void huge_release() { if (holds_huge) { (void)hipStreamSynchronize(stream); dev->huge_mu.unlock(); holds_huge = false; } }
@@ -229,6 +239,7 @@ struct Lane {
     void release_all() {
         Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small, &q_j};
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        if (side_stream) { (void)hipStreamSynchronize(side_stream); (void)hipStreamDestroy(side_stream); side_stream = nullptr; if (side_fork) (void)hipEventDestroy(side_fork); if (side_join) (void)hipEventDestroy(side_join); side_fork = side_join = nullptr; }
         for (Scratch* s : all) s->release();
         jobs_release();
         if (h_pinned) (void)hipHostFree(h_pinned);

@@ -3959,7 +3959,26 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     const bool use_hops = gsi_join ? false : hops_env ? hops_env[0] != '0' : ((n_pairs < 1024 && n_items / n_pairs > 4096) || n_items / n_pairs > (1u << 20));      // (few pairs of a contig's few hundred seeds: one wave per pair walks its heads - one launch instead of two)
     static const bool emit_heads_off = getenv("PSK_EMIT_HEADS") && getenv("PSK_EMIT_HEADS")[0] == '0';
     const bool emit_heads = emit_pairs && !use_hops && !emit_heads_off;
+    // Gb-scale pairs: the walk in ITEM space where the join left per-item offsets (chunk_hops_items_kernel); PSK_HOPS_ITEMS=1 / 0 force / forbid (tests, A/B)
+    const char* hi_env = getenv("PSK_HOPS_ITEMS");
+    const bool hops_items = use_hops && !gsl && !emit_pairs && !join_pairs && !getenv("PSK_HOPS_UNSLICED") && n_items <= 0x7FFFFFFFull &&
+                            (hi_env ? hi_env[0] == '1' : n_items / n_pairs > (1u << 20));
     ctx->t_begin(K_ANCHOR_EMIT);      // anchors out of the join's records + the chunk table
+    if (hops_items) {
+        // ... on the lane's SIDE stream, beside the emit: the walk is a few hundred waves each waiting on its own chain of LDS round trips (24 contigs x 11 pairs: 4 ms
+        // per batch with three quarters of the chip idle) and reads only the items' offsets and the query's positions; the emit fills the chip's memory pipes
+        const size_t o_scr = al256(4 * (size_t)n_pairs * HOP_SLICES + 256);
+        PSK_TRY(ctx->q_g.reserve(o_scr + sizeof(uint2) * n_rows + 256));
+        uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
+        uint2* scratch_rows = (uint2*)((char*)ctx->q_g.p + o_scr);
+        hipStream_t sd = nullptr;
+        PSK_TRY(ctx->side_lane(&sd));
+        PSK_HIP(hipEventRecord(ctx->side_fork, st));
+        PSK_HIP(hipStreamWaitEvent(sd, ctx->side_fork, 0));
+        hipLaunchKernelGGL(chunk_hops_items_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, sd, L.pstart, (const uint32_t*)L.aoff, L.pairs, L.sbase, L.cbase, n_pairs, slice_cnt, scratch_rows, L.misc);
+        hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, sd, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, 1, scratch_rows, L.chunks, L.nch, L.misc);
+        PSK_HIP(hipEventRecord(ctx->side_join, sd));
+    }
     if (gsl) { GL.anc = anc; PSK_TRY(gsl_heads_launch(GL, st)); PSK_TRY(gsl_emit_launch(GL, st)); }
     else if (gsi_join) { GA.anc = anc; GA.chunks = L.chunks; GA.n_chunks = L.nch; GA.onepass = gsi_one ? 1 : 0; GA.total = L.total; if (gsi_one) GA.pair_cnt = L.aoff;      /* (the per-item offsets array: not used by this join) */
                     { const char* e = getenv("PSK_GSI_STAGE"); GA.stage = e && e[0] == '0' ? 0 : 1; }      // (read per batch: tests switch it within a process)
@@ -3976,18 +3995,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                                 probe_local ? (const uint32_t*)L.pstart : (const uint32_t*)nullptr);
     }
     // few pairs (one wave each cannot fill the chip) or huge ones: nxt[] for every anchor in parallel + pointer chase
-    // Gb-scale pairs: the walk in ITEM space where the join left per-item offsets (chunk_hops_items_kernel); PSK_HOPS_ITEMS=1 / 0 force / forbid (tests, A/B)
-    const char* hi_env = getenv("PSK_HOPS_ITEMS");
-    const bool hops_items = use_hops && !emit_pairs && !join_pairs && !getenv("PSK_HOPS_UNSLICED") && n_items <= 0x7FFFFFFFull &&
-                            (hi_env ? hi_env[0] == '1' : n_items / n_pairs > (1u << 20));
-    if (hops_items) {
-        const size_t o_scr = al256(4 * (size_t)n_pairs * HOP_SLICES + 256);
-        PSK_TRY(ctx->q_g.reserve(o_scr + sizeof(uint2) * n_rows + 256));
-        uint32_t* slice_cnt = (uint32_t*)ctx->q_g.p;
-        uint2* scratch_rows = (uint2*)((char*)ctx->q_g.p + o_scr);
-        hipLaunchKernelGGL(chunk_hops_items_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, (const uint32_t*)L.aoff, L.pairs, L.sbase, L.cbase, n_pairs, slice_cnt, scratch_rows, L.misc);
-        hipLaunchKernelGGL(chunk_hops_sliced_kernel, dim3(n_pairs, HOP_SLICES), dim3(64), 0, st, L.pstart, a_nxt, anc, L.pairs, L.cbase, n_pairs, slice_cnt, 1, scratch_rows, L.chunks, L.nch, L.misc);
-    }
+    if (hops_items) PSK_HIP(hipStreamWaitEvent(st, ctx->side_join, 0));      // (the chunk table of Gb-scale pairs was built beside the emit: above)
     else if (use_hops) {
         if (n_items / n_pairs > (1u << 20)) {      // Gb-scale: every 64th anchor first (into the spare per-anchor array after a_nxt), then all of them between those
             uint32_t* coarse = E4;                  // sc_f's space: the serial path is not running yet
