@@ -879,13 +879,27 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
         recs = last["recs"]      # psk_hit_min: `query` = the hit's query within the call
         digest = records_digest(recs)
-        table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
+        # The timed steps keep two batches in flight on two lanes (query.hip: rounds of >= 2^31 (pair, seed) items): their kernels share the chip and a bracket's
+        # duration says little about the kernel. The per-kernel table comes from ONE more step run as a single chain of launches (PSK_PIPELINE=0), outside the timed region.
+        table_step = None
+        if "PSK_PIPELINE" not in os.environ:
+            os.environ["PSK_PIPELINE"] = "0"
+            try:
+                dt1, _, kern, work, _ = timed_loop(eng, step, 1, 0, lambda: job.fence(eng))
+                if records_digest(last["recs"]) != digest:
+                    raise SystemExit("all-vs-all: the one-chain step and the two-lane steps disagree")
+                table_step = {"mode": "one chain of launches (PSK_PIPELINE=0), one step outside the timed region", "ms_per_step": dt1 * 1e3}
+            finally:
+                del os.environ["PSK_PIPELINE"]
+        table = kernel_rooflines(kern, 1 if table_step else steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
         shape = {"plain": "single-contig genomes, substitutions only", "contigs": "every genome cut into 1-80 contigs",
                  "sv": "20 block inversions / translocations of 5-50 kb per genome on top of the substitutions"}[variant]
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                 "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}; {shape}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
-                "roofline": roofline_of(table, steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
+                "roofline": roofline_of(table, 1 if table_step else steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
+        if table_step:
+            line["kernel_table_step"] = table_step
         host = None
         if (cpu_queries > 0 and variant == "plain") or host_leg:
             try:

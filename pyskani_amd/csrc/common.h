@@ -254,7 +254,8 @@ struct Lane {
 // takes a free lane of the context for the duration of one call (creates one if all are busy and fewer than max_lanes exist)
 struct LaneGuard {
     psk_ctx* c; Lane* lane = nullptr; int idx = -1;
-    explicit LaneGuard(psk_ctx* ctx) : c(ctx) {
+    // nowait: no lane (lane == nullptr) rather than a wait when all are busy - a call that would like a SECOND lane must not wait for one (eight such callers would wait for each other)
+    explicit LaneGuard(psk_ctx* ctx, bool nowait = false) : c(ctx) {
         std::unique_lock<std::mutex> lk(c->lanes_mu);
         for (;;) {
             for (size_t i = 0; i < c->lanes.size(); i++) if (!c->busy[i]) { idx = (int)i; break; }
@@ -266,6 +267,7 @@ struct LaneGuard {
                 if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { delete L; if (c->lanes.empty()) return; }
                 else { c->lanes.push_back(L); c->busy.push_back(0); idx = (int)c->lanes.size() - 1; break; }
             }
+            if (nowait) return;
             c->lanes_cv.wait(lk);
         }
         c->busy[idx] = 1; lane = c->lanes[idx];

@@ -4544,6 +4544,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
     int64_t h_qd_gsi_round = -1;      // the round (its first query) whose descriptors h_qd holds in the seed-index form (make_desc(.., true))
     std::vector<BatchQ> bqs;
     std::vector<uint2> gsl_tab, gsl_ebase; std::vector<uint32_t> gsl_qn;      // slice join: a batch's wave table (host copies live until the batch's synchronisation)
+    std::unique_ptr<LaneGuard> lane2;      // the second lane of rounds that keep two batches in flight (taken at the first such round, held to the end of the call)
     for (uint32_t b = 0; b < n_queries; b += QB) {
         const uint32_t m = std::min(QB, n_queries - b);
         // ---- screen: pass matrix on the device, counts + flags to the host
@@ -4688,12 +4689,12 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
         // round - neither for the references nor for the round's 65 536 contigs) or, where the database cannot have one, through per-reference probe tables
         // (one 64-byte line per (pair, seed)). PSK_PROBE=0 never, =1 whatever the round's shape; PSK_GSI_JOIN=0: the probe tables (tests, A/B)
         bool round_probe = false, round_gsi = false, want_small = false, round_slice = false, round_bsi = false;
+        uint64_t round_items = 0;      // (pair, query seed) items of the round
+        for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
         static const double max_blocks_join = getenv("PSK_GSL_MAX_BLOCKS") ? atof(getenv("PSK_GSL_MAX_BLOCKS")) : 4.0;
         {
             const char* pb_env = getenv("PSK_PROBE");
             const bool pb_off = pb_env && pb_env[0] == '0', pb_force = pb_env && pb_env[0] == '1';
-            uint64_t round_items = 0;
-            for (uint32_t i = 0; i < m; i++) round_items += (uint64_t)h_cnt[i] * queries[b + i]->n_seeds;
             want_small = !pb_off && (pb_force || (round_pairs >= 16384 && round_items / round_pairs < 2048));
             const bool gsi_join_off = getenv("PSK_GSI_JOIN") && getenv("PSK_GSI_JOIN")[0] == '0';      // (read per round: tests switch it within a process; chain_run follows the plan)
             // Rounds of many MID-SIZED pairs (all-vs-all of ~5 Mb genomes: every query passes against its family) go through the same index by (query, slice) waves
@@ -4855,6 +4856,172 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             pend_n = 0;
             return PSK_OK;
         };
+        // ---- two batches in flight (rounds of mid-sized pairs joined by (query, slice) waves) ------------------------------------------------------------
+        // A batch is a chain of kernels with different appetites - the index walks wait on memory at an occupancy their LDS sets, the DP on instruction issue -
+        // and every one of them ends in a tail that leaves the chip half empty. Batches are independent: alternate ones run on a SECOND lane (its own stream,
+        // scratch and pinned staging), each driven by a helper thread, at half the seeds per batch, and the two chains fill each other's gaps (10 000 x 10 000:
+        // the query 587 -> 520 ms with two callers of half the queries each; profiles/r5/r5_ablation.md). This thread plans the batches and appends their hits in
+        // batch order; the helpers touch nothing of the database's lock. A batch that does not fit its lane (memory, too repetitive) ends the mode: the loop
+        // below takes over from that batch's first pair at a quarter of the size. PSK_PIPELINE=1 / 0 force / forbid (tests, A/B).
+        {
+            const int pipe_env = getenv("PSK_PIPELINE") ? atoi(getenv("PSK_PIPELINE")) : -1;      // (read per round: bench.py takes its kernel table from a step run as one chain)
+            const bool pipe_want = round_slice && pipe_env != 0 && (pipe_env == 1 || round_items >= (4ull << 29));
+            if (pipe_want && !lane2) {
+                lane2.reset(new (std::nothrow) LaneGuard(ctx->dev, true));
+                if (lane2 && !lane2->lane) lane2.reset();      // every lane is taken (other callers): one chain
+            }
+            if (pipe_want && lane2) {
+                if (!items_env) max_items = 1ull << 29;
+                struct PipeJob {
+                    uint32_t q0 = 0, r0 = 0, q1 = 0, r1 = 0;
+                    std::vector<BatchQ> bqs; std::vector<uint2> tab, ebase; std::vector<uint32_t> qn;      // (host copies feed asynchronous copies: alive until the job is reaped)
+                    uint64_t pairs = 0, items = 0, rows = 0, rows_pair_max = 0;
+                    psk_status rc = PSK_OK; bool refit = false; char err[512] = "";
+                    std::vector<H> hits; uint64_t anchors = 0, cands = 0, wrows = 0, visited = 0, lookups = 0;
+                };
+                PipeJob job[2];
+                std::thread th[2];
+                bool live[2] = {false, false};
+                struct JoinAll { std::thread* t; ~JoinAll() { for (int i = 0; i < 2; i++) if (t[i].joinable()) t[i].join(); } } join_all{th};      // (no way out of this block leaves a helper running)
+                Lane* lanes[2] = {ctx, lane2->lane};
+                PSK_HIP(hipStreamSynchronize(st));      // the round's tables (pass matrix, query descriptors) are complete before the other stream reads them
+                const SketchDesc* d_rd = (const SketchDesc*)db->d_refdesc.p;
+                auto exec = [&](Lane* ln, PipeJob* Jp) {
+                    PipeJob& J = *Jp;
+                    (void)hipSetDevice(ln->device);
+                    J.refit = false; J.hits.clear();
+                    J.rc = [&]() -> psk_status {
+                        hipStream_t s2 = ln->stream;
+                        const uint32_t n_pairs = (uint32_t)J.pairs;
+                        ChainBufs L;
+                        psk_status lrc = chain_layout(ln, n_pairs, (size_t)J.items, (size_t)J.rows, J.bqs.size(), &L);
+                        if (lrc == PSK_ENOMEM) { J.refit = true; return PSK_OK; }
+                        PSK_TRY(lrc);
+                        L.rows_pair_max = (uint32_t)std::min<uint64_t>(J.rows_pair_max, 0xFFFFFFFFu);
+                        L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks;
+                        L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)J.bqs.size();
+                        uint32_t pm = 1; for (const BatchQ& e : J.bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
+                        L.p_cap = (pm + 15u) & ~15u;
+                        L.gsi_onepass = false;
+                        J.qn.resize(J.bqs.size());
+                        for (size_t e = 0; e < J.bqs.size(); e++) J.qn[e] = h_qd[J.bqs[e].q].n;
+                        uint64_t n_rec = 0, n_sl = 0;
+                        gsl_make_tab(J.bqs.data(), J.bqs.size(), J.qn.data(), J.tab, J.ebase, &n_rec, &n_sl);
+                        if (n_rec >= 0x7FFFFF00ull) { psk_set_error("internal: %llu (pair, slice) records in one batch", (unsigned long long)n_rec); return PSK_ELIMIT; }
+                        const size_t o_tab = 0, o_eb = al256(o_tab + 8 * J.tab.size()), o_cnt = al256(o_eb + 8 * J.ebase.size()), o_rec = al256(o_cnt + 4 * (size_t)n_rec),
+                                     o_bm = al256(o_rec + 16 * (size_t)n_rec), o_un = al256(o_bm + 4 * (size_t)GSL_WORDS * (size_t)n_rec), o_endj = o_un + 4 * (size_t)GSL_WORDS * (size_t)n_sl;
+                        lrc = ln->q_j.reserve(o_endj + 256);
+                        if (lrc == PSK_ENOMEM) { J.refit = true; return PSK_OK; }
+                        PSK_TRY(lrc);
+                        char* Jb = (char*)ln->q_j.p;
+                        PSK_HIP(hipMemcpyAsync(Jb + o_tab, J.tab.data(), 8 * J.tab.size(), hipMemcpyHostToDevice, s2));
+                        PSK_HIP(hipMemcpyAsync(Jb + o_eb, J.ebase.data(), 8 * J.ebase.size(), hipMemcpyHostToDevice, s2));
+                        L.gsi_slice = true; L.gsl_tab = (const uint2*)(Jb + o_tab); L.gsl_n_tab = (uint32_t)J.tab.size(); L.gsl_ebase = (const uint2*)(Jb + o_eb); L.gsl_un = (uint32_t*)(Jb + o_un); L.gsl_n_slices = (uint32_t)n_sl;
+                        L.gsl_cnt = (uint32_t*)(Jb + o_cnt); L.gsl_rec = (uint4*)(Jb + o_rec); L.gsl_bm = (uint32_t*)(Jb + o_bm);
+                        PSK_HIP(hipMemcpyAsync(L.bq, J.bqs.data(), sizeof(BatchQ) * J.bqs.size(), hipMemcpyHostToDevice, s2));
+                        hipLaunchKernelGGL(pair_build_rows_kernel, dim3((uint32_t)J.bqs.size()), dim3(256), 0, s2, L.bq, d_pass, n, d_qd, d_rd, L.pairs, L.sbase, L.cbase, L.pair_qr, n_pairs, (uint32_t)J.items, (uint32_t)J.rows);
+                        const bool host_filter = n_pairs <= 4096;
+                        H* d_sel = nullptr;
+                        if (!host_filter) { lrc = ln->q_sel.reserve(al256(sizeof(H) * (size_t)n_pairs + 256)); if (lrc == PSK_ENOMEM) { J.refit = true; return PSK_OK; } PSK_TRY(lrc); d_sel = (H*)ln->q_sel.p; }
+                        void* hp = nullptr;
+                        PSK_TRY(ln->pinned(al256(sizeof(psk_hit) * (size_t)n_pairs + 512), &hp));
+                        ChainTail* T = (ChainTail*)hp; H* h_sel = (H*)((char*)hp + 256);
+                        uint64_t cap = anchor_cap_for(ln, (size_t)J.items, false, false);
+                        cap = std::min<uint64_t>(cap, std::max<uint64_t>(ln->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) > 128 ? ln->q_d.cap / (4 * CHAIN_ANCHOR_WORDS) - 128 : 0, (uint64_t)J.items / 4 * 3 + 65536));
+                        bool wide = join_wide_default();
+                        for (int attempt = 0;; attempt++) {
+                            psk_status rrc = chain_run(ln, L, n_pairs, (size_t)J.items, (size_t)J.rows, db->params, o, d_qd, d_rd, cap, wide, false);
+                            if (rrc == PSK_ENOMEM) { (void)hipStreamSynchronize(s2); J.refit = true; return PSK_OK; }
+                            PSK_TRY(rrc);
+                            if (!host_filter) {
+                                size_t tmp3 = 0;
+                                hipcub::TransformInputIterator<H, ToRec<H>, const psk_hit*> rec_it(L.hits, ToRec<H>());
+                                PSK_HIP(hipcub::DeviceSelect::If(nullptr, tmp3, rec_it, d_sel, L.misc + 12, (int)n_pairs, RecPasses<H>(), s2));
+                                PSK_TRY(ln->q_c.reserve(tmp3));
+                                PSK_HIP(hipcub::DeviceSelect::If(ln->q_c.p, tmp3, rec_it, d_sel, L.misc + 12, (int)n_pairs, RecPasses<H>(), s2));
+                                PSK_HIP(hipMemcpyAsync(T, L.misc, sizeof(ChainTail), hipMemcpyDeviceToHost, s2));
+                            } else PSK_HIP(hipMemcpyAsync(T, L.misc, 256 + sizeof(psk_hit) * (size_t)n_pairs, hipMemcpyDeviceToHost, s2));
+                            PSK_HIP(hipStreamSynchronize(s2));
+                            bool retry, was_wide = wide;
+                            psk_status rc = chain_check(*T, n_pairs, &cap, &wide, &retry);
+                            if ((rc == PSK_ELIMIT && n_pairs > 1) || wide != was_wide) { J.refit = true; return PSK_OK; }      // (the one-chain loop knows what to do with these)
+                            PSK_TRY(rc);
+                            if (!retry) break;
+                            if (attempt >= 3) { psk_set_error("internal: anchor capacity did not converge"); return PSK_EHIP; }
+                        }
+                        uint32_t n_sel = T->misc[12];
+                        if (host_filter) {
+                            const psk_hit* raw = (const psk_hit*)((char*)hp + 256);
+                            for (uint32_t i = 0; i < n_pairs; i++) { const psk_hit r = raw[i]; if (r.ani > 0.1f) J.hits.push_back(HitRec<H>::from_raw(r)); }
+                        } else if (n_sel) {
+                            PSK_HIP(hipMemcpyAsync(h_sel, d_sel, sizeof(H) * (size_t)n_sel, hipMemcpyDeviceToHost, s2));
+                            PSK_HIP(hipStreamSynchronize(s2));
+                            J.hits.assign(h_sel, h_sel + n_sel);
+                        }
+                        J.anchors = T->total64; J.cands = T->cands; J.wrows = T->rows; J.visited = T->visited;
+                        J.lookups = 0; for (const BatchQ& e : J.bqs) J.lookups += h_qd[e.q].n;
+                        return PSK_OK;
+                    }();
+                    if (J.rc != PSK_OK) snprintf(J.err, sizeof J.err, "%s", psk_last_error());
+                    if (J.rc != PSK_OK || J.refit) (void)hipStreamSynchronize(ln->stream);      // (whatever was enqueued reads the job's host tables and the lane's scratch)
+                };
+                bool refit = false;
+                auto reap = [&](int sl) -> psk_status {
+                    if (th[sl].joinable()) th[sl].join();
+                    live[sl] = false;
+                    PipeJob& J = job[sl];
+                    if (J.rc != PSK_OK) { psk_set_error("%s", J.err); return J.rc; }
+                    if (J.refit) { if (!refit) { refit = true; qi = J.q0; rank = J.r0; } return PSK_OK; }
+                    if (refit) return PSK_OK;      // a batch after one that is going to be run again: so is this one
+                    const size_t nh = J.hits.size();
+                    if (nh) {
+                        if (!all.reserve_for(nh)) { psk_set_error("out of host memory"); return PSK_ENOMEM; }
+                        memcpy(all.p + all.n, J.hits.data(), sizeof(H) * nh);
+                        for (size_t i = 0; i < nh; i++) { H& h = all.p[all.n + i]; const uint32_t lq = HitRec<H>::local_query(h); q_hits[lq]++; HitRec<H>::finish(h, b + lq); }
+                        all.n += nh;
+                    }
+                    ctx->dev->w_pairs += J.pairs; ctx->dev->w_items += J.items; ctx->dev->w_anchors += J.anchors; ctx->dev->w_cands += J.cands; ctx->dev->w_rows += J.wrows;
+                    ctx->dev->w_lookups += J.lookups; ctx->dev->w_visited += J.visited;
+                    return PSK_OK;
+                };
+                uint32_t k = 0;
+                for (;;) {
+                    while (qi < m && rank >= h_cnt[qi]) { qi++; rank = 0; }
+                    if (qi >= m || refit) break;
+                    const int sl = (int)(k & 1u);
+                    if (live[sl]) { PSK_TRY(reap(sl)); if (refit) break; }
+                    PipeJob& J = job[sl];
+                    J.bqs.clear(); J.pairs = J.items = J.rows = J.rows_pair_max = 0;
+                    J.q0 = qi; J.r0 = rank;
+                    uint32_t pq = qi, pr = rank;
+                    while (pq < m) {      // (the plan of the loop below)
+                        const uint32_t left = h_cnt[pq] - pr;
+                        if (left == 0) { pq++; pr = 0; continue; }
+                        const uint64_t qn = h_qd[pq].n, qrows = h_qd[pq].rows;
+                        uint64_t take = std::min<uint64_t>(left, max_pairs - J.pairs);
+                        take = std::min<uint64_t>(take, GSI_PMAX);
+                        if (qn) take = std::min<uint64_t>(take, (max_items - J.items) / qn);
+                        if (qrows) take = std::min<uint64_t>(take, (max_rows - J.rows) / qrows);
+                        if (take == 0) { if (J.pairs == 0) take = 1; else break; }
+                        J.bqs.push_back(BatchQ{pq, pr, pr + (uint32_t)take, (uint32_t)J.pairs, (uint32_t)J.items, (uint32_t)J.rows});
+                        J.rows_pair_max = std::max<uint64_t>(J.rows_pair_max, qrows);
+                        J.pairs += take; J.items += take * qn; J.rows += take * qrows;
+                        pr += (uint32_t)take;
+                        if (J.pairs >= max_pairs || J.items >= max_items || J.rows >= max_rows) break;
+                    }
+                    J.q1 = pq; J.r1 = pr;
+                    if (J.items >= 0xFFFFFF00ull || J.rows >= 0xFFFFFF00ull) { psk_set_error("a single pair exceeds the per-launch limits (%llu query seeds)", (unsigned long long)J.items); return PSK_ELIMIT; }
+                    qi = pq; rank = pr;
+                    if (J.items == 0 || J.rows == 0) continue;      // nothing to chain (queries without seeds): no hits
+                    try { th[sl] = std::thread(exec, lanes[sl], &J); }
+                    catch (...) { exec(lanes[sl], &J); }      // (no thread to be had: the batch runs here)
+                    live[sl] = true;
+                    k++;
+                }
+                for (int i = 0; i < 2; i++) { const int sl = (int)((k + (uint32_t)i) & 1u); if (live[sl]) PSK_TRY(reap(sl)); }
+                if (refit) max_items = std::max<uint64_t>(1, max_items / 4);
+            }
+        }
         while (qi < m) {
             if (rank >= h_cnt[qi]) { qi++; rank = 0; continue; }
             // plan one batch from (qi, rank)

@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL", "PSK_GSI_STAGE"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL", "PSK_GSI_STAGE", "PSK_PIPELINE"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -69,7 +69,8 @@ def test_all_vs_all_batch_paths_agree():
     # (switches that act on different stages share a run: every run is a process that loads the library and sketches the genomes again)
     # (the default joins such a batch through the database-wide seed index, one wave per (query, slice of 512 seeds): slice_join.hip; PSK_GSI_SLICE=0 = the per-pair
     # merge join + per-pair emit it replaced, which stays the route of databases that cannot have the index - its switches only act there)
-    for extra in ({"PSK_GSI_SLICE": "0"}, {"PSK_GSL_STAGE": "0", "PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_PAIRS": "0"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_HEADS": "0", "PSK_XCD_GROUP": "0"},
+    # (PSK_PIPELINE=1: alternate batches on a second lane, two in flight - the default of rounds of >= 2^31 (pair, seed) items - here over nine batches, and over one)
+    for extra in ({"PSK_GSI_SLICE": "0"}, {"PSK_GSL_STAGE": "0", "PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "22"}, {"PSK_PIPELINE": "1"}, {"PSK_PIPELINE": "0", "PSK_BATCH_ITEMS_LOG2": "23"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_PAIRS": "0"}, {"PSK_GSI_SLICE": "0", "PSK_EMIT_HEADS": "0", "PSK_XCD_GROUP": "0"},
                   {"PSK_GSI_SLICE": "0", "PSK_BATCH_ITEMS_LOG2": "22", "PSK_ROW_SORT": "0"}, {"PSK_GSI_SLICE": "0", "PSK_CHUNK_HOPS": "1", "PSK_REDUCE_SMALL": "0"}):
         assert _run(ALL_VS_ALL, extra) == base, extra
 
@@ -117,6 +118,7 @@ def test_slice_join_with_more_pairs_than_one_entry_holds(oracle):
     assert base[0] > 80000      # (the far ends of the family - 12 % apart - fall below the screen or the aligned fraction)
     assert _run(ONE_FAMILY, {"PSK_GSI_SLICE": "0"}) == base
     assert _run(ONE_FAMILY, {"PSK_GSL_STAGE": "0"}) == base
+    assert _run(ONE_FAMILY, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "21"}) == base      # two batches in flight, entries of one query in different batches
     import numpy as np
     import pyskani_amd as psk
     lut = np.frombuffer(b"ACGT", np.uint8)
