@@ -30,7 +30,7 @@ PLAN = {
                                "select": ([("select_tiny_kernel", "stream"), ("select_kernel", "stream")], "candidate", False),
                                "pair_reduce": ([("pair_reduce_tiny_kernel", "stream"), ("pair_reduce_small_kernel", "stream")], "row", False)}),
     "mammalian": ("r5_mammal", {"anchor": ([("anchor_join4_kernel", "stream")], "item", False),
-                                "anchor_emit": ([("anchor_emit_expand_kernel", "stream"), ("item_next_kernel", "gather"), ("chunk_hops_items_kernel", "stream"), ("chunk_hops_sliced_kernel", "gather")], "anchor", False),
+                                "anchor_emit": ([("anchor_emit_expand_kernel", "stream"), ("chunk_hops_items_kernel", "stream"), ("chunk_hops_sliced_kernel", "gather")], "anchor", False),
                                 "chain_chunk": ([("chain_lane20x_kernel", "stream"), ("chain_chunk_list_kernel", "stream")], "anchor", False),
                                 "select": ([("select_huge_kernel", "stream"), ("select_big_kernel", "stream")], "candidate", False),
                                 "pair_reduce": ([("pair_reduce_kernel", "stream"), ("pair_reduce_large_kernel", "stream")], "row", False)}),
@@ -53,7 +53,12 @@ def main():
     result = {"_method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/scripts/r5_pmc.sh), KiB x 1024, per timed step; FETCH scaled per kernel by its access "
                          "shape with the factors measured in profiles/r4/r4k_pmc_calibration.md (stream x 2, gather x 1, runs x 1 with x 2 as the upper bound); units = the library's own work counters "
                          "of the same workload (psk_ctx_work / psk_ctx_join_work); index_join: the timer held a walk of the seed index (bench.py prices it by lookups, index entries and anchors)"}
+    only = [a for a in sys.argv[1:] if a in PLAN]      # `pmc_summary_r5.py mammalian`: that workload's passes were run again, the others keep their entries
+    if only:
+        result.update({k: v for k, v in json.load(open(os.path.join(OUT, "pmc_kernels.json"))).items() if not k.startswith("_")})
     for workload, (tag, timers) in PLAN.items():
+        if only and workload not in only:
+            continue
         try:
             fetch, write = read_counter(tag, "FETCH_SIZE"), read_counter(tag, "WRITE_SIZE")
             line = json.load(open(os.path.join(PMC, f"r5_units_{workload}.json")))
@@ -83,6 +88,8 @@ def main():
         for k, v in t.items():
             print(f"{wl:11s} {k:12s} {v['bytes_per_unit']:8.2f} B/{v['unit']} (upper {v['bytes_per_unit_upper']:.2f})  fetch raw {v['fetch_bytes_raw_per_step'] / 1e9:.2f} GB, scaled {v['fetch_bytes_scaled_per_step'] / 1e9:.2f} GB, write {v['write_bytes_per_step'] / 1e9:.2f} GB per step")
     # the headline kernel: traffic per base + VALU wave-instructions per launch (bench.py: roofline.valu)
+    if only and "search" not in only:
+        return
     try:
         sq = {}
         for line in open(os.path.join(PMC, "r5_search_sq.sq.txt")):

@@ -1507,7 +1507,10 @@ __device__ uint32_t chain_chunk_serial(const ChainArgs& A, uint32_t s, uint32_t 
 constexpr int LANE_N = 24;          // predecessors held per lane (multiple of 4)
 constexpr int LANE_WAVES = 2;
 constexpr int LANE_TREES = 4;        // qualifying chain trees per chunk kept in registers
-constexpr int LANE_NEAR = 6;         // predecessors that are always scored; the rest of the band only where it could win (>= 4: they include the step's own anchors)
+#ifndef LANE_NEAR_N
+#define LANE_NEAR_N 3
+#endif
+constexpr int LANE_NEAR = LANE_NEAR_N;    // predecessors that are always scored; the rest of the band only where it could win. >= 3: the far loop reads the register window only, so it must start behind the step's own four anchors. Measured on the 10 000 x 10 000 step's DP: 8: 147, 6: 136, 5: 131, 4: 126, 3: 122 ms
 
 // XT: further tree slots per lane in LDS (0, or LANE_XTREES for Gb-scale pairs: there a seed has ~6 chance 15-mer matches beside the
 // true one, the band of 20 ANCHORS reaches back only ~3 seeds, a true chain breaks wherever three seeds in a row do not match and a
