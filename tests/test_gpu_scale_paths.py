@@ -75,6 +75,29 @@ def test_all_vs_all_batch_paths_agree():
         assert _run(ALL_VS_ALL, extra) == base, extra
 
 
+ALL_VS_ALL_CALLERS = COMMON + r"""
+import threading
+anc = [rng.integers(0, 4, 600_000, dtype=np.uint8) for _ in range(8)]
+genomes = [(f"g{f}_{j}", lut[mutate(anc[f], 0.002 * j)].tobytes()) for f in range(8) for j in range(40)]
+db = psk.Database()
+db.sketch_many(genomes)
+out = [None] * 5
+def run(i): out[i] = digest(db.query_many(genomes, learned_ani=False))
+th = [threading.Thread(target=run, args=(i,)) for i in range(5)]
+for t in th: t.start()
+for t in th: t.join()
+assert all(o == out[0] for o in out), out
+print(*out[0])
+"""
+
+
+def test_callers_that_each_want_a_second_lane():
+    """Five concurrent query_many callers whose rounds keep two batches in flight (PSK_PIPELINE=1, nine batches each): eight lanes for ten wishes - a caller that
+    finds no free lane runs one chain and never waits for one - and every caller gets the single caller's hits."""
+    base = _run(ALL_VS_ALL, {})
+    assert _run(ALL_VS_ALL_CALLERS, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "22"}) == base
+
+
 ONE_FAMILY = COMMON + r"""
 anc = rng.integers(0, 4, 90_000, dtype=np.uint8)
 rep = rng.integers(0, 4, 2_500, dtype=np.uint8)
