@@ -2182,8 +2182,8 @@ __global__ __launch_bounds__(256) void row_len_kernel(const uint2* __restrict__ 
     if (r >= n_rows) return;
     const uint32_t p = row_pair[r];
     uint32_t len = 0;
-    if (r - cbase[p] < n_chunks[p]) { const uint2 se = chunks[r]; len = se.y - se.x; len = len < 16383u ? len : 16383u; }
-    key[r] = len; val[r] = r;
+    if (r - cbase[p] < n_chunks[p]) { const uint2 se = chunks[r]; len = se.y - se.x; len = (len + 7u) >> 3; len = len < 255u ? len : 255u; }
+    key[r] = len; val[r] = r;      // eight bits: ONE pass of the radix sort - lanes of a wave want chunks of similar length, not of equal length (classes of eight anchors; 2 040 and more share the last)
 }
 
 // ---- wave-per-chunk DP with the look-back window in REGISTERS (launches of few rows) ----------------------------
@@ -4024,12 +4024,12 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
         static const bool rs_off = getenv("PSK_ROW_SORT") && getenv("PSK_ROW_SORT")[0] == '0';
         if (rs_off || n_rows < 4096) return PSK_OK;
         size_t ts = 0;
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_rows, 0, 14, st));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_rows, 0, 8, st));
         const size_t ob = al256(4 * n_rows);
         PSK_TRY(ctx->q_g.reserve(4 * ob + ts + 256));
         uint32_t* k_in = (uint32_t*)ctx->q_g.p; uint32_t* v_in = (uint32_t*)((char*)ctx->q_g.p + ob); uint32_t* k_out = (uint32_t*)((char*)ctx->q_g.p + 2 * ob); uint32_t* v_out = (uint32_t*)((char*)ctx->q_g.p + 3 * ob);
         hipLaunchKernelGGL(row_len_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, L.chunks, L.nch, L.cbase, L.row_pair, (uint32_t)n_rows, k_in, v_in);
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending((char*)ctx->q_g.p + 4 * ob, ts, (const uint32_t*)k_in, k_out, (const uint32_t*)v_in, v_out, (int)n_rows, 0, 14, st));
+        PSK_HIP(hipcub::DeviceRadixSort::SortPairsDescending((char*)ctx->q_g.p + 4 * ob, ts, (const uint32_t*)k_in, k_out, (const uint32_t*)v_in, v_out, (int)n_rows, 0, 8, st));
         A.row_order = v_out;
         return PSK_OK;
     };
@@ -4893,6 +4893,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                     PipeJob& J = *Jp;
                     (void)hipSetDevice(ln->device);
                     J.refit = false; J.hits.clear();
+                    try {
                     J.rc = [&]() -> psk_status {
                         hipStream_t s2 = ln->stream;
                         const uint32_t n_pairs = (uint32_t)J.pairs;
@@ -4965,6 +4966,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                         J.lookups = 0; for (const BatchQ& e : J.bqs) J.lookups += h_qd[e.q].n;
                         return PSK_OK;
                     }();
+                    } catch (...) { psk_set_error("out of host memory"); J.rc = PSK_ENOMEM; }      // (nothing may leave a helper thread as an exception)
                     if (J.rc != PSK_OK) snprintf(J.err, sizeof J.err, "%s", psk_last_error());
                     if (J.rc != PSK_OK || J.refit) (void)hipStreamSynchronize(ln->stream);      // (whatever was enqueued reads the job's host tables and the lane's scratch)
                 };

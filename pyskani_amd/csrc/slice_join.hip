@@ -44,10 +44,16 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
 // LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][EMIT: (cursor, first anchor) per pair, the step's lines]
 // [the walked block's pass row as eight (32 bits, prefix count) entries][passing references before every block: g_blocks x 4]
 // [COUNT: cursors: p_cap x 4; anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words | EMIT: (cursor, first anchor) per pair: p_cap x 8; rows so far per pair: p_cap x 4]
+// anchors per staged line of the emit walk (GSL_LINE_N = 4: whole 64-byte lines; 2: 32-byte halves - half the LDS per wave, two more waves per SIMD)
+#ifndef GSL_LINE_N
+#define GSL_LINE_N 4
+#endif
+constexpr uint32_t GSL_LW = GSL_LINE_N, GSL_LM = GSL_LW - 1u, GSL_LS = GSL_LW == 4 ? 2u : 1u;
+static_assert(GSL_LW == 4 || GSL_LW == 2, "a staged line holds four or two anchors");
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
     (void)nw;
-    return (emit ? (64 + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (((size_t)A.g_blocks + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+    return (emit ? (16 * GSL_LW + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (((size_t)A.g_blocks + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
 // an anchor leaves for HBM and is not read again before the DP kernels: a streaming store does not claim L2 lines the walk's index reads want to find again
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     const uint2 eb = A.ebase[te.x];
     const uint32_t rec0 = eb.x + te.y * P;
     uint4* s_line = s_gsl;                                                                  // EMIT: slot t of pair j at [t * pc + j]
-    unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? 4u * pc : 0u));       // EMIT: lim1 of the pair's open chunk
+    unsigned long long* s_lim = (unsigned long long*)(s_gsl + (EMIT ? GSL_LW * pc : 0u));       // EMIT: lim1 of the pair's open chunk
     uint2* s_cs = (uint2*)(s_lim + (EMIT ? pc : 0u));                                       // EMIT: (cursor, first anchor of the (pair, slice)): one 8-byte read
     uint2* s_fl = s_cs + (EMIT ? pc : 0u);                                                  // EMIT: the step's complete lines (pair | first slot << 16, first anchor of the line)
     uint2* s_bp = s_fl + (EMIT ? 64u : 0u);                                                 // the block being walked: its 256 references of the query's pass row, 32 per entry: (bits, passing references before them)
@@ -223,20 +229,20 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 if (!dup) {      // every valid lane has a pair of its own (a reference holds a k-mer once, nearly always): nothing to order between lanes
                     // (no capacity test on this path: the count walk's total was held against the capacity before this kernel started - see the guard at its top)
                     if (!STAGE) { if (valid) { s_cs[slot].x = base + 1u; A.anc[base] = av; } continue; }
-                    const uint32_t t3 = base & 3u;
+                    const uint32_t t3 = base & GSL_LM;
                     if (valid) { s_cs[slot].x = base + 1u; s_line[t3 * pc + slot] = av; }
                     // complete lines leave TOGETHER: four consecutive lanes write one pair's 64 bytes (one request per line where a lane writing its own line makes four)
-                    const bool fl = valid && t3 == 3u;
+                    const bool fl = valid && t3 == GSL_LM;
                     const unsigned long long fm = __ballot(fl);
                     if (fm) {
                         if (fl) {      // (from the pair's first anchor in this slice on - what is before belongs to the previous slice's wave)
-                            const uint32_t st0 = cs.y, lb = base & ~3u, ft = lb >= st0 ? 0u : st0 - lb;
+                            const uint32_t st0 = cs.y, lb = base & ~GSL_LM, ft = lb >= st0 ? 0u : st0 - lb;
                             s_fl[__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(slot | (ft << 16), lb);
                         }
                         lds_wave_sync();
-                        const uint32_t nf = (uint32_t)__popcll(fm), t = (uint32_t)lane & 3u;
-                        for (uint32_t g0 = 0; g0 < nf; g0 += 16) {
-                            const uint32_t r2 = g0 + ((uint32_t)lane >> 2);
+                        const uint32_t nf = (uint32_t)__popcll(fm), t = (uint32_t)lane & GSL_LM;
+                        for (uint32_t g0 = 0; g0 < nf; g0 += 64u / GSL_LW) {
+                            const uint32_t r2 = g0 + ((uint32_t)lane >> GSL_LS);
                             if (r2 < nf) { const uint2 f = s_fl[r2]; if (t >= (f.x >> 16)) gsl_store_anchor<NT>(A.anc + (f.y + t), s_line[t * pc + (f.x & 0xFFFFu)]); }
                         }
                     }
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 const uint32_t jj = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
                 const unsigned long long ends = __ballot(last);
                 const uint32_t tail = valid ? (uint32_t)__ffsll((long long)(ends >> lane)) - 1u : 0u;      // lanes of the group after this one
-                const uint32_t d = base + jj, e = d + tail, lastline = e >> 2;
+                const uint32_t d = base + jj, e = d + tail, lastline = e >> GSL_LS;
                 if (!STAGE) {
                     if (valid) { if (d < A.cap) A.anc[d] = av; else atomicOr(A.err, 2u); }
                     lds_wave_sync();
@@ -260,23 +266,23 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                     continue;
                 }
                 // (A) a group that runs past the line being staged: its first lane sends out what the line holds so far
-                if (valid && jj == 0 && (base >> 2) != lastline && e < A.cap) {
-                    const uint32_t f0 = (base & ~3u) > st0 ? (base & ~3u) : st0;
-                    for (uint32_t t = f0; t < base; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
+                if (valid && jj == 0 && (base >> GSL_LS) != lastline && e < A.cap) {
+                    const uint32_t f0 = (base & ~GSL_LM) > st0 ? (base & ~GSL_LM) : st0;
+                    for (uint32_t t = f0; t < base; t++) A.anc[t] = s_line[(t & GSL_LM) * pc + slot];
                 }
                 lds_wave_sync();
                 // (B) anchors of the group's last line are staged, the others complete their lines and go out directly
                 if (valid) {
-                    if ((d >> 2) == lastline) s_line[(d & 3u) * pc + slot] = av;
+                    if ((d >> GSL_LS) == lastline) s_line[(d & GSL_LM) * pc + slot] = av;
                     else if (e < A.cap) A.anc[d] = av;
                 }
                 lds_wave_sync();
                 // (C) the group's last lane moves the cursor and sends the line out if the group completed it
                 if (last) {
                     if (e >= A.cap) atomicOr(A.err, 2u);
-                    else if ((e & 3u) == 3u) {
-                        const uint32_t f0 = (e & ~3u) > st0 ? (e & ~3u) : st0;
-                        for (uint32_t t = f0; t <= e; t++) A.anc[t] = s_line[(t & 3u) * pc + slot];
+                    else if ((e & GSL_LM) == GSL_LM) {
+                        const uint32_t f0 = (e & ~GSL_LM) > st0 ? (e & ~GSL_LM) : st0;
+                        for (uint32_t t = f0; t <= e; t++) A.anc[t] = s_line[(t & GSL_LM) * pc + slot];
                     }
                     s_cs[slot].x = e + 1u;
                 }
@@ -301,9 +307,9 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     } else if (STAGE) {
         for (uint32_t j = lane; j < P; j += 64) {      // what is left in the lines: the pairs' last anchors of the slice
             const uint32_t c = s_cs[j].x, st0 = s_cs[j].y;
-            if (c > st0 && (c & 3u) && c <= A.cap) {
-                const uint32_t f0 = ((c - 1u) & ~3u) > st0 ? ((c - 1u) & ~3u) : st0;
-                for (uint32_t t = f0; t < c; t++) A.anc[t] = s_line[(t & 3u) * pc + j];
+            if (c > st0 && (c & GSL_LM) && c <= A.cap) {
+                const uint32_t f0 = ((c - 1u) & ~GSL_LM) > st0 ? ((c - 1u) & ~GSL_LM) : st0;
+                for (uint32_t t = f0; t < c; t++) A.anc[t] = s_line[(t & GSL_LM) * pc + j];
             }
         }
     }
