@@ -48,8 +48,8 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
 #ifndef GSL_LINE_N
 #define GSL_LINE_N 4
 #endif
-constexpr uint32_t GSL_LW = GSL_LINE_N, GSL_LM = GSL_LW - 1u, GSL_LS = GSL_LW == 4 ? 2u : 1u;
-static_assert(GSL_LW == 4 || GSL_LW == 2, "a staged line holds four or two anchors");
+constexpr uint32_t GSL_LW = GSL_LINE_N, GSL_LM = GSL_LW - 1u, GSL_LS = GSL_LW == 8 ? 3u : GSL_LW == 4 ? 2u : 1u;
+static_assert(GSL_LW == 8 || GSL_LW == 4 || GSL_LW == 2, "a staged line holds eight, four or two anchors");
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
     (void)nw;
