@@ -2951,8 +2951,9 @@ __global__ __launch_bounds__(256) void chunk_seeds_kernel(ChainArgs A) {
     // unchecked: found by a 480-seed fuzz sweep as a memory fault that needed seventeen earlier cases' leftovers in the scratch arrays)
     const uint2 ch0 = A.chunks[row];
     if (ch0.x > ch0.y || ch0.y > A.cap) return;
-    const uint32_t qc = A.anc[ch0.x].w;
-    if (qc < A.pairs[pair].q_nc) o->seeds = seeds_between(A.pairs[pair], qc, o->left, o->right);
+    const uint32_t nc = A.pairs[pair].q_nc;
+    const uint32_t qc = nc == 1u ? 0u : A.anc[ch0.x].w;      // (a one-contig query - most complete bacterial genomes - needs no look at the chunk's anchors: a cold 64-byte line per row)
+    if (qc < nc) o->seeds = seeds_between(A.pairs[pair], qc, o->left, o->right);
 }
 
 // ------------------------------------------------------------------ per-pair ANI / AF
