@@ -2987,6 +2987,8 @@ __global__ __launch_bounds__(256) void pair_empty_kernel(ReduceArgs R, uint32_t 
 // Two instantiations, like the selection: CAP = RED_SMALL for the bulk (12 KB of LDS instead of 49: residency: 4.1 -> 3.4 ms per 10^5
 // pairs of 5 Mb genomes), CAP = RED_CAP for the pairs with more chunk rows than that (and, beyond RED_CAP values, the global sort).
 constexpr int RED_SMALL = 1024;
+// groups of 64 chunk rows one wave reduces (pair_reduce_wave_kernel)
+constexpr int RW_PER = 8;      // 512 rows: a 5 Mb genome has ~250 chunks, and the pairs just past 256 rows took a workgroup each (15 of the 19 ms of reduction per 10 000 x 10 000 step)
 template <int CAP>
 __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     __shared__ double s_v[CAP];
@@ -2995,7 +2997,7 @@ __device__ void pair_reduce_pair(const ReduceArgs& R, const uint32_t p) {
     const uint32_t nc = R.n_chunks[p];
     if (CAP == RED_SMALL ? nc > (uint32_t)RED_SMALL : nc <= (uint32_t)RED_SMALL) return;      // the other instantiation's pair
     if (R.small_done && nc != 0 && nc <= 64) return;      // pair_reduce_small_kernel took it
-    if (R.wave_done && nc > 64 && nc <= 64u * 4) return;      // pair_reduce_wave_kernel took it
+    if (R.wave_done && nc > 64 && nc <= 64u * RW_PER) return;      // pair_reduce_wave_kernel took it
     if (nc == 0) {      // only reached when the launch visits every pair (no live list): the empty record of pair_empty_kernel
         if (threadIdx.x == 0) {
             psk_hit h{};
@@ -3293,7 +3295,6 @@ __global__ __launch_bounds__(256) void pair_reduce_tiny_kernel(ReduceArgs R, uin
 // wait (33 ns per pair of a 10^6-pair batch). Same arithmetic in the same order as pair_reduce_pair: the chunk values compacted in chunk order, mean and
 // deviation sums as that kernel's 256 threads form them (one value per thread, a shuffle tree per 64, the four trees added in order), the ANI mean as the
 // sequential sum in chunk order - here over lane reads of registers -, median / trimmed mean over an ascending order.
-constexpr int RW_PER = 4;
 __global__ __launch_bounds__(256) void pair_reduce_wave_kernel(ReduceArgs R, uint32_t n_pairs) {
     __shared__ double s_val[4][64 * RW_PER];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3336,9 +3337,10 @@ __global__ __launch_bounds__(256) void pair_reduce_wave_kernel(ReduceArgs R, uin
 #pragma unroll
         for (int g = 0; g < RW_PER; g++) cv[g] = 64u * g + (uint32_t)lane < m ? sv[64 * g + lane] : 0.0;
         auto tree4 = [&](const double* x) {      // block_sum of pair_reduce_pair: a shuffle tree per 64 threads, the four results added in order
-            double t[RW_PER];
+            // (thread t of that kernel's 256 adds elements t and t + 256 before the tree: groups g and g + 4 here)
+            double t[4];
 #pragma unroll
-            for (int g = 0; g < RW_PER; g++) { double y = 0.0 + x[g]; for (int o = 32; o > 0; o >>= 1) y += __shfl_xor(y, o); t[g] = y; }
+            for (int g = 0; g < 4; g++) { double y = 0.0 + x[g]; y += x[g + 4]; for (int o = 32; o > 0; o >>= 1) y += __shfl_xor(y, o); t[g] = y; }
             return t[0] + t[1] + t[2] + t[3];
         };
         const double mean_all = m ? tree4(cv) / (double)m : 0.0;
