@@ -2964,7 +2964,7 @@ struct ReduceArgs {
     const uint2* pair_qr;   // (query, reference) of every pair: travels with the hit (reserved, ref_index)
     const uint32_t* live; const uint32_t* n_live;   // pairs with a chunk table
     int small_done;                                 // chunk tables of <= 64 rows are reduced by pair_reduce_small_kernel
-    int wave_done;                                  // ... and those of 65 .. 256 rows by pair_reduce_wave_kernel
+    int wave_done;                                  // ... and those of 65 .. 64 RW_PER rows by pair_reduce_wave_kernel
     int tiny_done;                                  // ... and those of 1 .. 4 rows (contig pairs, mean ANI) by pair_reduce_tiny_kernel, a lane per pair
     int k, median, robust; double min_af;
     psk_hit* hits;
@@ -4195,9 +4195,9 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     // many pairs with short chunk tables (contigs): one wave per pair first; the workgroup-per-pair kernel then only sees the long tables
     const char* rs_env = getenv("PSK_REDUCE_SMALL");
     const bool no_small = rs_env && rs_env[0] == '0';
-    // tables of 65 .. 256 rows (pairs of ~5 Mb genomes): one wave per pair, four rows per lane; PSK_REDUCE_WAVE=0 leaves them to the workgroup kernel (tests, A/B)
+    // tables of 65 .. 512 rows (pairs of ~5 Mb genomes: ~250): one wave per pair, eight rows per lane; PSK_REDUCE_WAVE=0 leaves them to the workgroup kernel (tests, A/B)
     const bool no_wave = getenv("PSK_REDUCE_WAVE") && getenv("PSK_REDUCE_WAVE")[0] == '0';
-    R.wave_done = !no_wave && !no_small && L.rows_pair_max > 64u && n_rows / n_pairs <= 256u;
+    R.wave_done = !no_wave && !no_small && L.rows_pair_max > 64u && n_rows / n_pairs <= 64u * RW_PER;
     // tables of <= 64 rows (contigs; the short pairs beside the others): one wave per pair, a row per lane (also without the live list: the few pairs of one contig's query)
     R.small_done = !no_small && (n_rows / n_pairs < 16 || R.wave_done);
     // contig batches with the mean ANI: pairs of up to four chunk rows by one lane each first (PSK_REDUCE_TINY=0: by a wave each)
@@ -4208,7 +4208,7 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
     if (R.wave_done) hipLaunchKernelGGL(pair_reduce_wave_kernel, dim3(std::min<uint32_t>((n_pairs + 3) / 4, 16384u)), dim3(256), 0, st, R, n_pairs);
     // (when no pair of the batch can have more rows than the wave kernels take - contigs have 1-3 chunks, 5 Mb genomes ~250 - the two
     // workgroup-per-pair kernels would only walk the pairs to find that out: 24 ms per 17 M contig pairs)
-    if (!((R.small_done && L.rows_pair_max <= 64u) || (R.small_done && R.wave_done && L.rows_pair_max <= 256u)))
+    if (!((R.small_done && L.rows_pair_max <= 64u) || (R.small_done && R.wave_done && L.rows_pair_max <= 64u * RW_PER)))
         hipLaunchKernelGGL(pair_reduce_kernel, dim3(std::min<uint32_t>(n_pairs, 8192u)), dim3(256), 0, st, R, n_pairs);
     if (n_rows > (size_t)RED_SMALL && L.rows_pair_max > (uint32_t)RED_SMALL) hipLaunchKernelGGL(pair_reduce_large_kernel, dim3(std::min<uint32_t>(n_pairs, 512u)), dim3(256), 0, st, R, n_pairs);      // some pair may have more than RED_SMALL rows: a small grid walks the list for them
     ctx->t_end();
