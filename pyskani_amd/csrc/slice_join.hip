@@ -56,16 +56,9 @@ static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     return (emit ? (16 * GSL_LW + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (((size_t)A.g_blocks + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
-// an anchor leaves for HBM and is not read again before the DP kernels: a streaming store does not claim L2 lines the walk's index reads want to find again
-// - measured on the 10 000 x 10 000 step (PSK_GSL_STAGE=5): the walk takes the same time, and the DP kernel that reads the anchors next 178 instead of 165 ms; NT = false is the default
-typedef uint32_t gsl_u4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ void gsl_store_anchor(uint4* dst, const uint4 v) {
-    if (NT) { gsl_u4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w; __builtin_nontemporal_store(x, (gsl_u4*)dst); }
-    else *dst = v;
-}
-
-template <bool EMIT, bool STAGE, bool NT>
+// (streaming - nontemporal - stores of the anchors were measured on the 10 000 x 10 000 step: the walk takes the same time and the DP kernel that reads the anchors next 178 instead of
+// 165 ms: plain stores; profiles/r5/r5_ablation.md)
+template <bool EMIT, bool STAGE>
 __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     extern __shared__ uint4 s_gsl[];
     const int lane = threadIdx.x;
@@ -243,7 +236,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                         const uint32_t nf = (uint32_t)__popcll(fm), t = (uint32_t)lane & GSL_LM;
                         for (uint32_t g0 = 0; g0 < nf; g0 += 64u / GSL_LW) {
                             const uint32_t r2 = g0 + ((uint32_t)lane >> GSL_LS);
-                            if (r2 < nf) { const uint2 f = s_fl[r2]; if (t >= (f.x >> 16)) gsl_store_anchor<NT>(A.anc + (f.y + t), s_line[t * pc + (f.x & 0xFFFFu)]); }
+                            if (r2 < nf) { const uint2 f = s_fl[r2]; if (t >= (f.x >> 16)) A.anc[f.y + t] = s_line[t * pc + (f.x & 0xFFFFu)]; }
                         }
                     }
                     continue;
@@ -403,7 +396,7 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
 }
 
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st) {
-    hipLaunchKernelGGL((gsl_walk_kernel<false, false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
+    hipLaunchKernelGGL((gsl_walk_kernel<false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
     PSK_HIP(hipGetLastError());
     return PSK_OK;
 }
@@ -414,9 +407,8 @@ psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st) {
     return PSK_OK;
 }
 psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st) {
-    if (A.stage != 5 && A.stage) hipLaunchKernelGGL((gsl_walk_kernel<true, true, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
-    else if (A.stage == 5) hipLaunchKernelGGL((gsl_walk_kernel<true, true, true>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
-    else hipLaunchKernelGGL((gsl_walk_kernel<true, false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    if (A.stage) hipLaunchKernelGGL((gsl_walk_kernel<true, true>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
+    else hipLaunchKernelGGL((gsl_walk_kernel<true, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, true), st, A);
     PSK_HIP(hipGetLastError());
     return PSK_OK;
 }
