@@ -19,7 +19,7 @@ PMC = os.path.join(ROOT, "gpurun_out", "pmc")
 OUT = os.path.join(ROOT, "profiles", "r5")
 STEPS = 3      # 1 warm-up + 2 timed steps in every counter pass
 F = {"stream": 2.0, "gather": 1.0, "runs": 1.0}
-W_COUNT, W_EMIT = "gsl_walk_kernel<false, false, false>", "gsl_walk_kernel<true, true, false>"      # (the names of the round-5 counter passes; the third template flag - nontemporal stores - has since been removed)
+W_COUNT, W_EMIT = "gsl_walk_kernel<false, false>", "gsl_walk_kernel<true, true>"
 PLAN = {
     "search": ("r5_search", {"sketch_scan": ([("sketch_scan_kernel", "stream")], "base", False), "sketch_emit": ([("sketch_emit_kernel", "stream")], "base", False)}),
     "allvsall": ("r5_ava", {"anchor": ([(W_COUNT, "runs")], "anchor", True), "anchor_emit": ([(W_EMIT, "runs"), ("gsl_heads_kernel", "stream")], "anchor", True),
