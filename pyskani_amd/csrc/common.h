@@ -278,6 +278,24 @@ struct LaneGuard {
     LaneGuard(const LaneGuard&) = delete;
     LaneGuard& operator=(const LaneGuard&) = delete;
 };
+// The chain-stage scratch of the context's IDLE lanes (tens of GB each after an all-vs-all) goes back to the driver: a call that is about to size its batches by the free
+// memory (Gb-scale pairs) would otherwise plan around buffers nobody is using. The lanes stay; their next call allocates again.
+inline void psk_trim_idle_lanes(psk_ctx* c, Lane* self) {
+    std::vector<Lane*> idle;
+    {
+        std::lock_guard<std::mutex> lk(c->lanes_mu);
+        for (size_t i = 0; i < c->lanes.size(); i++) if (!c->busy[i] && c->lanes[i] != self) { c->busy[i] = 1; idle.push_back(c->lanes[i]); }
+    }
+    for (Lane* L : idle) {
+        (void)hipStreamSynchronize(L->stream);
+        Scratch* big[] = {&L->q_b, &L->q_c, &L->q_d, &L->q_e, &L->q_g, &L->q_j, &L->q_sel};
+        for (Scratch* s : big) s->release();
+    }
+    if (!idle.empty()) {
+        { std::lock_guard<std::mutex> lk(c->lanes_mu); for (Lane* L : idle) for (size_t i = 0; i < c->lanes.size(); i++) if (c->lanes[i] == L) c->busy[i] = 0; }
+        c->lanes_cv.notify_all();
+    }
+}
 #define PSK_LANE(guard, ctx) LaneGuard guard(ctx); if (!guard.lane) { psk_set_error("no execution lane (hipStreamCreate failed)"); return PSK_EHIP; }
 
 // grow-only device buffer taken from (and returned to) the context's block pool: for the per-database tables, which a

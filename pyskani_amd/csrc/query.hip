@@ -4797,7 +4797,13 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             // per batch instead of five - the per-pair chains of the chunk walk, the selection's group barriers and the reduction overlap across twice the pairs
             // (8 x 3 Gb: 234 -> 211 ms per step). 2^29 would pass the 2^31 anchors one launch sequence addresses.
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->q_d.cap + ctx->q_e.cap > ((size_t)212 << 30)) items_log2 = 28;
+            const size_t need = (size_t)212 << 30;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->q_d.cap + ctx->q_e.cap <= need && total_b > need) {
+                psk_trim_idle_lanes(ctx->dev, ctx);      // (an earlier all-vs-all left 47-94 GB of scratch on each of its two lanes)
+                if (lane2) { Scratch* big[] = {&lane2->lane->q_b, &lane2->lane->q_c, &lane2->lane->q_d, &lane2->lane->q_e, &lane2->lane->q_g, &lane2->lane->q_j, &lane2->lane->q_sel}; (void)hipStreamSynchronize(lane2->lane->stream); for (Scratch* s : big) s->release(); }
+                (void)hipMemGetInfo(&free_b, &total_b);
+            }
+            if (free_b + ctx->q_d.cap + ctx->q_e.cap > need) items_log2 = 28;
         }
         // Rounds of many small pairs (contigs): up to 2^22 pairs and 2^30 seeds per batch. The probe join visits a batch's pairs reference by reference, and a line of a
         // reference's table is probed about once per 2^20 pairs of a 5 000-reference database: with twice the pairs every line is probed twice while it is still
