@@ -3290,7 +3290,7 @@ __global__ __launch_bounds__(256) void pair_reduce_tiny_kernel(ReduceArgs R, uin
     R.hits[p] = h;
 }
 
-// Pairs whose chunk table has 65 .. 256 rows (a pair of 5 Mb genomes: ~170-250 chunks): ONE WAVE per pair, four rows per lane, four independent pairs per
+// Pairs whose chunk table has 65 .. 64 RW_PER rows (a pair of 5 Mb genomes: ~170-300 chunks): ONE WAVE per pair, RW_PER rows per lane, four independent pairs per
 // workgroup, no workgroup barrier - the workgroup-per-pair kernel spends its time in a dozen barriers and a one-thread sum over LDS while 255 threads
 // wait (33 ns per pair of a 10^6-pair batch). Same arithmetic in the same order as pair_reduce_pair: the chunk values compacted in chunk order, mean and
 // deviation sums as that kernel's 256 threads form them (one value per thread, a shuffle tree per 64, the four trees added in order), the ANI mean as the
