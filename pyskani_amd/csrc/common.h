@@ -274,7 +274,8 @@ struct LaneGuard {
         lk.unlock();
         (void)hipSetDevice(c->device);
     }
-    ~LaneGuard() { if (idx >= 0) { lane->huge_release(); { std::lock_guard<std::mutex> lk(c->lanes_mu); c->busy[idx] = 0; } c->lanes_cv.notify_one(); } }
+    ~LaneGuard() { if (idx >= 0) { lane->huge_release(); if (lane->side_stream) (void)hipStreamSynchronize(lane->side_stream);      /* (an error exit between the side stream's fork and join leaves it reading this lane's scratch) */
+                   { std::lock_guard<std::mutex> lk(c->lanes_mu); c->busy[idx] = 0; } c->lanes_cv.notify_one(); } }
     LaneGuard(const LaneGuard&) = delete;
     LaneGuard& operator=(const LaneGuard&) = delete;
 };

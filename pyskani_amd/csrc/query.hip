@@ -4912,7 +4912,6 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                 PipeJob job[2];
                 std::thread th[2];
                 bool live[2] = {false, false};
-                struct JoinAll { std::thread* t; ~JoinAll() { for (int i = 0; i < 2; i++) if (t[i].joinable()) t[i].join(); } } join_all{th};      // (no way out of this block leaves a helper running)
                 Lane* lanes[2] = {ctx, lane2->lane};
                 PSK_HIP(hipStreamSynchronize(st));      // the round's tables (pass matrix, query descriptors) are complete before the other stream reads them
                 const SketchDesc* d_rd = (const SketchDesc*)db->d_refdesc.p;
@@ -4996,8 +4995,10 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                     } catch (...) { psk_set_error("out of host memory"); J.rc = PSK_ENOMEM; }      // (nothing may leave a helper thread as an exception)
                     if (J.rc != PSK_OK) snprintf(J.err, sizeof J.err, "%s", psk_last_error());
                     if (J.rc != PSK_OK || J.refit) (void)hipStreamSynchronize(ln->stream);      // (whatever was enqueued reads the job's host tables and the lane's scratch)
+                    ln->huge_release();      // a batch with a Gb-scale pair took the device's group-selection mutex inside chain_run: it goes back with the batch, whatever its outcome - the other lane's next such batch waits for it
                 };
                 bool refit = false;
+                struct JoinAll { std::thread* t; ~JoinAll() { for (int i = 0; i < 2; i++) if (t[i].joinable()) t[i].join(); } } join_all{th};      // (no way out of this block leaves a helper running; declared after everything the helpers reach by reference)
                 auto reap = [&](int sl) -> psk_status {
                     if (th[sl].joinable()) th[sl].join();
                     live[sl] = false;
