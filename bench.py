@@ -5,16 +5,20 @@ One "step" = one pass of the whole hot path over one batch of synthetic genomes 
 sketch every genome (FracMinHash seeds, marker sets, k-mer index), load them into a fresh database, run the query (marker
 screen -> seed-index lookup -> chaining -> ANI/AF) and bring the hit list back to the host. Nothing is cached between steps.
 
-The ONE JSON line (rank 0) is the headline workload, BASELINE.json configs[1]: 1 query vs 1 000 synthetic ~5 Mb refs, c=125,
-marker_c=1000, k=15 (`--workload search`, the default). At N=1 the default run then also measures the other configurations
-`north_star` names, each as an entry of `extras.workloads` with its own ms/step, hits, dominant-kernel `roofline` and a bounded
-`cpu_baseline`:
-  allvsall_10k      BASELINE configs[2] on ONE GPU: 10 000 x 10 000 genomes (100 families of 100), 10^8 pairs, ~10^6 chained
+The ONE JSON line (rank 0) is the CONTRACT JOB - the job `north_star`'s target is quoted on, BASELINE.json configs[2] on the GPUs given: all-vs-all of 10 000
+synthetic ~5 Mb genomes (100 families of 100), 10^8 pairs, ~10^6 of them chained, c=125 marker_c=1000 k=15; a FIXED job (`scaling: "strong"`): at N>1 the references are
+sharded over the ranks, the shards' sketches all-gathered as the query side and the 20-byte hit records all-gathered once, so `--gpus N` reports the same job as N=1.
+`host_to_host` beside `value` is the same job from ASCII in HOST memory; `extras.oracle_check` = 8 random hits of the step recomputed by the CPU oracle;
+`extras.scaling_model` = a SINGLE-GPU EMULATION of rank 0's share of the 2-, 4- and 8-way job (no multi-GPU node was available: a prediction, not a measurement).
+At N=1 the default run then also measures the other configurations `north_star` names, each as an entry of `extras.workloads` with its own ms/step, hits,
+dominant-kernel `roofline` and a bounded `cpu_baseline`:
+  search_1k         BASELINE configs[1]: 1 query vs 1 000 synthetic ~5 Mb refs (the headline of rounds 1-5), with its host-memory API legs
+  allvsall_1k_*     SURVEY.md 8(d)'s harder generator variants (genomes cut into contigs / with block rearrangements), 8 hits of each recomputed by the oracle
   metagenome_100k   BASELINE configs[3]: 100 000 contigs (2-50 kb) vs a resident database of 5 000 x ~5 Mb refs, c=30 marker_c=200,
                     with the rescue of short contigs on (default) and off (`faster_small`)
   mammalian_8x3Gb   BASELINE configs[4] shape at reduced count: all-vs-all of 8 genomes of 24 x 125 Mb contigs; two of the chained
                     pairs are checked against the CPU oracle outside the timed region
-(`--no-workloads` skips them; `--workload X` runs X alone as the line.)
+(`--no-workloads` skips them; `--workload X` runs X alone as the line; `--refs N` without `--workload` runs the contract job at N genomes.)
 
 Every line / entry carries
   roofline      the workload's dominant kernel among those with a stated algorithmic byte count, timed with HIP events
@@ -25,11 +29,11 @@ Every line / entry carries
   clock         shader clock under an integer-VALU load, probed before the timed loop (sketch_scan is bound by VALU issue: its
                 time follows the clock the box holds)
 
-N>1 (one process per GPU, launched by torch.distributed.run): `search` shards the references (1 000 per GPU: weak scaling), the
-query is replicated and the per-shard hit lists are all-gathered; `--workload allvsall` shards a FIXED job of --refs genomes over
-the ranks (strong scaling): every rank sketches its share, the shards' sketches are all-gathered as packed device records in
-batches (the query side), queried against the local shard, and the hit records are all-gathered. `--comm torch` moves both
-through torch.distributed (backend nccl = RCCL), `--comm capi` through the library's own RCCL communicator (psk_comm_*).
+N>1 (one process per GPU, launched by torch.distributed.run): the contract job shards its FIXED set of genomes over the ranks (strong scaling): every rank sketches
+its share, the shards' sketches are all-gathered as packed device records in batches (the query side; round b + 1 travels while round b is queried), queried against
+the local shard, and the hit records are all-gathered. `--workload search` shards 1 000 references per GPU (weak scaling), the query is replicated and the per-shard hit
+lists are all-gathered. `--comm torch` moves the exchange steps through torch.distributed (backend nccl = RCCL), `--comm capi` through the library's own RCCL
+communicator (psk_comm_*).
 """
 import argparse
 import ctypes as C
@@ -157,6 +161,11 @@ def compact_line(full, full_path=None):
             ex[k] = _sig(ex_full[k])
     if "exchange" in ex_full:
         ex["exchange"] = _pick(ex_full["exchange"], ("ranks", "backend", "bytes_sent_per_rank_last_step", "collective_s_last_step", "psk_s_last_step", "outside_psk_and_collectives_frac"))
+    if "oracle_check" in ex_full:
+        ex["oracle_check"] = ex_full["oracle_check"].get("result")
+    if ex_full.get("scaling_model"):
+        ex["scaling_model"] = {"kind": _clip(ex_full["scaling_model"].get("kind", ""), 60),
+                               "ranks": {n: _pick(v, ("rank_ms", "speedup_vs_1", "pairs_chained", "index_lookups", "bytes_received")) for n, v in ex_full["scaling_model"].get("ranks", {}).items()}}
     if "workloads" in ex_full:
         ex["workloads"] = {k: compact_workload(v) for k, v in ex_full["workloads"].items() if v}
     line["extras"] = ex
@@ -164,6 +173,8 @@ def compact_line(full, full_path=None):
         line["full"] = full_path
     if len(json.dumps(line)) >= LINE_BUDGET:      # never exceed the budget: drop the least important parts, in this order
         line.pop("kernel_ms_per_step", None)
+    if len(json.dumps(line)) >= LINE_BUDGET and "scaling_model" in ex:
+        ex["scaling_model"]["ranks"] = {n: _pick(v, ("rank_ms", "speedup_vs_1")) for n, v in ex["scaling_model"]["ranks"].items()}
     if len(json.dumps(line)) >= LINE_BUDGET and "workloads" in ex:
         ex["workloads"] = {k: _pick(v, ("ms_per_step", "value", "unit")) for k, v in ex["workloads"].items()}
     while len(json.dumps(line)) >= LINE_BUDGET and ex.get("workloads"):
@@ -173,10 +184,10 @@ def compact_line(full, full_path=None):
 
 
 def write_full(full, tag):
-    """the complete object: profiles/r5/ (tracked) and gpurun_out/ (what travels back from the GPU box). Returns the repo-relative path."""
+    """the complete object: profiles/r6/ (tracked) and gpurun_out/ (what travels back from the GPU box). Returns the repo-relative path."""
     name = f"bench_full_{tag}_{time.strftime('%Y%m%d_%H%M%S')}.json"
     rel = None
-    for d in (os.path.join("gpurun_out"), os.path.join("profiles", "r5")):
+    for d in (os.path.join("gpurun_out"), os.path.join("profiles", "r6")):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
             with open(os.path.join(ROOT, d, name), "w") as f:
@@ -841,7 +852,7 @@ def records_digest(recs):
     return h.hexdigest()[:16]
 
 
-def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", verify_hits=0, host_leg=False):
+def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", verify_hits=0, host_leg=False, model_ranks=()):
     """BASELINE configs[2] shape: every genome against a database of all of them (families of 100). N=1: one psk_query_many. N>1: the
     FIXED job of n_total genomes is sharded over the ranks (strong scaling) and run through parallel.ShardedDatabase.all_vs_all_records."""
     torch, rank, world, args = job.torch, job.rank, job.world, job.args
@@ -897,7 +908,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                 "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}; {shape}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
-                "roofline": roofline_of(table, 1 if table_step else steps), "kernel_roofline": table, "clock": clock, "scaling": "n/a (one GPU)"}
+                "roofline": roofline_of(table, 1 if table_step else steps), "kernel_roofline": table, "clock": clock, "scaling": "strong"}
         if table_step:
             line["kernel_table_step"] = table_step
         host = None
@@ -948,6 +959,8 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
             raw["reserved"] = np.repeat(np.arange(n, dtype=np.uint32), np.diff(roffs))
             assert records_digest(raw) == digest, "the 80-byte and the 20-byte records of the same step disagree"
             line["oracle_check"] = allvsall_verify(buf, offs, lens, gfc_list, raw, verify_hits)
+        if model_ranks and variant == "plain":
+            line["scaling_model"] = scaling_model(eng, buf, offs, lens, n_total, args.exchange_batch, line["ms_per_step"], tuple(model_ranks))
         eng.close()
     else:
         import pyskani_amd as psk
@@ -975,13 +988,13 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
         dt = job.max_over_ranks(dt)
         if rank == 0:
             st = state["stats"]
-            other = st["total_s"] - st["psk_s"] - st["collective_s"]
+            other = st["total_s"] - st["psk_s"] - st.get("exposed_collective_s", st["collective_s"])      # (the gathers of later rounds run beside psk_s on a helper thread: only what the calling thread waited for is exposed)
             table = kernel_rooflines(kern, steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
             line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                     "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes sharded over {world} GPU(s) ({n_families} families), c=125 marker_c=1000 k=15, device-resident ASCII; "
                                 f"query side = all-gather of the shards' packed sketch records, {args.exchange_batch} genomes per rank and round; hit records all-gathered once ({args.comm})",
                     "hits": int(n_hits), "hits_digest": records_digest(state["recs"]), "scaling": "strong",
-                    "exchange": {"ranks": int(job.dist.get_world_size()), "backend": args.backend, "record_bytes": int(state["recs"].dtype.itemsize), "overlap": True, "bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "psk_s_last_step": st["psk_s"],
+                    "exchange": {"ranks": int(job.dist.get_world_size()), "backend": args.backend, "record_bytes": int(state["recs"].dtype.itemsize), "overlap": True, "bytes_sent_per_rank_last_step": int(state["bytes_sent"]), "collective_s_last_step": st["collective_s"], "exposed_collective_s_last_step": st.get("exposed_collective_s"), "psk_s_last_step": st["psk_s"],
                                  "python_s_last_step": other, "all_vs_all_s_last_step": st["total_s"],
                                  "outside_psk_and_collectives_frac": other / st["total_s"] if st["total_s"] > 0 else None,
                                  "note": "rank 0's split of the last step's ShardedDatabase.all_vs_all_records call (sketching the shard and loading the database come before it)"},
@@ -991,6 +1004,82 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
     del buf
     torch.cuda.empty_cache()
     return line
+
+
+XGMI_LINK_GBS = 153.0      # MI355X_MICROARCH.md: 7 point-to-point xGMI links per GPU, ~153 GB/s each
+
+
+def scaling_model(eng, buf, offs, lens, n_total, batch, t1_ms, ranks=(2, 4, 8)):
+    """A SINGLE-GPU EMULATION of one rank's share of the N-way strong-scaling job - not a measurement of N GPUs (none was available to this build). For N in `ranks` this
+    GPU plays rank 0: it sketches rank 0's shard (n_total / N genomes), loads it as the local database and queries it with every round ShardedDatabase.all_vs_all_records
+    would hand it (parallel.py: `batch` genomes of EVERY rank per round, rank-major; the other ranks' sketches are sketched here beforehand, untimed - on N GPUs they arrive
+    over xGMI while the previous round is queried). Reported per N: the rank's time (sketch + load + rounds), its work counters, the bytes it would send / receive, the
+    exchange time those bytes cost over direct xGMI links (overlapped with the queries except for the first round), and the implied speed-up against the measured N = 1 step.
+    The job's families are consecutive in insertion order, so a rank chains 1 / N of the pairs and only its own genomes' seeds are looked up (a query without a passing
+    reference in the shard costs its share of the marker screen and nothing else): what does not shrink with N is the screen of all n_total queries and the per-round set-up."""
+    capi, lib = eng.capi, eng.lib
+    n_all = len(offs)
+    c_off, c_len, gfc, n = eng.layout(offs, lens)
+    everyone = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, n)      # stand-ins for the gathered sketches
+    pack = np.zeros(n_all, np.int64)
+    sz = C.c_uint64()
+    for i in range(n_all):
+        capi.check(lib.psk_sketch_pack_size(C.c_void_p(everyone[i]), C.byref(sz)))
+        pack[i] = sz.value
+    out = {"kind": "single-GPU emulation of rank 0's share (NOT a multi-GPU measurement)", "batch": batch, "n1_measured_ms": t1_ms, "ranks": {}}
+    from pyskani_amd.parallel import shard_bounds
+    try:
+        for N in ranks:
+            bounds = [shard_bounds(n_total, r, N) for r in range(N)]
+            lo, hi = bounds[0]
+            m = hi - lo
+            s_off, s_len, s_gfc, _ = eng.layout(offs[lo:hi], lens[lo:hi])
+            names = (C.c_char_p * m)(*[f"g{i}".encode() for i in range(lo, hi)])
+            per_batch = {}
+            for bt in sorted({batch, max(b1 - b0 for b0, b1 in bounds)}):
+                rounds = (max(b1 - b0 for b0, b1 in bounds) + bt - 1) // bt
+                best = None
+                for rep in range(2):      # (the second pass is the warm one)
+                    eng.sync(); eng.work(reset=True)
+                    t0 = time.perf_counter()
+                    mine = eng.sketch_device_c(buf.data_ptr(), s_off, s_len, s_gfc, m)
+                    eng.sync(); t1 = time.perf_counter()
+                    db = eng.make_db(names, mine, m)
+                    t2 = time.perf_counter()
+                    hits, round_s, recv = 0, [], 0
+                    try:
+                        for b in range(rounds):
+                            ids = [i for (b0, b1) in bounds for i in range(min(b0 + b * bt, b1), min(b0 + (b + 1) * bt, b1))]
+                            if not ids:
+                                continue
+                            hs = (C.c_void_p * len(ids))(*[everyone[i] for i in ids])
+                            tr = time.perf_counter()
+                            hits += eng.query_many(db, hs, len(ids))
+                            round_s.append(time.perf_counter() - tr)
+                            recv += int(pack[[i for i in ids if not (lo <= i < hi)]].sum())
+                    finally:
+                        lib.psk_db_destroy(db)
+                    t3 = time.perf_counter()
+                    w = eng.work(reset=True)
+                    cur = {"rank_ms": (t3 - t0) * 1e3, "sketch_ms": (t1 - t0) * 1e3, "db_load_ms": (t2 - t1) * 1e3, "rounds": rounds, "rounds_ms": sum(round_s) * 1e3, "first_round_ms": round_s[0] * 1e3 if round_s else 0.0,
+                           "hits_rank": int(hits), "pairs_chained": int(w["chained_pairs"]), "index_lookups": int(w["index_lookups"]), "index_entries_visited": int(w["index_entries_visited"]), "anchors": int(w["anchors"]),
+                           "bytes_sent": int(pack[lo:hi].sum()) + 20 * int(hits), "bytes_received": recv + 20 * int(hits) * (N - 1),
+                           "exchange_ms_model": (recv / max(1, N - 1)) / (XGMI_LINK_GBS * 1e9) * 1e3, "first_round_exchange_ms_model": (recv / max(1, N - 1) / max(1, rounds)) / (XGMI_LINK_GBS * 1e9) * 1e3}
+                    if best is None or cur["rank_ms"] < best["rank_ms"]:
+                        best = cur
+                best["speedup_vs_1"] = t1_ms / (best["rank_ms"] + best["first_round_exchange_ms_model"])
+                best["efficiency"] = best["speedup_vs_1"] / N
+                per_batch[bt] = best
+            pick = min(per_batch, key=lambda k: per_batch[k]["rank_ms"])
+            e = dict(per_batch[batch], batch=batch)
+            if pick != batch:
+                e["best_batch"] = dict(per_batch[pick], batch=pick)
+            out["ranks"][str(N)] = e
+    finally:
+        lib.psk_sketch_free_many(everyone, n)
+    out["note"] = ("exchange_ms_model: the sketches a rank receives from ONE peer over that peer's direct xGMI link at %.0f GB/s (all peers send at once); only the first round's share is "
+                   "exposed (round b + 1 travels while round b is queried), which speedup_vs_1 adds to rank_ms. The hit all-gather (20 B per hit) is latency-bound and not priced." % XGMI_LINK_GBS)
+    return out
 
 
 def allvsall_verify(buf, offs, lens, gfc, recs, k):
@@ -1256,9 +1345,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--refs", type=int, default=None, help="search: references per GPU (default 1000 = BASELINE configs[1]); allvsall: TOTAL genomes of the job (default 1000); metagenome: database size (default 5000); mammalian: genomes (default 8)")
-    ap.add_argument("--workload", choices=["search", "allvsall", "metagenome", "mammalian"], default="search",
-                    help="search = BASELINE configs[1] (the headline, with the other configurations under extras.workloads at N=1); the others run alone as the line")
-    ap.add_argument("--no-workloads", action="store_true", help="search at N=1: skip extras.workloads (all-vs-all 10k, metagenome 100k, mammalian 8 x 3 Gb)")
+    ap.add_argument("--workload", choices=["search", "allvsall", "metagenome", "mammalian"], default=None,
+                    help="default (no flag) = the contract job: all-vs-all of 10 000 genomes (BASELINE configs[2], the job north_star's target is quoted on; a FIXED job, sharded over the ranks at N>1: strong scaling), "
+                         "with the other configurations under extras.workloads at N=1; a named workload runs alone as the line (search = BASELINE configs[1]: 1 query vs 1 000 refs per GPU, weak scaling)")
+    ap.add_argument("--no-workloads", action="store_true", help="the default run at N=1: skip extras.workloads (search 1 x 1 000, all-vs-all 1k variants, metagenome 100k, mammalian 8 x 3 Gb)")
     ap.add_argument("--queries", type=int, default=10000, help="metagenome: number of query contigs")
     ap.add_argument("--contig-mb", type=int, default=125, help="mammalian: contig length in Mb (24 contigs per genome; 125 = 3 Gb genomes)")
     ap.add_argument("--api-queries", type=int, default=10000, help="metagenome: contigs also sent one by one through Database.query() from host bytes (0 = skip)")
@@ -1271,8 +1361,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000, help="CPU-baseline sample size (0 = skip): search: references (1000 = the whole workload, ~10-20 s); allvsall: queries (capped at 128); metagenome: contigs (capped at 512)")
     ap.add_argument("--variant", choices=["plain", "contigs", "sv"], default="plain", help="allvsall at N=1: the generator variant of SURVEY.md 8(d) - genomes cut into 1-80 contigs / 20 block rearrangements per genome")
     ap.add_argument("--no-api", action="store_true", help="skip the host-memory API extras (N=1 search only)")
-    ap.add_argument("--ava-genomes", type=int, default=10000, help="search at N>1: genomes of the strong-scaling all-vs-all job under extras.workloads.allvsall_10k (dry runs on one GPU: a few hundred)")
-    ap.add_argument("--no-host-leg", action="store_true", help="search at N=1: skip the all-vs-all job from ASCII in HOST memory (extras.workloads.allvsall_10k.host_to_host; needs ~55 GB of host memory)")
+    ap.add_argument("--no-host-leg", action="store_true", help="the default run at N=1: skip the job from ASCII in HOST memory (host_to_host; needs ~55 GB of host memory)")
+    ap.add_argument("--emulate-rank-of", type=int, nargs="*", default=None, help="N=1 all-vs-all: after the timed steps, time rank 0's share of the N-way job on this one GPU for every N given (default run: 2 4 8) -> extras.scaling_model; an emulation, not a measurement")
     args = ap.parse_args()
 
     # --gpus N without a launcher: this process starts the N ranks itself, BEFORE torch is imported or any HIP call is made
@@ -1318,13 +1408,31 @@ def main():
         return line
 
     line = None
+    contract = args.workload is None      # no --workload: the contract job, 10 000 x 10 000 (with --refs: the same job at that size)
+    if contract:
+        args.workload = "allvsall"
     if args.workload == "search":
         line = run_search(job, args.steps, args.warmup, args.refs or N_REFS, cpu_n, with_api=(world == 1 and not args.no_api))
-        if world == 1 and not args.no_workloads:
+    elif args.workload == "allvsall":
+        n_total = args.refs or (10000 if contract else 1000)
+        full_job = contract and args.variant == "plain"
+        model_ranks = args.emulate_rank_of if args.emulate_rank_of is not None else ([2, 4, 8] if (full_job and not args.no_workloads) else [])
+        e = run_allvsall(job, args.steps, args.warmup, n_total, min(cpu_n, 128), variant=args.variant, verify_hits=8 if (cpu_n > 0 and world == 1) else 0,
+                         host_leg=(full_job and world == 1 and not args.no_host_leg), model_ranks=model_ranks if world == 1 else ())
+        if e:
+            line = as_line(e, "allvsall", {"genomes": n_total, "parallelism": f"references sharded over {world} GPU(s)" + (f"; the shards' sketches all-gathered as the query side, hit records all-gathered once ({args.comm})" if world > 1 else "")})
+            line["scaling"] = "strong"
+            if e.get("host_to_host"):
+                line["host_to_host"] = e["host_to_host"]
+            if e.get("exchange"):
+                line["extras"]["exchange"] = e["exchange"]
+        if full_job and world == 1 and not args.no_workloads:
             t0 = time.perf_counter()
             wl = {}
-            wl["allvsall_10k"] = run_allvsall(job, 2, 1, 10000, min(cpu_n, 128), host_leg=not args.no_host_leg)
-            # SURVEY.md §8d's harder shapes (every measured pair above is the easiest chaining case: one contig, substitutions only)
+            sl = run_search(job, 10, 2, N_REFS, cpu_n, with_api=not args.no_api)      # BASELINE configs[1]: the former headline
+            sl.update(workload=sl["config"]["workload"], hits=sl["config"]["hits"], kernel_roofline={})
+            wl["search_1k"] = sl
+            # SURVEY.md §8d's harder shapes (every pair of the contract job is the easiest chaining case: one contig, substitutions only)
             wl["allvsall_1k_contigs"] = run_allvsall(job, 2, 1, 1000, 0, variant="contigs", verify_hits=8 if cpu_n > 0 else 0)
             wl["allvsall_1k_sv"] = run_allvsall(job, 2, 1, 1000, 0, variant="sv", verify_hits=8 if cpu_n > 0 else 0)
             meta = run_metagenome(job, 2, 1, 5000, 100000, (False, True), min(cpu_n, 512), 10000)
@@ -1332,18 +1440,6 @@ def main():
             wl["mammalian_8x3Gb"] = run_mammalian(job, 2, 1, 8, 125, 2 if cpu_n > 0 else 0)
             line["extras"]["workloads"] = wl
             line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
-        elif world > 1 and not args.no_workloads:
-            # N > 1: after the (weak-scaled) search headline, the north-star job itself - a FIXED set of genomes sharded over the ranks (strong scaling): every rank
-            # sketches its shard, the shards' sketches are all-gathered round by round as the query side (round b + 1 travels while round b is queried),
-            # the 20-byte hit records are all-gathered once; hits_digest equals the N = 1 entry's
-            t0 = time.perf_counter()
-            e = run_allvsall(job, 2, 1, args.ava_genomes, 0)
-            if rank == 0 and e:
-                line["extras"]["workloads"] = {"allvsall_10k": e}
-                line["extras"]["workloads_wall_s"] = time.perf_counter() - t0
-    elif args.workload == "allvsall":
-        e = run_allvsall(job, args.steps, args.warmup, args.refs or 1000, min(cpu_n, 128), variant=args.variant, verify_hits=8 if (cpu_n > 0 and args.variant != "plain") else 0)
-        line = as_line(e, "allvsall") if e else None
     elif args.workload == "metagenome":
         m = run_metagenome(job, args.steps, args.warmup, args.refs or 5000, args.queries, (args.faster_small,), min(cpu_n, 512), args.api_queries)
         if rank == 0:

@@ -4167,7 +4167,8 @@ static psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, siz
                     slots = it->second;
                 }
                 uint32_t nb = BIG_GMAX;
-                if (n_items / n_pairs > (1u << 20)) {      // the device's one full-size launch: the largest power of two that is resident at once
+                const char* hm_env = getenv("PSK_HUGE_MIN_SEEDS");      // (tests: batches of small pairs take the full-size launch and its mutex too)
+                if (n_items / n_pairs > (hm_env ? strtoull(hm_env, nullptr, 10) : (1ull << 20))) {      // the device's one full-size launch: the largest power of two that is resident at once
                     ctx->huge_acquire();
                     while (nb > 1 && nb > slots) nb >>= 1;
                 } else {                                     // a share of what the full-size launch leaves, safe if every lane launched at once

@@ -297,7 +297,7 @@ class ShardedDatabase:
         self._lo = 0
         self._cuts = None        # shard cut points (world + 1), identical on every rank
         self.device = device
-        self.stats = {"psk_s": 0.0, "collective_s": 0.0, "total_s": 0.0}
+        self.stats = {"psk_s": 0.0, "collective_s": 0.0, "exposed_collective_s": 0.0, "total_s": 0.0}      # (exposed: what the calling thread WAITED for; with overlap the rest of collective_s ran beside psk_s)
         self.raw = bool(raw)
         self.rec_dtype = HIT_DTYPE if raw else HIT_MIN_DTYPE
         self.trace = None        # a list: all_vs_all_records appends (event, round) as it goes (tests)
@@ -375,7 +375,9 @@ class ShardedDatabase:
         except Exception as e:      # a rank whose local query failed still enters the collective (its peers are waiting in it) and raises afterwards
             failure = e
             recs = np.zeros(0, dt)
+        t_wait = time.perf_counter()
         got, _ = self._timed("collective_s", self.comm.gather_hit_records, recs)
+        self.stats["exposed_collective_s"] += time.perf_counter() - t_wait
         self.stats["total_s"] += time.perf_counter() - t0
         if failure is not None:
             raise failure
@@ -420,19 +422,28 @@ class ShardedDatabase:
         nxt = pool.submit(gather, 0) if pool else None
         nxt_taken = False      # the future in `nxt` has been waited for (its sketches are in `held`)
         held = []      # gathered handle sets not yet freed: (handles, total)
+        failure = None
         try:
             for b in range(rounds):
+                t_wait = time.perf_counter()
                 handles, counts = nxt.result() if pool else gather(b)
+                self.stats["exposed_collective_s"] += time.perf_counter() - t_wait
                 nxt_taken = True
                 total = sum(counts)
                 held.append((handles, total))
                 if pool and b + 1 < rounds:
                     nxt = pool.submit(gather, b + 1)      # round b + 1's sketches travel while round b is queried
                     nxt_taken = False
-                if total:
+                if total and failure is None:
                     if trace is not None:
                         trace.append(("query_start", b))
-                    recs, offs = self._timed("psk_s", local.query_handles, handles, total, raw=self.raw, **opts)
+                    try:
+                        recs, offs = self._timed("psk_s", local.query_handles, handles, total, raw=self.raw, **opts)
+                    except Exception as e:      # a rank whose local query failed keeps entering the remaining collectives (its peers are waiting in them) with nothing to add, and raises at the end
+                        failure = e
+                        lib.psk_sketch_free_many(handles, total)
+                        held.pop()
+                        continue
                     if trace is not None:
                         trace.append(("query_end", b))
                     # global query index of every hit: the batch's queries are rank-major, rank r contributes counts[r]
@@ -454,8 +465,13 @@ class ShardedDatabase:
                     held.append((h, sum(c)))
             for h, t in held:
                 lib.psk_sketch_free_many(h, t)
-        mine_recs = np.concatenate(chunks) if chunks else np.zeros(0, dt)
+        mine_recs = np.concatenate(chunks) if (chunks and failure is None) else np.zeros(0, dt)
+        t_wait = time.perf_counter()
         got, _ = self._timed("collective_s", self.comm.gather_hit_records, mine_recs)
+        self.stats["exposed_collective_s"] += time.perf_counter() - t_wait
+        if failure is not None:
+            self.stats["total_s"] += time.perf_counter() - t_all
+            raise failure
         qkey = (got["query"] & QUERY_MASK) if qf == "query" else got["reserved"]
         order = np.lexsort((got["ref_index"], qkey))
         out = got[order]

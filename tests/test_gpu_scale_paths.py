@@ -56,7 +56,7 @@ print(*digest(db.query_many(contigs, learned_ani=False)))
 
 def _run(code, extra):
     env = dict(os.environ)
-    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL", "PSK_GSI_STAGE", "PSK_PIPELINE"):
+    for k in ("PSK_EMIT_PAIRS", "PSK_EMIT_HEADS", "PSK_XCD_GROUP", "PSK_BATCH_ITEMS_LOG2", "PSK_PREFILTER", "PSK_JOIN_PAIRS", "PSK_CHUNK_HOPS", "PSK_PROBE", "PSK_CHAIN_QUAD_DEEP", "PSK_SELECT_TINY", "PSK_CHAIN_WAVE_REG", "PSK_ROW_SORT", "PSK_ROUND_QUERIES", "PSK_REDUCE_TINY", "PSK_PROBE_LOCAL", "PSK_REDUCE_SMALL", "PSK_GSI_JOIN", "PSK_GSI_ONEPASS", "PSK_DP_PRUNE", "PSK_GSI_SLICE", "PSK_GSL_STAGE", "PSK_GSL_MAX_BLOCKS", "PSK_BSI_SMALL", "PSK_GSI_STAGE", "PSK_PIPELINE", "PSK_BIG_SOLO", "PSK_HUGE_MIN_SEEDS", "PSK_HUGE_SLOTS"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
@@ -96,6 +96,16 @@ def test_callers_that_each_want_a_second_lane():
     finds no free lane runs one chain and never waits for one - and every caller gets the single caller's hits."""
     base = _run(ALL_VS_ALL, {})
     assert _run(ALL_VS_ALL_CALLERS, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "22"}) == base
+
+
+def test_two_lanes_whose_batches_both_take_the_full_size_selection_launch():
+    """a batch that holds a Gb-scale pair takes the device's one full-size group-selection launch under a host mutex (huge_mu) inside chain_run; the helper
+    threads of the two-batches-in-flight mode never gave it back, so the second such batch - on the other lane - waited forever. Forced here on small pairs
+    (PSK_HUGE_MIN_SEEDS=1: every batch counts as Gb-scale; PSK_BIG_SOLO at its floor: the cooperative launch is always made), nine batches over two lanes: the same hits,
+    and the call returns (the subprocess has a timeout; the deadlock was on the host, not on the GPU)."""
+    base = _run(ALL_VS_ALL, {})
+    assert _run(ALL_VS_ALL, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "22", "PSK_BIG_SOLO": "1024", "PSK_HUGE_MIN_SEEDS": "1"}) == base
+    assert _run(ALL_VS_ALL_CALLERS, {"PSK_PIPELINE": "1", "PSK_BATCH_ITEMS_LOG2": "22", "PSK_BIG_SOLO": "1024", "PSK_HUGE_MIN_SEEDS": "1"}) == base
 
 
 ONE_FAMILY = COMMON + r"""
@@ -277,6 +287,131 @@ def test_database_beyond_the_seed_index_limit(oracle, tmp_path):
         for f, v in ints.items():
             assert v == int(getattr(want, f)), (j, rname, f, v, int(getattr(want, f)))
         assert abs(ani - want.ani) < 1e-6 and abs(afq - want.af_query) < 1e-6
+
+
+MANY_BLOCKS = COMMON + r"""
+import os, pickle
+# 18 000 references of ~72 kb at c = 30 (~2 400 seeds each: the slice join's range) in families of 50 consecutive references: 71 index blocks of 256 references,
+# family 327 (references 16 350 - 16 399) straddles the boundary between blocks 63 and 64 - the second 64-bit word of the walks' block masks
+N, FAM, L = 18000, 50, 72000
+def near(a, n_mut):
+    b = a.copy(); p = rng.integers(0, len(a), n_mut); b[p] = (b[p] + rng.integers(1, 4, n_mut, dtype=np.uint8)) & 3; return b
+refs = []
+for f in range(N // FAM):
+    a = rng.integers(0, 4, L + 500, dtype=np.uint8)
+    for j in range(FAM):
+        refs.append((f"r{f * FAM + j}", lut[near(a, 30 * j)[: L + (j * 37) % 500]].tobytes()))
+db = psk.Database(compression=30, marker_compression=200)
+db.sketch_many(refs)
+# genome queries: whole families around the block 63 | 64 boundary and in the last blocks, and every 40th genome of the rest
+qg = sorted(set(list(range(16300, 16450)) + list(range(17850, 18000)) + list(range(0, 100)) + list(range(0, N, 40))))
+genomes = [refs[i] for i in qg]
+res_g = db.query_many(genomes, learned_ani=False)
+# contig queries (< 2 048 seeds: the contig join), cut from references all over the database, half of them from blocks >= 64
+contigs = []
+for j in range(6000):
+    i = int(rng.integers(16384, N)) if j % 2 else int(rng.integers(0, N)); g = np.frombuffer(refs[i][1], np.uint8)
+    ln = int(rng.integers(2500, 9000)); st = int(rng.integers(0, len(g) - ln))
+    c = g[st:st + ln].copy(); p = rng.integers(0, ln, ln // 100); c[p] = lut[rng.integers(0, 4, len(p))]
+    contigs.append((f"c{j}", c.tobytes()))
+res_c = db.query_many(contigs, learned_ani=False)
+ng, dg = digest(res_g); nc, dc = digest(res_c)
+if os.environ.get("PSK_TEST_SAMPLE"):
+    pick = np.random.default_rng(3)
+    sample = []
+    ints = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
+    for kind, queries, res in (("g", genomes, res_g), ("c", contigs, res_c)):
+        cand = [x for x in range(len(queries)) if res[x] and any(int(h.reference_name[1:]) >= 16384 for h in res[x])]
+        for x in pick.choice(cand, 12, replace=False):
+            hs = [h for h in res[int(x)] if int(h.reference_name[1:]) >= 16384]
+            h = hs[int(pick.integers(0, len(hs)))]
+            sample.append((queries[int(x)][1], refs[int(h.reference_name[1:])][1], {f: int(h._raw[f]) for f in ints}, h.identity, h.query_fraction, h.reference_fraction))
+    pickle.dump(sample, open(os.environ["PSK_TEST_SAMPLE"], "wb"))
+import ctypes as C
+lk, vis = C.c_uint64(), C.c_uint64()
+db._lib.psk_ctx_join_work(db._ctx._h, C.byref(lk), C.byref(vis), None, None, 0)
+print(ng + nc, dg + dc, lk.value, vis.value)
+"""
+
+
+def test_index_blocks_beyond_the_first_sixty_four(oracle, tmp_path):
+    """databases of 16 385 - 65 536 references are joined through index blocks 64 - 255, which the walks reach through the second to fourth word of their
+    block masks (slice_join.hip gsl_walk_kernel, query.hip gsi_join_kernel) - code no test ran. 18 000 references (71 blocks), a family astride blocks 63 | 64, genome queries
+    (slice join) and contig queries (contig join) whose passing references sit in blocks >= 64: the index walks ran (the library's lookup counter), the hits equal those of
+    the per-pair / probe-table joins that use no index, and 24 sampled hits against references in blocks >= 64 are recomputed by the oracle (lib.rs:617-657)."""
+    import pickle
+    sample_file = str(tmp_path / "sample.pkl")
+    env = dict(os.environ, PSK_TEST_SAMPLE=sample_file)
+    for k in ("PSK_GSI_JOIN", "PSK_GSI_SLICE", "PSK_BSI_SMALL", "PSK_PIPELINE", "PSK_PROBE", "PSK_PREFILTER"):
+        env.pop(k, None)
+    out = subprocess.check_output([sys.executable, "-c", MANY_BLOCKS], env=env, timeout=1500).decode().split()
+    n_hits, dig, lookups = int(out[0]), out[1], int(out[2])
+    assert n_hits > 500 * 40 and lookups > 0, out      # (the index joins count their lookups; the joins without an index leave the counter alone)
+    env.pop("PSK_TEST_SAMPLE")
+    for extra in ({"PSK_GSI_SLICE": "0", "PSK_GSI_JOIN": "0"}, {"PSK_BSI_SMALL": "0", "PSK_GSL_STAGE": "0"}):
+        o2 = subprocess.check_output([sys.executable, "-c", MANY_BLOCKS], env=dict(env, **extra), timeout=1500).decode().split()
+        assert (int(o2[0]), o2[1]) == (n_hits, dig), (extra, o2, out)
+        if extra.get("PSK_GSI_JOIN") == "0":
+            assert int(o2[2]) == 0, o2      # no index walk took part in the cross-check
+    sample = pickle.load(open(sample_file, "rb"))
+    assert len(sample) == 24
+    for q, r, ints, ani, afq, afr in sample:
+        want = oracle.chain(oracle.Sketch([r], c=30, marker_c=200), oracle.Sketch([q], c=30, marker_c=200))
+        for f, v in ints.items():
+            assert v == int(getattr(want, f)), (f, v, int(getattr(want, f)))
+        assert abs(ani - want.ani) < 1e-6 and abs(afq - want.af_query) < 1e-6 and abs(afr - want.af_ref) < 1e-6
+
+
+MIXED = r"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, %r)
+import torch
+import bench as B
+dev = torch.device("cuda:0")
+eng = B.Engine(0)
+def free_gb(): return torch.cuda.mem_get_info()[0] / 2**30
+n = 2000
+anc_lens, fam_of = B.family_layout(3, n, n // 100)
+buf, offs, lens = B.make_genomes(torch, dev, 3, 31, list(range(n)), fam_of, anc_lens, variant="plain")
+torch.cuda.synchronize()
+names = (C.c_char_p * n)(*[f"g{i}".encode() for i in range(n)])
+c_off, c_len, gfc, nn = eng.layout(offs, lens, None)
+out = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, nn)
+db = eng.make_db(names, out, nn)
+os.environ["PSK_PIPELINE"] = "1"      # two lanes, each with its own chain scratch
+h1 = eng.query_many(db, out, nn)
+del os.environ["PSK_PIPELINE"]
+eng.lib.psk_db_destroy(db); del buf; torch.cuda.empty_cache()      # (the database owns the sketches it was given)
+held = free_gb()
+g = 4
+buf, offs, lens, gfc_l = B.make_big_genomes(torch, dev, g, 8, 40_000_000, 2, seed=5)      # 4 genomes of 8 x 40 Mb: pairs of > 2^20 seeds, the Gb-scale plan
+torch.cuda.synchronize()
+names = (C.c_char_p * g)(*[f"m{i}".encode() for i in range(g)])
+c_off, c_len, gfc, nn = eng.layout(offs, lens, gfc_l)
+hits, ms = [], []
+for rep in range(3):
+    handles = eng.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, nn)
+    db = eng.make_db(names, handles, nn)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    hits.append(eng.query_many(db, handles, nn)); ms.append(1e3 * (time.perf_counter() - t0))
+    eng.lib.psk_db_destroy(db)
+after = free_gb()
+# the same Gb-scale job in a context that never ran the all-vs-all
+eng2 = B.Engine(0)
+handles = eng2.sketch_device_c(buf.data_ptr(), c_off, c_len, gfc, nn)
+db = eng2.make_db(names, handles, nn)
+fresh = eng2.query_many(db, handles, nn)
+print(h1, hits[0], hits[1], hits[2], fresh, round(held, 1), round(after, 1), " ".join(f"{x:.0f}" for x in ms))
+""" % (ROOT,)
+
+
+def test_gb_scale_call_after_an_all_vs_all_on_the_same_context():
+    """VERDICT r5 item 2c (was profiles/scripts/r5_trim_lanes.py): an all-vs-all on two lanes leaves each lane holding its chain scratch; a Gb-scale call on the same
+    context sizes its batches by the free memory and takes the idle lane's scratch back (psk_trim_idle_lanes). The Gb-scale call must return the hits a fresh context
+    returns, three times over, and the library must end up holding less memory than the all-vs-all left it with."""
+    out = subprocess.check_output([sys.executable, "-c", MIXED], env={k: v for k, v in os.environ.items() if not k.startswith("PSK_")}, timeout=1500).decode().split()
+    h1, a, b, c, fresh = (int(x) for x in out[:5])
+    assert h1 >= 2000 * 50 and a == b == c == fresh and a >= 4, out
 
 
 def test_prefilter_scratch_returns_to_the_pool():

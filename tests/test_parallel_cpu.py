@@ -131,6 +131,29 @@ for raw in (False, True):
     for b in range(2):
         assert tr.index(("gather_start", b + 1)) < tr.index(("query_end", b)), tr       # the next round's exchange runs beside this round's query
     assert comm.calls == 3
+# a rank whose local query fails in round 1 (ADVICE r5): it keeps entering the remaining sketch gathers and the hit gather with nothing to add - its peer returns
+# (with its own shard's hits only) instead of blocking in a collective the failed rank never enters - and raises when the call is over; every gathered handle is released
+class Failing(ALocal):
+    def query_handles(self, handles, total, raw=False, **kw):
+        if rank == 1 and self.round == 1:
+            self.round += 1
+            raise RuntimeError("local query failed")
+        return super().query_handles(handles, total, raw=raw, **kw)
+lo, hi = shard_bounds(N, rank, world)
+loc = Failing(lo, hi)
+comm = AComm(dist, rounds=3)
+loc.comm = comm
+sdb4 = ShardedDatabase(dist, local=loc, comm=comm)
+sdb4.adopt_local(["g%%d" %% i for i in range(N)])
+Lib.freed = 0
+try:
+    recs = sdb4.all_vs_all_records(batch=2)
+    assert rank == 0, "the failed rank must raise"
+    r0 = shard_bounds(N, 0, world)
+    assert sorted(set(recs["ref_index"].tolist())) == [r for r in range(*r0) if any((q + r) %% 3 == 0 for q in range(N))], recs["ref_index"]
+except RuntimeError as e:
+    assert rank == 1 and "local query failed" in str(e), (rank, e)
+assert comm.calls == 3 and Lib.freed == N, (comm.calls, Lib.freed)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
