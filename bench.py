@@ -890,7 +890,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
         recs = last["recs"]      # psk_hit_min: `query` = the hit's query within the call
         digest = records_digest(recs)
-        # The timed steps keep two batches in flight on two lanes (query.hip: rounds of >= 2^31 (pair, seed) items): their kernels share the chip and a bracket's
+        # The timed steps keep two batches in flight on two lanes (query_many.hip: rounds of >= 2^31 (pair, seed) items): their kernels share the chip and a bracket's
         # duration says little about the kernel. The per-kernel table comes from ONE more step run as a single chain of launches (PSK_PIPELINE=0), outside the timed region.
         table_step = None
         if "PSK_PIPELINE" not in os.environ:

@@ -1,4 +1,4 @@
-// Device helpers shared by the translation units that chain anchors (query.hip: the batched path; small_query.hip: the
+// Device helpers shared by the translation units that chain anchors (join.hip / dp.hip / select.hip / reduce.hip: the batched path; small_query.hip: the
 // one-launch-sequence query of a small genome). Header-only: every translation unit gets its own copy (no relocatable device code).
 #pragma once
 #include "common.h"

@@ -496,14 +496,14 @@ struct psk_db {
     uint64_t desc_indexed = 0; uint32_t desc_n = 0;
     PoolScratch d_refdesc, d_canon;
     std::vector<SketchDesc> h_refdesc;
-    // database-wide seed index (query.hip build_gsi): EVERY reference's seeds sorted by k-mer (stable: within a k-mer by reference, contig, position).
+    // database-wide seed index (seed_index.hip build_gsi): EVERY reference's seeds sorted by k-mer (stable: within a k-mer by reference, contig, position).
     // One lookup per query seed finds its matches in all references at once: the seed prefilter of a rescued contig in the one-launch-sequence
     // query, the join of batches of many small pairs (metagenome). gsi_val = ref << 48 | contig << 33 | pos << 1 | (fwd < rc); built once per
     // database state for databases of <= 65 536 references with <= 32 768 contigs each and < 2^31 seeds in all, dropped when references are added.
     int gsi_state = 0;      // 0 = not built, 1 = built, 2 = this database cannot have one (limits, memory)
     PoolScratch gsi_key, gsi_val, gsi_bucket;
     uint64_t gsi_n = 0; int gsi_shift = 0;
-    // the same index in BLOCKS of 2^BSI_BLOG consecutive references, each block sorted by k-mer with a bucket table of its own (query.hip build_bsi): what the seed-index
+    // the same index in BLOCKS of 2^BSI_BLOG consecutive references, each block sorted by k-mer with a bucket table of its own (seed_index.hip build_bsi): what the seed-index
     // join of mid-sized pairs walks (slice_join.hip). A random genome of L bases holds a given 15-mer with probability 2 L / 4^15 ~ 1 %, and a k-mer that is a seed in one
     // genome is a seed in every genome that holds it (seeds are chosen by content): one run of the database-wide index holds ~0.01 N chance entries beside the query's
     // relatives - 93 of 147 entries per lookup at 10 000 genomes. A query's passing references are few and usually neighbours in insertion order: walking only the
@@ -684,6 +684,6 @@ psk_status chain_impl(Lane* ctx, const psk_sketch* const* refs, uint32_t n_refs,
 constexpr uint32_t SQ_MAX_REFS = 24 * 1024;      // the screen workgroup keeps one shared-marker counter per reference in LDS
 psk_status query_host_small(Lane* ctx, psk_db* db, const uint8_t* const* contigs, const uint64_t* lens, uint32_t n_contigs, const psk_query_opts* o,
                             HitList& all, bool* done);
-// what that path reads on the device (query.hip): marker table, inverted marker index, canon table, every reference indexed and described.
+// what that path reads on the device (seed_index.hip): marker table, inverted marker index, canon table, every reference indexed and described.
 // Called with the database locked SHARED through `sh`; *ok = false: this database cannot take the path (a reference without seeds, other parameters)
 psk_status small_query_prepare(Lane* ctx, psk_db* db, std::shared_lock<std::shared_mutex>& sh, bool* ok);

@@ -1,11 +1,11 @@
 // The join of batches of MID-SIZED pairs (all-vs-all of ~5 Mb genomes) through the database-wide seed index, one wave per
-// (query, slice of GSL_SEEDS query seeds): slice_join.hip. Shared with query.hip, which plans the batches and launches the rest
+// (query, slice of GSL_SEEDS query seeds): slice_join.hip. Shared with query_many.hip / chain.hip, which plan the batches and launches the rest
 // of the chain stage (lib.rs:640-657 is the loop this replaces: chain_seeds of the query against every shortlisted reference).
 #pragma once
 #include "common.h"
 
 // one entry of a batch: query q against its passing references of rank [rank_lo, rank_hi); the entry's pairs, (pair, query seed)
-// items and chunk-table rows start at pair_off / item_off / row_off (query.hip: pair_build_rows_kernel)
+// items and chunk-table rows start at pair_off / item_off / row_off (chain.hip: pair_build_rows_kernel)
 struct BatchQ { uint32_t q, rank_lo, rank_hi, pair_off, item_off, row_off; };
 constexpr uint32_t GSI_PMAX = 256;      // most pairs of one entry: their cursors (and staged anchor lines) sit in one wave's LDS
 

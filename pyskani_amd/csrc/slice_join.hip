@@ -11,7 +11,7 @@
 // (q contig, q pos, r contig, r pos) order, get their places from a COUNT walk:
 //
 //   gsl_walk_kernel<false>  COUNT: per (pair, slice) the number of anchors and a bitmap of the slice's seeds that have one
-//   (scan over the pairs' totals -> pstart: query.hip)
+//   (scan over the pairs' totals -> pstart: chain.hip)
 //   gsl_heads_kernel        per pair, slice after slice: first anchor of every (pair, slice), and - from the bitmaps - which seeds head
 //                           a CHUNK (a chunk = the anchors of one query contig within FRAGMENT_LENGTH of its first anchor - a property of
 //                           the query's seed positions, so no anchor is read for it): the rows before, and the head open at, every slice

@@ -336,7 +336,7 @@ print(ng + nc, dg + dc, lk.value, vis.value)
 
 def test_index_blocks_beyond_the_first_sixty_four(oracle, tmp_path):
     """databases of 16 385 - 65 536 references are joined through index blocks 64 - 255, which the walks reach through the second to fourth word of their
-    block masks (slice_join.hip gsl_walk_kernel, query.hip gsi_join_kernel) - code no test ran. 18 000 references (71 blocks), a family astride blocks 63 | 64, genome queries
+    block masks (slice_join.hip gsl_walk_kernel, join.hip gsi_join_kernel) - code no test ran. 18 000 references (71 blocks), a family astride blocks 63 | 64, genome queries
     (slice join) and contig queries (contig join) whose passing references sit in blocks >= 64: the index walks ran (the library's lookup counter), the hits equal those of
     the per-pair / probe-table joins that use no index, and 24 sampled hits against references in blocks >= 64 are recomputed by the oracle (lib.rs:617-657)."""
     import pickle
