@@ -501,7 +501,7 @@ def load_pmc():
     """offline counter passes (rocprofv3 --pmc, separate runs; profiles/scripts/pmc_summary.py writes the JSON): HBM bytes per unit of work of
     the profiled kernels, {workload: {timer name: {"bytes_per_unit": x, "unit": "base" | "item" | "anchor", "source": ...}}}"""
     out = {}
-    rel = "profiles/r5/r5_pmc_sketch_scan.json" if os.path.exists(os.path.join(ROOT, "profiles", "r5", "r5_pmc_sketch_scan.json")) else "profiles/r2/r2n_pmc_sketch_scan.json"
+    rel = next((r for r in ("profiles/r6/r6_pmc_sketch_scan.json", "profiles/r5/r5_pmc_sketch_scan.json") if os.path.exists(os.path.join(ROOT, *r.split("/")))), "profiles/r2/r2n_pmc_sketch_scan.json")
     p = os.path.join(ROOT, *rel.split("/"))
     if os.path.exists(p):      # (counted again in round 5: the kernel's body became a template in round 4)
         d = json.load(open(p))
@@ -509,7 +509,7 @@ def load_pmc():
         for wl in ("search", "allvsall", "metagenome", "mammalian"):
             out.setdefault(wl, {})["sketch_scan"] = ss
     # (round 4: scale factors calibrated per access shape, profiles/r4/r4k_pmc_calibration.md; the round-3 file for whatever the newer one lacks)
-    for rel in (("profiles", "r3", "pmc_kernels.json"), ("profiles", "r4", "pmc_kernels.json"), ("profiles", "r5", "pmc_kernels.json")):
+    for rel in (("profiles", "r3", "pmc_kernels.json"), ("profiles", "r4", "pmc_kernels.json"), ("profiles", "r5", "pmc_kernels.json"), ("profiles", "r6", "pmc_kernels.json")):
         p = os.path.join(ROOT, *rel)
         if os.path.exists(p):
             for wl, timers in json.load(open(p)).items():

@@ -428,7 +428,7 @@ void psk_db_destroy(psk_db* db) {
     db->inv_key.release(); db->inv_ref.release(); db->inv_tmp.release(); db->inv_bucket.release();
     db->d_refdesc.release(); db->d_canon.release();
     db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release();
-    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release();
+    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_base.release();
     delete db;
 }
 
@@ -440,7 +440,7 @@ psk_status psk_db_add(psk_db* db, const char* name, psk_sketch* s) {
     db->names.emplace_back(name);
     db->note_added((uint32_t)db->refs.size() - 1);
     db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); db->gsi_state = 0;
-    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_state = 0;
+    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_base.release(); db->bsi_state = 0;
     return PSK_OK;
 }
 
@@ -455,7 +455,7 @@ psk_status psk_db_add_batch(psk_db* db, const char* const* names, psk_sketch* co
         db->note_added((uint32_t)db->refs.size() - 1);
     }
     db->tables_dirty = true; db->inv_dirty = true; db->desc_dirty = true; db->small_state = 0; db->gsi_key.release(); db->gsi_val.release(); db->gsi_bucket.release(); db->gsi_state = 0;
-    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_state = 0;
+    db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_base.release(); db->bsi_state = 0;
     return PSK_OK;
 }
 

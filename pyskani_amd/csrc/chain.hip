@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256) void pass_count_kernel(const uint8_t* __restri
     if (threadIdx.x == 0) { row_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3]; row_blocks[blockIdx.x] = blocks; }
 }
 
+// ONE-PASS index join: pair p's anchors start at sbase[p] * 9 / 8 + 8 p - its (pair, query seed) items' offset, stretched: room for one anchor per query seed, an
+// eighth more and eight (a contig that IS part of the reference matches with every seed, and ~1 % of a 5 Mb reference's k-mers sit in it twice)
 __global__ __launch_bounds__(256) void gsi_room_kernel(const uint32_t* __restrict__ sbase, uint32_t n_pairs, uint32_t* __restrict__ pstart) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p <= n_pairs) { const uint32_t a = sbase[p]; pstart[p] = a + (a >> 3) + 8u * p; }
@@ -179,21 +181,35 @@ psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_i
     const uint32_t gi4 = (gi + JT - 1) / JT;
     uint32_t n_sum = gi;
     const char* jp_env = sw.join_pairs.get();      // "1" / "0" force / forbid the pair-major join (tests, A/B)
-    const bool gsi_join = !wide && L.g_key && L.d_pass && L.n_bq && L.n_refs <= 65536u;      // (the PLAN decides - PSK_GSI_JOIN is read there, once per round: the round's sketches carry no k-mer index to fall back on)      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
+    const bool gsi_join = !wide && (L.g_key || L.b_key) && L.d_pass && L.n_bq;      // (the PLAN decides - PSK_GSI_JOIN is read there, once per round: the round's sketches carry no k-mer index to fall back on)      // (every batch of a round that was planned for it: its sketches carry no k-mer index)
     const bool join_pairs = !wide && (gsi_join || (jp_env ? jp_env[0] == '1' : (n_pairs >= 16384 && n_items / n_pairs < 2048)));
     const bool gsl = gsi_join && L.gsi_slice;      // one wave per (query, slice of its seeds): count walk -> scan over the pairs -> heads -> emit walk
     const bool gsi_one = gsi_join && !gsl && L.gsi_onepass && cap >= n_items + n_items / 8 + 8 * ((size_t)n_pairs + 1);      // (gsi_room_kernel's layout fits)
     bool probe_local = false;
     GsiJoinArgs GA{};
     GslArgs GL{};
-    const size_t gsi_lds_row = 8 * (size_t)((L.n_refs + 63) / 64) + 4 * (size_t)((((L.n_refs + 63) / 64) + 1) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
+    // (the contig join's pass bitset in LDS: the query's whole row where a wave may walk the database-wide index, the four words of one block where only blocks are walked)
+    const uint32_t gsi_nw = (L.g_key && !L.gsi_slice) ? std::max(4u, (L.n_refs + 63u) / 64u) : 4u;      // (never fewer than one block's four words: a wave of the same launch may walk blocks)
+    const size_t gsi_lds_row = 8 * (size_t)gsi_nw + 4 * (size_t)((gsi_nw + 1u) & ~1u), gsi_lds_count = gsi_lds_row + 4 * (size_t)L.p_cap, gsi_lds_emit = gsi_lds_row + 4 * (size_t)L.p_cap * 5;
     if (gsi_join) {
         GA.bq = L.bq; GA.pass = L.d_pass; GA.n_refs = L.n_refs; GA.qd = d_qd; GA.g_key = L.g_key; GA.g_val = L.g_val; GA.g_bucket = L.g_bucket; GA.g_shift = L.g_shift;
         GA.b_key = L.b_key; GA.b_val = L.b_val; GA.b_bucket = L.b_bucket; GA.b_shift = L.b_shift; GA.b_nb1 = L.b_nb1; GA.b_blocks = L.b_blocks; GA.b_max = L.b_max;
-        GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap;
+        GA.pair_cnt = L.big_list; GA.pstart = L.pstart; GA.cap = (uint32_t)cap; GA.err = L.misc; GA.p_cap = L.p_cap; GA.nw_lds = gsi_nw;
+        // the entries' block tables: which blocks of the blocked index hold a reference of an entry's pairs (one sweep of the query's pass row per entry; both index joins read them)
+        const uint32_t t_blocks = gsl ? L.g_blocks : L.b_blocks;
+        const unsigned long long* t_base = gsl ? L.g_base : L.b_base;
+        const uint32_t bcap = std::max(1u, std::min<uint32_t>(t_blocks, GSI_PMAX));
+        uint32_t* d_btab = nullptr; uint32_t* d_bcnt = nullptr;
+        if (t_blocks) {
+            const size_t o_bc = al256(4 * (size_t)L.n_bq * bcap * GSL_BT_WORDS);
+            PSK_TRY(ctx->q_k.reserve(o_bc + 4 * (size_t)L.n_bq + 256));
+            d_btab = (uint32_t*)ctx->q_k.p; d_bcnt = (uint32_t*)((char*)ctx->q_k.p + o_bc);
+            PSK_TRY(gsl_blocks_launch(L.bq, L.n_bq, L.d_pass, L.n_refs, t_blocks, t_base, d_btab, d_bcnt, bcap, st));
+        }
+        GA.blk_tab = d_btab; GA.blk_cnt = d_bcnt; GA.blk_cap = bcap;
         if (gsl) {
             GL.bq = L.bq; GL.n_entries = L.n_bq; GL.tab = L.gsl_tab; GL.n_tab = L.gsl_n_tab; GL.ebase = L.gsl_ebase; GL.pass = L.d_pass; GL.n_refs = L.n_refs; GL.qd = d_qd;
-            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.g_nb1 = L.g_nb1; GL.g_blocks = L.g_blocks; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm; GL.un = L.gsl_un; GL.n_slices = L.gsl_n_slices;
+            GL.g_key = L.g_key; GL.g_val = L.g_val; GL.g_bucket = L.g_bucket; GL.g_shift = L.g_shift; GL.g_nb1 = L.g_nb1; GL.g_blocks = L.g_blocks; GL.g_base = L.g_base; GL.blk_tab = d_btab; GL.blk_cnt = d_bcnt; GL.blk_cap = bcap; GL.cnt = L.gsl_cnt; GL.rec = L.gsl_rec; GL.bm = L.gsl_bm; GL.un = L.gsl_un; GL.n_slices = L.gsl_n_slices;
             GL.pair_cnt = L.big_list; GL.pstart = L.pstart; GL.cap = (uint32_t)cap; GL.err = L.misc; GL.p_cap = L.p_cap; GL.chunks = L.chunks; GL.n_chunks = L.nch;
             { const char* e = sw.gsl_stage.get(); GL.stage = e ? atoi(e) : 1; }      // (A/B: every anchor its own 16-byte store)
             PSK_HIP(hipMemsetAsync(L.big_list, 0, 4 * ((size_t)n_pairs + 1), st));      // the slices of a pair add their counts

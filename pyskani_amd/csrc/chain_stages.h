@@ -146,9 +146,9 @@ constexpr uint32_t BIG_TILE = 4096;       // keys of one LDS-staged sort tile
 constexpr uint32_t BIG_SOLO = 32768;      // up to here one workgroup per pair: a barrier between workgroups costs more than it divides
 
 #ifndef BIG_GMAX_N
-#define BIG_GMAX_N 128
+#define BIG_GMAX_N 256
 #endif
-constexpr uint32_t BIG_GMAX = BIG_GMAX_N;        // workgroups of the cooperative launch (co-resident: one per CU, at most two launches per CU pair of lanes)
+constexpr uint32_t BIG_GMAX = BIG_GMAX_N;        // workgroups of the cooperative launch (co-resident: one per CU of the 512 slots the chip has for them; 128 -> 256: the group selection of an 8 x 3 Gb step 19.8 -> 14.6 ms, the sweeps of its sorts are spread over twice the workgroups)
 
 constexpr uint32_t BIG_GROUPS = 16;       // pairs in flight in the cooperative launch
 
@@ -181,6 +181,8 @@ struct GsiJoinArgs {
     // b_blocks > 0: the index is ALSO there in blocks of 2^BSI_BLOG references with a bucket table of b_nb1 entries each (psk_db::bsi_*): a wave whose query has its passing
     // references in at most b_max of them walks those blocks (a run of the database-wide index holds ~1 % of all genomes by chance), any other wave the database-wide index
     const uint32_t* b_key; const unsigned long long* b_val; const uint32_t* b_bucket; int b_shift; uint32_t b_nb1, b_blocks, b_max;
+    const uint32_t* blk_tab; const uint32_t* blk_cnt; uint32_t blk_cap;      // per entry: the blocks that hold one of its pairs' references (slice_join.h: gsl_blocks_kernel; rows of GSL_BT_WORDS words)
+    uint32_t nw_lds;      // 64-reference words of the pass bitset the launch's LDS holds: the whole row where the database-wide index may be walked, four (one block) otherwise
     uint32_t* pair_cnt; const uint32_t* pstart; uint4* anc; uint32_t cap; uint32_t* err;
     uint32_t p_cap;      // most pairs any entry of the batch holds, rounded up: what the cursor arrays in LDS are sized for (<= GSI_PMAX)
     uint2* chunks; uint32_t* n_chunks;      // EMIT: the pairs' chunk tables, written by the same walk (rows at entry.row_off + slot * query rows)

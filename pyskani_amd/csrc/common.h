@@ -221,6 +221,7 @@ struct Lane {
     Scratch s_desc, s_packed, s_mask, s_counts, s_offs, s_tmp, s_mark, s_flags, s_misc;  // sketch
     Scratch q_a, q_b, q_c, q_d, q_e, q_f, q_g, q_h, q_i;                                  // query
     Scratch q_j;                                                                           // slice join (slice_join.hip): wave table, per-(pair, slice) records and bitmaps of a batch
+    Scratch q_k;                                                                           // seed-index joins: per batch entry, the index blocks that hold one of its pairs' references (gsl_blocks_kernel)
     Scratch q_small;                                                                       // the one-launch-sequence query's workspace (small_query.hip)
     uint32_t sq_last_short = 192;                                                          // ... and the shortlist length of its last call on this lane: sizes the next chain launch
     void* h_pinned = nullptr;      // pinned host staging for small D2H/H2D
@@ -237,7 +238,7 @@ struct Lane {
         return PSK_OK;
     }
     void release_all() {
-        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small, &q_j};
+        Scratch* all[] = {&s_desc, &s_packed, &s_mask, &s_counts, &s_offs, &s_tmp, &s_mark, &s_flags, &s_misc, &q_a, &q_b, &q_c, &q_d, &q_e, &q_f, &q_g, &q_h, &q_i, &q_sel, &q_small, &q_j, &q_k};
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (side_stream) { (void)hipStreamSynchronize(side_stream); (void)hipStreamDestroy(side_stream); side_stream = nullptr; if (side_fork) (void)hipEventDestroy(side_fork); if (side_join) (void)hipEventDestroy(side_join); side_fork = side_join = nullptr; }
         for (Scratch* s : all) s->release();
@@ -289,7 +290,7 @@ inline void psk_trim_idle_lanes(psk_ctx* c, Lane* self) {
     }
     for (Lane* L : idle) {
         (void)hipStreamSynchronize(L->stream);
-        Scratch* big[] = {&L->q_b, &L->q_c, &L->q_d, &L->q_e, &L->q_g, &L->q_j, &L->q_sel};
+        Scratch* big[] = {&L->q_b, &L->q_c, &L->q_d, &L->q_e, &L->q_g, &L->q_j, &L->q_k, &L->q_sel};
         for (Scratch* s : big) s->release();
     }
     if (!idle.empty()) {
@@ -509,7 +510,10 @@ struct psk_db {
     // relatives - 93 of 147 entries per lookup at 10 000 genomes. A query's passing references are few and usually neighbours in insertion order: walking only the
     // blocks that hold one of them leaves 256 x 0.01 = 2.4 chance entries per lookup whatever the database size.
     int bsi_state = 0;      // 0 = not built, 1 = built, 2 = this database cannot have one
-    PoolScratch bsi_key, bsi_val, bsi_bucket;
+    // Entries carry BLOCK-LOCAL reference ids (bsi_val = local ref << 48 | contig << 33 | pos << 1 | (fwd < rc), local ref = reference & 255) and the bucket tables offsets
+    // WITHIN their block (block b's entries start at bsi_base[b], a 64-bit offset): the number of references and the seeds of the database are bounded by memory only
+    // (12 bytes per seed); a block of 256 references must stay below 2^31 seeds (one radix sort), a reference below 32 768 contigs.
+    PoolScratch bsi_key, bsi_val, bsi_bucket, bsi_base;
     uint64_t bsi_n = 0; int bsi_shift = 0; uint32_t bsi_nb1 = 0, bsi_blocks = 0;      // nb1 = bucket-table entries per block (2^bits + 1)
     // the one-launch-sequence query (small_query.hip): 1 = every device table it reads is up to date, 2 = this database cannot take it; reset when references are added
     std::atomic<int> small_state{0};

@@ -1021,11 +1021,16 @@ __global__ __launch_bounds__(64) void chunk_hops_items_kernel(const uint32_t* __
 template <bool EMIT>
 __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     extern __shared__ unsigned long long s_gsi[];
-    const uint32_t nw = (A.n_refs + 63u) / 64u;
+    // Which index this wave walks. The entry's block table (gsl_blocks_kernel) lists the blocks that hold one of its pairs' references: at most b_max of them - or no
+    // database-wide index to turn to (databases beyond its 16-bit reference ids) - and the wave walks those blocks, with the pass bits of ONE block (four words) in LDS at a
+    // time; otherwise the database-wide index, with the query's whole row of the pass matrix as a bitset.
+    const uint32_t n_blk = A.b_blocks ? A.blk_cnt[blockIdx.x] : 0u;
+    const bool blocked = A.b_blocks && (n_blk <= A.b_max || !A.g_key);
+    const uint32_t nw = blocked ? 4u : (A.n_refs + 63u) / 64u;      // words of the bitset in use (the launch's LDS holds nw_lds)
     uint4* s_line = (uint4*)s_gsi;      // EMIT with A.stage: the even-indexed anchor every pair holds back (16 B per pair, at the front: 16-byte aligned)
     unsigned long long* s_bits = s_gsi + ((EMIT && A.stage) ? 2u * A.p_cap : 0u);
-    uint32_t* s_pref = (uint32_t*)(s_bits + nw);
-    uint32_t* s_cur = s_pref + ((nw + 1u) & ~1u);
+    uint32_t* s_pref = (uint32_t*)(s_bits + A.nw_lds);
+    uint32_t* s_cur = s_pref + ((A.nw_lds + 1u) & ~1u);
     uint32_t* s_ps = s_cur + A.p_cap;       // EMIT: first anchor of every pair of the entry (GSI_DEAD: fewer than MIN_ANCHORS anchors - it cannot chain: no anchors, no chunk table),
     uint32_t* s_hq = s_ps + A.p_cap;        //       query position, anchor index and (q contig << 16 | rows so far) of the chunk being filled
     uint32_t* s_hi = s_hq + A.p_cap;
@@ -1034,10 +1039,10 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     const int lane = threadIdx.x;
     const BatchQ B = A.bq[blockIdx.x];
     const uint32_t P = B.rank_hi - B.rank_lo;
-    {   // pass row -> bitset + prefix counts
+    {   // pass row -> bitset + prefix counts (the database-wide index; a wave that walks blocks fills four words per block from its table)
         const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
         uint32_t run = 0;
-        for (uint32_t w0 = 0; w0 < nw; w0 += 4) {
+        for (uint32_t w0 = 0; w0 < nw && !blocked; w0 += 4) {
             uint8_t f[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { const uint32_t r = (w0 + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
@@ -1059,33 +1064,27 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     // before step t is dealt out - the second and third step of a long run (a k-mer that a whole family of references holds) included.
     constexpr uint32_t GSI_AHEAD = 4;
     unsigned long long visited = 0;      // index entries in the runs this lane's seeds found (psk_ctx_join_work)
-    // (blocked index: one walk of the query's seeds per block that holds a passing reference - a pair's reference sits in ONE block, so its anchors keep their order)
-    unsigned long long masks[4] = {1ull, 0ull, 0ull, 0ull};      // blocks to walk, 64 per word (the database-wide index: "block" 0)
-    bool blocked = false;
-    if (A.b_blocks && A.b_blocks <= 256u) {
-        uint32_t n_with = 0; unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (uint32_t g = 0; g < 4; g++) {
-            const uint32_t bk = g * 64u + (uint32_t)lane;
-            unsigned long long any = 0;
-            if (bk < A.b_blocks) {
-                const uint32_t w0 = bk << (BSI_BLOG - 6), w1 = (w0 + (1u << (BSI_BLOG - 6))) < nw ? w0 + (1u << (BSI_BLOG - 6)) : nw;
-                for (uint32_t w = w0; w < w1; w++) any |= s_bits[w];
-            }
-            mk[g] = __ballot(any != 0);
-            n_with += (uint32_t)__popcll(mk[g]);
-        }
-        if (n_with <= A.b_max) { blocked = true; masks[0] = mk[0]; masks[1] = mk[1]; masks[2] = mk[2]; masks[3] = mk[3]; }
-    }
-    const uint32_t* __restrict__ x_key = blocked ? A.b_key : A.g_key; const unsigned long long* __restrict__ x_val = blocked ? A.b_val : A.g_val;
+    // (blocked index: one walk of the query's seeds per listed block - a pair's reference sits in ONE block, so its anchors keep their order)
     const int x_shift = blocked ? A.b_shift : A.g_shift;
+    const uint32_t n_it = blocked ? n_blk : 1u;
+    const uint32_t* __restrict__ brow = A.blk_tab + (size_t)blockIdx.x * A.blk_cap * GSL_BT_WORDS;
 #pragma unroll 1
-    for (uint32_t blk0 = 0; blk0 < 256u; blk0 += 64) {
-    unsigned long long blk_mask = masks[blk0 >> 6];
-    while (blk_mask) {
-    const uint32_t blk = blk0 + (uint32_t)__ffsll((long long)blk_mask) - 1u;
-    blk_mask &= blk_mask - 1ull;
-    const uint32_t* __restrict__ bkt = blocked ? A.b_bucket + (size_t)blk * A.b_nb1 : A.g_bucket;
+    for (uint32_t bi = 0; bi < n_it; bi++, brow += GSL_BT_WORDS) {
+    {
+    const uint32_t* __restrict__ x_key = A.g_key; const unsigned long long* __restrict__ x_val = A.g_val; const uint32_t* __restrict__ bkt = A.g_bucket;
+    if (blocked) {
+        const uint32_t blk = brow[8];
+        const unsigned long long x_base = ((unsigned long long)brow[11] << 32) | brow[10];
+        x_key = A.b_key + x_base; x_val = A.b_val + x_base; bkt = A.b_bucket + (size_t)blk * A.b_nb1;
+        lds_wave_sync();      // (the previous block's last lookups are through)
+        if (lane < 4) {
+            uint32_t run = brow[9];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const uint32_t w = brow[u]; if (u < 2 * lane) run += (uint32_t)__popc(w); }
+            s_bits[lane] = ((unsigned long long)brow[2 * lane + 1] << 32) | brow[2 * lane]; s_pref[lane] = run;
+        }
+        lds_wave_sync();
+    }
     uint32_t km1 = (uint32_t)lane < nq ? Q.kmer[lane] : 0u, km2 = 64u + (uint32_t)lane < nq ? Q.kmer[64 + lane] : 0u;
     uint32_t lo1 = 0, hi1 = 0;
     if ((uint32_t)lane < nq) { const uint32_t b = km1 >> x_shift; lo1 = bkt[b]; hi1 = bkt[b + 1]; }
@@ -1130,7 +1129,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 const uint32_t sqp = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qp, (int)s) : 0u, sqm = EMIT ? (uint32_t)__builtin_amdgcn_readlane((int)qm, (int)s) : 0u;
                 const bool match = x < shi && k == skm;
                 if (!__any(match)) continue;
-                const uint32_t ref = (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;
+                const uint32_t ref = blocked ? (uint32_t)(v >> 48) & 255u : (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;      // (a block's entries carry the reference's id within the block)
                 uint32_t slot = 0xFFFFFFFFu;
                 if (match) {
                     const unsigned long long bits = s_bits[w];
@@ -1196,8 +1195,8 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         }
 #undef GSI_FETCH
     }
-    }      // the group's blocks that hold a passing reference
-    }      // groups of 64 blocks
+    }
+    }      // the listed blocks (or the one walk of the database-wide index)
     lds_wave_sync();
     if (EMIT) {
 #pragma unroll
@@ -1229,8 +1228,6 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         }
     }
 }
-// ONE-PASS index join: pair p's anchors start at sbase[p] * 9 / 8 + 8 p - its (pair, query seed) items' offset, stretched: room for one anchor per query seed, an
-// eighth more and eight (a contig that IS part of the reference matches with every seed, and ~1 % of a 5 Mb reference's k-mers sit in it twice)
 
 // (launched from chain.hip)
 template __global__ void anchor_next_kernel<0>(const uint4* __restrict__ anc,

@@ -136,6 +136,28 @@ __global__ __launch_bounds__(256) void gsi_prefilter_kernel(const SketchDesc* __
     for (uint32_t r = threadIdx.x; r < n_refs; r += blockDim.x) if (((s_pc[r >> 1] >> ((r & 1u) * 16u)) & 0xFFFFu) < MIN_ANCHORS) row[r] = 0;
 }
 
+// The same prefilter where the database has no database-wide index (more than 65 536 references: its entries carry 16-bit reference ids): one wave per (rescued query, block
+// of the blocked index), the block's 256 counters in LDS, a lane per query seed.
+__global__ __launch_bounds__(64) void bsi_prefilter_kernel(const SketchDesc* __restrict__ qd, const uint32_t* __restrict__ rq, uint32_t n_refs,
+                                                           const uint32_t* __restrict__ b_key, const unsigned long long* __restrict__ b_val, const uint32_t* __restrict__ b_bucket,
+                                                           const unsigned long long* __restrict__ b_base, int b_shift, uint32_t b_nb1, uint32_t blk0, uint8_t* __restrict__ pass) {
+    __shared__ uint32_t s_c[1u << BSI_BLOG];
+    const uint32_t q = rq[blockIdx.x], blk = blk0 + blockIdx.y, lane = threadIdx.x;
+    const SketchDesc Q = qd[q];
+    for (uint32_t i = lane; i < (1u << BSI_BLOG); i += 64u) s_c[i] = 0;
+    lds_wave_sync();
+    const unsigned long long base = b_base[blk];
+    const uint32_t* __restrict__ key = b_key + base; const unsigned long long* __restrict__ val = b_val + base; const uint32_t* __restrict__ bkt = b_bucket + (size_t)blk * b_nb1;
+    for (uint32_t i = lane; i < Q.n; i += 64u) {
+        const uint32_t km = Q.kmer[i], b = km >> b_shift;
+        for (uint32_t x = bkt[b], hi = bkt[b + 1]; x < hi; x++)
+            if (key[x] == km) { const uint32_t ref = (uint32_t)(val[x] >> 48) & ((1u << BSI_BLOG) - 1u); if (s_c[ref] < MIN_ANCHORS) atomicAdd(&s_c[ref], 1u); }
+    }
+    lds_wave_sync();
+    uint8_t* row = pass + (size_t)q * n_refs + ((size_t)blk << BSI_BLOG);
+    for (uint32_t r = lane; r < (1u << BSI_BLOG); r += 64u) if (((size_t)blk << BSI_BLOG) + r < n_refs && s_c[r] < MIN_ANCHORS) row[r] = 0;
+}
+
 uint64_t index_stamp(const psk_db* db) {
     uint64_t v = 0;
     for (const psk_sketch* r : db->refs) v += (uint64_t)(r->idx != nullptr) + ((uint64_t)(r->ptab != nullptr) << 32);
@@ -258,9 +280,10 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             if (refs_ok) for (const psk_sketch* rs : db->refs) if (!rs->has_seeds || rs->params.k != db->params.k || rs->params.c != db->params.c) { refs_ok = false; break; }
             // through the database-wide seed index where the database can have one (no per-reference index, no gather, no sort); PSK_GSI_JOIN=0: the per-reference path
             const bool gsi_pf_off = sw.gsi_join.get() && sw.gsi_join.get()[0] == '0';      // (read per call: tests switch it within a process)
-            if (refs_ok && !gsi_pf_off && n <= 65536u && !sw.join_wide()) {
+            if (refs_ok && !gsi_pf_off && !sw.join_wide()) {
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
-                if (db->gsi_state == 1) {
+                if (db->gsi_state != 1 && db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));      // (no database-wide index - more than 65 536 references -: the blocked one)
+                if (db->gsi_state == 1 || db->bsi_state == 1) {
                     const uint32_t nr = (uint32_t)rq.size();
                     h_qd.resize(m);
                     for (uint32_t i = 0; i < m; i++) h_qd[i] = make_desc(queries[b + i], true);
@@ -273,8 +296,14 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                     static std::once_flag pf_once; static hipError_t pf_rc = hipSuccess;
                     std::call_once(pf_once, [] { pf_rc = hipFuncSetAttribute((const void*)gsi_prefilter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 16); });
                     PSK_HIP(pf_rc);
+                    if (db->gsi_state == 1)
                     hipLaunchKernelGGL(gsi_prefilter_kernel, dim3(nr), dim3(256), 4 * (size_t)((n + 1) / 2), st, (const SketchDesc*)(Bp + o_qd), (const uint32_t*)Bp, n,
                                        (const uint32_t*)db->gsi_key.p, (const unsigned long long*)db->gsi_val.p, (const uint32_t*)db->gsi_bucket.p, db->gsi_shift, d_pass);
+                    else
+                    for (uint32_t b0 = 0; b0 < db->bsi_blocks; b0 += 32768u)      // (grid.y holds 65 535)
+                        hipLaunchKernelGGL(bsi_prefilter_kernel, dim3(nr, std::min<uint32_t>(32768u, db->bsi_blocks - b0)), dim3(64), 0, st, (const SketchDesc*)(Bp + o_qd), (const uint32_t*)Bp, n,
+                                           (const uint32_t*)db->bsi_key.p, (const unsigned long long*)db->bsi_val.p, (const uint32_t*)db->bsi_bucket.p,
+                                           (const unsigned long long*)db->bsi_base.p, db->bsi_shift, db->bsi_nb1, b0, d_pass);
                     refs_ok = false;      // (done)
                 }
             }
@@ -385,20 +414,21 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             const double max_blocks = sw.gsl_max_blocks.get() ? atof(sw.gsl_max_blocks.get()) : 4.0;
             uint64_t q_with = 0; for (uint32_t i = 0; i < m; i++) q_with += h_cnt[i] != 0;
             const bool few_blocks = (double)round_blocks <= max_blocks * (double)std::max<uint64_t>(q_with, 1);
-            if (want_small && !gsi_join_off && n <= 65536u && !sw.join_wide()) {
+            if (want_small && !gsi_join_off && !sw.join_wide()) {
                 // contigs: through the index in blocks of references when their passing references sit in few of them (a contig's relatives - what the marker screen and the
                 // prefilter of rescued contigs leave), through the database-wide index otherwise (a rescued contig against EVERY reference: one walk instead of one per block)
                 const bool bsi_small_off = sw.bsi_small.get() && sw.bsi_small.get()[0] == '0';      // (tests, A/B)
                 if (db->gsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_gsi(ctx, db); }));
                 round_gsi = db->gsi_state == 1;
-                if (round_gsi && !bsi_small_off) {      // (every wave of the join chooses by its own query: both indexes are handed over)
+                if (!bsi_small_off || !round_gsi) {      // (every wave of the join chooses by its own query: both indexes are handed over; a database beyond the database-wide index's 65 536 references has the blocked one alone)
                     if (db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));
                     round_bsi = db->bsi_state == 1;
+                    round_gsi = round_gsi || round_bsi;
                 }
             }
             // (the slice join walks, per query, the index BLOCKS that hold one of its passing references: worth it while those are few - relatives that sit next to each
             // other in the database; a query whose references are scattered over many blocks would walk its seeds once per block: PSK_GSL_MAX_BLOCKS, default 4 on average)
-            if (want_slice && !gsi_join_off && n <= 65536u && !sw.join_wide() && (sl_force || few_blocks)) {
+            if (want_slice && !gsi_join_off && !sw.join_wide() && (sl_force || few_blocks)) {
                 if (db->bsi_state == 0) PSK_TRY(exclusive([&]() -> psk_status { return build_bsi(ctx, db); }));
                 round_gsi = round_slice = round_bsi = db->bsi_state == 1;
             }
@@ -455,7 +485,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
             const size_t need = (size_t)212 << 30;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->q_d.cap + ctx->q_e.cap <= need && total_b > need) {
                 psk_trim_idle_lanes(ctx->dev, ctx);      // (an earlier all-vs-all left 47-94 GB of scratch on each of its two lanes)
-                if (lane2) { Scratch* big[] = {&lane2->lane->q_b, &lane2->lane->q_c, &lane2->lane->q_d, &lane2->lane->q_e, &lane2->lane->q_g, &lane2->lane->q_j, &lane2->lane->q_sel}; (void)hipStreamSynchronize(lane2->lane->stream); for (Scratch* s : big) s->release(); }
+                if (lane2) { Scratch* big[] = {&lane2->lane->q_b, &lane2->lane->q_c, &lane2->lane->q_d, &lane2->lane->q_e, &lane2->lane->q_g, &lane2->lane->q_j, &lane2->lane->q_k, &lane2->lane->q_sel}; (void)hipStreamSynchronize(lane2->lane->stream); for (Scratch* s : big) s->release(); }
                 (void)hipMemGetInfo(&free_b, &total_b);
             }
             if (free_b + ctx->q_d.cap + ctx->q_e.cap > need) items_log2 = 28;
@@ -583,7 +613,7 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                         if (lrc == PSK_ENOMEM) { J.refit = true; return PSK_OK; }
                         PSK_TRY(lrc);
                         L.rows_pair_max = (uint32_t)std::min<uint64_t>(J.rows_pair_max, 0xFFFFFFFFu);
-                        L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks;
+                        L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks; L.g_base = (const unsigned long long*)db->bsi_base.p;
                         L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)J.bqs.size();
                         uint32_t pm = 1; for (const BatchQ& e : J.bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);
                         L.p_cap = (pm + 15u) & ~15u;
@@ -742,10 +772,10 @@ static psk_status query_many_t(Lane* ctx, psk_db* db, const psk_sketch* const* q
                 psk_status lrc = chain_layout(ctx, n_pairs, (size_t)items, (size_t)rows, bqs.size(), &L);
                 L.rows_pair_max = (uint32_t)std::min<uint64_t>(rows_pair_max, 0xFFFFFFFFu);
                 if (round_gsi) {
-                    if (round_slice) { L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks; }
+                    if (round_slice) { L.g_key = (const uint32_t*)db->bsi_key.p; L.g_val = (const unsigned long long*)db->bsi_val.p; L.g_bucket = (const uint32_t*)db->bsi_bucket.p; L.g_shift = db->bsi_shift; L.g_nb1 = db->bsi_nb1; L.g_blocks = db->bsi_blocks; L.g_base = (const unsigned long long*)db->bsi_base.p; }
                     else {
-                        L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift;
-                        if (round_bsi) { L.b_key = (const uint32_t*)db->bsi_key.p; L.b_val = (const unsigned long long*)db->bsi_val.p; L.b_bucket = (const uint32_t*)db->bsi_bucket.p; L.b_shift = db->bsi_shift; L.b_nb1 = db->bsi_nb1; L.b_blocks = db->bsi_blocks; L.b_max = (uint32_t)std::max(1.0, max_blocks_join); }
+                        if (db->gsi_state == 1) { L.g_key = (const uint32_t*)db->gsi_key.p; L.g_val = (const unsigned long long*)db->gsi_val.p; L.g_bucket = (const uint32_t*)db->gsi_bucket.p; L.g_shift = db->gsi_shift; }
+                        if (round_bsi) { L.b_key = (const uint32_t*)db->bsi_key.p; L.b_val = (const unsigned long long*)db->bsi_val.p; L.b_bucket = (const uint32_t*)db->bsi_bucket.p; L.b_shift = db->bsi_shift; L.b_nb1 = db->bsi_nb1; L.b_blocks = db->bsi_blocks; L.b_base = (const unsigned long long*)db->bsi_base.p; L.b_max = (uint32_t)std::max(1.0, max_blocks_join); }
                     }
                     L.d_pass = d_pass; L.n_refs = n; L.n_bq = (uint32_t)bqs.size();
                     uint32_t pm = 1; for (const BatchQ& e : bqs) pm = std::max(pm, e.rank_hi - e.rank_lo);

@@ -91,8 +91,8 @@ struct ChainBufs {
     uint32_t rows_pair_max = 0xFFFFFFFFu;      // most chunk-table rows any pair of the batch can have (the host knows its queries): which reduce kernels have work
     // join through the database-wide seed index (gsi_join_kernel): the index, the pass matrix the pairs came from and the batch's entries; g_key null: not available
     const uint32_t* g_key = nullptr; const unsigned long long* g_val = nullptr; const uint32_t* g_bucket = nullptr; int g_shift = 0;
-    uint32_t g_nb1 = 0, g_blocks = 0;      // (the slice join's index comes in blocks of references: psk_db::bsi_*)
-    const uint32_t* b_key = nullptr; const unsigned long long* b_val = nullptr; const uint32_t* b_bucket = nullptr; int b_shift = 0; uint32_t b_nb1 = 0, b_blocks = 0, b_max = 0;      // the contig join: the blocked index beside the database-wide one
+    uint32_t g_nb1 = 0, g_blocks = 0; const unsigned long long* g_base = nullptr;      // (the slice join's index comes in blocks of references: psk_db::bsi_*; g_base: the blocks' first entries)
+    const uint32_t* b_key = nullptr; const unsigned long long* b_val = nullptr; const uint32_t* b_bucket = nullptr; int b_shift = 0; uint32_t b_nb1 = 0, b_blocks = 0, b_max = 0; const unsigned long long* b_base = nullptr;      // the contig join: the blocked index beside the database-wide one
     const uint8_t* d_pass = nullptr; uint32_t n_refs = 0, n_bq = 0, p_cap = 0;
     // mid-sized pairs (all-vs-all of genomes): the index join by (query, slice) waves (slice_join.hip); the batch's wave table, record offsets and per-record arrays
     bool gsi_slice = false; const uint2* gsl_tab = nullptr; uint32_t gsl_n_tab = 0; const uint2* gsl_ebase = nullptr; uint32_t *gsl_cnt = nullptr, *gsl_bm = nullptr, *gsl_un = nullptr, gsl_n_slices = 0; uint4* gsl_rec = nullptr;

@@ -94,59 +94,64 @@ psk_status build_bsi(Lane* ctx, psk_db* db) {
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)db->refs.size();
     db->bsi_state = 2;
-    if (off || n == 0 || n > 65536u || db->params.k > 16) return PSK_OK;
-    std::vector<GsiSeg> segs(n);
-    uint64_t N = 0; uint32_t maxn = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const psk_sketch* r = db->refs[i];
-        if (!r->has_seeds || r->contig_len.size() > 32768u || r->params.k != db->params.k || r->params.c != db->params.c) return PSK_OK;
-        const uint32_t ns = r->store ? (uint32_t)r->n_seeds : 0u;
-        segs[i] = GsiSeg{ns ? r->store->seed_kmer + r->seed_off : nullptr, ns ? r->store->seed_pm + r->seed_off : nullptr, ns, (uint32_t)N};
-        N += ns; maxn = std::max(maxn, ns);
-        if (N >= 0x7FFFFF00ull) return PSK_OK;
-    }
-    if (N == 0) return PSK_OK;
+    if (off || n == 0 || db->params.k > 16) return PSK_OK;
+    // one segment per reference, offsets WITHIN its block; the blocks' own offsets are 64-bit (no bound on the references or the seeds of the database but memory)
     const uint32_t n_blocks = (n + (1u << BSI_BLOG) - 1) >> BSI_BLOG;
-    uint64_t max_block = 0;
+    std::vector<GsiSeg> segs(n);
+    std::vector<uint64_t> base(n_blocks + 1, 0);
+    uint64_t N = 0, max_block = 0; uint32_t maxn = 0;
     for (uint32_t b = 0; b < n_blocks; b++) {
         const uint32_t r0 = b << BSI_BLOG, r1 = std::min<uint32_t>(n, (b + 1) << BSI_BLOG);
-        max_block = std::max<uint64_t>(max_block, (uint64_t)segs[r1 - 1].off + segs[r1 - 1].n - segs[r0].off);
+        uint64_t in_block = 0;
+        for (uint32_t i = r0; i < r1; i++) {
+            const psk_sketch* r = db->refs[i];
+            if (!r->has_seeds || r->contig_len.size() > 32768u || r->params.k != db->params.k || r->params.c != db->params.c) return PSK_OK;
+            const uint32_t ns = r->store ? (uint32_t)r->n_seeds : 0u;
+            if (in_block + ns >= 0x7FFFFF00ull) return PSK_OK;      // (a block is one radix sort: 256 references of more than 8 M seeds each - 1 Gb at c = 125 - have none)
+            segs[i] = GsiSeg{ns ? r->store->seed_kmer + r->seed_off : nullptr, ns ? r->store->seed_pm + r->seed_off : nullptr, ns, (uint32_t)in_block};
+            in_block += ns; maxn = std::max(maxn, ns);
+        }
+        base[b] = N; N += in_block; max_block = std::max(max_block, in_block);
     }
+    base[n_blocks] = N;
+    if (N == 0) return PSK_OK;
     const int kbits = 2 * db->params.k;
     int bits = 4; while (bits < 24 && (8ull << bits) < max_block) bits++;      // ~8 entries per bucket of the largest block
     if (bits > kbits) bits = kbits;
     const uint32_t nb = 1u << bits;
-    if ((uint64_t)n_blocks * (nb + 1) >= 0x7FFFFF00ull) return PSK_OK;
     size_t ts = 0;
-    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)std::min<uint64_t>(max_block, 0x7FFFFFFFull), 0, kbits, st));
-    PoolScratch tmp;      // unsorted copies + sort scratch + segment table: back to the pool when the build is done
-    const size_t o_k = 0, o_v = al256(4 * (size_t)N), o_t = al256(o_v + 8 * (size_t)N), o_s = al256(o_t + ts), o_end = o_s + sizeof(GsiSeg) * (size_t)n;
+    PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, ts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)max_block, 0, kbits, st));
+    PoolScratch tmp;      // ONE block's unsorted copy + sort scratch, and the segment table: back to the pool when the build is done
+    const size_t o_k = 0, o_v = al256(4 * (size_t)max_block), o_t = al256(o_v + 8 * (size_t)max_block), o_s = al256(o_t + ts), o_end = o_s + sizeof(GsiSeg) * (size_t)n;
     psk_status rc = tmp.reserve(ctx->dev, o_end + 256);
     if (rc == PSK_OK) rc = db->bsi_key.reserve(ctx->dev, 4 * (size_t)N + 256);
     if (rc == PSK_OK) rc = db->bsi_val.reserve(ctx->dev, 8 * (size_t)N + 256);
     if (rc == PSK_OK) rc = db->bsi_bucket.reserve(ctx->dev, 4 * ((size_t)n_blocks * (nb + 1) + 2));
-    if (rc != PSK_OK) { db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); if (rc == PSK_ENOMEM) return PSK_OK; return rc; }      // no room: the join takes its other route
+    if (rc == PSK_OK) rc = db->bsi_base.reserve(ctx->dev, 8 * ((size_t)n_blocks + 1) + 256);
+    auto drop = [&]() { db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release(); db->bsi_base.release(); };
+    if (rc != PSK_OK) { drop(); if (rc == PSK_ENOMEM) return PSK_OK; return rc; }      // no room: the join takes its other route
     char* T = (char*)tmp.p;
     auto fail = [&](hipError_t e, const char* what) -> psk_status {      // (an optional index: a failed build leaves nothing behind and does not fail the query)
         (void)hipStreamSynchronize(st);
-        db->bsi_key.release(); db->bsi_val.release(); db->bsi_bucket.release();
+        drop();
         psk_set_error("%s: %s", what, hipGetErrorString(e));
         return PSK_OK;
     };
     hipError_t e = hipMemcpyAsync(T + o_s, segs.data(), sizeof(GsiSeg) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->bsi_base.p, base.data(), 8 * ((size_t)n_blocks + 1), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return fail(e, "bsi: upload");
-    hipLaunchKernelGGL(gsi_gather_kernel, dim3(std::max(1u, std::min(64u, (maxn + 4095u) / 4096u)), n), dim3(256), 0, st, (const GsiSeg*)(T + o_s), (uint32_t*)(T + o_k), (unsigned long long*)(T + o_v));
-    for (uint32_t b = 0; b < n_blocks; b++) {      // one stable sort per block: within a k-mer the entries stay in (reference, contig, position) order
+    for (uint32_t b = 0; b < n_blocks; b++) {      // per block: gather (the kernel's y index = the reference's id WITHIN the block), one stable sort - within a k-mer the entries stay in (reference, contig, position) order -, the bucket table
         const uint32_t r0 = b << BSI_BLOG, r1 = std::min<uint32_t>(n, (b + 1) << BSI_BLOG);
-        const size_t o = segs[r0].off; const uint32_t cnt = (uint32_t)((uint64_t)segs[r1 - 1].off + segs[r1 - 1].n - o);
+        const size_t o = (size_t)base[b]; const uint32_t cnt = (uint32_t)(base[b + 1] - base[b]);
         if (cnt) {
+            hipLaunchKernelGGL(gsi_gather_kernel, dim3(std::max(1u, std::min(64u, (maxn + 4095u) / 4096u)), r1 - r0), dim3(256), 0, st, (const GsiSeg*)(T + o_s) + r0, (uint32_t*)(T + o_k), (unsigned long long*)(T + o_v));
             size_t ts_b = ts;
-            e = hipcub::DeviceRadixSort::SortPairs(T + o_t, ts_b, (const uint32_t*)(T + o_k) + o, (uint32_t*)db->bsi_key.p + o, (const unsigned long long*)(T + o_v) + o, (unsigned long long*)db->bsi_val.p + o, (int)cnt, 0, kbits, st);
+            e = hipcub::DeviceRadixSort::SortPairs(T + o_t, ts_b, (const uint32_t*)(T + o_k), (uint32_t*)db->bsi_key.p + o, (const unsigned long long*)(T + o_v), (unsigned long long*)db->bsi_val.p + o, (int)cnt, 0, kbits, st);
             if (e != hipSuccess) return fail(e, "bsi: sort");
         }
-        hipLaunchKernelGGL(bsi_bucket_kernel, dim3(std::max(1u, (cnt + 255u) / 256u)), dim3(256), 0, st, (const uint32_t*)db->bsi_key.p + o, cnt, kbits - bits, nb, (uint32_t*)db->bsi_bucket.p + (size_t)b * (nb + 1), (uint32_t)o);
+        hipLaunchKernelGGL(bsi_bucket_kernel, dim3(std::max(1u, (cnt + 255u) / 256u)), dim3(256), 0, st, (const uint32_t*)db->bsi_key.p + o, cnt, kbits - bits, nb, (uint32_t*)db->bsi_bucket.p + (size_t)b * (nb + 1), 0u);
     }
-    e = hipStreamSynchronize(st);      // (segs and tmp die with this frame)
+    e = hipStreamSynchronize(st);      // (segs, base and tmp die with this frame)
     if (e != hipSuccess) return fail(e, "bsi: build");
     db->bsi_n = N; db->bsi_shift = kbits - bits; db->bsi_nb1 = nb + 1; db->bsi_blocks = n_blocks;
     db->bsi_state = 1;

@@ -14,6 +14,9 @@ constexpr uint32_t GSI_PMAX = 256;      // most pairs of one entry: their cursor
 #endif
 constexpr uint32_t GSL_SEEDS = GSL_SEEDS_N;    // query seeds per slice = per wave (~64 kb of a genome at c = 125: about three chunks)
 constexpr uint32_t GSL_WORDS = GSL_SEEDS / 32;
+// One row of an entry's block table: the block's 256 references of the query's row of the pass matrix as eight 32-bit words, the block, the query's passing references
+// before it, the block's first index entry (64 bits). An entry holds at most GSI_PMAX pairs, so at most GSI_PMAX blocks hold one of their references.
+constexpr uint32_t GSL_BT_WORDS = 12;
 struct GslArgs {
     const BatchQ* bq; uint32_t n_entries;
     const uint2* tab; uint32_t n_tab;       // wave -> (entry, slice)
@@ -21,7 +24,9 @@ struct GslArgs {
     uint32_t* un; uint32_t n_slices;        // per (entry, slice) GSL_WORDS words: the seeds that head a chunk of some pair of the entry (heads kernel; zeroed by its launcher)
     const uint8_t* pass; uint32_t n_refs; const SketchDesc* qd;
     const uint32_t* g_key; const unsigned long long* g_val; const uint32_t* g_bucket; int g_shift;      // psk_db::bsi_*: the seed index in blocks of 2^BSI_BLOG references
+    const unsigned long long* g_base;       // first entry of every block (the bucket tables hold offsets within their block)
     uint32_t g_nb1, g_blocks;               // bucket-table entries per block; blocks
+    uint32_t* blk_tab; uint32_t* blk_cnt; uint32_t blk_cap;      // per entry: the index blocks that hold one of its pairs' references (gsl_blocks_kernel): blk_cnt[e] rows of GSL_BT_WORDS words at blk_tab[e * blk_cap * GSL_BT_WORDS]
     uint32_t* cnt;       // per record: anchors of the (pair, slice) (count walk)
     uint4* rec;          // per record, from the heads kernel: {first anchor of the (pair, slice), chunk-table rows of the pair before the slice, lim1 lo, lim1 hi} -
                          // lim1 = (key of the chunk head open at the slice's start) + 1 + FRAGMENT_LENGTH, 0 before the pair's first anchor (key = q contig << 32 | q pos)
@@ -35,6 +40,9 @@ struct GslArgs {
 
 // wave table of a batch: (entry, slice) for every slice of every entry's query, a query's slices one after the other; ebase: per entry (first record, first slice)
 void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds /* per entry */, std::vector<uint2>& tab, std::vector<uint2>& ebase, uint64_t* n_records, uint64_t* n_slices);
+// the block tables of a batch's entries (one wave per entry sweeps its query's row of the pass matrix once; the walks - slice_join.hip's and join.hip's gsi_join_kernel - read the rows)
+psk_status gsl_blocks_launch(const BatchQ* bq, uint32_t n_entries, const uint8_t* pass, uint32_t n_refs, uint32_t g_blocks, const unsigned long long* g_base,
+                             uint32_t* blk_tab, uint32_t* blk_cnt, uint32_t blk_cap, hipStream_t st);
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st);
 psk_status gsl_heads_launch(const GslArgs& A, hipStream_t st);
 psk_status gsl_emit_launch(const GslArgs& A, hipStream_t st);

@@ -42,7 +42,7 @@ void gsl_make_tab(const BatchQ* bq, size_t n_entries, const uint32_t* q_seeds, s
 }
 
 // LDS of one walk wave, the 16-byte units first: [EMIT: 4 x p_cap staged anchors][EMIT: lim1 per pair: p_cap x 8][EMIT: (cursor, first anchor) per pair, the step's lines]
-// [the walked block's pass row as eight (32 bits, prefix count) entries][passing references before every block: g_blocks x 4]
+// [the walked block's pass row as eight (32 bits, prefix count) entries]
 // [COUNT: cursors: p_cap x 4; anchor-seed bitmaps, GSL_WORDS rows of p_cap + 1 words | EMIT: (cursor, first anchor) per pair: p_cap x 8; rows so far per pair: p_cap x 4]
 // anchors per staged line of the emit walk (GSL_LINE_N = 4: whole 64-byte lines; 2: 32-byte halves - half the LDS per wave, two more waves per SIMD)
 #ifndef GSL_LINE_N
@@ -53,7 +53,7 @@ static_assert(GSL_LW == 8 || GSL_LW == 4 || GSL_LW == 2, "a staged line holds ei
 static size_t gsl_walk_lds(const GslArgs& A, bool emit) {
     const size_t nw = (A.n_refs + 63) / 64;
     (void)nw;
-    return (emit ? (16 * GSL_LW + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (((size_t)A.g_blocks + 1) & ~(size_t)1) + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
+    return (emit ? (16 * GSL_LW + 8 + 8) * (size_t)A.p_cap + 8 * 64 : 0) + 64 + 4 * (size_t)A.p_cap + (emit ? 0 : 4 * (size_t)GSL_WORDS * (A.p_cap + 1));
 }
 
 // (streaming - nontemporal - stores of the anchors were measured on the 10 000 x 10 000 step: the walk takes the same time and the DP kernel that reads the anchors next 178 instead of
@@ -78,28 +78,13 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     uint2* s_cs = (uint2*)(s_lim + (EMIT ? pc : 0u));                                       // EMIT: (cursor, first anchor of the (pair, slice)): one 8-byte read
     uint2* s_fl = s_cs + (EMIT ? pc : 0u);                                                  // EMIT: the step's complete lines (pair | first slot << 16, first anchor of the line)
     uint2* s_bp = s_fl + (EMIT ? 64u : 0u);                                                 // the block being walked: its 256 references of the query's pass row, 32 per entry: (bits, passing references before them)
-    uint32_t* s_bpre = (uint32_t*)(s_bp + 8u);                                              // passing references before every block of the index
-    uint32_t* s_cur = s_bpre + ((A.g_blocks + 1u) & ~1u);                                   // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
+    uint32_t* s_cur = (uint32_t*)(s_bp + 8u);                                               // COUNT: anchors so far; EMIT: chunk-table rows of the pair so far
     uint32_t* s_rows = s_cur;
     uint32_t* s_bm = s_cur + pc;                                                            // COUNT: word w of pair j at [w * (pc + 1) + j]
-    // The index comes in blocks of 2^BSI_BLOG references: only the blocks that hold a passing reference of the query are walked (a run of the whole database's index
-    // holds ~1 % of ALL genomes by chance - see psk_db::bsi_*). A pair's reference sits in one block, so its anchors still come out in seed order.
-    const uint8_t* __restrict__ row = A.pass + (size_t)B.q * A.n_refs;
-    unsigned long long masks[4] = {0ull, 0ull, 0ull, 0ull};      // blocks with a passing reference (g_blocks <= 256: the indexes carry 16-bit reference ids)
-    {   // one sweep over the query's row of the pass matrix, a block (four 64-reference words) at a time: which blocks to walk, passing references before each
-        static_assert(BSI_BLOG == 8, "four ballots of 64 references = one index block");
-        uint32_t run = 0;
-        for (uint32_t blk = 0; blk < A.g_blocks; blk++) {
-            uint8_t f[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t r = (blk * 4u + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
-            if (lane == 0) s_bpre[blk] = run;
-            uint32_t n_here = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) n_here += (uint32_t)__popcll(__ballot(f[u] != 0));
-            if (n_here) { const unsigned long long bit = 1ull << (blk & 63u); const uint32_t g = blk >> 6; masks[0] |= g == 0 ? bit : 0ull; masks[1] |= g == 1 ? bit : 0ull; masks[2] |= g == 2 ? bit : 0ull; masks[3] |= g == 3 ? bit : 0ull; }
-            run += n_here;
-        }
+    // The index comes in blocks of 2^BSI_BLOG references: only the blocks that hold a reference of one of the entry's pairs are walked (a run of the whole database's index
+    // holds ~1 % of ALL genomes by chance - see psk_db::bsi_*). A pair's reference sits in one block, so its anchors still come out in seed order. Which blocks those are,
+    // and their 256 references of the query's pass row, comes from the entry's block table (gsl_blocks_kernel: one sweep of the row per ENTRY, not per wave).
+    {
         if (EMIT) for (uint32_t j = lane; j < P; j += 64) { const uint4 v = A.rec[rec0 + j]; s_cs[j] = make_uint2(v.x, v.x); s_rows[j] = v.y; s_lim[j] = ((unsigned long long)v.w << 32) | v.z; }
         else {
             for (uint32_t j = lane; j < P; j += 64) s_cur[j] = 0;
@@ -114,23 +99,21 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
     // of 64 index entries, numbered through the batch, and the entries of step t + GSL_AHEAD are requested before step t is dealt out.
     constexpr uint32_t GSL_AHEAD = 4;
     unsigned long long visited = 0;      // COUNT: index entries in the runs this lane's seeds found (psk_ctx_join_work)
-    for (uint32_t blk0 = 0; blk0 < 256u && blk0 < A.g_blocks; blk0 += 64) {
-    unsigned long long blk_mask = blk0 == 0 ? masks[0] : blk0 == 64 ? masks[1] : blk0 == 128 ? masks[2] : masks[3];
+    const uint32_t n_blk = A.blk_cnt[te.x];
+    const uint32_t* __restrict__ brow = A.blk_tab + (size_t)te.x * A.blk_cap * GSL_BT_WORDS;
 #pragma unroll 1
-    while (blk_mask) {
-    const uint32_t blk = blk0 + (uint32_t)__ffsll((long long)blk_mask) - 1u;
-    blk_mask &= blk_mask - 1ull;
+    for (uint32_t bi = 0; bi < n_blk; bi++, brow += GSL_BT_WORDS) {
+    {
+    const uint32_t blk = brow[8];
+    const unsigned long long x_base = ((unsigned long long)brow[11] << 32) | brow[10];
+    const uint32_t* __restrict__ x_key = A.g_key + x_base; const unsigned long long* __restrict__ x_val = A.g_val + x_base;
     {   // the block's 256 references of the pass row -> eight (32 bits, passing references before them) entries: reference -> pair of the entry in ONE 8-byte LDS read
-        uint8_t f[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t r = (blk * 4u + u) * 64u + (uint32_t)lane; f[u] = r < A.n_refs ? row[r] : (uint8_t)0; }
         lds_wave_sync();      // (the previous block's last lookups are through)
-        uint32_t run = s_bpre[blk];
+        if (lane < 8) {
+            uint32_t run = brow[9];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned long long m = __ballot(f[u] != 0);
-            if (lane == 0) { s_bp[2 * u] = make_uint2((uint32_t)m, run); s_bp[2 * u + 1] = make_uint2((uint32_t)(m >> 32), run + (uint32_t)__popc((uint32_t)m)); }
-            run += (uint32_t)__popcll(m);
+            for (int u = 0; u < 7; u++) { const uint32_t w = brow[u]; if (u < lane) run += (uint32_t)__popc(w); }
+            s_bp[lane] = make_uint2(brow[lane], run);
         }
         lds_wave_sync();
     }
@@ -161,7 +144,7 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
                 ns[u] = 63u - (uint32_t)__clzll((long long)own); \
                 nx[u] = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)ns[u]) + 64u * ((t) - (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)ns[u])); \
                 nh[u] = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)ns[u]); \
-                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = A.g_key[nx[u] + lane]; nv[u] = A.g_val[nx[u] + lane]; } \
+                if (nx[u] + (uint32_t)lane < nh[u]) { nk[u] = x_key[nx[u] + lane]; nv[u] = x_val[nx[u] + lane]; } \
             } } while (0)
 #pragma unroll
         for (uint32_t u = 0; u < GSL_AHEAD; u++) GSL_FETCH(u, u);
@@ -284,8 +267,8 @@ __global__ __launch_bounds__(64) void gsl_walk_kernel(GslArgs A) {
         }
 #undef GSL_FETCH
     }
-    }      // the group's blocks that hold a passing reference
-    }      // groups of 64 blocks
+    }
+    }      // the entry's index blocks
     lds_wave_sync();
     if (!EMIT) {
 #pragma unroll
@@ -395,6 +378,48 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
     }
 }
 
+// The block table of every entry of a batch: one wave per entry sweeps its query's row of the pass matrix ONCE (the walks did, per wave: 160 slices of a 5 Mb query each
+// read the whole row) and lists the index blocks that hold a reference of one of the entry's pairs - a block whose passing references' ranks [run, run + n) meet the entry's
+// [rank_lo, rank_hi) - each with its 256 pass bits, the passing references before it and where its index entries start. No bound on the number of blocks.
+__global__ __launch_bounds__(64) void gsl_blocks_kernel(const BatchQ* __restrict__ bq, uint32_t n_entries, const uint8_t* __restrict__ pass, uint32_t n_refs, uint32_t g_blocks,
+                                                        const unsigned long long* __restrict__ g_base, uint32_t* __restrict__ blk_tab, uint32_t* __restrict__ blk_cnt, uint32_t blk_cap) {
+    static_assert(BSI_BLOG == 8, "four ballots of 64 references = one index block");
+    const uint32_t e = blockIdx.x;
+    if (e >= n_entries) return;
+    const int lane = threadIdx.x;
+    const BatchQ B = bq[e];
+    const uint8_t* __restrict__ row = pass + (size_t)B.q * n_refs;
+    uint32_t* __restrict__ out = blk_tab + (size_t)e * blk_cap * GSL_BT_WORDS;
+    uint32_t run = 0, cnt = 0;
+    for (uint32_t blk = 0; blk < g_blocks && run < B.rank_hi; blk++) {
+        uint8_t f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t r = (blk * 4u + u) * 64u + (uint32_t)lane; f[u] = r < n_refs ? row[r] : (uint8_t)0; }
+        unsigned long long m[4]; uint32_t n_here = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { m[u] = __ballot(f[u] != 0); n_here += (uint32_t)__popcll(m[u]); }
+        if (n_here && run + n_here > B.rank_lo) {
+            if (cnt < blk_cap) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { if (lane == 2 * u) w = (uint32_t)m[u]; if (lane == 2 * u + 1) w = (uint32_t)(m[u] >> 32); }
+                const unsigned long long base = g_base[blk];
+                if (lane == 8) w = blk; if (lane == 9) w = run; if (lane == 10) w = (uint32_t)base; if (lane == 11) w = (uint32_t)(base >> 32);
+                if (lane < (int)GSL_BT_WORDS) out[(size_t)cnt * GSL_BT_WORDS + lane] = w;
+            }
+            cnt++;
+        }
+        run += n_here;
+    }
+    if (lane == 0) blk_cnt[e] = cnt < blk_cap ? cnt : blk_cap;      // (an entry has at most GSI_PMAX pairs and blk_cap >= min(blocks, GSI_PMAX): never cut)
+}
+psk_status gsl_blocks_launch(const BatchQ* bq, uint32_t n_entries, const uint8_t* pass, uint32_t n_refs, uint32_t g_blocks, const unsigned long long* g_base,
+                             uint32_t* blk_tab, uint32_t* blk_cnt, uint32_t blk_cap, hipStream_t st) {
+    if (!n_entries) return PSK_OK;
+    hipLaunchKernelGGL(gsl_blocks_kernel, dim3(n_entries), dim3(64), 0, st, bq, n_entries, pass, n_refs, g_blocks, g_base, blk_tab, blk_cnt, blk_cap);
+    PSK_HIP(hipGetLastError());
+    return PSK_OK;
+}
 psk_status gsl_count_launch(const GslArgs& A, hipStream_t st) {
     hipLaunchKernelGGL((gsl_walk_kernel<false, false>), dim3(A.n_tab), dim3(64), gsl_walk_lds(A, false), st, A);
     PSK_HIP(hipGetLastError());

@@ -263,23 +263,31 @@ for j in pick:
     if hs:
         h = hs[len(hs) // 2]
         sample.append((int(j), h.reference_name, {f: int(h._raw[f]) for f in ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")}, h.identity, h.query_fraction))
-pickle.dump((sample, {n: g for n, g in refs if any(n == s[1] for s in sample)}, {j: contigs[j][1] for j, *_ in sample}), open(os.environ["PSK_TEST_SAMPLE"], "wb"))
-print(n, d, free0 - free1, round(t2 - t1, 3))
+if os.environ.get("PSK_TEST_SAMPLE"):
+    pickle.dump((sample, {n: g for n, g in refs if any(n == s[1] for s in sample)}, {j: contigs[j][1] for j, *_ in sample}), open(os.environ["PSK_TEST_SAMPLE"], "wb"))
+import ctypes as C
+lk = C.c_uint64()
+db._lib.psk_ctx_join_work(db._ctx._h, C.byref(lk), None, None, None, 0)
+print(n, d, free0 - free1, round(t2 - t1, 3), lk.value)
 """
 
 
 def test_database_beyond_the_seed_index_limit(oracle, tmp_path):
-    """the seed indexes carry 16-bit reference ids and are not built for more than 65 536 references; the plan then joins contigs through the
-    references' probe tables (and filters rescued contigs through the per-reference indexes). 70 000 references of 2-2.8 kb, 2 000 contig queries (every contig has fewer
-    than 20 markers: rescued, i.e. screened against EVERY reference): the same hits from a second call, free device memory flat across it, 40 sampled hits recomputed by
-    the oracle. (The cost of the cliff is measured by tools/many_refs_cliff.py: DESIGN.md section 8.)"""
+    """the reference loop has no limit on the number of references (lib.rs:617-637). The database-wide seed index carries 16-bit reference
+    ids and stops at 65 536 references; the BLOCKED index (block-local ids, 64-bit block offsets) does not, and since round 6 a larger database is joined - and its rescued contigs
+    prefiltered - through it. 70 000 references of 2-2.8 kb, 2 000 contig queries (every contig has fewer than 20 markers: rescued, i.e. screened against EVERY reference): the
+    index walks ran (the library's lookup counter), the same hits from a second call, free device memory flat across it, the same hits with the index joins switched off
+    (PSK_GSI_JOIN=0: probe-table join + per-reference prefilter, the route of such databases until round 5), 40 sampled hits recomputed by the oracle."""
     import pickle
     sample_file = str(tmp_path / "sample.pkl")
     env = dict(os.environ, PSK_TEST_SAMPLE=sample_file)
-    for k in ("PSK_GSI_JOIN", "PSK_PROBE", "PSK_PREFILTER", "PSK_BSI_SMALL"):
+    for k in ("PSK_GSI_JOIN", "PSK_PROBE", "PSK_PREFILTER", "PSK_BSI_SMALL", "PSK_GSI"):
         env.pop(k, None)
     out = subprocess.check_output([sys.executable, "-c", "import os\n" + MANY_REFS], env=env, timeout=1500).decode().split()
-    assert int(out[0]) > 2000 * 20 and int(out[2]) < (64 << 20), out      # hits; device memory the second call kept
+    assert int(out[0]) > 2000 * 20 and int(out[2]) < (64 << 20) and int(out[4]) > 0, out      # hits; device memory the second call kept; index lookups
+    env.pop("PSK_TEST_SAMPLE")
+    o2 = subprocess.check_output([sys.executable, "-c", "import os\n" + MANY_REFS], env=dict(env, PSK_GSI_JOIN="0"), timeout=1500).decode().split()
+    assert o2[:2] == out[:2] and int(o2[4]) == 0, (o2, out)      # the same hits without any index walk
     sample, refs, contigs = pickle.load(open(sample_file, "rb"))
     assert len(sample) >= 30
     for j, rname, ints, ani, afq in sample:
@@ -293,7 +301,8 @@ MANY_BLOCKS = COMMON + r"""
 import os, pickle
 # 18 000 references of ~72 kb at c = 30 (~2 400 seeds each: the slice join's range) in families of 50 consecutive references: 71 index blocks of 256 references,
 # family 327 (references 16 350 - 16 399) straddles the boundary between blocks 63 and 64 - the second 64-bit word of the walks' block masks
-N, FAM, L = 18000, 50, 72000
+N, FAM, L, CC, MC = (int(x) for x in os.environ.get("PSK_TEST_SHAPE", "18000 50 72000 30 200").split())
+EDGE = (N // 16384 - (N % 16384 < 300)) * 16384 if N < 65536 else 65536      # the reference index the test is about: 16 384 (index blocks 63 | 64) / 65 536 (beyond the 16-bit ids)
 def near(a, n_mut):
     b = a.copy(); p = rng.integers(0, len(a), n_mut); b[p] = (b[p] + rng.integers(1, 4, n_mut, dtype=np.uint8)) & 3; return b
 refs = []
@@ -301,17 +310,17 @@ for f in range(N // FAM):
     a = rng.integers(0, 4, L + 500, dtype=np.uint8)
     for j in range(FAM):
         refs.append((f"r{f * FAM + j}", lut[near(a, 30 * j)[: L + (j * 37) % 500]].tobytes()))
-db = psk.Database(compression=30, marker_compression=200)
+db = psk.Database(compression=CC, marker_compression=MC)
 db.sketch_many(refs)
-# genome queries: whole families around the block 63 | 64 boundary and in the last blocks, and every 40th genome of the rest
-qg = sorted(set(list(range(16300, 16450)) + list(range(17850, 18000)) + list(range(0, 100)) + list(range(0, N, 40))))
+# genome queries: whole families around the boundary and in the last blocks, and every 40th genome of the rest
+qg = sorted(set(list(range(EDGE - 84, EDGE + 66)) + list(range(N - 150, N)) + list(range(0, 100)) + list(range(0, N, 40))))
 genomes = [refs[i] for i in qg]
 res_g = db.query_many(genomes, learned_ani=False)
 # contig queries (< 2 048 seeds: the contig join), cut from references all over the database, half of them from blocks >= 64
 contigs = []
 for j in range(6000):
-    i = int(rng.integers(16384, N)) if j % 2 else int(rng.integers(0, N)); g = np.frombuffer(refs[i][1], np.uint8)
-    ln = int(rng.integers(2500, 9000)); st = int(rng.integers(0, len(g) - ln))
+    i = int(rng.integers(EDGE, N)) if j % 2 else int(rng.integers(0, N)); g = np.frombuffer(refs[i][1], np.uint8)
+    ln = int(rng.integers(L // 30, L // 8)); st = int(rng.integers(0, len(g) - ln))
     c = g[st:st + ln].copy(); p = rng.integers(0, ln, ln // 100); c[p] = lut[rng.integers(0, 4, len(p))]
     contigs.append((f"c{j}", c.tobytes()))
 res_c = db.query_many(contigs, learned_ani=False)
@@ -321,11 +330,11 @@ if os.environ.get("PSK_TEST_SAMPLE"):
     sample = []
     ints = ("n_anchors", "n_chunks", "n_intervals", "covered_query", "covered_ref", "sum_chain_anchors", "sum_chunk_seeds")
     for kind, queries, res in (("g", genomes, res_g), ("c", contigs, res_c)):
-        cand = [x for x in range(len(queries)) if res[x] and any(int(h.reference_name[1:]) >= 16384 for h in res[x])]
+        cand = [x for x in range(len(queries)) if res[x] and any(int(h.reference_name[1:]) >= EDGE for h in res[x])]
         for x in pick.choice(cand, 12, replace=False):
-            hs = [h for h in res[int(x)] if int(h.reference_name[1:]) >= 16384]
+            hs = [h for h in res[int(x)] if int(h.reference_name[1:]) >= EDGE]
             h = hs[int(pick.integers(0, len(hs)))]
-            sample.append((queries[int(x)][1], refs[int(h.reference_name[1:])][1], {f: int(h._raw[f]) for f in ints}, h.identity, h.query_fraction, h.reference_fraction))
+            sample.append((queries[int(x)][1], refs[int(h.reference_name[1:])][1], {f: int(h._raw[f]) for f in ints}, h.identity, h.query_fraction, h.reference_fraction, CC, MC))
     pickle.dump(sample, open(os.environ["PSK_TEST_SAMPLE"], "wb"))
 import ctypes as C
 lk, vis = C.c_uint64(), C.c_uint64()
@@ -353,13 +362,36 @@ def test_index_blocks_beyond_the_first_sixty_four(oracle, tmp_path):
         assert (int(o2[0]), o2[1]) == (n_hits, dig), (extra, o2, out)
         if extra.get("PSK_GSI_JOIN") == "0":
             assert int(o2[2]) == 0, o2      # no index walk took part in the cross-check
+    _check_sample(oracle, sample_file)
+
+
+def _check_sample(oracle, sample_file):
+    import pickle
     sample = pickle.load(open(sample_file, "rb"))
     assert len(sample) == 24
-    for q, r, ints, ani, afq, afr in sample:
-        want = oracle.chain(oracle.Sketch([r], c=30, marker_c=200), oracle.Sketch([q], c=30, marker_c=200))
+    for q, r, ints, ani, afq, afr, cc, mc in sample:
+        want = oracle.chain(oracle.Sketch([r], c=cc, marker_c=mc), oracle.Sketch([q], c=cc, marker_c=mc))
         for f, v in ints.items():
             assert v == int(getattr(want, f)), (f, v, int(getattr(want, f)))
         assert abs(ani - want.ani) < 1e-6 and abs(afq - want.af_query) < 1e-6 and abs(afr - want.af_ref) < 1e-6
+
+
+def test_genomes_beyond_65536_references_go_through_the_blocked_index(oracle, tmp_path):
+    """the blocked seed index has block-local reference ids and 64-bit block offsets since round 6 - no bound on the references of a database but memory -
+    and the walks take their blocks from per-entry block tables instead of four 64-bit masks. 66 000 references of ~21 kb at c = 10 (2 100 seeds: the slice join's range; 258
+    index blocks), a family astride reference 65 536, genome queries (slice join) and contig queries (contig join: blocks only - such a database has no database-wide index):
+    the index walks ran, the hits equal those of the joins that use no index, 24 sampled hits against references beyond 65 536 recomputed by the oracle (lib.rs:617-657)."""
+    sample_file = str(tmp_path / "sample.pkl")
+    env = dict(os.environ, PSK_TEST_SAMPLE=sample_file, PSK_TEST_SHAPE="66000 50 21000 10 100")
+    for k in ("PSK_GSI_JOIN", "PSK_GSI_SLICE", "PSK_BSI_SMALL", "PSK_PIPELINE", "PSK_PROBE", "PSK_PREFILTER", "PSK_GSI"):
+        env.pop(k, None)
+    out = subprocess.check_output([sys.executable, "-c", MANY_BLOCKS], env=env, timeout=1800).decode().split()
+    n_hits, dig, lookups = int(out[0]), out[1], int(out[2])
+    assert n_hits > 500 * 40 and lookups > 0, out
+    env.pop("PSK_TEST_SAMPLE")
+    o2 = subprocess.check_output([sys.executable, "-c", MANY_BLOCKS], env=dict(env, PSK_GSI_SLICE="0", PSK_GSI_JOIN="0"), timeout=1800).decode().split()
+    assert (int(o2[0]), o2[1]) == (n_hits, dig) and int(o2[2]) == 0, (o2, out)
+    _check_sample(oracle, sample_file)
 
 
 MIXED = r"""
