@@ -17,7 +17,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PMC = os.path.join(ROOT, "gpurun_out", "pmc")
 OUT = os.path.join(ROOT, "profiles", "r6")
-STEPS = 3      # 1 warm-up + 2 timed steps in every counter pass
+STEPS = 3      # 1 warm-up + 2 timed steps in every counter pass ...
+STEPS_OF = {"allvsall": 4}      # ... and, for the all-vs-all at N = 1, bench.py's one more step as ONE chain of launches (the per-kernel table step): four passes of the step under the counters
 F = {"stream": 2.0, "gather": 1.0, "runs": 1.0}
 W_COUNT, W_EMIT = "gsl_walk_kernel<false, false>", "gsl_walk_kernel<true, true>"
 PLAN = {
@@ -72,9 +73,9 @@ def main():
         units = {"item": work["items"], "anchor": work["anchors"], "candidate": work.get("candidates", 0.0), "row": work.get("chunk_rows", 0.0), "base": bases}
         result[workload] = {}
         for timer, (kernels, unit, index_join) in timers.items():
-            raw = sum(fetch.get(k, (0, 0.0))[1] for k, _ in kernels) / STEPS
-            scaled = sum(fetch.get(k, (0, 0.0))[1] * F[shape] for k, shape in kernels) / STEPS
-            w = sum(write.get(k, (0, 0.0))[1] for k, _ in kernels) / STEPS
+            raw = sum(fetch.get(k, (0, 0.0))[1] for k, _ in kernels) / STEPS_OF.get(workload, STEPS)
+            scaled = sum(fetch.get(k, (0, 0.0))[1] * F[shape] for k, shape in kernels) / STEPS_OF.get(workload, STEPS)
+            w = sum(write.get(k, (0, 0.0))[1] for k, _ in kernels) / STEPS_OF.get(workload, STEPS)
             if units[unit] <= 0 or (raw == 0 and w == 0):
                 continue
             result[workload][timer] = {"kernels": [k for k, _ in kernels if k in fetch or k in write], "shapes": [s for k, s in kernels if k in fetch or k in write], "unit": unit, "units_per_step": units[unit], "index_join": index_join,
@@ -102,8 +103,8 @@ def main():
                "traffic_bytes_corrected": s["fetch_bytes_scaled_per_step"] + s["write_bytes_per_step"], "traffic_bytes_per_base": s["bytes_per_unit"],
                "valu_wave_instructions_per_launch": sq[("sketch_scan_kernel", "SQ_INSTS_VALU")][1] / launches,
                "grbm_gui_active_cycles_per_launch": sq[("sketch_scan_kernel", "GRBM_GUI_ACTIVE")][1] / sq[("sketch_scan_kernel", "GRBM_GUI_ACTIVE")][0],
-               "source": "round 5: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters in separate passes (profiles/scripts/r6_pmc.sh) over `bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-api "
-                         "--no-workloads` (3 launches of 1 001 genomes); counters in KiB; FETCH x 2 for coalesced streams (profiles/r4/r4k_pmc_calibration.md). Raw files: profiles/r6/pmc_raw/r6_search*"}
+               "source": "round 6: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters in separate passes (profiles/scripts/r6_pmc.sh) over `bench.py --workload search --steps 2 --warmup 1 --cpu-sample 0 --no-api` "
+                         "(3 launches of 1 001 genomes); counters in KiB; FETCH x 2 for coalesced streams (profiles/r4/r4k_pmc_calibration.md). Raw files: profiles/r6/pmc_raw/r6_search*"}
         json.dump(doc, open(os.path.join(OUT, "r6_pmc_sketch_scan.json"), "w"), indent=1)
         print("wrote r6_pmc_sketch_scan.json:", doc["traffic_bytes_per_base"], "B per base,", doc["valu_wave_instructions_per_launch"] / doc["bases_per_launch"] * 64, "VALU wave-instructions per 64 bases")
     except (OSError, KeyError, ValueError) as e:
