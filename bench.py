@@ -902,7 +902,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
                 table_step = {"mode": "one chain of launches (PSK_PIPELINE=0), one step outside the timed region", "ms_per_step": dt1 * 1e3}
             finally:
                 del os.environ["PSK_PIPELINE"]
-        table = kernel_rooflines(kern, 1 if table_step else steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall", {}))
+        table = kernel_rooflines(kern, 1 if table_step else steps, {"bases": bases_local, "c": 125, "marker_c": 1000, **work}, job.pmc.get("allvsall10k" if (n_total >= 10000 and "allvsall10k" in job.pmc) else "allvsall", {}))      # (the 10 000 x 10 000 job has a counter pass of its own)
         shape = {"plain": "single-contig genomes, substitutions only", "contigs": "every genome cut into 1-80 contigs",
                  "sv": "20 block inversions / translocations of 5-50 kb per genome on top of the substitutions"}[variant]
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 PMC = os.path.join(ROOT, "gpurun_out", "pmc")
 OUT = os.path.join(ROOT, "profiles", "r6")
 STEPS = 3      # 1 warm-up + 2 timed steps in every counter pass ...
-STEPS_OF = {"allvsall": 4}      # ... and, for the all-vs-all at N = 1, bench.py's one more step as ONE chain of launches (the per-kernel table step): four passes of the step under the counters
+STEPS_OF = {"allvsall": 4, "allvsall10k": 2}      # (the 10 000 x 10 000 pass: no warm-up, 1 timed step + the table step)
+TAG_UNITS = {"allvsall10k": "allvsall10k"}      # ... and, for the all-vs-all at N = 1, bench.py's one more step as ONE chain of launches (the per-kernel table step): four passes of the step under the counters
 F = {"stream": 2.0, "gather": 1.0, "runs": 1.0}
 W_COUNT, W_EMIT = "gsl_walk_kernel<false, false>", "gsl_walk_kernel<true, true>"
 PLAN = {
@@ -26,6 +27,8 @@ PLAN = {
     "allvsall": ("r6_ava", {"anchor": ([(W_COUNT, "runs")], "anchor", True), "anchor_emit": ([(W_EMIT, "runs"), ("gsl_heads_kernel", "stream")], "anchor", True),
                             "chain_chunk": ([("chain_lane20_kernel", "stream")], "anchor", False), "select": ([("select_kernel", "stream"), ("chunk_seeds_kernel", "gather")], "candidate", False),
                             "pair_reduce": ([("pair_reduce_kernel", "stream"), ("pair_reduce_wave_kernel", "stream")], "row", False)}),
+    "allvsall10k": ("r6_ava10k", {"anchor": ([(W_COUNT, "runs")], "anchor", True), "anchor_emit": ([(W_EMIT, "runs"), ("gsl_heads_kernel", "stream")], "anchor", True),
+                               "chain_chunk": ([("chain_lane20_kernel", "stream")], "anchor", False), "select": ([("select_kernel", "stream"), ("chunk_seeds_kernel", "gather")], "candidate", False)}),
     "metagenome": ("r6_meta", {"anchor_emit": ([("gsi_join_kernel<true>", "runs")], "anchor", True),
                                "chain_chunk": ([("chain_quad_deep_kernel", "stream"), ("chain_chunk_list_kernel", "stream")], "anchor", False),
                                "select": ([("select_tiny_kernel", "stream"), ("select_kernel", "stream")], "candidate", False),
