@@ -1356,7 +1356,7 @@ def main():
     ap.add_argument("--faster-small", action="store_true", help="metagenome: Database.query(faster_small=True) (no rescue of contigs with < 20 markers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--comm", choices=["torch", "capi"], default="torch", help="N>1: who moves the exchange steps — torch.distributed, or the library's own RCCL communicator (psk_comm_*)")
-    ap.add_argument("--exchange-batch", type=int, default=256, help="allvsall N>1: genomes per rank and round of the sketch all-gather")
+    ap.add_argument("--exchange-batch", type=int, default=1024, help="allvsall N>1: genomes per rank and round of the sketch all-gather (1 024: a round of 5 Mb genomes is then large enough - 2^31 (pair, seed) items - for two batches in flight; the single-GPU emulation of a rank: 7.35 x at N = 8 against 6.79 x with 256)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses device 0 (needs --backend gloo); never for reported numbers")
     ap.add_argument("--cpu-sample", type=int, default=1000, help="CPU-baseline sample size (0 = skip): search: references (1000 = the whole workload, ~10-20 s); allvsall: queries (capped at 128); metagenome: contigs (capped at 512)")
     ap.add_argument("--variant", choices=["plain", "contigs", "sv"], default="plain", help="allvsall at N=1: the generator variant of SURVEY.md 8(d) - genomes cut into 1-80 contigs / 20 block rearrangements per genome")

@@ -198,7 +198,7 @@ psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_i
         // the entries' block tables: which blocks of the blocked index hold a reference of an entry's pairs (one sweep of the query's pass row per entry; both index joins read them)
         const uint32_t t_blocks = gsl ? L.g_blocks : L.b_blocks;
         const unsigned long long* t_base = gsl ? L.g_base : L.b_base;
-        const uint32_t bcap = std::max(1u, std::min<uint32_t>(t_blocks, GSI_PMAX));
+        const uint32_t bcap = std::max(1u, std::min<uint32_t>(t_blocks, std::min<uint32_t>(GSI_PMAX, std::max(1u, L.p_cap))));      // (an entry of P pairs has references in at most P blocks; p_cap >= every entry's P)
         uint32_t* d_btab = nullptr; uint32_t* d_bcnt = nullptr;
         if (t_blocks) {
             const size_t o_bc = al256(4 * (size_t)L.n_bq * bcap * GSL_BT_WORDS);

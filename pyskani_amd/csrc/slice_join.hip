@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void gsl_blocks_kernel(const BatchQ* __restrict
         }
         run += n_here;
     }
-    if (lane == 0) blk_cnt[e] = cnt < blk_cap ? cnt : blk_cap;      // (an entry has at most GSI_PMAX pairs and blk_cap >= min(blocks, GSI_PMAX): never cut)
+    if (lane == 0) blk_cnt[e] = cnt < blk_cap ? cnt : blk_cap;      // (an entry of P pairs has references in at most P blocks and blk_cap >= min(blocks, the batch's largest P): never cut)
 }
 psk_status gsl_blocks_launch(const BatchQ* bq, uint32_t n_entries, const uint8_t* pass, uint32_t n_refs, uint32_t g_blocks, const unsigned long long* g_base,
                              uint32_t* blk_tab, uint32_t* blk_cnt, uint32_t blk_cap, hipStream_t st) {

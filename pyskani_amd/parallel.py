@@ -385,7 +385,7 @@ class ShardedDatabase:
         base = Hit.__mro__[1]      # (the storage class takes `learned`; Hit's own constructor is the reference's five arguments, hit.rs:26-33)
         return [base.__new__(Hit, float(r["ani"]), name, float(r["af_query"]), self.names[int(r["ref_index"])], float(r["af_ref"]), bool(l)) for r, l in zip(got, learned.tolist())]
 
-    def all_vs_all_records(self, batch=256, overlap=True, **opts):
+    def all_vs_all_records(self, batch=1024, overlap=True, **opts):
         """Every genome of the job against every other (and itself), as RECORDS: a numpy array of psk_hit_min (psk_hit with `raw`)
         sorted by (query, reference) with GLOBAL indices (`query` - `reserved` in raw records - and `ref_index`), identical on every rank.
 
@@ -394,7 +394,9 @@ class ShardedDatabase:
         the local shard in one psk_query_many(_min), the hits get their global indices with numpy, and ONE all-gather of the hit
         records ends the call. No Python object per hit or per pair anywhere. With `overlap` the gather of round b + 1 is
         issued (on a helper thread: its collectives and the library's packing run on their own streams) BEFORE round b is queried,
-        so the exchange leaves the critical path: two rounds' gathered sketches are alive at a time."""
+        so the exchange leaves the critical path: two rounds' gathered sketches are alive at a time. `batch` = 1 024: a round of ~5 Mb genomes (1 024 x its ~100 relatives x 40 000
+        seeds) is then above the 2^31 (pair, seed) items from which the library keeps two batches in flight on two lanes; at 256 a rank ran every round as one chain (single-GPU
+        emulation of a rank's share of the 10 000-genome job, bench.py extras.scaling_model: 70 against 77 ms per rank at N = 8). 2 x 1 024 x N packed sketches of 0.9 MB are alive: 14 GB at N = 8."""
         t_all = time.perf_counter()
         local = self.local
         n_local = len(local)
@@ -478,7 +480,7 @@ class ShardedDatabase:
         self.stats["total_s"] += time.perf_counter() - t_all
         return out
 
-    def all_vs_all(self, batch=256, **opts):
+    def all_vs_all(self, batch=1024, **opts):
         """`all_vs_all_records` as {query_name: [Hit, ...]}, identical on every rank, hits in global reference order."""
         recs = self.all_vs_all_records(batch=batch, **opts)
         from .database import Hit
