@@ -1,6 +1,6 @@
 // Seed-index join of batches of MID-SIZED pairs (all-vs-all of ~5 Mb genomes): the anchors of lib.rs:640-657's chain_seeds calls,
-// for every pair of a batch at once, through the database-wide seed index (psk_db::gsi_*: EVERY reference's seeds sorted by k-mer,
-// within a k-mer by reference, contig, position).
+// for every pair of a batch at once, through the seed index in blocks of 256 references (psk_db::bsi_*: a block's seeds sorted by k-mer,
+// within a k-mer by reference, contig, position; block-local reference ids, 64-bit block offsets: no bound on the database).
 //
 // The per-pair join (anchor_join4_kernel + anchor_emit_pairs_kernel) looks every query seed up once per PAIR: 4 x 10^10 (pair, seed)
 // lookups and as many 8-byte records written in k-mer order and read back in position order for 10 000 x 10 000 genomes, where the
@@ -10,6 +10,7 @@
 // is cut into SLICES of GSL_SEEDS seeds, one wave per (query, slice), and a pair's anchors, which must end up contiguous and in
 // (q contig, q pos, r contig, r pos) order, get their places from a COUNT walk:
 //
+//   gsl_blocks_kernel       per batch ENTRY (a query and <= 256 of its passing references): the index blocks that hold one of those references, with their pass bits
 //   gsl_walk_kernel<false>  COUNT: per (pair, slice) the number of anchors and a bitmap of the slice's seeds that have one
 //   (scan over the pairs' totals -> pstart: chain.hip)
 //   gsl_heads_kernel        per pair, slice after slice: first anchor of every (pair, slice), and - from the bitmaps - which seeds head
