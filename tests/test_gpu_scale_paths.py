@@ -91,6 +91,33 @@ print(*out[0])
 """
 
 
+def test_switches_are_read_once_per_call_not_once_per_process():
+    """profiles/r6/paths.md: the query path's PSK_* switches are read into a struct when a call begins (csrc/query_parts.h Switches) - a test, or bench.py, may flip them between
+    two calls of ONE process. The same all-vs-all three times in one process: index joins off (no index lookups counted), on by default (lookups counted), off again - the same hits."""
+    code = COMMON + r"""
+import ctypes as C, os
+anc = [rng.integers(0, 4, 300_000, dtype=np.uint8) for _ in range(4)]
+genomes = [(f"g{f}_{j}", lut[mutate(anc[f], 0.002 * j)].tobytes()) for f in range(4) for j in range(40)]      # 160 genomes x 40 relatives: 6 400 pairs of ~2 400 seeds
+db = psk.Database()
+db.sketch_many(genomes)
+def lookups():
+    lk = C.c_uint64(); db._lib.psk_ctx_join_work(db._ctx._h, C.byref(lk), None, None, None, 1); return lk.value
+out = []
+for setting in ("0", None, "0"):
+    if setting is None: os.environ.pop("PSK_GSI_SLICE", None); os.environ.pop("PSK_GSI_JOIN", None)
+    else: os.environ["PSK_GSI_SLICE"] = setting; os.environ["PSK_GSI_JOIN"] = setting
+    lookups()
+    d = digest(db.query_many(genomes, learned_ani=False))
+    out.append((d, lookups()))
+assert out[0][0] == out[1][0] == out[2][0], out
+assert out[0][1] == 0 and out[1][1] > 0 and out[2][1] == 0, out
+print(*out[0][0])
+"""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PSK_")}
+    n, _ = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
+    assert int(n) >= 160 * 40
+
+
 def test_callers_that_each_want_a_second_lane():
     """Five concurrent query_many callers whose rounds keep two batches in flight (PSK_PIPELINE=1, nine batches each): eight lanes for ten wishes - a caller that
     finds no free lane runs one chain and never waits for one - and every caller gets the single caller's hits."""
