@@ -1081,6 +1081,26 @@ __global__ __launch_bounds__(256) void index_bucket_kernel(const IdxSeg* __restr
     if (li == sg.n - 1) for (uint32_t bb = b + 1; bb <= sg.nb; bb++) bucket[sg.boff + bb] = sg.n;
 }
 
+// Gb-scale sketches (>= IDX_OWN_SORT seeds): every sketch its own sort of (u32 k-mer, u32 position rank) pairs straight from its seed array - 8 bytes per element and
+// 2k key bits instead of the group sort's 12 bytes and 33 bits (a slot tag above the k-mer): four passes of 16 B per element instead of five of 24 (8 x 3 Gb: the index
+// bracket 15.3 -> 9 ms per step). The values are the same iota for every sketch; the bucket tables and the position | meta copies come from one launch over (entry, sketch).
+constexpr uint32_t IDX_OWN_SORT = 1u << 22;
+__global__ __launch_bounds__(256) void index_iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+__global__ __launch_bounds__(256) void index_bucket32_kernel(const IdxSeg* __restrict__ segs, const uint32_t* __restrict__ km32, const uint32_t* __restrict__ perm,
+                                                             uint32_t* __restrict__ bucket, uint64_t* __restrict__ pms) {
+    const IdxSeg sg = segs[blockIdx.y];
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= sg.n) return;
+    const uint32_t i = sg.out_off + li, k = km32[i], b = k >> sg.bshift;
+    pms[i] = sg.pm[perm[i]];
+    uint32_t from = 0;
+    if (li > 0) from = (km32[i - 1] >> sg.bshift) + 1;
+    for (uint32_t bb = from; bb <= b; bb++) bucket[sg.boff + bb] = li;
+    if (li == sg.n - 1) for (uint32_t bb = b + 1; bb <= sg.nb; bb++) bucket[sg.boff + bb] = sg.n;
+}
+
 // ---- index of one sketch by ONE workgroup (sketches up to IDXB_MAX_SEEDS seeds, i.e. genomes up to ~30 Mb at
 // c = 125): counting sort on the k-mer's top bits in LDS (hash-selected k-mers are uniform, ~2-4 per bucket), then
 // every bucket is put in (k-mer, seed index) order by one thread. The bucket starts ARE the lookup table. One launch
@@ -1285,18 +1305,37 @@ psk_status ensure_index(Lane* ctx, const psk_sketch* const* refs, uint32_t n, bo
             i0 = i1;
             continue;
         }
-        PSK_TRY(ctx->s_mark.reserve(kb + vb));
-        uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint32_t* v_in = (uint32_t*)((char*)ctx->s_mark.p + kb);
-        ctx->t_begin(K_SKETCH_SORT);
-        hipLaunchKernelGGL(index_gather_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 2048), m), dim3(256), 0, st,      // (64 workgroups per sketch: 0.74 ms for two 24 M-seed sketches, a quarter of the chip)
-                           (const IdxSeg*)ctx->s_offs.p, k_in, v_in);
-        int slot_bits = 1; while ((1u << slot_bits) < m) slot_bits++;
-        size_t tmp = 0;
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
-        PSK_TRY(ctx->s_tmp.reserve(tmp));
-        PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
-        hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms, ix->km32);
-        ctx->t_end();
+        bool own_sort = getenv("PSK_INDEX_GROUP_SORT") == nullptr;      // (tests, A/B: the group sort for sketches of any size)
+        int kb_max = 0;
+        for (uint32_t j = 0; j < m; j++) { own_sort = own_sort && segs[j].n >= IDX_OWN_SORT; kb_max = std::max(kb_max, 2 * todo[i0 + j]->params.k); }
+        if (own_sort) {
+            PSK_TRY(ctx->s_mark.reserve(align_up(4 * (size_t)maxn, 256)));
+            uint32_t* v_in = (uint32_t*)ctx->s_mark.p;
+            size_t tmp = 0;
+            PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)maxn, 0, kb_max, st));
+            PSK_TRY(ctx->s_tmp.reserve(tmp));
+            ctx->t_begin(K_SKETCH_SORT);
+            hipLaunchKernelGGL(index_iota_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 4096)), dim3(256), 0, st, v_in, maxn);
+            for (uint32_t j = 0; j < m; j++) {
+                size_t tj = tmp;
+                PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tj, segs[j].kmer, ix->km32 + segs[j].out_off, (const uint32_t*)v_in, ix->perm + segs[j].out_off, (int)segs[j].n, 0, 2 * todo[i0 + j]->params.k, st));
+            }
+            hipLaunchKernelGGL(index_bucket32_kernel, dim3((maxn + 255) / 256, m), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint32_t*)ix->km32, (const uint32_t*)ix->perm, ix->bucket, ix->pms);
+            ctx->t_end();
+        } else {
+            PSK_TRY(ctx->s_mark.reserve(kb + vb));
+            uint64_t* k_in = (uint64_t*)ctx->s_mark.p; uint32_t* v_in = (uint32_t*)((char*)ctx->s_mark.p + kb);
+            ctx->t_begin(K_SKETCH_SORT);
+            hipLaunchKernelGGL(index_gather_kernel, dim3(std::min<uint32_t>((maxn + 255) / 256, 2048), m), dim3(256), 0, st,      // (64 workgroups per sketch: 0.74 ms for two 24 M-seed sketches, a quarter of the chip)
+                               (const IdxSeg*)ctx->s_offs.p, k_in, v_in);
+            int slot_bits = 1; while ((1u << slot_bits) < m) slot_bits++;
+            size_t tmp = 0;
+            PSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
+            PSK_TRY(ctx->s_tmp.reserve(tmp));
+            PSK_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->s_tmp.p, tmp, k_in, ix->key, v_in, ix->perm, (int)T, 0, 32 + slot_bits, st));
+            hipLaunchKernelGGL(index_bucket_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, st, (const IdxSeg*)ctx->s_offs.p, (const uint64_t*)ix->key, (const uint32_t*)ix->perm, (uint32_t)T, ix->bucket, ix->pms, ix->km32);
+            ctx->t_end();
+        }
         PSK_HIP(hipStreamSynchronize(st));   // segs (host vector) feeds the async copy above
         for (uint32_t j = 0; j < m; j++) {
             todo[i0 + j]->idx = ix; todo[i0 + j]->idx_off = segs[j].out_off;
