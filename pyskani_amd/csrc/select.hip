@@ -378,6 +378,13 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
     uint32_t* ord = B.ord + base; uint32_t* clist = B.clist + base; uint8_t* conf = B.conf + base;
     unsigned long long* t_key = (unsigned long long*)s_raw; uint32_t* t_pay = (uint32_t*)(s_raw + 8 * BIG_TILE);
     __syncthreads();
+#ifdef SEL_TRACE
+    unsigned long long t_ph[8]; int n_ph = 0;
+#define SEL_STAMP() do { if (gr == 0 && tid == 0 && n_ph < 8) t_ph[n_ph++] = wall_clock64(); } while (0)
+#else
+#define SEL_STAMP() do {} while (0)
+#endif
+    SEL_STAMP();
     // ---- candidates in generation order: every workgroup takes a span of rows; spans are stitched by the partial sums ----
     const uint32_t rspan = (((nrows + G - 1) / G) + BIG_T - 1) / BIG_T * BIG_T;
     const uint32_t ra = gr * rspan < nrows ? gr * rspan : nrows, rb = ra + rspan < nrows ? ra + rspan : nrows;
@@ -414,10 +421,12 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         conf[j] = cf;
     }
     grp_sync(g);
+    SEL_STAMP();      // (1: candidates listed, query-side conflicts)
     // ---- conflicts on the reference: order by (ref contig, r0), running max of r1 by doubling ----
     for (uint32_t j = gt; j < P; j += GT) { key[j] = j < C ? (((unsigned long long)S.c_rc[slot[j]] << 32) | S.c_r0[slot[j]]) : ~0ull; idx[j] = j; }
     grp_sync(g);
     big_bitonic(key, idx, P, false, g, t_key, t_pay);
+    SEL_STAMP();      // (2: the reference-order sort)
     for (uint32_t u = gt; u < C; u += GT) pm[u] = S.c_r1[slot[idx[u]]];
     grp_sync(g);
     uint32_t* src = pm; uint32_t* dst = pm2;
@@ -439,6 +448,7 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         if (cf) conf[j] = 1;
     }
     grp_sync(g);
+    SEL_STAMP();      // (3: running maximum + reference-side conflicts)
     // ---- unconflicted chains are kept; conflicted ones listed (spans of candidates, stitched as above), then put in priority order ----
     const uint32_t tspan = (((C + G - 1) / G) + BIG_T - 1) / BIG_T * BIG_T;
     const uint32_t ta = gr * tspan < C ? gr * tspan : C, tb = ta + tspan < C ? ta + tspan : C;
@@ -484,6 +494,7 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
         for (uint32_t t = gt; t < ncf; t += GT) clist[t] = 0xFFFFFFFFu - (uint32_t)key[t];
         grp_sync(g);
     }
+    SEL_STAMP();      // (4: commits of the unconflicted, list + sort of the conflicted)
     if (gr != 0) return;
     // ---- greedy over the conflicted chains in priority order, by the group's first workgroup: candidates staged 1024 at a time
     // in LDS, kept chains in LDS (the first KL) and in compact global arrays (pm, pm2, idx, ord and the key array are free now) ----
@@ -556,6 +567,10 @@ __device__ void select_big_pair(const BigArgs& B, const uint32_t p, BigGrp& g, u
             nk = s_nk;
         }
     }
+    SEL_STAMP();      // (5: greedy)
+#ifdef SEL_TRACE
+    if (tid == 0 && G > 1) printf("SEL_TRACE pair %u C %u ncf %u G %u us: list %.0f sort %.0f max %.0f commit %.0f greedy %.0f\n", p, C, ncf, G, (t_ph[1] - t_ph[0]) * 0.01, (t_ph[2] - t_ph[1]) * 0.01, (t_ph[3] - t_ph[2]) * 0.01, (t_ph[4] - t_ph[3]) * 0.01, (t_ph[5] - t_ph[4]) * 0.01);
+#endif
     if (tid == 0) atomicAdd(&S.stats[3], 1u);
 }
 
