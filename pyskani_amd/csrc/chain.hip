@@ -297,7 +297,7 @@ psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_i
     // 3 Gb pairs asks for, and a cold pass pays ~25 ms per GB it is handed)
     const size_t na = ((size_t)cap + 64 + 63) & ~(size_t)63;     // multiple of 64: every per-anchor array stays 256-byte aligned (16-byte loads in the lane kernels)
     PSK_TRY(ctx->q_d.reserve(4 * na * CHAIN_ANCHOR_WORDS));
-    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64)));   // select_big_kernel / select_huge_kernel scratch
+    PSK_TRY(ctx->q_e.reserve(na * (8 + 4 * 7 + 1) + 512 + 4 * 2 * BIG_GMAX * (BIG_GROUPS + 64) + 4 * BIG_GROUPS));   // select_big_kernel / select_huge_kernel scratch
     uint32_t* D = (uint32_t*)ctx->q_d.p;
     uint32_t* E4 = (uint32_t*)ctx->q_e.p;   // (37 bytes per anchor: room for the serial DP's 16)
     uint4* anc = (uint4*)D;                 // the first four u32 arrays' worth of space: one 16-byte record per anchor
@@ -476,7 +476,7 @@ psk_status chain_run(Lane* ctx, const ChainBufs& L, uint32_t n_pairs, size_t n_i
             BA.slot = U; BA.crow = U + na; BA.idx = U + 2 * na; BA.pm = U + 3 * na; BA.pm2 = U + 4 * na; BA.ord = U + 5 * na; BA.clist = U + 6 * na;
             BA.conf = (uint8_t*)(U + 7 * na);
             BA.parts = (uint32_t*)(E + (((size_t)na * (8 + 4 * 7 + 1) + 255) & ~(size_t)255));
-            BA.huge_list = L.huge_list; BA.huge_count = L.misc + 11; BA.ctr = L.misc + 32;
+            BA.huge_list = L.huge_list; BA.huge_count = L.misc + 11; BA.ctr = L.misc + 32; BA.huge_c = BA.parts + (size_t)2 * BIG_GMAX * (BIG_GROUPS + 64);
             const uint32_t solo = sw.big_solo.get() ? (uint32_t)std::max(atoi(sw.big_solo.get()), CMAX) : BIG_SOLO;
             BA.solo = solo;
             hipLaunchKernelGGL(select_big_kernel, dim3(std::min<uint32_t>(n_pairs, 64u)), dim3(BIG_T), 0, st, BA);

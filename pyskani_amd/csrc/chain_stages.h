@@ -135,6 +135,7 @@ struct BigArgs {
     uint32_t *ord, *clist;
     uint8_t* conf;
     uint32_t *huge_list, *huge_count;   // pairs with more than BIG_SOLO candidates, listed by the solo kernel for the cooperative one
+    uint32_t* huge_c;                   // ... and the candidates of the first BIG_GROUPS of them: the cooperative launch deals its workgroups by these weights
     uint32_t *ctr, *parts;              // per group: barrier counter; 2 x BIG_GMAX partial sums of the two ordered compactions
     uint32_t solo;                      // BIG_SOLO ($PSK_BIG_SOLO in tests)
 };

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
     const uint32_t n = *B.S.big_count;
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
         const uint32_t p = B.S.big_list[k];
-        if (big_count_candidates(B.S, p, s_scan) > B.solo) { if (threadIdx.x == 0) B.huge_list[atomicAdd(B.huge_count, 1u)] = p; continue; }
+        const uint32_t n_cand = big_count_candidates(B.S, p, s_scan);
+        if (n_cand > B.solo) { if (threadIdx.x == 0) { const uint32_t at = atomicAdd(B.huge_count, 1u); B.huge_list[at] = p; if (at < BIG_GROUPS) B.huge_c[at] = n_cand; } continue; }
         BigGrp g{1, 0, 0, nullptr, B.parts, B.parts + BIG_GMAX};
         g.part_a = B.parts + (size_t)(BIG_GROUPS + blockIdx.x) * 2 * BIG_GMAX; g.part_b = g.part_a + BIG_GMAX;
         select_big_pair(B, p, g, s_raw, s_scan);
@@ -591,14 +592,34 @@ __global__ __launch_bounds__(BIG_T) void select_big_kernel(BigArgs B) {
     }
 }
 
-// Gb-scale pairs: the launch's workgroups (all co-resident: at most BIG_GMAX, one per CU) split into min(16, pairs) groups, each
-// group takes every groups-th listed pair. Workgroups of a group sit on as few XCDs as possible (workgroup b runs on XCD b % 8).
+// Gb-scale pairs: the launch's workgroups (all co-resident: at most BIG_GMAX, one per CU) split into groups, one per listed pair; a group's workgroups sit on as few XCDs as
+// possible (workgroup b runs on XCD b % 8). Up to BIG_GROUPS pairs (a batch of eleven 3 Gb pairs): the workgroups are dealt BY WEIGHT - a pair's candidates, counted by the solo
+// kernel - because the launch lasts as long as its largest pair (150 000 to 480 000 candidates in one batch of the 8 x 3 Gb step: with sixteen workgroups each, the largest
+// pair's sort, running maximum and commits took 3.8 of the launch's 4.8 ms while the groups of the small pairs had long finished; the phases' times: profiles/r6/r6_ablation.md).
+// More pairs than that: equal groups, each taking every groups-th pair. Any group size gives the same result (select_big_pair).
 __global__ __launch_bounds__(BIG_T) void select_huge_kernel(BigArgs B) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[12 * BIG_TILE];
     __shared__ uint32_t s_scan[BIG_T / 64 + 1];
     const uint32_t n = *B.huge_count;
     if (n == 0) return;
     const uint32_t NB = gridDim.x;                  // a power of two, >= 8 (or 1)
+    if (n <= BIG_GROUPS && NB >= 8 && NB >= 2 * n) {
+        const uint32_t l = (blockIdx.x & 7u) * (NB >> 3) + (blockIdx.x >> 3);      // consecutive logical workgroups share an XCD
+        unsigned long long total = 0;
+        for (uint32_t k = 0; k < n; k++) total += B.huge_c[k];
+        uint32_t start = 0, gid = 0, G = 1; unsigned long long cum = 0;
+        for (uint32_t k = 0; k < n; k++) {      // group k = logical workgroups [start, end): its share of the candidates, at least one workgroup, room left for the pairs behind it
+            cum += B.huge_c[k];
+            uint32_t end = k + 1 == n ? NB : (uint32_t)((unsigned long long)NB * cum / (total ? total : 1ull));
+            if (end < start + 1u) end = start + 1u;
+            if (end > NB - (n - 1u - k)) end = NB - (n - 1u - k);
+            if (l >= start && l < end) { gid = k; G = end - start; break; }
+            start = end;
+        }
+        BigGrp g{G, l - start, 0, B.ctr + gid, B.parts + (size_t)gid * 2 * BIG_GMAX, B.parts + (size_t)gid * 2 * BIG_GMAX + BIG_GMAX};
+        select_big_pair(B, B.huge_list[gid], g, s_raw, s_scan);
+        return;
+    }
     uint32_t groups = 1; while (groups < n && groups < BIG_GROUPS && groups < NB) groups <<= 1;
     const uint32_t G = NB / groups;
     uint32_t gid, gr;
