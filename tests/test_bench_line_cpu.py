@@ -48,6 +48,22 @@ def test_compact_line_fits_the_driver_tail_and_keeps_the_contract(bench):
     assert "model" not in line["config"] and "workload" in line["config"]
 
 
+def test_contract_line_of_round_6_leads_with_the_contract_job(bench):
+    """the line the driver parses is the 10 000 x 10 000 job (strong scaling) with host_to_host, the oracle check and the single-GPU scaling emulation beside it,
+    the former headline under extras.workloads.search_1k - and it still fits the 4 kB budget. The mock is a full object a default run wrote (profiles/r6)."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r6", "r6z_bench_default_full.json")))
+    line = bench.compact_line(full, "profiles/r6/bench_full_allvsall_x.json")
+    assert len(json.dumps(line)) < bench.LINE_BUDGET
+    assert line["scaling"] == "strong" and "10000 x 10000" in line["config"]["workload"] and line["config"]["genomes"] == 10000
+    assert line["unit"] == "genome-pairs/s" and line["value"] == pytest.approx(1e8 / (line["ms_per_step"] * 1e-3), rel=1e-3)
+    assert {"value", "ms_per_step", "vs_cpu_all_cores"} <= set(line["host_to_host"])
+    assert line["extras"]["oracle_check"] == "8 random hits bit-exact"
+    sm = line["extras"]["scaling_model"]
+    assert "emulation" in sm["kind"] and set(sm["ranks"]) == {"2", "4", "8"} and all(1.0 < v["speedup_vs_1"] <= int(n) * 1.05 for n, v in sm["ranks"].items())
+    assert "search_1k" in line["extras"]["workloads"] and line["extras"]["workloads"]["search_1k"]["scaling"] == "weak"
+    assert line["roofline"]["kernel"] in bench.KERNELS and 0 < line["roofline"]["frac"] <= 1 and line["cpu_baseline"]["kind"] == "port"
+
+
 def test_compact_line_never_exceeds_the_budget_even_with_many_workloads(bench):
     full = _mock_full()
     w = full["extras"]["workloads"]
