@@ -317,34 +317,36 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
     const bool live = act && !guard && pend - cursor >= MIN_ANCHORS;      // fewer: no chain can form, no chunk table
     uint32_t rows = 0; unsigned long long lim1 = live ? 0ull : ~0ull;      // (a pair without a chunk table: no key is beyond the limit, the emit walk opens no chunk)
     uint32_t* my_bm = s_bm + lane * (GSL_WORDS + 1);
-    uint32_t kp[GSL_HK], kmt[GSL_HK]; uint4 bw[GSL_WORDS / 4]; uint32_t c_next = 0;
-    auto load_slice = [&](uint32_t sl) {
+    // a slice's inputs - the seeds' positions and contigs, the (pair, slice)'s anchor count and bitmap - are requested TWO slices ahead (two register sets, taken in turn): a
+    // lane's walk over its pair's ~160 slices is a chain of these loads, and one slice of look-ahead left every step waiting for most of a memory round trip
+    struct HSlice { uint32_t kp[GSL_HK], kmt[GSL_HK]; uint4 bw[GSL_WORDS / 4]; uint32_t c; };
+    HSlice S0, S1;
+    auto load_slice = [&](HSlice& X, uint32_t sl) {
         const uint32_t sb = sl * GSL_SEEDS;
 #pragma unroll
-        for (uint32_t u = 0; u < GSL_HK; u++) { const uint32_t i = sb + u * 64u + (uint32_t)lane; kp[u] = 0; kmt[u] = 0; if (i < Q.n) { kp[u] = Q.pos[i]; kmt[u] = Q.meta[i]; } }
+        for (uint32_t u = 0; u < GSL_HK; u++) { const uint32_t i = sb + u * 64u + (uint32_t)lane; X.kp[u] = 0; X.kmt[u] = 0; if (i < Q.n) { X.kp[u] = Q.pos[i]; X.kmt[u] = Q.meta[i]; } }
         const size_t r = (size_t)eb.x + (size_t)sl * P + j;
-        c_next = 0;
+        X.c = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) bw[u] = make_uint4(0, 0, 0, 0);
+        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) X.bw[u] = make_uint4(0, 0, 0, 0);
         if (act) {
-            c_next = A.cnt[r];
+            X.c = A.cnt[r];
             const uint4* __restrict__ src = (const uint4*)(A.bm + r * GSL_WORDS);
 #pragma unroll
-            for (uint32_t u = 0; u < GSL_WORDS / 4; u++) bw[u] = src[u];
+            for (uint32_t u = 0; u < GSL_WORDS / 4; u++) X.bw[u] = src[u];
         }
     };
-    load_slice(0);
-    for (uint32_t sl = 0; sl < nsl; sl++) {
+    auto step = [&](HSlice& X, uint32_t sl) {
         const uint32_t sb = sl * GSL_SEEDS, ns = Q.n - sb > GSL_SEEDS ? GSL_SEEDS : Q.n - sb;
         const size_t r = (size_t)eb.x + (size_t)sl * P + j;
         lds_wave_sync();
         if (lane < (int)GSL_WORDS) s_un[lane] = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < GSL_HK; u++) s_key[u * 64u + lane] = (((unsigned long long)(kmt[u] >> 1) << 32) | kp[u]) + 1ull;
+        for (uint32_t u = 0; u < GSL_HK; u++) s_key[u * 64u + lane] = (((unsigned long long)(X.kmt[u] >> 1) << 32) | X.kp[u]) + 1ull;
 #pragma unroll
-        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) { my_bm[4 * u] = bw[u].x; my_bm[4 * u + 1] = bw[u].y; my_bm[4 * u + 2] = bw[u].z; my_bm[4 * u + 3] = bw[u].w; }
-        const uint32_t c = c_next;
-        if (sl + 1 < nsl) load_slice(sl + 1);
+        for (uint32_t u = 0; u < GSL_WORDS / 4; u++) { my_bm[4 * u] = X.bw[u].x; my_bm[4 * u + 1] = X.bw[u].y; my_bm[4 * u + 2] = X.bw[u].z; my_bm[4 * u + 3] = X.bw[u].w; }
+        const uint32_t c = X.c;
+        if (sl + 2 < nsl) load_slice(X, sl + 2);
         lds_wave_sync();
         if (act) {
             A.rec[r] = make_uint4(cursor, rows, (uint32_t)lim1, (uint32_t)(lim1 >> 32));
@@ -370,6 +372,12 @@ __global__ __launch_bounds__(64) void gsl_heads_kernel(GslArgs A) {
         }
         lds_wave_sync();
         if (lane < (int)GSL_WORDS && s_un[lane]) atomicOr(&A.un[(size_t)(eb.y + sl) * GSL_WORDS + lane], s_un[lane]);
+    };
+    load_slice(S0, 0);
+    if (nsl > 1) load_slice(S1, 1);
+    for (uint32_t sl = 0; sl < nsl; sl += 2) {
+        step(S0, sl);
+        if (sl + 1 < nsl) step(S1, sl + 1);
     }
     if (act) {
         if (live && rows) {      // the last row's end (its first anchor comes from the emit walk)
