@@ -487,10 +487,13 @@ def timed_loop(eng, step, steps, warmup, fence):
     eng.work(reset=True)
     fence()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(steps):
         res = step()
+        marks.append(time.perf_counter())      # (every step ends with its results on the host: the marks are the steps' own wall times; nothing is added to the timed region but this call)
     fence()
     dt = time.perf_counter() - t0
+    timed_loop.last_step_ms = [round((b - a) * 1e3, 2) for a, b in zip(marks, marks[1:])]
     kern = {k: eng.timing(k) for k in KERNELS}
     eng.capi.check(eng.lib.psk_ctx_set_timing(eng.ctx, 0))
     work = {k: v / max(1, steps) for k, v in eng.work(reset=True).items()}
@@ -888,6 +891,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
             finally:
                 eng.lib.psk_db_destroy(db)
         dt, n_hits, kern, work, clock = timed_loop(eng, step, steps, warmup, lambda: job.fence(eng))
+        step_ms = list(getattr(timed_loop, "last_step_ms", []))      # every timed step's own wall time (the line's ms_per_step is their mean)
         recs = last["recs"]      # psk_hit_min: `query` = the hit's query within the call
         digest = records_digest(recs)
         # The timed steps keep two batches in flight on two lanes (query_many.hip: rounds of >= 2^31 (pair, seed) items): their kernels share the chip and a bracket's
@@ -908,7 +912,7 @@ def run_allvsall(job, steps, warmup, n_total, cpu_queries, variant="plain", veri
         line = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": float(n_total) * n_total * steps / dt, "unit": "genome-pairs/s",
                 "workload": f"all-vs-all {n_total} x {n_total} synthetic ~5 Mb genomes on one GPU ({n_families} families x {n_total // n_families}; {shape}), c=125 marker_c=1000 k=15; device-resident ASCII",
                 "hits": int(n_hits), "hits_digest": digest, "chain_work_per_step": work, "bases_sketched_per_s": bases_local * steps / dt,
-                "roofline": roofline_of(table, 1 if table_step else steps), "kernel_roofline": table, "clock": clock, "scaling": "strong"}
+                "roofline": roofline_of(table, 1 if table_step else steps), "kernel_roofline": table, "clock": clock, "scaling": "strong", "step_ms": step_ms}
         if table_step:
             line["kernel_table_step"] = table_step
         host = None
