@@ -170,6 +170,45 @@ def test_slice_join_walks_every_index_block_that_holds_a_passing_reference():
     assert _run(INTERLEAVED, {"PSK_GSL_MAX_BLOCKS": "1"}) == base
 
 
+SCATTERED = COMMON + r"""
+import os, ctypes as C
+# 47 index blocks of 256 references; family f = the references f, 256 + f, 512 + f, ...: ONE member per block, so a query's 47 passing references sit in 47 different blocks
+NB, FAMS, L = 47, 256, 21000
+def near(a, n_mut):
+    b = a.copy(); p = rng.integers(0, len(a), n_mut); b[p] = (b[p] + rng.integers(1, 4, n_mut, dtype=np.uint8)) & 3; return b
+anc = [rng.integers(0, 4, L, dtype=np.uint8) for _ in range(FAMS)]
+refs = [(f"r{b * FAMS + f}", lut[near(anc[f], 8 * b)].tobytes()) for b in range(NB) for f in range(FAMS)]
+db = psk.Database(compression=10, marker_compression=100)
+db.sketch_many(refs)
+genomes = [refs[i] for i in range(0, NB * FAMS, 50)]      # 241 genome queries x 47 passing references
+contigs = []
+for j in range(3000):
+    i = int(rng.integers(0, NB * FAMS)); g = np.frombuffer(refs[i][1], np.uint8); ln = int(rng.integers(1500, 4000)); st = int(rng.integers(0, len(g) - ln))
+    contigs.append((f"c{j}", g[st:st + ln].tobytes()))
+ng, dg = digest(db.query_many(genomes, learned_ani=False))
+nc, dc = digest(db.query_many(contigs, learned_ani=False))
+lk = C.c_uint64(); db._lib.psk_ctx_join_work(db._ctx._h, C.byref(lk), None, None, None, 0)
+print(ng, nc, dg + dc, lk.value)
+"""
+
+
+def test_block_tables_of_entries_whose_references_sit_in_dozens_of_blocks():
+    """Round 6: the index walks take their blocks from per-entry block tables (gsl_blocks_kernel; up to one row per pair of the entry). Here a query's 47 passing references sit in 47
+    DIFFERENT index blocks - the plan refuses the index joins for such a round (more than four blocks per query: the per-pair join for genomes, the database-wide index for
+    contigs) unless told otherwise: with PSK_GSI_SLICE=1 / PSK_GSL_MAX_BLOCKS=64 the slice join and the contig join walk 47 listed blocks per entry. The same hits."""
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PSK_")}
+        env.update(extra)
+        o = subprocess.check_output([sys.executable, "-c", SCATTERED], env=env, timeout=1200).decode().split()
+        return int(o[0]), int(o[1]), o[2], int(o[3])
+    base = run({"PSK_GSI_SLICE": "0", "PSK_GSI_JOIN": "0"})      # no index walk at all
+    assert base[0] >= 241 * 40 and base[1] >= 3000 * 30 and base[3] == 0, base
+    forced = run({"PSK_GSI_SLICE": "1", "PSK_GSL_MAX_BLOCKS": "64"})
+    assert forced[:3] == base[:3] and forced[3] > 0, (forced, base)
+    default = run({})
+    assert default[:3] == base[:3], (default, base)
+
+
 def test_slice_join_with_more_pairs_than_one_entry_holds(oracle):
     """The seed-index join by (query, slice) waves where a query has more passing references than one wave's LDS holds cursors for (300 > 256: two entries per query,
     the heads kernel's second 64-pair group partly filled), genomes of several contigs and a planted repeat (seeds with two anchors in one pair: the heads kernel cannot
