@@ -1027,14 +1027,16 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
     const uint32_t n_blk = A.b_blocks ? A.blk_cnt[blockIdx.x] : 0u;
     const bool blocked = A.b_blocks && (n_blk <= A.b_max || !A.g_key);
     const uint32_t nw = blocked ? 4u : (A.n_refs + 63u) / 64u;      // words of the bitset in use (the launch's LDS holds nw_lds)
-    uint4* s_line = (uint4*)s_gsi;      // EMIT with A.stage: the even-indexed anchor every pair holds back (16 B per pair, at the front: 16-byte aligned)
-    unsigned long long* s_bits = s_gsi + ((EMIT && A.stage) ? 2u * A.p_cap : 0u);
+    // LDS of the wave. EMIT: [with A.stage: the even-indexed anchor every pair holds back, 16 B per pair][the pairs' STATE, one 16-byte record each: {anchors so far, first
+    // anchor of the pair (GSI_DEAD: fewer than MIN_ANCHORS anchors - it cannot chain: no anchors, no chunk table), query position of the open chunk's head, q contig << 16 | rows
+    // so far}: ONE read per anchor in the walk's chain of dependent LDS round trips, where four arrays took three trips][the open chunk's first anchor per pair][the pass bitset
+    // and its prefix counts]. COUNT: [bitset][prefix counts][the pairs' anchor counts].
+    uint4* s_line = (uint4*)s_gsi;
+    uint4* s_st = s_line + ((EMIT && A.stage) ? A.p_cap : 0u);
+    uint32_t* s_hi = (uint32_t*)(s_st + (EMIT ? A.p_cap : 0u));
+    unsigned long long* s_bits = (unsigned long long*)(s_hi + (EMIT ? A.p_cap : 0u));
     uint32_t* s_pref = (uint32_t*)(s_bits + A.nw_lds);
-    uint32_t* s_cur = s_pref + ((A.nw_lds + 1u) & ~1u);
-    uint32_t* s_ps = s_cur + A.p_cap;       // EMIT: first anchor of every pair of the entry (GSI_DEAD: fewer than MIN_ANCHORS anchors - it cannot chain: no anchors, no chunk table),
-    uint32_t* s_hq = s_ps + A.p_cap;        //       query position, anchor index and (q contig << 16 | rows so far) of the chunk being filled
-    uint32_t* s_hi = s_hq + A.p_cap;
-    uint32_t* s_hc = s_hi + A.p_cap;
+    uint32_t* s_cur = s_pref + ((A.nw_lds + 1u) & ~1u);      // (COUNT only)
     constexpr uint32_t GSI_DEAD = 0xFFFFFFFFu;
     const int lane = threadIdx.x;
     const BatchQ B = A.bq[blockIdx.x];
@@ -1053,7 +1055,10 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 run += (uint32_t)__popcll(m);
             }
         }
-        for (uint32_t j = lane; j < P; j += 64) { s_cur[j] = 0; if (EMIT) { const uint32_t a = A.pstart[B.pair_off + j], z = A.pstart[B.pair_off + j + 1]; s_ps[j] = !A.onepass && z - a < MIN_ANCHORS ? GSI_DEAD : a; s_hc[j] = 0; } }
+        for (uint32_t j = lane; j < P; j += 64) {
+            if (EMIT) { const uint32_t a = A.pstart[B.pair_off + j], z = A.pstart[B.pair_off + j + 1]; s_st[j] = make_uint4(0u, !A.onepass && z - a < MIN_ANCHORS ? GSI_DEAD : a, 0u, 0u); }
+            else s_cur[j] = 0;
+        }
     }
     lds_wave_sync();
     const SketchDesc Q = A.qd[B.q];
@@ -1131,11 +1136,12 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                 if (!__any(match)) continue;
                 const uint32_t ref = blocked ? (uint32_t)(v >> 48) & 255u : (uint32_t)(v >> 48), w = ref >> 6, bpos = ref & 63u;      // (a block's entries carry the reference's id within the block)
                 uint32_t slot = 0xFFFFFFFFu;
+                uint4 st = make_uint4(0u, 0u, 0u, 0u);      // EMIT: the pair's state, read once
                 if (match) {
                     const unsigned long long bits = s_bits[w];
                     const uint32_t rk = s_pref[w] + (uint32_t)__popcll(bits & ((1ull << bpos) - 1ull));
                     if (((bits >> bpos) & 1ull) && rk >= B.rank_lo && rk < B.rank_hi) slot = rk - B.rank_lo;
-                    if (EMIT && slot != 0xFFFFFFFFu && s_ps[slot] == GSI_DEAD) slot = 0xFFFFFFFFu;
+                    if (EMIT && slot != 0xFFFFFFFFu) { st = s_st[slot]; if (st.y == GSI_DEAD) slot = 0xFFFFFFFFu; }
                 }
                 const bool valid = slot != 0xFFFFFFFFu;
                 if (!__any(valid)) continue;
@@ -1156,13 +1162,13 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                     const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
                     j = valid ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)upto)) : 0u;
                 }
-                const uint32_t base = valid ? s_cur[slot] : 0u;
+                const uint32_t base = valid ? st.x : 0u;
                 // Anchors leave in PAIRS (A.stage): a scattered 16-byte store costs 32 bytes of HBM write traffic (profiles/r4/r4k_pmc_calibration.md), so an anchor
                 // with an even index waits in LDS (one 16-byte slot per pair) for its odd neighbour, and the lane that brings that one writes both: one 32-byte granule.
                 // Inside a group of several lanes (a reference holding the k-mer several times) neighbours go out directly; only a group's last even anchor waits.
                 bool hold = false; uint4 av = make_uint4(0, 0, 0, 0);
                 if (EMIT && valid) {
-                    const unsigned long long dst = (unsigned long long)s_ps[slot] + base + j;
+                    const unsigned long long dst = (unsigned long long)st.y + base + j;
                     if (A.onepass && base + j >= nq + (nq >> 3) + 8u) atomicOr(A.err, 4u);      // the pair's room (gsi_room_kernel) is used up
                     else if (dst < A.cap) {
                         const uint32_t rmeta = (uint32_t)((((v >> 33) & 0x7FFFull) << 1) | (v & 1ull));      // ref contig << 1 | (fwd < rc)
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                         const uint32_t d32 = (uint32_t)dst;
                         if (!A.stage) A.anc[dst] = av;
                         else if (d32 & 1u) {      // odd: out it goes - with its even neighbour from LDS when that one is the pair's own and is not the lane before this one
-                            if (!same && d32 > s_ps[slot]) A.anc[d32 - 1u] = s_line[slot];
+                            if (!same && d32 > st.y) A.anc[d32 - 1u] = s_line[slot];
                             A.anc[d32] = av;
                         } else if (last) hold = true;      // even and the group's last: waits (written to LDS below, after the step's reads of the slots)
                         else A.anc[d32] = av;                // even with its odd neighbour in the next lane: both go out directly
@@ -1178,18 +1184,19 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
                     // chunk table: a chunk = the pair's anchors of one query contig within FRAGMENT_LENGTH of its first anchor (chunk_heads_kernel's rule), decided
                     // by the first lane of the (seed, reference) group - one group per pair and step
                     if (!same) {
-                        const uint32_t idx = s_ps[slot] + base, qc = sqm >> 1, hc = s_hc[slot];
-                        if (base == 0) { s_hq[slot] = sqp; s_hi[slot] = idx; s_hc[slot] = qc << 16; }
-                        else if ((hc >> 16) != qc || (unsigned long long)sqp > (unsigned long long)s_hq[slot] + FRAGMENT_LENGTH) {
+                        const uint32_t idx = st.y + base, qc = sqm >> 1, hc = st.w;
+                        uint32_t* stw = (uint32_t*)&s_st[slot];
+                        if (base == 0) { stw[2] = sqp; s_hi[slot] = idx; stw[3] = qc << 16; }
+                        else if ((hc >> 16) != qc || (unsigned long long)sqp > (unsigned long long)st.z + FRAGMENT_LENGTH) {
                             const uint32_t rows = hc & 0xFFFFu;
                             if (rows < Q.rows && rows < 0xFFFFu) A.chunks[(size_t)B.row_off + (size_t)slot * Q.rows + rows] = make_uint2(s_hi[slot], idx < A.cap ? idx : A.cap); else atomicOr(A.err, 1u);
-                            s_hq[slot] = sqp; s_hi[slot] = idx; s_hc[slot] = (qc << 16) | (rows + 1u);
+                            stw[2] = sqp; s_hi[slot] = idx; stw[3] = (qc << 16) | (rows + 1u);
                         }
                     }
                 }
                 if (dup) lds_wave_sync();
                 if (EMIT && hold) s_line[slot] = av;
-                if (last) s_cur[slot] = base + j + 1u;
+                if (last) { if (EMIT) ((uint32_t*)&s_st[slot])[0] = base + j + 1u; else s_cur[slot] = base + j + 1u; }
                 if (dup) lds_wave_sync();
             }
         }
@@ -1208,14 +1215,15 @@ __global__ __launch_bounds__(64) void gsi_join_kernel(GsiJoinArgs A) {
         unsigned long long sum = 0;
         for (uint32_t j = lane; j < P; j += 64) {      // the last chunk of every pair, and its row count
             uint32_t rows = 0;
-            const uint32_t n = s_cur[j];
-            if (A.stage && n && s_ps[j] != GSI_DEAD && !(A.onepass && n > nq + (nq >> 3) + 8u)) {      // an even last anchor is still waiting for a neighbour that never came
-                const unsigned long long e = (unsigned long long)s_ps[j] + n - 1u;
+            const uint4 fin = s_st[j];
+            const uint32_t n = fin.x;
+            if (A.stage && n && fin.y != GSI_DEAD && !(A.onepass && n > nq + (nq >> 3) + 8u)) {      // an even last anchor is still waiting for a neighbour that never came
+                const unsigned long long e = (unsigned long long)fin.y + n - 1u;
                 if (!(e & 1ull) && e < A.cap) A.anc[e] = s_line[j];
             }
-            if (s_ps[j] != GSI_DEAD && n && !(A.onepass && n < MIN_ANCHORS)) {      // (fewer than MIN_ANCHORS anchors: no chain, no chunk table - the rows written on the way are not counted)
-                rows = s_hc[j] & 0xFFFFu;
-                const unsigned long long e = (unsigned long long)s_ps[j] + n;
+            if (fin.y != GSI_DEAD && n && !(A.onepass && n < MIN_ANCHORS)) {      // (fewer than MIN_ANCHORS anchors: no chain, no chunk table - the rows written on the way are not counted)
+                rows = fin.w & 0xFFFFu;
+                const unsigned long long e = (unsigned long long)fin.y + n;
                 if (rows < Q.rows) { A.chunks[(size_t)B.row_off + (size_t)j * Q.rows + rows] = make_uint2(s_hi[j], e < A.cap ? (uint32_t)e : A.cap); rows++; } else atomicOr(A.err, 1u);
             }
             A.n_chunks[B.pair_off + j] = rows;
